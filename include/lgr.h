@@ -1,0 +1,177 @@
+/*
+ * lgr.h -- C ABI of the MI355X-native global-registration hot path (liblgr_hip.so).
+ *
+ * Drop-in boundary for aleksandrina-streltsova/lidar-global-registration.  The reference has no FFI layer: its
+ * boundary is the C++ header surface include/alignment.h:6-19, include/correspondence_search.h:9-28,
+ * include/sac_prerejective_omp.h:21-56 plus the free functions named below.  Each entry point cites the reference
+ * interface it replaces; lidar-global-registration_amd/host/ holds the header-only C++ shim that re-exposes the
+ * reference names on top of this ABI, and INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.  Every call returns an int status (LGR_OK == 0, negative =
+ *     error); nothing throws across the ABI.  "not converged" is NOT an error: see lgr_result.converged.
+ *   - point  : 12 floats, pcl::PointXYZINormal layout {x,y,z,1 | nx,ny,nz,0 | intensity,curvature,pad,pad} (48 B)
+ *   - fpfh   : 33 floats (pcl::FPFHSignature33, 132 B, row-major M x 33)
+ *   - corr   : lgr_corr (include/common.h:120-127 Correspondence), 16 B
+ *   - T      : 16 floats COLUMN-major (Eigen::Matrix4f default)
+ *   - host entry points (no suffix) borrow caller memory for the duration of the call, upload, run the device
+ *     path and download.  *_dev entry points take DEVICE pointers (HIP), enqueue on the context stream and are
+ *     asynchronous unless stated; outputs are caller-allocated device buffers.
+ *   - one lgr_ctx per host thread / GPU.  A ctx owns its workspace (grown on demand, never inside a timed launch
+ *     once warmed up).
+ *   - the HIP extension is mandatory: there is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef LGR_H
+#define LGR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGR_VERSION 1
+
+enum {
+    LGR_OK = 0,
+    LGR_ERR_INVALID_ARG = -1,
+    LGR_ERR_NO_DEVICE = -2,
+    LGR_ERR_OOM = -3,
+    LGR_ERR_HIP = -4,          /* a HIP runtime call failed; see lgr_last_error */
+    LGR_ERR_UNSUPPORTED = -5,  /* e.g. n_samples != 3, randomness != 1, alignment teaser (throws in the reference) */
+    LGR_ERR_VOXEL_TOO_SMALL = -6
+};
+
+enum { LGR_MATCH_LR = 0, LGR_MATCH_ONE_SIDED = 1, LGR_MATCH_CLUSTER = 2 };      /* src/matching.cpp:21-75 */
+enum { LGR_METRIC_CORRESPONDENCES = 0, LGR_METRIC_UNIFORMITY = 1 };             /* src/metric.cpp:272-301 */
+enum { LGR_SCORE_CONSTANT = 0, LGR_SCORE_MAE = 1, LGR_SCORE_MSE = 2, LGR_SCORE_EXP = 3 };
+enum { LGR_ALIGN_RANSAC = 0, LGR_ALIGN_GROR = 1 };                              /* src/alignment.cpp:92-101 */
+enum { LGR_ORDER_REFERENCE = 0, LGR_ORDER_CANONICAL = 1 };                      /* downsample output order */
+
+typedef struct { int32_t index_query, index_match; float distance, threshold; } lgr_corr;
+
+/* mirrors AlignmentParameters (include/common.h:135-163); string ids become enums; optionals become has_* flags */
+typedef struct {
+    int32_t feature_nr_points;   /* 352 */
+    int32_t normal_nr_points;    /* 30 */
+    float   edge_thr_coef;       /* 0.95 */
+    float   distance_thr;
+    float   feature_radius;      /* > 0: single scale (multi-scale is SURVEY 8f "next") */
+    float   scale_factor;        /* 2.0 */
+    float   confidence;          /* 0.999 */
+    int32_t bf_block_size;       /* 10000 */
+    int32_t cluster_k;           /* 40 */
+    int32_t randomness;          /* 1 (only 1, as data/test.yaml:14 says) */
+    int32_t n_samples;           /* 3 */
+    int32_t alignment_id, matching_id, metric_id, score_id;
+    int32_t max_iterations;
+    int32_t normals_available;
+    int32_t fix_seed;            /* 1: seed = 566 (SEED include/common.h:25); 0: seed field below */
+    int32_t has_vp_src, has_vp_tgt;
+    float   vp_src[3], vp_tgt[3];
+    int32_t ransac_batch;        /* iterations per device batch (deterministic schedule), default 16384 */
+    uint64_t seed;
+} lgr_params;
+
+/* mirrors AlignmentResult (include/common.h:165-174) + diagnostics */
+typedef struct {
+    float   transformation[16];  /* column-major */
+    int32_t iterations;
+    int32_t converged;
+    int32_t n_inliers;
+    float   metric;
+    float   best_metric_before_refit;
+    int32_t best_iteration;
+    int32_t num_rejections;
+    int32_t estimated_iters;
+    int32_t n_correspondences;
+    double  time_cs, time_te;    /* seconds, device-synchronised wall time */
+    float   stage_ms[12];        /* 0 downsample 1 normals 2 fpfh 3 match 4 filter 5 ransac 6 refit (hipEvent) */
+} lgr_result;
+
+typedef struct lgr_ctx lgr_ctx;
+
+/* ---- context ---- */
+int  lgr_version(void);
+/* device: HIP ordinal.  stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL -> ctx creates one */
+int  lgr_ctx_create(int device, void* stream, lgr_ctx** out);
+int  lgr_ctx_destroy(lgr_ctx* ctx);
+int  lgr_ctx_sync(lgr_ctx* ctx);
+const char* lgr_last_error(lgr_ctx* ctx);
+void lgr_default_params(lgr_params* p);                      /* defaults of src/common.cpp:216-223,335-413 */
+/* on-device stage timers of the last lgr_align*/
+int  lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12);
+
+/* ---- include/common.h:266-280 calculateBoundingBox ---- */
+int lgr_bbox_dev(lgr_ctx*, const float* d_pts, int n, float* d_min3_max3 /* 6 floats */);
+
+/* ---- include/downsample.h:32 downsamplePointCloud(pcd, pcd_down, voxel_size)  (src/downsample.cpp:5-41) ----
+ * out may alias the input (the reference passes the same cloud, src/common.cpp:455-456).  n_out <= n.
+ * order: LGR_ORDER_REFERENCE reproduces the libstdc++ unordered_map iteration order (host post-pass),
+ *        LGR_ORDER_CANONICAL = voxels sorted by (iz,iy,ix). */
+int lgr_downsample(lgr_ctx*, const float* pts, int n, float voxel, int order, float* out, int* n_out);
+int lgr_downsample_dev(lgr_ctx*, const float* d_pts, int n, float voxel, float* d_out, int* n_out /* host */);
+
+/* ---- src/common.cpp:644-655 estimateNormalsPoints(k, pcd, surface, vp, normals_available) ----
+ * writes normal_x/y/z + curvature of pts in place; surf NULL -> pts is its own surface; vp NULL -> origin */
+int lgr_normals_knn(lgr_ctx*, float* pts, int n, const float* surf, int ns, int k, const float* vp3, int normals_available);
+int lgr_normals_knn_dev(lgr_ctx*, float* d_pts, int n, const float* d_surf, int ns, int k, const float* vp3 /* host */, int normals_available);
+
+/* ---- include/common.h:322-332 estimateFeatures<FPFH>(kps, surface, features, radius, params) ---- */
+int lgr_fpfh(lgr_ctx*, const float* kps, int m, const float* surf, int n, float radius, float* out_m_x_33);
+int lgr_fpfh_dev(lgr_ctx*, const float* d_kps, int m, const float* d_surf, int n, float radius, float* d_out);
+
+/* ---- include/matching.h:373-376 matchBF<FPFH>(query, train, params), randomness = 1 ----
+ * idx[i] = matched train row or -1 (invalid / NaN query), dist[i] = L2 distance (sqrt) */
+int lgr_match_bf(lgr_ctx*, const float* q33, int mq, const float* t33, int mt, int block, int32_t* idx, float* dist);
+int lgr_match_bf_dev(lgr_ctx*, const float* d_q33, int mq, const float* d_t33, int mt, int block, int32_t* d_idx, float* d_dist);
+/* both directions in one MFMA pass (what LeftToRight/Cluster matchers need, include/matching.h:431-432,495-496) */
+int lgr_match_bf2_dev(lgr_ctx*, const float* d_a33, int ma, const float* d_b33, int mb, int block,
+                      int32_t* d_ab_idx, float* d_ab_dist, int32_t* d_ba_idx, float* d_ba_dist);
+
+/* ---- src/common.cpp:531-547 calculateSmoothedDensities(pcd, k) / :202-208 calculatePointCloudDensity ---- */
+int lgr_smoothed_densities(lgr_ctx*, const float* pts, int n, int k, float* out);
+int lgr_smoothed_densities_dev(lgr_ctx*, const float* d_pts, int n, int k, float* d_out);
+int lgr_knn_dev(lgr_ctx*, const float* d_q, int nq, const float* d_pts, int n, int k, int32_t* d_idx, float* d_d2);
+
+/* ---- include/matching.h:395-411 / 428-453 / 492-550 match_impl of OneSided / LeftToRight / Cluster matcher ---- */
+int lgr_filter_dev(lgr_ctx*, int matching_id, const float* d_src, int ns, const float* d_tgt, int nt,
+                   const int32_t* d_ij_idx, const float* d_ij_dist, const int32_t* d_ji_idx, const float* d_ji_dist,
+                   float distance_thr, int cluster_k, lgr_corr* d_out, int* n_out /* host */);
+
+/* ---- include/correspondence_search.h:14-28 FeatureBasedCorrespondenceSearch::calculateCorrespondences (keypoint any) ---- */
+int lgr_correspondences(lgr_ctx*, const float* src, int ns, const float* tgt, int nt, const lgr_params*, lgr_corr* out, int* n_out);
+int lgr_correspondences_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params*, lgr_corr* d_out, int* n_out /* host */);
+
+/* ---- include/sac_prerejective_omp.h:21-56 SampleConsensusPrerejectiveOMP(src,tgt,corrs,params).align() ----
+ * final_mask (optional): c bytes, inlier mask of the refit transform */
+int lgr_ransac(lgr_ctx*, const float* src, int ns, const float* tgt, int nt, const lgr_corr* corr, int c,
+               const lgr_params*, lgr_result*, uint8_t* final_mask);
+int lgr_ransac_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                   const lgr_params*, lgr_result* /* host */, uint8_t* d_final_mask);
+/* replay mode (SURVEY section 7 "RANSAC RNG"): evaluate n caller-supplied sample triples (correspondence indices) */
+int lgr_ransac_replay_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                          const lgr_params*, const int32_t* d_triples, int n,
+                          uint8_t* d_ok, float* d_T16, int32_t* d_n_inliers, float* d_metric);
+/* the on-device sampler alone: triples of iterations [first, first+n) (Philox4x32-10 + selectCorrespondences :33-77) */
+int lgr_ransac_samples_dev(lgr_ctx*, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples);
+/* src/metric.cpp:125-179 buildInliersAndEstimateMetric for one transform */
+int lgr_evaluate_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                     const float T16[16] /* host */, int metric_id, int score_id,
+                     uint8_t* d_mask, int* n_inliers, float* rmse, float* metric /* host outs */);
+
+/* ---- include/transformation.h:6-7 estimateOptimalRigidTransformation(src, tgt, inliers, T) ---- */
+int lgr_refit_svd(lgr_ctx*, const float* src, const float* tgt, int ns, int nt, const lgr_corr* inliers, int n, float T16[16]);
+int lgr_refit_svd_dev(lgr_ctx*, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c,
+                      const uint8_t* d_mask /* NULL: all */, float T16[16] /* host */);
+
+/* ---- include/alignment.h:18-19 alignPointClouds(src, tgt, params) (src/alignment.cpp:72-109, no CSV side effects);
+ *      alignRansac (:14-19) is lgr_ransac; alignGror (:21-35) via params.alignment_id ---- */
+int lgr_align(lgr_ctx*, const float* src, int ns, const float* tgt, int nt, const lgr_params*, lgr_result*);
+int lgr_align_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params*, lgr_result* /* host */);
+
+/* ---- include/hypotheses.h:10-16 (host bookkeeping; compiled out in the reference, SAVE_MULTIPLE_HYPOTHESES false) ---- */
+int lgr_update_hypotheses(float* tns16, float* metrics, int n, int cap, const float* new_T16, float new_metric, float distance_thr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+// lgr_ctx.hip -- context, workspace, error plumbing of liblgr_hip.so.
+#include "lgr_internal.h"
+
+int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line) {
+    if (ctx) {
+        char b[768];
+        snprintf(b, sizeof b, "[lgr %d] %s (%s:%d)", code, what, file, line);
+        ctx->err = b;
+    }
+    return code;
+}
+
+int lgr_ws(lgr_ctx* ctx, int slot, size_t bytes, void** out) {
+    lgr_buf& b = ctx->ws[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.cap < bytes) {
+        // growing a buffer: everything enqueued so far may still use the old one
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (b.p) LGR_HIP(ctx, hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        want = (want + 255) & ~(size_t) 255;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            want = (bytes + 255) & ~(size_t) 255;
+            LGR_HIP(ctx, hipMalloc(&b.p, want));
+        }
+        b.cap = want;
+    }
+    *out = b.p;
+    return LGR_OK;
+}
+
+int lgr_pinned(lgr_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->pinned_cap < bytes) {
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) LGR_HIP(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr; ctx->pinned_cap = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        LGR_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_cap = want;
+    }
+    *out = ctx->pinned;
+    return LGR_OK;
+}
+
+extern "C" int lgr_version(void) { return LGR_VERSION; }
+
+extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
+    if (!out) return LGR_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LGR_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return LGR_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return LGR_ERR_NO_DEVICE;
+    lgr_ctx* c = new lgr_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t) stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LGR_ERR_HIP; }
+        c->own_stream = true;
+    }
+    for (int i = 0; i < 16; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return LGR_ERR_HIP; }
+    for (int i = 0; i < 12; ++i) c->stage_ms[i] = 0.f;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return LGR_OK;
+}
+
+extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
+    if (!ctx) return LGR_OK;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < WS_COUNT; ++i)
+        if (ctx->ws[i].p) (void) hipFree(ctx->ws[i].p);
+    if (ctx->pinned) (void) hipHostFree(ctx->pinned);
+    for (int i = 0; i < 16; ++i) (void) hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return LGR_OK;
+}
+
+extern "C" int lgr_ctx_sync(lgr_ctx* ctx) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LGR_OK;
+}
+
+extern "C" const char* lgr_last_error(lgr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12) {
+    if (!ctx || !out12) return LGR_ERR_INVALID_ARG;
+    for (int i = 0; i < 12; ++i) out12[i] = ctx->stage_ms[i];
+    return LGR_OK;
+}
+
+// defaults of getParametersFromConfig (src/common.cpp:216-223, 335-413) and include/common.h:38-57
+extern "C" void lgr_default_params(lgr_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->feature_nr_points = 352;
+    p->normal_nr_points = 30;
+    p->edge_thr_coef = 0.95f;
+    p->distance_thr = 0.1f;
+    p->feature_radius = 0.25f;
+    p->scale_factor = 2.0f;
+    p->confidence = 0.999f;
+    p->bf_block_size = 10000;
+    p->cluster_k = 40;
+    p->randomness = 1;
+    p->n_samples = 3;
+    p->alignment_id = LGR_ALIGN_RANSAC;
+    p->matching_id = LGR_MATCH_CLUSTER;
+    p->metric_id = LGR_METRIC_UNIFORMITY;
+    p->score_id = LGR_SCORE_MSE;
+    p->max_iterations = 2147483647;
+    p->normals_available = 0;
+    p->fix_seed = 1;
+    p->ransac_batch = 16384;
+    p->seed = 566;
+}

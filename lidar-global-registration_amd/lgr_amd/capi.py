@@ -1,0 +1,159 @@
+"""ctypes binding of liblgr_hip.so (the C ABI declared in include/lgr.h).
+
+The HIP extension is mandatory: importing this module raises if the shared library is missing; nothing here (or
+anywhere in the product) falls back to a CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+LIB_PATH = os.path.join(_CSRC, "liblgr_hip.so")
+
+MATCH_LR, MATCH_ONE_SIDED, MATCH_CLUSTER = 0, 1, 2
+METRIC_CORRESPONDENCES, METRIC_UNIFORMITY = 0, 1
+SCORE_CONSTANT, SCORE_MAE, SCORE_MSE, SCORE_EXP = 0, 1, 2, 3
+ALIGN_RANSAC, ALIGN_GROR = 0, 1
+ORDER_REFERENCE, ORDER_CANONICAL = 0, 1
+
+CORR_DTYPE = np.dtype([("index_query", "<i4"), ("index_match", "<i4"), ("distance", "<f4"), ("threshold", "<f4")])
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("feature_nr_points", C.c_int32), ("normal_nr_points", C.c_int32), ("edge_thr_coef", C.c_float),
+        ("distance_thr", C.c_float), ("feature_radius", C.c_float), ("scale_factor", C.c_float),
+        ("confidence", C.c_float), ("bf_block_size", C.c_int32), ("cluster_k", C.c_int32),
+        ("randomness", C.c_int32), ("n_samples", C.c_int32),
+        ("alignment_id", C.c_int32), ("matching_id", C.c_int32), ("metric_id", C.c_int32), ("score_id", C.c_int32),
+        ("max_iterations", C.c_int32), ("normals_available", C.c_int32), ("fix_seed", C.c_int32),
+        ("has_vp_src", C.c_int32), ("has_vp_tgt", C.c_int32), ("vp_src", C.c_float * 3), ("vp_tgt", C.c_float * 3),
+        ("ransac_batch", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("transformation", C.c_float * 16), ("iterations", C.c_int32), ("converged", C.c_int32),
+        ("n_inliers", C.c_int32), ("metric", C.c_float), ("best_metric_before_refit", C.c_float),
+        ("best_iteration", C.c_int32), ("num_rejections", C.c_int32), ("estimated_iters", C.c_int32),
+        ("n_correspondences", C.c_int32), ("time_cs", C.c_double), ("time_te", C.c_double),
+        ("stage_ms", C.c_float * 12),
+    ]
+
+    def matrix(self):
+        return np.array(self.transformation, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class LgrError(RuntimeError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {_CSRC}` (or __graft_entry__.build()). "
+            "The MI355X HIP extension is mandatory; there is no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+_lib = load()
+_lib.lgr_last_error.restype = C.c_char_p
+_lib.lgr_last_error.argtypes = [C.c_void_p]
+
+
+def lib():
+    return _lib
+
+
+def default_params(**kw):
+    p = Params()
+    _lib.lgr_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k in ("vp_src", "vp_tgt"):
+            setattr(p, k, (C.c_float * 3)(*[float(x) for x in v]))
+            setattr(p, "has_" + k, 1)
+        else:
+            assert hasattr(p, k), k
+            setattr(p, k, v)
+    return p
+
+
+def _ptr(t):
+    """device (torch tensor) or host (numpy) pointer as void*."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One lgr_ctx bound to a torch device + (by default) torch's current stream on it."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        self.torch = torch
+        self.device = int(device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        rc = _lib.lgr_ctx_create(self.device, C.c_void_p(stream), C.byref(h))
+        if rc != 0:
+            raise LgrError(f"lgr_ctx_create failed: {rc}")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            _lib.lgr_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise LgrError(f"rc={rc}: {_lib.lgr_last_error(self.h).decode()}")
+
+    def sync(self):
+        self.check(_lib.lgr_ctx_sync(self.h))
+
+    def _dev(self):
+        return self.torch.device("cuda", self.device)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self._dev())
+
+    # ---- matching -------------------------------------------------------------------------------------------
+    def match_bf(self, q, t, block=10000):
+        """q, t: cuda float32 [m,33].  returns (idx int32 [mq], dist float32 [mq])."""
+        torch = self.torch
+        q = q.contiguous(); t = t.contiguous()
+        idx = self.empty((q.shape[0],), torch.int32)
+        dist = self.empty((q.shape[0],), torch.float32)
+        self.check(_lib.lgr_match_bf_dev(self.h, _ptr(q), q.shape[0], _ptr(t), t.shape[0], int(block), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def match_bf2(self, a, b, block=10000):
+        torch = self.torch
+        a = a.contiguous(); b = b.contiguous()
+        ab_i = self.empty((a.shape[0],), torch.int32); ab_d = self.empty((a.shape[0],), torch.float32)
+        ba_i = self.empty((b.shape[0],), torch.int32); ba_d = self.empty((b.shape[0],), torch.float32)
+        self.check(_lib.lgr_match_bf2_dev(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], int(block),
+                                          _ptr(ab_i), _ptr(ab_d), _ptr(ba_i), _ptr(ba_d)))
+        return ab_i, ab_d, ba_i, ba_d
+
+    def match_bf_host(self, q, t, block=10000):
+        q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+        idx = np.zeros(q.shape[0], np.int32); dist = np.zeros(q.shape[0], np.float32)
+        self.check(_lib.lgr_match_bf(self.h, _ptr(q), q.shape[0], _ptr(t), t.shape[0], int(block), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def match_stats(self):
+        out = (C.c_uint * 6)()
+        _lib.lgr_match_last_stats(out)
+        return dict(items_ab=out[0], dense_ab=out[1], items_ba=out[2], dense_ba=out[3], sub_cols=out[4], rg_rows=out[5])

@@ -1,0 +1,168 @@
+/*
+ * lgr_oracle.h -- C API of the CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * This library is a CPU restatement of the hot path of
+ * aleksandrina-streltsova/lidar-global-registration (reference file:line cited at
+ * every function in src/).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (liblgr_hip.so) never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" for every stage except KNNResult: the reference
+ * cannot be built here (needs PCL 1.12.1 / OpenCV 4.5.1 / Eigen / FLANN / yaml-cpp,
+ * none installed, no network) and ships no golden vectors for this path other than
+ * tests/knn_result.cpp:30-51.  Third-party arithmetic (PCL FPFH / normals / polygon
+ * rejector / umeyama, OpenCV batchDistance, libstdc++ RNG + unordered_map) is restated
+ * from the pinned upstream versions and property-tested (tests/test_oracle_*.py).
+ *
+ * Layouts (all host pointers):
+ *   point  : 12 floats = pcl::PointXYZINormal {x,y,z,1 | nx,ny,nz,0 | intensity,curvature,pad,pad}
+ *   fpfh   : 33 floats (pcl::FPFHSignature33)
+ *   corr   : lgr_orc_corr {int query; int match; float distance; float threshold}  (include/common.h:120-127)
+ *   T      : 16 floats, COLUMN-major 4x4 (Eigen::Matrix4f default)
+ */
+#ifndef LGR_ORACLE_H
+#define LGR_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int32_t query, match; float distance, threshold; } lgr_orc_corr;
+
+enum { ORC_ORDER_LIBSTDCXX = 0, ORC_ORDER_CANONICAL = 1 };
+enum { ORC_METRIC_CORRESPONDENCES = 0, ORC_METRIC_UNIFORMITY = 1 };
+enum { ORC_SCORE_CONSTANT = 0, ORC_SCORE_MAE = 1, ORC_SCORE_MSE = 2, ORC_SCORE_EXP = 3 };
+enum { ORC_MATCH_LR = 0, ORC_MATCH_ONE_SIDED = 1, ORC_MATCH_CLUSTER = 2 };
+enum { ORC_RNG_MT19937_LEMIRE = 0, ORC_RNG_MT19937_REJECT = 1, ORC_RNG_PHILOX = 2 };
+
+typedef struct {
+    /* mirrors AlignmentParameters (include/common.h:135-163), enum ids instead of strings */
+    int   feature_nr_points;   /* 352 */
+    int   normal_nr_points;    /* 30 */
+    float edge_thr_coef;       /* 0.95 */
+    float distance_thr;
+    float feature_radius;      /* must be > 0 (single scale) */
+    float scale_factor;        /* 2.0 */
+    float confidence;          /* 0.999 */
+    int   bf_block_size;       /* 10000 struct default, 200000 in shipped yaml */
+    int   cluster_k;           /* 40 */
+    int   n_samples;           /* 3 (only 3 supported) */
+    int   matching_id;         /* ORC_MATCH_* */
+    int   metric_id;           /* ORC_METRIC_* */
+    int   score_id;            /* ORC_SCORE_* */
+    int   max_iterations;
+    int   normals_available;   /* 0 */
+    int   has_vp_src, has_vp_tgt;
+    float vp_src[3], vp_tgt[3];
+    /* RANSAC schedule */
+    int   rng_mode;            /* ORC_RNG_* */
+    int   n_threads;           /* reference schedule (mt19937 modes): emulated OpenMP team size */
+    int   batch_size;          /* philox schedule: iterations per batch */
+    uint64_t seed;             /* 566 */
+} lgr_orc_params;
+
+typedef struct {
+    float T[16];               /* column-major */
+    int   iterations;          /* ransac_iterations */
+    int   converged;
+    int   n_inliers;           /* of the final (refit) transform */
+    float metric;              /* of the final transform */
+    float best_metric_before_refit;
+    int   best_iteration;      /* philox schedule: iteration index of the winning hypothesis */
+    int   num_rejections;
+    int   estimated_iters;
+} lgr_orc_result;
+
+void orc_default_params(lgr_orc_params* p);
+int  orc_num_threads(void);
+void orc_set_num_threads(int n);
+
+/* include/common.h:266-280 (FLT_MIN-initialised max quirk reproduced) */
+int orc_bbox(const float* pts, int n, float* mn3, float* mx3);
+
+/* src/downsample.cpp:5-41, include/downsample.h:6-30.  out must hold n points. */
+int orc_downsample(const float* pts, int n, float voxel, int order, float* out, int* n_out);
+
+/* src/common.cpp:644-655,593-628 + PCL NormalEstimationOMP (k-NN).  Writes nx,ny,nz,curvature of pts in place.
+ * surf==NULL -> surface = pts itself. vp==NULL -> (0,0,0). */
+int orc_normals_knn(float* pts, int n, const float* surf, int ns, int k, const float* vp, int normals_available);
+
+/* include/common.h:322-332 -> pcl::FPFHEstimationOMP.  libm_mode=1 uses libm atan2f instead of the canonical polynomial. */
+int orc_fpfh(const float* kps, int m, const float* surf, int n, float radius, float* out33, int libm_mode);
+/* SPFH rows (n x 33) for every surface point, for stage-wise tests. */
+int orc_spfh(const float* surf, int n, float radius, float* out33, int libm_mode);
+
+/* include/matching.h:594-634 + cv::BFMatcher(NORM_L2) knnMatch k=1 + src/common.cpp:517-529. idx=-1: no match */
+int orc_match_bf(const float* q33, int mq, const float* t33, int mt, int block, int* idx, float* dist);
+/* same, only for the queries listed in qsel (bounded CPU baseline sample) */
+int orc_match_bf_subset(const float* q33, const int* qsel, int nsel, const float* t33, int mt, int block, int* idx, float* dist);
+
+/* exact k-NN in 3-D, sorted by (d2, index); idx/d2 are n*k. Used by several stages and by tests. */
+int orc_knn(const float* qpts, int nq, const float* pts, int n, int k, int* idx, float* d2);
+
+/* src/common.cpp:531-547 */
+int orc_smoothed_densities(const float* pts, int n, int k, float* out);
+/* src/common.cpp:202-208 */
+int orc_cloud_density(const float* pts, int n, float quantile, float* out);
+
+/* include/matching.h:395-411 / 428-453 / 492-550 : build correspondences from the two directional 1-NN tables.
+ * out must hold ns entries. */
+int orc_filter(int matching_id, const float* src, int ns, const float* tgt, int nt,
+               const int* ij_idx, const float* ij_dist, const int* ji_idx, const float* ji_dist,
+               float distance_thr, int cluster_k, lgr_orc_corr* out, int* n_out);
+
+/* src/correspondence_search.cpp:4-15 with keypoint 'any': whole correspondence search */
+int orc_correspondences(const float* src, int ns, const float* tgt, int nt, const lgr_orc_params* p,
+                        lgr_orc_corr* out, int* n_out, double* stage_seconds /* 8 doubles or NULL */);
+
+/* ---- RANSAC pieces ---- */
+/* include/utils.h:13-26: first n outputs of UniformRandIntGenerator(0,INT_MAX,seed) */
+int orc_rng_stream(int rng_mode, uint64_t seed, int n, int* out);
+/* Philox4x32-10: counter=(iter,0,0,0) key=(seed_lo,seed_hi) -> 4 words */
+void orc_philox(uint64_t seed, uint32_t iter, uint32_t out[4]);
+/* src/sac_prerejective_omp.cpp:33-77 given the three raw draws r[3] (already non-negative) */
+void orc_select3(const int r[3], int n_corr, int sample[3]);
+/* pcl CorrespondenceRejectorPoly::thresholdPolygon (call site src/sac_prerejective_omp.cpp:214) */
+int orc_poly_ok(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float edge_thr);
+/* pcl TransformationEstimationSVD (umeyama, no scaling) on 3 pairs (call site :220) */
+void orc_umeyama3(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float T[16]);
+/* src/metric.cpp:125-179 : inlier mask (n_corr bytes), rmse, metric for transform T */
+int orc_evaluate(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
+                 const float T[16], int metric_id, int score_id,
+                 uint8_t* mask, int* n_inl, float* rmse, float* metric);
+/* src/metric.cpp:103-123 */
+int orc_estimate_max_iterations(const float* src, const float* tgt, const lgr_orc_corr* corr, int c,
+                                const float T[16], float confidence, int nr_samples);
+/* src/transformation.cpp:4-38 on the inliers flagged in mask */
+int orc_refit(const float* src, const float* tgt, const lgr_orc_corr* corr, int c, const uint8_t* mask, float T[16]);
+/* replay mode: evaluate a list of sample triples (3*n ints = correspondence indices, as produced by select3).
+ * per hypothesis: ok flag, T (16 floats, identity if rejected), n_inliers, metric */
+int orc_replay(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
+               const lgr_orc_params* p, const int* triples, int n,
+               uint8_t* ok, float* Ts, int* n_inl, float* metric);
+/* src/sac_prerejective_omp.cpp:115-314 */
+int orc_ransac(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
+               const lgr_orc_params* p, lgr_orc_result* res, uint8_t* final_mask /* c bytes or NULL */);
+/* src/alignment.cpp:72-109 (RANSAC branch, no CSV side effects) */
+int orc_align(const float* src, int ns, const float* tgt, int nt, const lgr_orc_params* p,
+              lgr_orc_result* res, lgr_orc_corr* corr_out, int* n_corr_out, double* stage_seconds);
+
+/* src/hypotheses.cpp:14-48.  tns: n*16 (col-major) in/out, capacity cap. returns new n */
+int orc_update_hypotheses(float* tns, float* metrics, int n, int cap, const float* new_T, float new_metric, float distance_thr);
+/* src/analysis.cpp:19-24 */
+void orc_rot_trans_diff(const float* T1, const float* T2, float* angle, float* tdist);
+
+/* include/matching.h:44-94 KNNResult<float> exercised by tests/knn_result.cpp */
+int orc_knnresult_run(int capacity, const float* dists, const int* indices, int n, int* out_idx, float* out_dist);
+
+/* canonical elementary functions (exposed for property tests vs libm) */
+float orc_atan2f(float y, float x);
+float orc_logf(float x);
+float orc_cbrtf(float x);
+float orc_expf(float x);
+void  orc_svd3(const float A[9] /*row-major*/, float U[9], float S[3], float V[9]);
+void  orc_eig3_smallest(const float C[9] /*row-major symmetric*/, float* eval, float evec[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

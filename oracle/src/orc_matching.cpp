@@ -1,0 +1,231 @@
+// orc_matching.cpp -- ORACLE (test infrastructure): brute-force descriptor matching, densities, match filters,
+// whole correspondence search.  Reference paths relative to /root/reference.
+#include <omp.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <unordered_set>
+#include <vector>
+
+#include "../lgr_oracle.h"
+#include "orc_grid.h"
+
+using namespace orc;
+
+namespace {
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// cv::hal::normL2Sqr_(const float*, const float*, int) [3P, OpenCV 4.5.1 modules/core/src/norm.cpp] as compiled for
+// the x86-64 baseline (SSE, 4 lanes, v_muladd = mul + add, four accumulators, blocks of 16 floats):
+//   acc[a][l] += t*t for j = 16*blk + 4*a + l;  d = reduce(acc0 + acc1 + acc2 + acc3) with SSE reduce
+//   (s0 + s2) + (s1 + s3); scalar tail d += t*t.  For n = 33: two blocks, tail j = 32.
+typedef float v4sf __attribute__((vector_size(16)));
+inline v4sf ld4(const float* p) { v4sf r; std::memcpy(&r, p, 16); return r; }
+inline float l2sqr33(const float* a, const float* b) {
+    // written with 4-lane vectors so that it is literally the SSE lane structure (and runs at SSE speed); every lane
+    // operation is an IEEE mul followed by an IEEE add (-ffp-contract=off).
+    v4sf acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    for (int blk = 0; blk < 2; ++blk) {
+        const float *pa = a + 16 * blk, *pb = b + 16 * blk;
+        v4sf t0 = ld4(pa) - ld4(pb), t1 = ld4(pa + 4) - ld4(pb + 4), t2 = ld4(pa + 8) - ld4(pb + 8), t3 = ld4(pa + 12) - ld4(pb + 12);
+        acc0 = t0 * t0 + acc0; acc1 = t1 * t1 + acc1; acc2 = t2 * t2 + acc2; acc3 = t3 * t3 + acc3;
+    }
+    v4sf s = ((acc0 + acc1) + acc2) + acc3;
+    float d = (s[0] + s[2]) + (s[1] + s[3]);
+    float t = a[32] - b[32];
+    d += t * t;
+    return d;
+}
+inline bool row_valid(const float* r) { for (int j = 0; j < 33; ++j) if (!std::isfinite(r[j])) return false; return true; }
+
+// one query against the whole train set with the reference's block structure:
+//   include/matching.h:594-634 matchBF: for each train block j: cv::batchDistance K=1 keeps the first minimum with a
+//   strict '<' on the int bit pattern of sqrt(d2) (NaN never enters) -> lowest index wins inside a block;
+//   src/common.cpp:517-529 updateMultivaluedCorrespondence inserts BEFORE an equal distance -> a later block wins ties.
+inline void match_one(const float* q, const float* t33, int mt, int block, int& best_idx, float& best_dist) {
+    best_idx = -1; best_dist = 0.f;
+    for (int j0 = 0; j0 < mt; j0 += block) {
+        int j1 = std::min(mt, j0 + block);
+        int bi = -1; float bd = std::numeric_limits<float>::max();   // batchDistance init: FLT_MAX / -1
+        for (int j = j0; j < j1; ++j) {
+            float d = std::sqrt(l2sqr33(q, t33 + 33 * (size_t) j));
+            if (d < bd) { bd = d; bi = j; }   // NaN compares false; for non-negative floats int-bit compare == float compare
+        }
+        if (bi < 0) continue;                 // matches[l] empty / queryIdx == -1
+        if (best_idx < 0 || !(best_dist < bd)) { best_idx = bi; best_dist = bd; }   // insert before >= entries, keep k=1
+    }
+}
+}  // namespace
+
+extern "C" int orc_match_bf(const float* q33, int mq, const float* t33, int mt, int block, int* idx, float* dist) {
+    if (block <= 0) return -1;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < mq; ++i) match_one(q33 + 33 * (size_t) i, t33, mt, block, idx[i], dist[i]);
+    return 0;
+}
+
+extern "C" int orc_match_bf_subset(const float* q33, const int* qsel, int nsel, const float* t33, int mt, int block, int* idx, float* dist) {
+    if (block <= 0) return -1;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int s = 0; s < nsel; ++s) match_one(q33 + 33 * (size_t) qsel[s], t33, mt, block, idx[s], dist[s]);
+    return 0;
+}
+
+// src/common.cpp:531-547 calculateSmoothedDensities: k-NN of point i (itself included, sorted by (d2, index));
+// density = sqrt(d2[k-1]); then the same for nn_indices[1] and take the min.
+extern "C" int orc_smoothed_densities(const float* pts, int n, int k, float* out) {
+    if (n <= 1 || k < 2) return -1;  // rassert(pcd->size() > 1 && k >= 2)
+    Grid g;
+    g.build(pts, n, auto_cell(pts, n, 4.f));
+    std::vector<float> dk(n);
+    std::vector<int> nn1(n);
+#pragma omp parallel
+    {
+        std::vector<Grid::Cand> c(k);
+#pragma omp for schedule(dynamic, 256)
+        for (int i = 0; i < n; ++i) {
+            int f = g.knn(pts + 12 * (size_t) i, k, c.data());
+            dk[i] = f >= k ? std::sqrt(c[k - 1].d2) : std::numeric_limits<float>::quiet_NaN();
+            nn1[i] = f >= 2 ? c[1].idx : i;
+        }
+    }
+    for (int i = 0; i < n; ++i) out[i] = std::min(dk[i], dk[nn1[i]]);
+    return 0;
+}
+
+// src/common.cpp:202-208 calculatePointCloudDensity
+extern "C" int orc_cloud_density(const float* pts, int n, float quantile, float* out) {
+    std::vector<float> d(n);
+    if (orc_smoothed_densities(pts, n, 8, d.data())) return -1;
+    int k = std::max(std::min((int) (quantile * (float) d.size() - 1), (int) d.size() - 1), 0);
+    std::nth_element(d.begin(), d.begin() + k, d.end());
+    *out = d[k];
+    return 0;
+}
+
+// include/matching.h:395-411 (OneSided), :428-453 (LeftToRight), :492-550 (Cluster) with randomness = 1 and a single
+// scale (match_multiscale :264-354 is then the identity on the 1-NN tables).
+extern "C" int orc_filter(int matching_id, const float* src, int ns, const float* tgt, int nt,
+                          const int* ij_idx, const float* ij_dist, const int* ji_idx, const float* ji_dist,
+                          float distance_thr, int cluster_k, lgr_orc_corr* out, int* n_out) {
+    std::vector<float> thr_s(ns), thr_t(nt);
+    if (orc_smoothed_densities(src, ns, 2, thr_s.data())) return -1;
+    if (orc_smoothed_densities(tgt, nt, 2, thr_t.data())) return -1;
+    int cnt = 0;
+    if (matching_id == ORC_MATCH_ONE_SIDED) {
+        for (int i = 0; i < ns; ++i) {
+            int j = ij_idx[i];
+            if (j < 0) continue;
+            float thr = std::min(std::max(thr_s[i], thr_t[j]), distance_thr);
+            out[cnt++] = lgr_orc_corr{i, j, ij_dist[i], thr};
+        }
+    } else if (matching_id == ORC_MATCH_LR) {
+        for (int i = 0; i < ns; ++i) {
+            int j = ij_idx[i];
+            if (j < 0) continue;
+            if (ji_idx[j] == i) {
+                float thr = std::min(std::max(thr_s[i], thr_t[j]), distance_thr);
+                out[cnt++] = lgr_orc_corr{i, j, ji_dist[j], thr};   // distance of the reverse direction (:444)
+            }
+        }
+    } else if (matching_id == ORC_MATCH_CLUSTER) {
+        int k = cluster_k;
+        std::vector<int> knn_s((size_t) ns * k), knn_t((size_t) nt * k);
+        {
+            std::vector<float> d2s((size_t) ns * k), d2t((size_t) nt * k);
+            orc_knn(src, ns, src, ns, k, knn_s.data(), d2s.data());
+            orc_knn(tgt, nt, tgt, nt, k, knn_t.data(), d2t.data());
+        }
+        // calculateCorrespondenceDistance(i, j, k, mv_ij, tree_src, tree_tgt)  (:524-550)
+        auto cdist = [&](int i, int j, const int* knn_a, const int* knn_b, const int* ab_idx) {
+            const int* nb = knn_b + (size_t) j * k;
+            int consistent = 0, pairs = 0;
+            for (int a = 0; a < k; ++a) {
+                int in = knn_a[(size_t) i * k + a];
+                if (in < 0) continue;
+                int mt = ab_idx[in];
+                if (mt < 0) continue;          // empty match list
+                bool hit = false;
+                for (int b = 0; b < k; ++b) if (nb[b] == mt) { hit = true; break; }
+                if (hit) consistent++;
+                pairs++;
+            }
+            if (pairs == 0) return 0.f;
+            return 1.f - (float) consistent / (float) pairs;
+        };
+        std::vector<float> di(ns), dj(ns);
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int i = 0; i < ns; ++i) {
+            int j = ij_idx[i];
+            if (j < 0) continue;
+            di[i] = cdist(i, j, knn_s.data(), knn_t.data(), ij_idx);
+            dj[i] = cdist(j, i, knn_t.data(), knn_s.data(), ji_idx);
+        }
+        for (int i = 0; i < ns; ++i) {
+            int j = ij_idx[i];
+            if (j < 0) continue;
+            if (di[i] < 0.95f && dj[i] < 0.95f) {   // MATCHING_CLUSTER_THRESHOLD include/common.h:52
+                float thr = std::min(std::max(thr_s[i], thr_t[j]), distance_thr);
+                out[cnt++] = lgr_orc_corr{i, j, std::max(di[i], dj[i]), thr};
+            }
+        }
+    } else {
+        return -2;
+    }
+    *n_out = cnt;
+    return 0;
+}
+
+// src/correspondence_search.cpp:4-15 + include/matching.h:148-262 with keypoint 'any' (kps = whole cloud,
+// src/common.cpp:680-689) and feature_radius set (single scale):
+//   log2_radius = floor(log2(r)/log2(scale)); search_radius = powf(scale, log2_radius)        (:172, :230)
+//   voxel = sqrtf(M_PI * r*r / feature_nr_points)                                              (:231)
+//   downsample (:234) -> normals k (:235) -> [kps normals re-estimate :243-246: no observable effect for FPFH,
+//   skipped] -> FPFH (:248) -> 1-NN both ways (:306) -> filter.  The surface is kept in ORC_ORDER_CANONICAL.
+// stage_seconds: [0] downsample [1] normals [2] fpfh [3] match [4] filter
+extern "C" int orc_correspondences(const float* src, int ns, const float* tgt, int nt, const lgr_orc_params* p,
+                                   lgr_orc_corr* out, int* n_out, double* st) {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!(p->feature_radius > 0.f)) return -3;
+    int log2_radius = (int) std::floor(std::log2(p->feature_radius) / std::log2(p->scale_factor));
+    float search_radius = powf(p->scale_factor, (float) log2_radius);
+    float voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
+    std::vector<float> feat[2];
+    const float* clouds[2] = {src, tgt};
+    int sizes[2] = {ns, nt};
+    for (int c = 0; c < 2; ++c) {
+        double t0 = now_s();
+        std::vector<float> ds((size_t) sizes[c] * 12);
+        int nd = 0;
+        if (orc_downsample(clouds[c], sizes[c], voxel, ORC_ORDER_CANONICAL, ds.data(), &nd)) return -4;
+        double t1 = now_s();
+        const float* vp = c == 0 ? (p->has_vp_src ? p->vp_src : nullptr) : (p->has_vp_tgt ? p->vp_tgt : nullptr);
+        orc_normals_knn(ds.data(), nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available);
+        double t2 = now_s();
+        feat[c].resize((size_t) sizes[c] * 33);
+        orc_fpfh(clouds[c], sizes[c], ds.data(), nd, search_radius, feat[c].data(), 0);
+        double t3 = now_s();
+        t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2;
+    }
+    double t0 = now_s();
+    std::vector<int> ij(ns), ji(nt);
+    std::vector<float> dij(ns), dji(nt);
+    orc_match_bf(feat[0].data(), ns, feat[1].data(), nt, p->bf_block_size, ij.data(), dij.data());
+    bool need_ji = p->matching_id != ORC_MATCH_ONE_SIDED;
+    if (need_ji) orc_match_bf(feat[1].data(), nt, feat[0].data(), ns, p->bf_block_size, ji.data(), dji.data());
+    // NaN query rows have no match (include/matching.h:576,614)
+    for (int i = 0; i < ns; ++i) if (!row_valid(feat[0].data() + 33 * (size_t) i)) ij[i] = -1;
+    if (need_ji) for (int i = 0; i < nt; ++i) if (!row_valid(feat[1].data() + 33 * (size_t) i)) ji[i] = -1;
+    double t1 = now_s();
+    int rc = orc_filter(p->matching_id, src, ns, tgt, nt, ij.data(), dij.data(), ji.data(), dji.data(),
+                        p->distance_thr, p->cluster_k, out, n_out);
+    double t2 = now_s();
+    t[3] = t1 - t0; t[4] = t2 - t1;
+    if (st) for (int i = 0; i < 8; ++i) st[i] = t[i];
+    return rc;
+}
