@@ -230,7 +230,7 @@ __device__ __forceinline__ float exact_l2(const float* __restrict__ a, const flo
     float d = (s[0] + s[2]) + (s[1] + s[3]);
     float t = a[32] - b[32];
     d = d + t * t;
-    return __fsqrt_rn(d);
+    return __builtin_sqrtf(d);   // IEEE-correct sequence (NOT __fsqrt_rn, which is the 1-ulp v_sqrt_f32 on gfx950)
 }
 
 // tie rank of train index j: highest bf block first, lowest index inside a block first (smaller rank wins)

@@ -6,7 +6,7 @@ all computation happens in liblgr_hip.so (hand-written HIP for gfx950).
 from . import synthetic  # noqa: F401  (numpy only)
 
 
-def capi():
+def load_capi():
     """Import the C-ABI binding lazily (raises ImportError when liblgr_hip.so has not been built)."""
-    from . import capi as _c
-    return _c
+    import importlib
+    return importlib.import_module(".capi", __name__)

@@ -1,0 +1,104 @@
+"""GPU parity: brute-force FPFH matcher (lgr_match_bf*_dev through the C ABI) vs the oracle.
+
+Bar: match indices AND distances bit-exact (integer / canonical-order float work), including exact ties inside a bf
+block (lowest index wins), exact ties across blocks (later block wins, src/common.cpp:517-529), NaN rows
+(include/matching.h:576,614), empty and ragged sizes.  Mirrors the idea of the reference's
+tests/flann_bf_matcher.h:70-88 (brute force == exact argmin, both directions).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def fpfh_like(rng, m, spread=1.0):
+    """rows shaped like FPFH: three 11-bin blocks, each summing to 100."""
+    x = rng.gamma(0.6 * spread, 1.0, (m, 3, 11)).astype(np.float64) + 1e-3
+    x = 100.0 * x / x.sum(2, keepdims=True)
+    return x.reshape(m, 33).astype(np.float32)
+
+
+def run_both(lgr, oracle, a, b, block):
+    import torch
+    ta = torch.from_numpy(a).cuda(); tb = torch.from_numpy(b).cuda()
+    ab_i, ab_d, ba_i, ba_d = lgr.match_bf2(ta, tb, block)
+    lgr.sync()
+    oi, od = oracle.match_bf(a, b, block)
+    ri, rd = oracle.match_bf(b, a, block)
+    np.testing.assert_array_equal(ab_i.cpu().numpy(), oi)
+    np.testing.assert_array_equal(ba_i.cpu().numpy(), ri)
+    ok = oi >= 0
+    np.testing.assert_array_equal(ab_d.cpu().numpy()[ok].view(np.uint32), od[ok].view(np.uint32))
+    ok = ri >= 0
+    np.testing.assert_array_equal(ba_d.cpu().numpy()[ok].view(np.uint32), rd[ok].view(np.uint32))
+    # single-direction entry point agrees too
+    i1, d1 = lgr.match_bf(ta, tb, block)
+    lgr.sync()
+    np.testing.assert_array_equal(i1.cpu().numpy(), oi)
+    return oi, ri
+
+
+@pytest.mark.parametrize("ma,mb,block", [(1, 1, 10), (5, 300, 100), (257, 255, 64), (1000, 1500, 10000),
+                                          (3000, 5000, 1024), (4097, 4100, 200000)])
+def test_match_random(lgr, oracle, ma, mb, block):
+    rng = np.random.default_rng(ma * 7919 + mb)
+    run_both(lgr, oracle, fpfh_like(rng, ma), fpfh_like(rng, mb), block)
+
+
+def test_match_ties_and_nan(lgr, oracle):
+    rng = np.random.default_rng(5)
+    a = fpfh_like(rng, 700)
+    b = fpfh_like(rng, 900)
+    # exact duplicates of train rows inside one block and across blocks (block = 128)
+    b[10] = b[200]; b[300] = b[200]; b[301] = b[200]; b[850] = b[200]
+    a[3] = b[200]                     # distance exactly 0 to five train rows
+    a[4] = b[200]; a[4, 0] += 0.5     # equal non-zero distance to the same five rows
+    b[5] = a[77]; b[6] = a[77]        # in-block tie -> lowest index
+    a[50, 7] = np.nan                 # NaN query row -> -1
+    b[20, :] = np.nan                 # NaN train row never matches
+    b[21, 3] = np.inf
+    a[60] = a[61]                     # duplicate queries
+    oi, ri = run_both(lgr, oracle, a, b, 128)
+    assert oi[50] == -1 and ri[20] == -1 and ri[21] == -1
+    assert oi[3] == 850 and oi[4] == 850          # later block wins the exact tie
+    assert oi[77] == 5                            # lowest index inside a block
+    oi2, _ = run_both(lgr, oracle, a, b, 100000)  # one block: lowest index wins
+    assert oi2[3] == 10
+
+
+def test_match_degenerate_all_identical(lgr, oracle):
+    """every row identical: all groups are candidates -> exercises the dense fallback path."""
+    rng = np.random.default_rng(9)
+    row = fpfh_like(rng, 1)
+    a = np.repeat(row, 300, 0)
+    b = np.repeat(row, 2500, 0)
+    b[1234, 5] += 1.0
+    oi, ri = run_both(lgr, oracle, a, b, 1000)
+    assert (oi == 2000).all()      # last block (2000..2499), lowest index inside it
+
+
+def test_match_host_entry_and_empty(lgr, oracle):
+    rng = np.random.default_rng(11)
+    a = fpfh_like(rng, 100); b = fpfh_like(rng, 50)
+    i, d = lgr.match_bf_host(a, b, 16)
+    oi, od = oracle.match_bf(a, b, 16)
+    np.testing.assert_array_equal(i, oi)
+    np.testing.assert_array_equal(d.view(np.uint32), od.view(np.uint32))
+    i, d = lgr.match_bf_host(a, np.zeros((0, 33), np.float32), 16)
+    assert (i == -1).all()
+
+
+def test_match_large_property(lgr):
+    """BASELINE-size-independent property at a larger size: matching a set against a permuted noisy copy of
+    itself recovers the permutation (noise far below the nearest-neighbour spacing), in both directions."""
+    import torch
+    rng = np.random.default_rng(3)
+    m = 60000
+    a = fpfh_like(rng, m)
+    perm = rng.permutation(m)
+    b = (a[perm] + rng.normal(0, 1e-3, (m, 33))).astype(np.float32)
+    ab_i, ab_d, ba_i, ba_d = lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 10000)
+    lgr.sync()
+    inv = np.empty(m, np.int64); inv[perm] = np.arange(m)
+    assert (ab_i.cpu().numpy() == inv).mean() > 0.999
+    assert (ba_i.cpu().numpy() == perm).mean() > 0.999
