@@ -91,7 +91,9 @@ typedef struct lgr_ctx lgr_ctx;
 
 /* ---- context ---- */
 int  lgr_version(void);
-/* device: HIP ordinal.  stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL -> ctx creates one */
+/* device: HIP ordinal.  stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's null
+ * stream, which is what torch uses by default) or LGR_STREAM_OWN -> the ctx creates and owns a non-blocking stream */
+#define LGR_STREAM_OWN ((void*) (intptr_t) -1)
 int  lgr_ctx_create(int device, void* stream, lgr_ctx** out);
 int  lgr_ctx_destroy(lgr_ctx* ctx);
 int  lgr_ctx_sync(lgr_ctx* ctx);

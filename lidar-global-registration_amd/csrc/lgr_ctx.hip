@@ -56,7 +56,7 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return LGR_ERR_NO_DEVICE;
     lgr_ctx* c = new lgr_ctx();
     c->device = device;
-    if (stream) { c->stream = (hipStream_t) stream; c->own_stream = false; }
+    if (stream != LGR_STREAM_OWN) { c->stream = (hipStream_t) stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LGR_ERR_HIP; }
         c->own_stream = true;

@@ -1,0 +1,475 @@
+// lgr_features.hip -- voxel downsample, k-NN PCA normals, SPFH / FPFH (gfx950).
+//
+//   src/downsample.cpp:5-41 + include/downsample.h:6-30      -> lgr_downsample*
+//   src/common.cpp:644-655, 593-628 (pcl::NormalEstimationOMP) -> lgr_normals_knn*
+//   include/common.h:322-332 (pcl::FPFHEstimationOMP)          -> lgr_fpfh*
+// Every parity-critical float sequence below restates the oracle op for op (oracle/src/orc_features.cpp,
+// orc_math.h); the translation unit is compiled with -ffp-contract=off.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <unordered_map>
+#include <vector>
+
+#include "lgr_grid.cuh"
+#include "lgr_math.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ downsample
+__global__ void voxel_keys(const float* __restrict__ pts, int n, float bx, float by, float bz, float voxel,
+                           unsigned long long* __restrict__ keys, int* __restrict__ vals, int* __restrict__ bad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = pts[(size_t) i * 12], y = pts[(size_t) i * 12 + 1], z = pts[(size_t) i * 12 + 2];
+    unsigned long long k = ~0ull;   // invalid points sort last and are dropped (isValid, src/downsample.cpp:25)
+    if (lgr_finite3(x, y, z)) {
+        // voxel_index = int(floor((p - voxel_min_bound) / voxel_size))   src/downsample.cpp:26-28
+        int ix = (int) floorf((x - bx) / voxel), iy = (int) floorf((y - by) / voxel), iz = (int) floorf((z - bz) / voxel);
+        if (ix < 0 || iy < 0 || iz < 0 || ix >= (1 << 21) || iy >= (1 << 21) || iz >= (1 << 21)) { atomicExch(bad, 1); ix = iy = iz = 0; }
+        k = ((unsigned long long) iz << 42) | ((unsigned long long) iy << 21) | (unsigned long long) ix;
+    }
+    keys[i] = k; vals[i] = i;
+}
+
+__global__ void head_flags(const unsigned long long* __restrict__ keys, int n, int* __restrict__ flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long k = keys[i];
+    flags[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+// one thread per voxel: sequential intensity-weighted sums in input order (AccumulatedPoint::AddPoint /
+// GetAveragePoint, include/downsample.h:8-27), written at the voxel's rank in (iz,iy,ix) order.
+__global__ void voxel_accumulate(const float* __restrict__ pts, const unsigned long long* __restrict__ keys,
+                                 const int* __restrict__ vals, const int* __restrict__ flags,
+                                 const int* __restrict__ rank /* exclusive scan of flags */, int n,
+                                 float* __restrict__ out, unsigned long long* __restrict__ out_keys, int* __restrict__ out_first) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    unsigned long long k = keys[i];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f, snx = 0.f, sny = 0.f, snz = 0.f;
+    for (int j = i; j < n && keys[j] == k; ++j) {
+        const float4* p = reinterpret_cast<const float4*>(pts + (size_t) vals[j] * 12);
+        float4 a = p[0], b = p[1], c = p[2];
+        float w = c.x;
+        sx += w * a.x; sy += w * a.y; sz += w * a.z;
+        sw += w;
+        snx += w * b.x; sny += w * b.y; snz += w * b.z;
+    }
+    float ax = snx / sw, ay = sny / sw, az = snz / sw;
+    float norm = __builtin_sqrtf(ax * ax + ay * ay + az * az);
+    norm = ((double) norm < 1e-5) ? 1.f : norm;
+    int r = rank[i];
+    float4* o = reinterpret_cast<float4*>(out + (size_t) r * 12);
+    o[0] = make_float4(sx / sw, sy / sw, sz / sw, 1.f);
+    o[1] = make_float4(ax / norm, ay / norm, az / norm, 0.f);
+    o[2] = make_float4(sw, 0.f, 0.f, 0.f);
+    if (out_keys) { out_keys[r] = k; out_first[r] = vals[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------ normals
+constexpr int NB = 128;
+
+// pcl::NormalEstimationOMP (k-NN) + flipNormalTowardsViewpoint + postprocessNormals; see oracle orc_normals_knn.
+__global__ __launch_bounds__(NB) void normals_kernel(GridDev g, const float* __restrict__ surf, float* __restrict__ pts, int n,
+                                                      int k, float vpx, float vpy, float vpz) {
+    extern __shared__ float smem[];
+    float* sd = smem;
+    int* si = (int*) (smem + (size_t) k * NB);
+    int i = blockIdx.x * NB + threadIdx.x;
+    if (i >= n) return;
+    float* p = pts + (size_t) i * 12;
+    float px = p[0], py = p[1], pz = p[2];
+    KnnList<NB> L;
+    L.init(sd, si, k, threadIdx.x);
+    if (lgr_finite3(px, py, pz) && g.n > 0) lgr_knn_query(g, px, py, pz, L);
+    const float nanv = __uint_as_float(0x7fc00000u);
+    if (L.count < 3) { p[4] = nanv; p[5] = nanv; p[6] = nanv; p[9] = nanv; return; }
+    const float* K = surf + (size_t) L.index(0) * 12;
+    float Kx = K[0], Ky = K[1], Kz = K[2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f;
+    for (int j = 0; j < L.count; ++j) {
+        const float* q = surf + (size_t) L.index(j) * 12;
+        float x = q[0] - Kx, y = q[1] - Ky, z = q[2] - Kz;
+        a0 += x * x; a1 += x * y; a2 += x * z; a3 += y * y; a4 += y * z; a5 += z * z;
+        a6 += x; a7 += y; a8 += z;
+    }
+    float fn = (float) L.count;
+    a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
+    float C[9];
+    C[0] = a0 - a6 * a6; C[1] = a1 - a6 * a7; C[2] = a2 - a6 * a8;
+    C[4] = a3 - a7 * a7; C[5] = a4 - a7 * a8; C[8] = a5 - a8 * a8;
+    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+    float U[9], Sg[3], V[9];
+    lgr_svd3(C, U, Sg, V);
+    float nx = V[2], ny = V[5], nz = V[8];
+    float eig_sum = C[0] + C[4] + C[8];
+    float curv = (eig_sum != 0.f) ? fabsf(Sg[2] / eig_sum) : 0.f;
+    float dx = vpx - px, dy = vpy - py, dz = vpz - pz;
+    float cos_theta = (dx * nx + dy * ny + dz * nz);
+    if (cos_theta < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+    if (lgr_finite3(nx, ny, nz)) {
+        float norm = __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+        nx /= norm; ny /= norm; nz /= norm;
+    }
+    p[4] = nx; p[5] = ny; p[6] = nz; p[9] = curv;
+}
+
+// ------------------------------------------------------------------------------------------------ FPFH
+__device__ __forceinline__ float dot3e(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + az * bz) + ay * by;   // Eigen 4-float SSE reduction (a0+a2)+(a1+a3), a3 = 0
+}
+
+// pcl::computePairFeatures.  Returns false when the pair is skipped.
+__device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, float n1x, float n1y, float n1z,
+                                              float p2x, float p2y, float p2z, float n2x, float n2y, float n2z,
+                                              float& f1, float& f2, float& f3) {
+    float dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    float f4 = __builtin_sqrtf(dot3e(dx, dy, dz, dx, dy, dz));
+    if (f4 == 0.0f) return false;
+    float angle1 = dot3e(n1x, n1y, n1z, dx, dy, dz) / f4;
+    float angle2 = dot3e(n2x, n2y, n2z, dx, dy, dz) / f4;
+    float ux = n1x, uy = n1y, uz = n1z, mx = n2x, my = n2y, mz = n2z;
+    float a1 = fabsf(angle1), a2 = fabsf(angle2);
+    if (a1 <= 1.0f && a2 <= 1.0f && a1 < a2) {
+        ux = n2x; uy = n2y; uz = n2z; mx = n1x; my = n1y; mz = n1z;
+        dx = -dx; dy = -dy; dz = -dz;
+        f3 = -angle2;
+    } else {
+        f3 = angle1;
+    }
+    float vx = dy * uz - dz * uy, vy = dz * ux - dx * uz, vz = dx * uy - dy * ux;
+    float v_norm = __builtin_sqrtf(dot3e(vx, vy, vz, vx, vy, vz));
+    if (v_norm == 0.0f) return false;
+    float inv = 1.0f / v_norm;
+    vx *= inv; vy *= inv; vz *= inv;
+    float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
+    f2 = dot3e(vx, vy, vz, mx, my, mz);
+    float yy = dot3e(wx, wy, wz, mx, my, mz), xx = dot3e(ux, uy, uz, mx, my, mz);
+    f1 = lgr_atan2f(yy, xx);
+    return true;
+}
+
+__device__ __forceinline__ int bin11(double t) {
+    double v = floor(11 * t);
+    if (!(v == v)) return 0;
+    if (v < 0) return 0;
+    if (v >= 11) return 10;
+    return (int) v;
+}
+
+constexpr int SB = 128;
+// SPFH rows for the surface points listed in the sorted order of the grid (thread t handles sorted position t).
+// Counters live in LDS as [bin][thread] (bank = thread % 32: conflict-free).
+__global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uint8_t* __restrict__ need /* by original index or NULL */,
+                                                   float* __restrict__ spfh /* [n_surface][33] by original index */) {
+    __shared__ int cnt[33 * SB];
+    int t = blockIdx.x * SB + threadIdx.x;
+    if (t >= g.n) return;
+    float4 P = g.pxyz[t];
+    float4 N = g.pnrm[t];
+    int p = __float_as_int(P.w);
+    if (need && !need[p]) return;
+    for (int b = 0; b < 33; ++b) cnt[b * SB + threadIdx.x] = 0;
+    int k = 0;
+    const float d_pi = 1.0f / (2.0f * 3.14159274101257324f);   // 1.0f / (2.0f * static_cast<float>(M_PI))
+    const double MPI = 3.14159265358979323846;
+    lgr_visit27(g, P.x, P.y, P.z, [&](int s, float4 Q) {
+        float d2 = lgr_dist2(P.x, P.y, P.z, Q.x, Q.y, Q.z);
+        if (!(d2 < r2)) return;
+        ++k;
+        if (s == t) return;
+        float4 M = g.pnrm[s];
+        float f1, f2, f3;
+        if (!pair_features(P.x, P.y, P.z, N.x, N.y, N.z, Q.x, Q.y, Q.z, M.x, M.y, M.z, f1, f2, f3)) return;
+        int b1 = bin11(((double) f1 + MPI) * (double) d_pi);
+        int b2 = 11 + bin11(((double) f2 + 1.0) * 0.5);
+        int b3 = 22 + bin11(((double) f3 + 1.0) * 0.5);
+        cnt[b1 * SB + threadIdx.x]++; cnt[b2 * SB + threadIdx.x]++; cnt[b3 * SB + threadIdx.x]++;
+    });
+    float* row = spfh + (size_t) p * 33;
+    float incr = 100.0f / (float) (k - 1);
+    for (int b = 0; b < 33; ++b) {
+        int c = cnt[b * SB + threadIdx.x];
+        float s = 0.f;
+        for (int i = 0; i < c; ++i) s += incr;
+        row[b] = s;
+    }
+}
+
+// marks the surface points within r of any keypoint (PCL's spfh_indices set)
+__global__ void need_kernel(GridDev g, const float* __restrict__ kps, int m, float r2, uint8_t* __restrict__ need) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float x = kps[(size_t) i * 12], y = kps[(size_t) i * 12 + 1], z = kps[(size_t) i * 12 + 2];
+    if (!lgr_finite3(x, y, z)) return;
+    lgr_visit27(g, x, y, z, [&](int s, float4 Q) {
+        if (lgr_dist2(x, y, z, Q.x, Q.y, Q.z) < r2) need[__float_as_int(Q.w)] = 1;
+    });
+}
+
+// FPFH row of keypoint order[t] (keypoints processed in grid-cell order for locality; output by original index)
+__global__ __launch_bounds__(128) void fpfh_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m,
+                                                    float r2, const float* __restrict__ spfh, float* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    int i = order ? order[t] : t;
+    float x = kps[(size_t) i * 12], y = kps[(size_t) i * 12 + 1], z = kps[(size_t) i * 12 + 2];
+    float fp[33];
+#pragma unroll
+    for (int b = 0; b < 33; ++b) fp[b] = 0.f;
+    double sum0 = 0, sum1 = 0, sum2 = 0;
+    int found = 0;
+    if (lgr_finite3(x, y, z)) {
+        lgr_visit27(g, x, y, z, [&](int s, float4 Q) {
+            float d2 = lgr_dist2(x, y, z, Q.x, Q.y, Q.z);
+            if (!(d2 < r2)) return;
+            ++found;
+            if (d2 == 0.f) return;
+            float weight = 1.0f / d2;
+            const float* h = spfh + (size_t) __float_as_int(Q.w) * 33;
+#pragma unroll
+            for (int b = 0; b < 33; ++b) {
+                float val = h[b] * weight;
+                if (b < 11) sum0 += (double) val; else if (b < 22) sum1 += (double) val; else sum2 += (double) val;
+                fp[b] += val;
+            }
+        });
+    }
+    float* o = out + (size_t) i * 33;
+    if (found == 0) {
+        const float nanv = __uint_as_float(0x7fc00000u);
+#pragma unroll
+        for (int b = 0; b < 33; ++b) o[b] = nanv;
+        return;
+    }
+    if (sum0 != 0) sum0 = 100.0 / sum0;
+    if (sum1 != 0) sum1 = 100.0 / sum1;
+    if (sum2 != 0) sum2 = 100.0 / sum2;
+#pragma unroll
+    for (int b = 0; b < 33; ++b) o[b] = (float) ((double) fp[b] * (b < 11 ? sum0 : (b < 22 ? sum1 : sum2)));
+}
+
+__global__ void kp_cell_keys(GridDev g, const float* __restrict__ kps, int m, unsigned* __restrict__ keys, int* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    float x = kps[(size_t) i * 12], y = kps[(size_t) i * 12 + 1], z = kps[(size_t) i * 12 + 2];
+    unsigned k = 0xffffffffu;
+    if (lgr_finite3(x, y, z)) {
+        int cx = min(max(lgr_cellc(x, g.ox, g.h), 0), g.dx - 1), cy = min(max(lgr_cellc(y, g.oy, g.h), 0), g.dy - 1), cz = min(max(lgr_cellc(z, g.oz, g.h), 0), g.dz - 1);
+        k = (unsigned) ((cz * g.dy + cy) * g.dx + cx);
+    }
+    keys[i] = k; vals[i] = i;
+}
+
+struct Key3 { int x, y, z; bool operator==(const Key3& o) const { return x == o.x && y == o.y && z == o.z; } };
+// include/common.h:212-223 HashEigen<Eigen::Vector3i> (std::hash<int> is the identity)
+struct HashKey3 {
+    std::size_t operator()(const Key3& k) const {
+        std::size_t seed = 0;
+        const int e[3] = {k.x, k.y, k.z};
+        for (int i = 0; i < 3; ++i) seed ^= std::hash<int>()(e[i]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+        return seed;
+    }
+};
+
+}  // namespace
+
+// device pipeline; n_out on host.  keys_first (optional, host vectors) receive per-voxel key and first input index.
+static int downsample_core(lgr_ctx* ctx, const float* d_pts, int n, float voxel, float* d_out, int* n_out,
+                           std::vector<unsigned long long>* h_keys, std::vector<int>* h_first) {
+    LGR_CHECK(ctx, voxel > 0.f, LGR_ERR_INVALID_ARG);   // reference only prints an error; a non-positive voxel is meaningless
+    *n_out = 0;
+    if (n == 0) return LGR_OK;
+    float bb[12];
+    LGR_TRY(lgr_bbox_host(ctx, d_pts, n, bb));
+    // voxel_min_bound = min_point_AABB - voxel_size * 0.5  (quirk bbox, src/downsample.cpp:13-14)
+    float bx = bb[6] - voxel * 0.5f, by = bb[7] - voxel * 0.5f, bz = bb[8] - voxel * 0.5f;
+    unsigned long long *keys, *keys2;
+    int *vals, *vals2, *flags, *rank, *bad;
+    LGR_TRY(lgr_ws_t(ctx, WS_DS_KEYS, (size_t) n, &keys));
+    LGR_TRY(lgr_ws_t(ctx, WS_DS_KEYS2, (size_t) n, &keys2));
+    LGR_TRY(lgr_ws_t(ctx, WS_DS_VALS, (size_t) n, &vals));
+    LGR_TRY(lgr_ws_t(ctx, WS_DS_VALS2, (size_t) n, &vals2));
+    LGR_TRY(lgr_ws_t(ctx, WS_DS_FLAGS, (size_t) 2 * n + 16, &flags));
+    rank = flags + n;
+    bad = rank + n;
+    LGR_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
+    voxel_keys<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_pts, n, bx, by, bz, voxel, keys, vals, bad);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) n, 0, 64, ctx->stream));
+    size_t tb2 = 0;
+    LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, flags, rank, 0, (size_t) n, rocprim::plus<int>(), ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, std::max(tb, tb2), &tmp));
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) n, 0, 64, ctx->stream));
+    head_flags<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys2, n, flags);
+    LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb2, flags, rank, 0, (size_t) n, rocprim::plus<int>(), ctx->stream));
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, rank + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 1, flags + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 2, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int nv = h[0] + h[1];
+    if (h[2]) return lgr_fail(ctx, LGR_ERR_VOXEL_TOO_SMALL, "voxel index exceeds 21 bits per axis", __FILE__, __LINE__);
+    unsigned long long* okeys = nullptr;
+    int* ofirst = nullptr;
+    if (h_keys) {
+        LGR_TRY(lgr_ws_t(ctx, WS_DS_MISC, (size_t) nv * 3 + 4, (int**) &ofirst));
+        okeys = (unsigned long long*) (ofirst + ((nv + 1) & ~1));
+    }
+    // out may alias the input: accumulate into a staging buffer first when it does
+    float* stage = d_out;
+    bool alias = d_out == d_pts;
+    if (alias) LGR_TRY(lgr_ws_t(ctx, WS_HOST_F, (size_t) nv * 12 + 4, &stage));
+    voxel_accumulate<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_pts, keys2, vals2, flags, rank, n, stage, okeys, ofirst);
+    if (alias) LGR_HIP(ctx, hipMemcpyAsync(d_out, stage, (size_t) nv * 48, hipMemcpyDeviceToDevice, ctx->stream));
+    if (h_keys) {
+        h_keys->resize(nv); h_first->resize(nv);
+        LGR_HIP(ctx, hipMemcpyAsync(h_keys->data(), okeys, (size_t) nv * 8, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(h_first->data(), ofirst, (size_t) nv * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    LGR_HIP(ctx, hipGetLastError());
+    *n_out = nv;
+    return LGR_OK;
+}
+
+extern "C" int lgr_downsample_dev(lgr_ctx* ctx, const float* d_pts, int n, float voxel, float* d_out, int* n_out) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, (d_pts || n == 0) && (d_out || n == 0) && n_out && n >= 0, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    return downsample_core(ctx, d_pts, n, voxel, d_out, n_out, nullptr, nullptr);
+}
+
+extern "C" int lgr_downsample(lgr_ctx* ctx, const float* pts, int n, float voxel, int order, float* out, int* n_out) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, (pts || n == 0) && out && n_out && n >= 0, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, order == LGR_ORDER_REFERENCE || order == LGR_ORDER_CANONICAL, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    *n_out = 0;
+    if (n == 0) return LGR_OK;
+    float *dp, *dout;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) n * 12, &dp));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_B, (size_t) n * 12, &dout));
+    LGR_HIP(ctx, hipMemcpyAsync(dp, pts, (size_t) n * 48, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<unsigned long long> keys;
+    std::vector<int> first;
+    int nv = 0;
+    LGR_TRY(downsample_core(ctx, dp, n, voxel, dout, &nv, order == LGR_ORDER_REFERENCE ? &keys : nullptr, &first));
+    if (order == LGR_ORDER_CANONICAL) {
+        LGR_HIP(ctx, hipMemcpyAsync(out, dout, (size_t) nv * 48, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        // reference order = iteration order of std::unordered_map<Vector3i, AccumulatedPoint, HashEigen>
+        // (src/downsample.cpp:20,32-34).  Replay the insertion sequence (voxels by first input index) through
+        // the very same container and walk it; the values were computed on the device.
+        std::vector<float> tmp((size_t) nv * 12);
+        LGR_HIP(ctx, hipMemcpyAsync(tmp.data(), dout, (size_t) nv * 48, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int> by_first(nv);
+        for (int i = 0; i < nv; ++i) by_first[i] = i;
+        std::sort(by_first.begin(), by_first.end(), [&](int a, int b) { return first[a] < first[b]; });
+        std::unordered_map<Key3, int, HashKey3> m;
+        for (int v : by_first) {
+            unsigned long long k = keys[v];
+            Key3 k3{(int) (k & 0x1fffff), (int) ((k >> 21) & 0x1fffff), (int) ((k >> 42) & 0x1fffff)};
+            m[k3] = v;
+        }
+        size_t o = 0;
+        for (const auto& kv : m) { memcpy(out + 12 * o, tmp.data() + 12 * (size_t) kv.second, 48); ++o; }
+    }
+    *n_out = nv;
+    return LGR_OK;
+}
+
+extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const float* d_surf, int ns, int k, const float* vp3, int normals_available) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, (d_pts || n == 0) && n >= 0 && k >= 1 && k <= 64, LGR_ERR_INVALID_ARG);
+    (void) normals_available;   // no observable effect in the reference (src/common.cpp:597-598 compares a point with itself)
+    if (n == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    const float* S = d_surf;
+    if (!S) {
+        // surface = the cloud itself: normals are written in place, so query a snapshot
+        float* snap;
+        LGR_TRY(lgr_ws_t(ctx, WS_HOST_F, (size_t) n * 12, &snap));
+        LGR_HIP(ctx, hipMemcpyAsync(snap, d_pts, (size_t) n * 48, hipMemcpyDeviceToDevice, ctx->stream));
+        S = snap; ns = n;
+    }
+    GridDev g;
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, S, ns, 0.f, 4.f, &g));
+    size_t sm = (size_t) k * NB * 8;
+    normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vp3 ? vp3[0] : 0.f, vp3 ? vp3[1] : 0.f, vp3 ? vp3[2] : 0.f);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+extern "C" int lgr_normals_knn(lgr_ctx* ctx, float* pts, int n, const float* surf, int ns, int k, const float* vp3, int normals_available) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, (pts || n == 0) && n >= 0, LGR_ERR_INVALID_ARG);
+    if (n == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    float *dp, *ds = nullptr;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) n * 12, &dp));
+    LGR_HIP(ctx, hipMemcpyAsync(dp, pts, (size_t) n * 48, hipMemcpyHostToDevice, ctx->stream));
+    if (surf) {
+        LGR_TRY(lgr_ws_t(ctx, WS_HOST_B, (size_t) ns * 12 + 4, &ds));
+        LGR_HIP(ctx, hipMemcpyAsync(ds, surf, (size_t) ns * 48, hipMemcpyHostToDevice, ctx->stream));
+    }
+    LGR_TRY(lgr_normals_knn_dev(ctx, dp, n, ds, ns, k, vp3, normals_available));
+    LGR_HIP(ctx, hipMemcpyAsync(pts, dp, (size_t) n * 48, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LGR_OK;
+}
+
+extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float* d_surf, int n, float radius, float* d_out) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, (d_kps || m == 0) && (d_surf || n == 0) && (d_out || m == 0) && m >= 0 && n >= 0 && radius > 0.f, LGR_ERR_INVALID_ARG);
+    if (m == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    GridDev g;
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_B, d_surf, n, radius * 1.001f, 0.f, &g));
+    float r2 = radius * radius;
+    float* spfh;
+    LGR_TRY(lgr_ws_t(ctx, WS_SPFH, (size_t) n * 33 + 64 + (size_t) n, &spfh));
+    uint8_t* need = (uint8_t*) (spfh + (size_t) n * 33 + 16);
+    LGR_HIP(ctx, hipMemsetAsync(need, 0, (size_t) n + 1, ctx->stream));
+    need_kernel<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, m, r2, need);
+    if (g.n > 0) spfh_kernel<<<cdiv(g.n, SB), SB, 0, ctx->stream>>>(g, r2, need, spfh);
+    // keypoints in grid-cell order (locality of the SPFH row gathers)
+    unsigned *keys, *keys2;
+    int *vals, *vals2;
+    LGR_TRY(lgr_ws_t(ctx, WS_KP_ORDER, (size_t) m * 4 + 16, &keys));
+    keys2 = keys + m; vals = (int*) (keys2 + m); vals2 = vals + m;
+    kp_cell_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, m, keys, vals);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
+    fpfh_kernel<<<cdiv(m, 128), 128, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+extern "C" int lgr_fpfh(lgr_ctx* ctx, const float* kps, int m, const float* surf, int n, float radius, float* out) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, (kps || m == 0) && (surf || n == 0) && (out || m == 0) && m >= 0 && n >= 0, LGR_ERR_INVALID_ARG);
+    if (m == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    float *dk, *ds, *dout;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) m * 12, &dk));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_B, (size_t) n * 12 + 4, &ds));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_C, (size_t) m * 33, &dout));
+    LGR_HIP(ctx, hipMemcpyAsync(dk, kps, (size_t) m * 48, hipMemcpyHostToDevice, ctx->stream));
+    if (n) LGR_HIP(ctx, hipMemcpyAsync(ds, surf, (size_t) n * 48, hipMemcpyHostToDevice, ctx->stream));
+    LGR_TRY(lgr_fpfh_dev(ctx, dk, m, ds, n, radius, dout));
+    LGR_HIP(ctx, hipMemcpyAsync(out, dout, (size_t) m * 132, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LGR_OK;
+}

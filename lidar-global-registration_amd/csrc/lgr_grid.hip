@@ -1,0 +1,258 @@
+// lgr_grid.hip -- bounding boxes, uniform grid build, exact k-NN tables, smoothed densities (gfx950).
+//
+// include/common.h:266-280 calculateBoundingBox; src/common.cpp:531-547 calculateSmoothedDensities and :202-208
+// calculatePointCloudDensity.  The reference queries pcl::KdTreeFLANN; here a counting-sorted uniform grid is built
+// per cloud (rocPRIM radix sort = plumbing) and queried by the hand-written kernels in lgr_grid.cuh.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+#include "lgr_grid.cuh"
+
+namespace {
+
+__device__ __forceinline__ unsigned fkey(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float fkey_inv(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+// out[0..2] true min keys, [3..5] true max keys (finite points only), [6..8] quirk min, [9..11] quirk max
+__global__ void bbox_kernel(const float* __restrict__ pts, int n, unsigned* __restrict__ out) {
+    float tmn[3] = {INFINITY, INFINITY, INFINITY}, tmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float qmn[3] = {3.4028234663852886e38f, 3.4028234663852886e38f, 3.4028234663852886e38f};
+    float qmx[3] = {1.17549435e-38f, 1.17549435e-38f, 1.17549435e-38f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float p[3] = {pts[(size_t) i * 12], pts[(size_t) i * 12 + 1], pts[(size_t) i * 12 + 2]};
+        bool fin = lgr_finite3(p[0], p[1], p[2]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (fin) { tmn[a] = fminf(tmn[a], p[a]); tmx[a] = fmaxf(tmx[a], p[a]); }
+            qmn[a] = (p[a] < qmn[a]) ? p[a] : qmn[a];   // std::min(mn, p)
+            qmx[a] = (qmx[a] < p[a]) ? p[a] : qmx[a];   // std::max(mx, p)
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            tmn[a] = fminf(tmn[a], __shfl_xor(tmn[a], o)); tmx[a] = fmaxf(tmx[a], __shfl_xor(tmx[a], o));
+            qmn[a] = fminf(qmn[a], __shfl_xor(qmn[a], o)); qmx[a] = fmaxf(qmx[a], __shfl_xor(qmx[a], o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&out[a], fkey(tmn[a])); atomicMax(&out[3 + a], fkey(tmx[a]));
+            atomicMin(&out[6 + a], fkey(qmn[a])); atomicMax(&out[9 + a], fkey(qmx[a]));
+        }
+    }
+}
+
+__global__ void cell_keys(const float* __restrict__ pts, int n, float ox, float oy, float oz, float h, int dx, int dy, int dz,
+                          unsigned invalid_key, unsigned* __restrict__ keys, int* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = pts[(size_t) i * 12], y = pts[(size_t) i * 12 + 1], z = pts[(size_t) i * 12 + 2];
+    unsigned k = invalid_key;
+    if (lgr_finite3(x, y, z)) {
+        int cx = min(max(lgr_cellc(x, ox, h), 0), dx - 1), cy = min(max(lgr_cellc(y, oy, h), 0), dy - 1), cz = min(max(lgr_cellc(z, oz, h), 0), dz - 1);
+        k = (unsigned) ((cz * dy + cy) * dx + cx);
+    }
+    keys[i] = k; vals[i] = i;
+}
+
+// cell_start[c] = first sorted position whose key >= c  (keys sorted ascending; invalid keys == ncell at the end)
+__global__ void cell_starts(const unsigned* __restrict__ keys, int n, int ncell, int* __restrict__ start) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    unsigned k = i < n ? min(keys[i], (unsigned) ncell) : (unsigned) ncell;
+    unsigned kp = i > 0 ? min(keys[i - 1], (unsigned) ncell) : 0u;
+    unsigned lo = i > 0 ? kp + 1 : 0u;
+    for (unsigned c = lo; c <= k; ++c) start[c] = i;
+}
+
+__global__ void gather_points(const float* __restrict__ pts, const int* __restrict__ vals, int nvalid,
+                              float4* __restrict__ pxyz, float4* __restrict__ pnrm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvalid) return;
+    int o = vals[i];
+    const float4* p = reinterpret_cast<const float4*>(pts + (size_t) o * 12);
+    float4 a = p[0], b = p[1], c = p[2];
+    pxyz[i] = make_float4(a.x, a.y, a.z, __int_as_float(o));
+    pnrm[i] = make_float4(b.x, b.y, b.z, c.y);
+}
+
+constexpr int KNN_BLOCK = 128;
+
+// mode 0: full table idx/d2 [nq][k];  mode 1: dk[i] = sqrt(d2[k-1]) (NaN if fewer), nn1[i] = idx[1] (i if fewer)
+template <int MODE>
+__global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(GridDev g, const float* __restrict__ q, int nq, int k,
+                                                        int32_t* __restrict__ idx, float* __restrict__ d2) {
+    extern __shared__ float smem[];
+    float* sd = smem;
+    int* si = (int*) (smem + (size_t) k * KNN_BLOCK);
+    int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    if (i >= nq) return;
+    float x = q[(size_t) i * 12], y = q[(size_t) i * 12 + 1], z = q[(size_t) i * 12 + 2];
+    KnnList<KNN_BLOCK> L;
+    L.init(sd, si, k, threadIdx.x);
+    if (lgr_finite3(x, y, z) && g.n > 0) lgr_knn_query(g, x, y, z, L);
+    if (MODE == 0) {
+        for (int j = 0; j < k; ++j) {
+            idx[(size_t) i * k + j] = j < L.count ? L.index(j) : -1;
+            d2[(size_t) i * k + j] = j < L.count ? L.dist(j) : INFINITY;
+        }
+    } else {
+        d2[i] = L.count >= k ? __builtin_sqrtf(L.dist(k - 1)) : __uint_as_float(0x7fc00000u);
+        idx[i] = L.count >= 2 ? L.index(1) : i;
+    }
+}
+
+__global__ void density_min(const float* __restrict__ dk, const int32_t* __restrict__ nn1, int n, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = dk[i], b = dk[nn1[i]];
+    out[i] = (b < a) ? b : a;   // std::min(a, b)
+}
+
+}  // namespace
+
+int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12) {
+    unsigned* d;
+    LGR_TRY(lgr_ws_t(ctx, WS_GRID_MISC, 16, &d));
+    unsigned init[12];
+    unsigned pinf = 0x7f800000u | 0x80000000u;         // fkey(+inf)
+    unsigned ninf = ~0xff800000u;                       // fkey(-inf)
+    float fmx = 3.4028234663852886e38f, fmn = 1.17549435e-38f;
+    unsigned kfmx, kfmn;
+    memcpy(&kfmx, &fmx, 4); kfmx |= 0x80000000u;
+    memcpy(&kfmn, &fmn, 4); kfmn |= 0x80000000u;
+    for (int a = 0; a < 3; ++a) { init[a] = pinf; init[3 + a] = ninf; init[6 + a] = kfmx; init[9 + a] = kfmn; }
+    LGR_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    if (n > 0) bbox_kernel<<<std::min(cdiv(n, 256), ctx->n_cu * 8), 256, 0, ctx->stream>>>(d_pts, n, d);
+    unsigned* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, d, 48, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 12; ++i) out12[i] = fkey_inv(h[i]);
+    return LGR_OK;
+}
+
+extern "C" int lgr_bbox_dev(lgr_ctx* ctx, const float* d_pts, int n, float* d_min3_max3) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, (d_pts || n == 0) && d_min3_max3 && n >= 0, LGR_ERR_INVALID_ARG);
+    float bb[12];
+    LGR_TRY(lgr_bbox_host(ctx, d_pts, n, bb));
+    LGR_HIP(ctx, hipMemcpyAsync(d_min3_max3, bb + 6, 24, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // bb is a stack buffer
+    return LGR_OK;
+}
+
+int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, float target, GridDev* out) {
+    float bb[12];
+    LGR_TRY(lgr_bbox_host(ctx, d_pts, n, bb));
+    float mn[3] = {bb[0], bb[1], bb[2]}, mx[3] = {bb[3], bb[4], bb[5]};
+    if (!(mn[0] <= mx[0])) { for (int a = 0; a < 3; ++a) { mn[a] = 0.f; mx[a] = 0.f; } }
+    if (!(h > 0.f)) {
+        float e[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        std::sort(e, e + 3);
+        float area = std::max(e[2] * e[1], 1e-12f);
+        h = std::sqrt(area * target / (float) std::max(n, 1));
+        h = std::max(h, std::max(e[2] / 1024.f, 1e-6f));
+    }
+    int dim[3];
+    for (;;) {
+        double cells = 1;
+        for (int a = 0; a < 3; ++a) {
+            dim[a] = (int) std::floor((mx[a] - mn[a]) / h) + 1;   // same float expression as lgr_cellc
+            if (dim[a] < 1) dim[a] = 1;
+            cells *= dim[a];
+        }
+        if (cells <= 256e6) break;
+        h *= 2.f;
+    }
+    int ncell = dim[0] * dim[1] * dim[2];
+    unsigned *keys, *keys2;
+    int *vals, *vals2, *start;
+    float4 *pxyz, *pnrm;
+    LGR_TRY(lgr_ws_t(ctx, sb + 0, (size_t) n + 1, &keys));
+    LGR_TRY(lgr_ws_t(ctx, sb + 1, (size_t) n + 1, &vals));
+    LGR_TRY(lgr_ws_t(ctx, sb + 2, (size_t) n + 1, &keys2));
+    LGR_TRY(lgr_ws_t(ctx, sb + 3, (size_t) n + 1, &vals2));
+    LGR_TRY(lgr_ws_t(ctx, sb + 4, (size_t) ncell + 2, &start));
+    LGR_TRY(lgr_ws_t(ctx, sb + 5, (size_t) n + 1, &pxyz));
+    LGR_TRY(lgr_ws_t(ctx, sb + 6, (size_t) n + 1, &pnrm));
+    int nvalid = 0;
+    if (n > 0) {
+        cell_keys<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_pts, n, mn[0], mn[1], mn[2], h, dim[0], dim[1], dim[2], (unsigned) ncell, keys, vals);
+        int bits = 1;
+        while (((unsigned long long) 1 << bits) <= (unsigned long long) ncell) ++bits;
+        size_t tmp_bytes = 0;
+        LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, bits, ctx->stream));
+        void* tmp;
+        LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tmp_bytes, &tmp));
+        LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, bits, ctx->stream));
+        cell_starts<<<cdiv(n + 1, 256), 256, 0, ctx->stream>>>(keys2, n, ncell, start);
+        int* h_n;
+        LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_n));
+        LGR_HIP(ctx, hipMemcpyAsync(h_n, start + ncell, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        nvalid = *h_n;
+        if (nvalid > 0) gather_points<<<cdiv(nvalid, 256), 256, 0, ctx->stream>>>(d_pts, vals2, nvalid, pxyz, pnrm);
+    } else {
+        LGR_HIP(ctx, hipMemsetAsync(start, 0, ((size_t) ncell + 2) * 4, ctx->stream));
+    }
+    LGR_HIP(ctx, hipGetLastError());
+    out->ox = mn[0]; out->oy = mn[1]; out->oz = mn[2]; out->h = h;
+    out->dx = dim[0]; out->dy = dim[1]; out->dz = dim[2];
+    out->n = nvalid; out->cell_start = start; out->pxyz = pxyz; out->pnrm = pnrm;
+    return LGR_OK;
+}
+
+extern "C" int lgr_knn_dev(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, int n, int k, int32_t* d_idx, float* d_d2) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, nq >= 0 && n >= 0 && k >= 1 && k <= 128 && (d_q || nq == 0) && (d_pts || n == 0) && d_idx && d_d2, LGR_ERR_INVALID_ARG);
+    if (nq == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    GridDev g;
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, 4.f, &g));
+    size_t sm = (size_t) k * KNN_BLOCK * 8;
+    knn_kernel<0><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+// src/common.cpp:531-547
+extern "C" int lgr_smoothed_densities_dev(lgr_ctx* ctx, const float* d_pts, int n, int k, float* d_out) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, d_pts && d_out && n > 1 && k >= 2 && k <= 128, LGR_ERR_INVALID_ARG);   // rassert(pcd->size() > 1 && k >= 2)
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    GridDev g;
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, 4.f, &g));
+    float* dk; int32_t* nn1;
+    LGR_TRY(lgr_ws_t(ctx, WS_DENS_A, (size_t) n, &dk));
+    LGR_TRY(lgr_ws_t(ctx, WS_DENS_B, (size_t) n, &nn1));
+    size_t sm = (size_t) k * KNN_BLOCK * 8;
+    knn_kernel<1><<<cdiv(n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_pts, n, k, nn1, dk);
+    density_min<<<cdiv(n, 256), 256, 0, ctx->stream>>>(dk, nn1, n, d_out);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+extern "C" int lgr_smoothed_densities(lgr_ctx* ctx, const float* pts, int n, int k, float* out) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, pts && out && n > 1, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    float *dp, *dout;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) n * 12, &dp));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_C, (size_t) n, &dout));
+    LGR_HIP(ctx, hipMemcpyAsync(dp, pts, (size_t) n * 48, hipMemcpyHostToDevice, ctx->stream));
+    LGR_TRY(lgr_smoothed_densities_dev(ctx, dp, n, k, dout));
+    LGR_HIP(ctx, hipMemcpyAsync(out, dout, (size_t) n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LGR_OK;
+}

@@ -23,7 +23,7 @@ struct lgr_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    lgr_buf ws[64];
+    lgr_buf ws[96];
     void* pinned = nullptr;  // small pinned host scratch for read-backs
     size_t pinned_cap = 0;
     hipEvent_t ev[16];
@@ -58,16 +58,17 @@ int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int lin
 enum {
     WS_MATCH_AP = 0, WS_MATCH_BP, WS_MATCH_NA, WS_MATCH_NB, WS_MATCH_ROWMIN, WS_MATCH_COLMIN, WS_MATCH_ITEMS,
     WS_MATCH_BEST_A, WS_MATCH_BEST_B, WS_MATCH_MISC, WS_MATCH_DENSE,
-    WS_GRID_KEYS, WS_GRID_VALS, WS_GRID_KEYS2, WS_GRID_VALS2, WS_GRID_START, WS_GRID_TMP, WS_GRID_PTS, WS_GRID_MISC,
-    WS_GRID2_KEYS, WS_GRID2_VALS, WS_GRID2_KEYS2, WS_GRID2_VALS2, WS_GRID2_START, WS_GRID2_PTS,
-    WS_DS_OUT, WS_DS_MISC, WS_SPFH, WS_KNN_IDX, WS_KNN_D2, WS_DENS_A, WS_DENS_B,
-    WS_RANSAC_T, WS_RANSAC_FLAGS, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK,
+    // three independent uniform grids (7 slots each: keys, vals, keys2, vals2, start, xyz, nrm) + shared sort temp
+    WS_GRID_A, WS_GRID_B = WS_GRID_A + 7, WS_GRID_C = WS_GRID_B + 7, WS_GRID_TMP = WS_GRID_C + 7, WS_GRID_MISC,
+    WS_DS_KEYS, WS_DS_VALS, WS_DS_KEYS2, WS_DS_VALS2, WS_DS_FLAGS, WS_DS_MISC,
+    WS_SPFH, WS_KP_ORDER, WS_DENS_A, WS_DENS_B, WS_DENS_C,
+    WS_RANSAC_T, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK,
     WS_PIPE_SURF_S, WS_PIPE_SURF_T, WS_PIPE_FEAT_S, WS_PIPE_FEAT_T, WS_PIPE_IJ, WS_PIPE_JI, WS_PIPE_DIJ, WS_PIPE_DJI,
-    WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_MISC,
+    WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_FLAGS, WS_PIPE_MISC,
     WS_HOST_A, WS_HOST_B, WS_HOST_C, WS_HOST_D, WS_HOST_E, WS_HOST_F,
     WS_COUNT
 };
-static_assert(WS_COUNT <= 64, "grow lgr_ctx::ws");
+static_assert(WS_COUNT <= 96, "grow lgr_ctx::ws");
 
 // returns device pointer of at least `bytes` (contents undefined unless kept); grows with 25% slack
 int lgr_ws(lgr_ctx* ctx, int slot, size_t bytes, void** out);
@@ -84,5 +85,17 @@ static inline int lgr_ws_t(lgr_ctx* ctx, int slot, size_t count, T** out) {
 static inline int cdiv(long long a, long long b) { return (int) ((a + b - 1) / b); }
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 
-// ---- stage functions implemented across translation units (device pointers) ----
-struct lgr_grid;  // lgr_grid.hip
+// ---- uniform grid over a cloud (lgr_grid.hip); device view in lgr_grid.cuh ----
+struct GridDev {
+    float ox, oy, oz, h;
+    int dx, dy, dz;
+    int n;                      // number of valid (finite) points = entries of the sorted arrays
+    const int* cell_start;      // dx*dy*dz + 1
+    const float4* pxyz;         // sorted by (cell, original index): x, y, z, bits(original index)
+    const float4* pnrm;         // sorted: nx, ny, nz, curvature
+};
+// h <= 0: automatic cell (about `target` points per occupied cell, 2-D manifold heuristic)
+int lgr_grid_build(lgr_ctx* ctx, int slot_base, const float* d_pts, int n, float h, float target, GridDev* out);
+// both bounding boxes of a cloud: out12 (host) = true min3, true max3 (finite points only; +-inf when empty),
+// reference-quirk min3, max3 (include/common.h:266-280)
+int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);

@@ -1,0 +1,175 @@
+// lgr_math.cuh -- device elementary functions with a FIXED binary32 operation sequence (gfx950).
+//
+// libm results (std::atan2 in pcl::computePairFeatures, std::log / std::cbrt in src/analysis.cpp:95-130, std::exp
+// in src/metric.cpp:72) and Eigen::JacobiSVD (src/transformation.cpp:27, pcl::umeyama) are not reproducible bit for
+// bit across CPU and GPU math libraries.  The parity contract therefore fixes each of them as a sequence of IEEE
+// + - * / sqrt operations (documented in DESIGN.md "canonical elementary functions"); this header is the device
+// statement of those sequences and must be compiled with -ffp-contract=off.  Accuracy vs libm: <= 2 ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// atan2: Cephes-style atanf polynomial on min/max in [0,1] (two ranges), then octant fix-up.
+__device__ __forceinline__ float lgr_atan2f(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = (ax > ay) ? ax : ay;
+    float mn = (ax > ay) ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx;
+    float base = 0.0f;
+    float z = a;
+    if (a > 0.41421356237f) { base = 0.78539816339f; z = (a - 1.0f) / (a + 1.0f); }
+    float z2 = z * z;
+    float p = 8.05374449538e-2f * z2 - 1.38776856032e-1f;
+    p = p * z2 + 1.99777106478e-1f;
+    p = p * z2 - 3.33329491539e-1f;
+    p = p * z2 * z + z;
+    float r = base + p;
+    if (ay > ax) r = 1.57079632679f - r;
+    if (x < 0.0f) r = 3.14159265359f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+// log for normal x > 0: x = m 2^e with m in (sqrt(1/2), sqrt(2)], log m = 2 atanh((m-1)/(m+1)), 4-term series.
+__device__ __forceinline__ float lgr_logf(float x) {
+    unsigned b = __float_as_uint(x);
+    int e = (int) ((b >> 23) & 0xff) - 127;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m = m * 0.5f; e = e + 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float q = 0.111111111111f;
+    q = q * z + 0.142857142857f;
+    q = q * z + 0.2f;
+    q = q * z + 0.333333333333f;
+    q = q * z;
+    float r = 2.0f * s + 2.0f * s * q;
+    float fe = (float) e;
+    return fe * 0.693359375f + (r + fe * (-2.12194440e-4f));
+}
+
+// cube root for x >= 0: exponent/3 bit seed, four Newton steps.
+__device__ __forceinline__ float lgr_cbrtf(float x) {
+    if (!(x > 0.0f)) return x == 0.0f ? 0.0f : x;
+    unsigned b = __float_as_uint(x);
+    float y = __uint_as_float(b / 3u + 0x2a5137a0u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y = (y + y + x / (y * y)) / 3.0f;
+    return y;
+}
+
+// exp (Cephes polynomial), argument clamped to [-87, 88].
+__device__ __forceinline__ float lgr_expf(float x) {
+    if (x < -87.0f) x = -87.0f;
+    if (x > 88.0f) x = 88.0f;
+    float fn = floorf(x * 1.44269504089f + 0.5f);
+    float r = x - fn * 0.693359375f;
+    r = r - fn * (-2.12194440e-4f);
+    float z = r * r;
+    float p = 1.9875691500e-4f * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    p = p * z + r + 1.0f;
+    int n = (int) fn;
+    return p * __uint_as_float((unsigned) (n + 127) << 23);
+}
+
+__device__ __forceinline__ float lgr_det3(const float* M) {
+    return (M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6])) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// One-sided (Hestenes) Jacobi SVD of a row-major 3x3: A = U diag(S) V^T, S descending.  12 fixed sweeps over the
+// column pairs (0,1),(0,2),(1,2); a pair is skipped when gamma^2 <= 1e-14 alpha beta.  Rank-deficient completion:
+// sigma_j <= 1e-5 sigma_0 -> u_j from cross products.
+__device__ __forceinline__ void lgr_svd3(const float* A, float* U, float* S, float* V) {
+    float W[3][3], Vm[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { W[i][j] = A[3 * i + j]; Vm[i][j] = (i == j) ? 1.0f : 0.0f; }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
+            float alpha = (W[0][p] * W[0][p] + W[1][p] * W[1][p]) + W[2][p] * W[2][p];
+            float beta = (W[0][q] * W[0][q] + W[1][q] * W[1][q]) + W[2][q] * W[2][q];
+            float gamma = (W[0][p] * W[0][q] + W[1][p] * W[1][q]) + W[2][p] * W[2][q];
+            if (gamma * gamma <= 1e-14f * alpha * beta) continue;
+            float zeta = (beta - alpha) / (2.0f * gamma);
+            float az = fabsf(zeta);
+            float t = 1.0f / (az + __builtin_sqrtf(1.0f + zeta * zeta));
+            if (zeta < 0.0f) t = -t;
+            float c = 1.0f / __builtin_sqrtf(1.0f + t * t);
+            float s = c * t;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float wp = W[i][p], wq = W[i][q];
+                W[i][p] = c * wp - s * wq;
+                W[i][q] = s * wp + c * wq;
+                float vp = Vm[i][p], vq = Vm[i][q];
+                Vm[i][p] = c * vp - s * vq;
+                Vm[i][q] = s * vp + c * vq;
+            }
+        }
+    }
+    float sg[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sg[j] = __builtin_sqrtf((W[0][j] * W[0][j] + W[1][j] * W[1][j]) + W[2][j] * W[2][j]);
+    // column order by descending sigma; ties keep the lower column first (same selection network as the oracle)
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (sg[o1] > sg[o0]) { int t = o0; o0 = o1; o1 = t; }
+    if (sg[o2] > sg[o0]) { int t = o0; o0 = o2; o2 = t; }
+    if (sg[o2] > sg[o1]) { int t = o1; o1 = o2; o2 = t; }
+    const int ord[3] = {o0, o1, o2};
+    float Uc[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int o = ord[j];
+        float s0 = (o == 0) ? sg[0] : ((o == 1) ? sg[1] : sg[2]);
+        S[j] = s0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float vv = (o == 0) ? Vm[i][0] : ((o == 1) ? Vm[i][1] : Vm[i][2]);
+            float ww = (o == 0) ? W[i][0] : ((o == 1) ? W[i][1] : W[i][2]);
+            V[3 * i + j] = vv;
+            Uc[j][i] = ww;
+        }
+    }
+    float tiny = 1e-5f * S[0];
+    if (!(S[0] > 0.0f)) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Uc[0][i] = Uc[0][i] / S[0];
+    if (S[1] > tiny) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Uc[1][i] = Uc[1][i] / S[1];
+    } else {
+        float a0 = fabsf(Uc[0][0]), a1 = fabsf(Uc[0][1]), a2 = fabsf(Uc[0][2]);
+        int ax = 0;
+        if (a1 < a0) { ax = 1; a0 = a1; }
+        if (a2 < a0) { ax = 2; }
+        float e0 = ax == 0 ? 1.0f : 0.0f, e1 = ax == 1 ? 1.0f : 0.0f, e2 = ax == 2 ? 1.0f : 0.0f;
+        float cx = Uc[0][1] * e2 - Uc[0][2] * e1;
+        float cy = Uc[0][2] * e0 - Uc[0][0] * e2;
+        float cz = Uc[0][0] * e1 - Uc[0][1] * e0;
+        float nn = __builtin_sqrtf((cx * cx + cy * cy) + cz * cz);
+        Uc[1][0] = cx / nn; Uc[1][1] = cy / nn; Uc[1][2] = cz / nn;
+    }
+    if (S[2] > tiny) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Uc[2][i] = Uc[2][i] / S[2];
+    } else {
+        Uc[2][0] = Uc[0][1] * Uc[1][2] - Uc[0][2] * Uc[1][1];
+        Uc[2][1] = Uc[0][2] * Uc[1][0] - Uc[0][0] * Uc[1][2];
+        Uc[2][2] = Uc[0][0] * Uc[1][1] - Uc[0][1] * Uc[1][0];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) U[3 * i + j] = Uc[j][i];
+}

@@ -157,3 +157,51 @@ class Context:
         out = (C.c_uint * 6)()
         _lib.lgr_match_last_stats(out)
         return dict(items_ab=out[0], dense_ab=out[1], items_ba=out[2], dense_ba=out[3], sub_cols=out[4], rg_rows=out[5])
+
+    # ---- geometry stages ------------------------------------------------------------------------------------
+    def bbox(self, pts):
+        out = self.empty((6,), self.torch.float32)
+        self.check(_lib.lgr_bbox_dev(self.h, _ptr(pts), pts.shape[0], _ptr(out)))
+        return out
+
+    def knn(self, q, pts, k):
+        torch = self.torch
+        idx = self.empty((q.shape[0], k), torch.int32); d2 = self.empty((q.shape[0], k), torch.float32)
+        self.check(_lib.lgr_knn_dev(self.h, _ptr(q), q.shape[0], _ptr(pts), pts.shape[0], int(k), _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def smoothed_densities(self, pts, k=2):
+        out = self.empty((pts.shape[0],), self.torch.float32)
+        self.check(_lib.lgr_smoothed_densities_dev(self.h, _ptr(pts), pts.shape[0], int(k), _ptr(out)))
+        return out
+
+    def downsample(self, pts, voxel):
+        out = self.empty((pts.shape[0], 12), self.torch.float32)
+        n = C.c_int(0)
+        self.check(_lib.lgr_downsample_dev(self.h, _ptr(pts), pts.shape[0], C.c_float(voxel), _ptr(out), C.byref(n)))
+        return out[: n.value]
+
+    def downsample_host(self, pts, voxel, order=ORDER_CANONICAL):
+        pts = np.ascontiguousarray(pts, np.float32)
+        out = np.zeros_like(pts)
+        n = C.c_int(0)
+        self.check(_lib.lgr_downsample(self.h, _ptr(pts), pts.shape[0], C.c_float(voxel), int(order), _ptr(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def normals_knn(self, pts, k=30, surf=None, vp=None):
+        """in place on the cuda tensor pts"""
+        v = (C.c_float * 3)(*[float(x) for x in vp]) if vp is not None else None
+        self.check(_lib.lgr_normals_knn_dev(self.h, _ptr(pts), pts.shape[0], _ptr(surf), 0 if surf is None else surf.shape[0],
+                                            int(k), v, 0))
+        return pts
+
+    def fpfh(self, kps, surf, radius):
+        out = self.empty((kps.shape[0], 33), self.torch.float32)
+        self.check(_lib.lgr_fpfh_dev(self.h, _ptr(kps), kps.shape[0], _ptr(surf), surf.shape[0], C.c_float(radius), _ptr(out)))
+        return out
+
+    def fpfh_host(self, kps, surf, radius):
+        kps = np.ascontiguousarray(kps, np.float32); surf = np.ascontiguousarray(surf, np.float32)
+        out = np.zeros((kps.shape[0], 33), np.float32)
+        self.check(_lib.lgr_fpfh(self.h, _ptr(kps), kps.shape[0], _ptr(surf), surf.shape[0], C.c_float(radius), _ptr(out)))
+        return out

@@ -1,0 +1,131 @@
+"""GPU parity: bounding box, voxel downsample, k-NN, smoothed densities, k-NN normals, FPFH vs the oracle.
+
+Bar: bit-exact (every stage is either integer/index work or a float sequence restated op for op; tolerance 0).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from lgr_amd import synthetic
+    return synthetic.make_pair(20000, seed=7)
+
+
+def cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_bbox_quirk(lgr, oracle):
+    rng = np.random.default_rng(0)
+    from lgr_amd.synthetic import make_points
+    for shift in (0.0, -50.0, 50.0):       # all-negative clouds hit the FLT_MIN-initialised max (include/common.h:268-270)
+        p = make_points(rng.normal(shift, 3, (5000, 3)))
+        p[17, 0] = np.nan
+        mn, mx = oracle.bbox(p)
+        g = lgr.bbox(cuda(p)).cpu().numpy()
+        np.testing.assert_array_equal(bits(g[:3]), bits(mn))
+        np.testing.assert_array_equal(bits(g[3:]), bits(mx))
+
+
+@pytest.mark.parametrize("voxel", [0.0236, 0.1, 5.0])
+def test_downsample(lgr, oracle, pair, voxel):
+    src = pair["src"].copy()
+    src[:, 8] = np.random.default_rng(1).uniform(0.5, 2.0, src.shape[0]).astype(np.float32)   # intensity weights
+    src[:, 4:7] = np.random.default_rng(2).normal(size=(src.shape[0], 3)).astype(np.float32)
+    src[100, 1] = np.inf                                                                         # skipped (isValid)
+    want = oracle.downsample(src, voxel, oracle.ORDER_CANONICAL)
+    got = lgr.downsample(cuda(src), voxel).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(bits(got), bits(want))
+    # reference (libstdc++ unordered_map) output order through the host entry point
+    want_ref = oracle.downsample(src, voxel, oracle.ORDER_LIBSTDCXX)
+    got_ref = lgr.downsample_host(src, voxel, 0)
+    np.testing.assert_array_equal(bits(got_ref), bits(want_ref))
+    got_can = lgr.downsample_host(src, voxel, 1)
+    np.testing.assert_array_equal(bits(got_can), bits(want))
+
+
+def test_downsample_edge_cases(lgr, oracle):
+    import torch
+    from lgr_amd.synthetic import make_points
+    empty = torch.zeros((0, 12), dtype=torch.float32, device="cuda")
+    assert lgr.downsample(empty, 0.1).shape[0] == 0
+    one = make_points(np.array([[1.0, 2.0, 3.0]]))
+    np.testing.assert_array_equal(bits(lgr.downsample(cuda(one), 0.1).cpu().numpy()), bits(oracle.downsample(one, 0.1)))
+    # duplicates collapse into one voxel; zero intensity gives 0/0 exactly like the reference
+    dup = make_points(np.repeat(np.array([[0.5, 0.5, 0.5]]), 7, 0))
+    np.testing.assert_array_equal(bits(lgr.downsample(cuda(dup), 0.1).cpu().numpy()), bits(oracle.downsample(dup, 0.1)))
+
+
+@pytest.mark.parametrize("k", [1, 2, 8, 30, 40])
+def test_knn(lgr, oracle, pair, k):
+    src, tgt = pair["src"], pair["tgt"][:5000]
+    oi, od = oracle.knn(tgt, src, k)
+    gi, gd = lgr.knn(cuda(tgt), cuda(src), k)
+    lgr.sync()
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits(gd.cpu().numpy()), bits(od))
+
+
+def test_knn_ties_on_grid(lgr, oracle):
+    """regular lattice: many exactly equidistant neighbours -> (d2, index) tie rule"""
+    from lgr_amd.synthetic import make_points
+    g = np.stack(np.meshgrid(np.arange(30), np.arange(30), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    p = make_points(g)
+    oi, od = oracle.knn(p, p, 12)
+    gi, gd = lgr.knn(cuda(p), cuda(p), 12)
+    lgr.sync()
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+
+
+@pytest.mark.parametrize("k", [2, 8])
+def test_smoothed_densities(lgr, oracle, pair, k):
+    want = oracle.smoothed_densities(pair["src"], k)
+    got = lgr.smoothed_densities(cuda(pair["src"]), k).cpu().numpy()
+    np.testing.assert_array_equal(bits(got), bits(want))
+
+
+def test_normals(lgr, oracle, pair):
+    ds = oracle.downsample(pair["src"], 0.0236)
+    want = oracle.normals_knn(ds, 30, vp=pair["vp_src"])
+    t = cuda(ds)
+    lgr.normals_knn(t, 30, vp=pair["vp_src"])
+    got = t.cpu().numpy()
+    np.testing.assert_array_equal(bits(got), bits(want))
+    # first-principles: unit normals pointing to the viewpoint side
+    nrm = got[:, 4:7]
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-5)
+    assert ((pair["vp_src"] - got[:, :3]) * nrm).sum(1).min() >= -1e-6
+    # separate search surface (matching.h:244 form)
+    q = pair["src"][:3000].copy()
+    want2 = oracle.normals_knn(q, 30, surf=ds, vp=pair["vp_src"])
+    tq = cuda(q)
+    lgr.normals_knn(tq, 30, surf=cuda(ds), vp=pair["vp_src"])
+    np.testing.assert_array_equal(bits(tq.cpu().numpy()), bits(want2))
+
+
+def test_fpfh(lgr, oracle, pair):
+    ds = oracle.normals_knn(oracle.downsample(pair["src"], 0.0236), 30, vp=pair["vp_src"])
+    kps = pair["src"][:6000].copy()
+    kps[5, 2] = np.nan                      # non-finite keypoint -> NaN row
+    kps[6, :3] = [1e3, 1e3, 1e3]            # no neighbours -> NaN row
+    want = oracle.fpfh(kps, ds, 0.25)
+    got = lgr.fpfh(cuda(kps), cuda(ds), 0.25).cpu().numpy()
+    assert np.isnan(want[5]).all() and np.isnan(want[6]).all()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_array_equal(bits(got)[ok], bits(want)[ok])
+    # each 11-bin block sums to 100
+    blocks = got[~np.isnan(got).any(1)].reshape(-1, 3, 11).sum(2)
+    assert np.allclose(blocks, 100, atol=1e-2)
+    # keypoints == surface (the reference's tests/flann_bf_matcher.h:55-56 call shape), host entry point
+    sub = ds[:4000]
+    np.testing.assert_array_equal(bits(lgr.fpfh_host(sub, sub, 0.25)), bits(oracle.fpfh(sub, sub, 0.25)))
