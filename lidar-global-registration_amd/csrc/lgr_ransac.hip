@@ -1,0 +1,875 @@
+// lgr_ransac.hip -- prerejective RANSAC on gfx950: on-device Philox sampling, polygon prerejection, 3-point Umeyama,
+// batched hypothesis verification, uniformity / score metrics, adaptive bound, final SVD refit.
+//
+// Replaces src/sac_prerejective_omp.cpp:115-314 (SampleConsensusPrerejectiveOMP::align), src/metric.cpp:55-179,
+// src/analysis.cpp:95-130 (uniformity), src/transformation.cpp:4-38 and the PCL pieces called from there
+// (CorrespondenceRejectorPoly::thresholdPolygon, TransformationEstimationSVD -> umeyama).
+//
+// Schedule (deterministic, order-independent; the oracle's ORC_RNG_PHILOX mode states the same thing on the CPU):
+//   iteration i draws Philox4x32-10(counter = i, key = seed); iterations are processed in batches; after a batch
+//   the record inlier set (largest count, ties -> lowest i) tightens the bound through estimateMaxIterations and the
+//   best hypothesis is the maximum metric (strict '>', ties -> lowest i).
+// Float sequences restate the oracle op for op (oracle/src/orc_ransac.cpp); compiled with -ffp-contract=off.
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <vector>
+
+#include "lgr_internal.h"
+#include "lgr_math.cuh"
+
+namespace {
+
+constexpr int MIN_NR_INLIERS = 10;         // src/sac_prerejective_omp.cpp:8
+constexpr int MIN_NR_FINAL_INLIERS = 20;   // :9
+constexpr double MIN_INLIER_RATE = 0.15;   // :10
+
+// ---------------------------------------------------------------------------------------------------- sampling
+__device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned iter, unsigned out[4]) {
+    unsigned c0 = iter, c1 = 0, c2 = 0, c3 = 0;
+    unsigned k0 = (unsigned) seed, k1 = (unsigned) (seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        unsigned n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// src/sac_prerejective_omp.cpp:33-77 selectCorrespondences, nr_samples = 3 (control flow kept literally)
+__device__ __forceinline__ void select3(const int r[3], int n_corr, int sample[3]) {
+    for (int i = 0; i < 3; i++) {
+        sample[i] = r[i] % n_corr;
+        for (int j = 0; j < i; j++) {
+            if (sample[i] >= sample[j]) {
+                if (sample[i] < n_corr - 1) { sample[i]++; continue; }
+                else if (sample[j] == 0) { sample[i] = 1; continue; }
+                else { sample[i] = 0; }
+            }
+            int tmp = sample[i];
+            for (int k = i; k > j; k--) sample[k] = sample[k - 1];
+            sample[j] = tmp;
+            break;
+        }
+    }
+}
+
+__global__ void samples_kernel(unsigned long long seed, int first, int n, int n_corr, int32_t* __restrict__ triples) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    unsigned w[4];
+    philox4x32(seed, (unsigned) (first + b), w);
+    int r[3] = {(int) (w[0] >> 1), (int) (w[1] >> 1), (int) (w[2] >> 1)}, s[3];
+    select3(r, n_corr, s);
+    triples[3 * b] = s[0]; triples[3 * b + 1] = s[1]; triples[3 * b + 2] = s[2];
+}
+
+// ---------------------------------------------------------------------------------------------------- hypotheses
+struct P3 { float x, y, z; };
+__device__ __forceinline__ P3 ldp(const float* pts, int i) { const float* p = pts + (size_t) i * 12; return P3{p[0], p[1], p[2]}; }
+
+// pcl::registration::CorrespondenceRejectorPoly::thresholdPolygon
+__device__ __forceinline__ bool poly_ok(const P3 s[3], const P3 t[3], float thr2) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int j = (i + 1) % 3;
+        float dx = s[i].x - s[j].x, dy = s[i].y - s[j].y, dz = s[i].z - s[j].z;
+        float ds = dx * dx + dy * dy + dz * dz;
+        dx = t[i].x - t[j].x; dy = t[i].y - t[j].y; dz = t[i].z - t[j].z;
+        float dt = dx * dx + dy * dy + dz * dz;
+        float sim = ds < dt ? ds / dt : dt / ds;
+        if (!(sim >= thr2)) return false;
+    }
+    return true;
+}
+
+// pcl::umeyama (no scaling) on 3 pairs; T column-major
+__device__ __forceinline__ void umeyama3(const P3 s[3], const P3 d[3], float* T) {
+    const float one_over_n = 1.0f / 3.0f;
+    float sv[3][3] = {{s[0].x, s[1].x, s[2].x}, {s[0].y, s[1].y, s[2].y}, {s[0].z, s[1].z, s[2].z}};
+    float dv[3][3] = {{d[0].x, d[1].x, d[2].x}, {d[0].y, d[1].y, d[2].y}, {d[0].z, d[1].z, d[2].z}};
+    float sm[3], dm[3], S[3][3], D[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        sm[a] = ((sv[a][0] + sv[a][1]) + sv[a][2]) * one_over_n;
+        dm[a] = ((dv[a][0] + dv[a][1]) + dv[a][2]) * one_over_n;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { S[a][j] = sv[a][j] - sm[a]; D[a][j] = dv[a][j] - dm[a]; }
+    }
+    float sigma[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            sigma[3 * i + j] = one_over_n * ((D[i][0] * S[j][0] + D[i][1] * S[j][1]) + D[i][2] * S[j][2]);
+    float U[9], Sg[3], V[9];
+    lgr_svd3(sigma, U, Sg, V);
+    float sgn = (lgr_det3(U) * lgr_det3(V) < 0.f) ? -1.f : 1.f;
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            R[3 * i + j] = (U[3 * i + 0] * V[3 * j + 0] + U[3 * i + 1] * V[3 * j + 1]) + (U[3 * i + 2] * sgn) * V[3 * j + 2];
+    float t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = dm[i] - ((R[3 * i + 0] * sm[0] + R[3 * i + 1] * sm[1]) + R[3 * i + 2] * sm[2]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[4 * j + i] = R[3 * i + j];
+        T[12 + i] = t[i];
+    }
+    T[15] = 1.f;
+}
+
+// one thread per iteration of the batch: sample (or replay a given triple) -> prerejection -> 3-point transform
+__global__ void hypotheses_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr,
+                                  int c, unsigned long long seed, int first, int n, const int32_t* __restrict__ triples,
+                                  float edge_thr, float* __restrict__ Ts, int* __restrict__ ok) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    int smp[3];
+    if (triples) { smp[0] = triples[3 * b]; smp[1] = triples[3 * b + 1]; smp[2] = triples[3 * b + 2]; }
+    else {
+        unsigned w[4];
+        philox4x32(seed, (unsigned) (first + b), w);
+        int r[3] = {(int) (w[0] >> 1), (int) (w[1] >> 1), (int) (w[2] >> 1)};
+        select3(r, c, smp);
+    }
+    P3 s[3], t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { lgr_corr cr = corr[smp[j]]; s[j] = ldp(src, cr.index_query); t[j] = ldp(tgt, cr.index_match); }   // buildIndices :17-31
+    bool good = poly_ok(s, t, edge_thr * edge_thr);
+    float T[16];
+    if (good) umeyama3(s, t, T);
+    else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    }
+    float4* o = reinterpret_cast<float4*>(Ts + (size_t) b * 16);
+    o[0] = make_float4(T[0], T[1], T[2], T[3]); o[1] = make_float4(T[4], T[5], T[6], T[7]);
+    o[2] = make_float4(T[8], T[9], T[10], T[11]); o[3] = make_float4(T[12], T[13], T[14], T[15]);
+    ok[b] = good ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- packing
+// pack[i] = {sx, sy, sz, thr | tx, ty, tz, bins}; sstar[i] = smallest float s with sqrt_rn(s) >= thr, so that the
+// inlier test `sqrtf(s) < thr` (src/metric.cpp:141-144) is exactly `s < sstar` without a square root per pair.
+__device__ __forceinline__ float next_up(float x) { return __uint_as_float(__float_as_uint(x) + 1u); }
+__device__ __forceinline__ float next_down(float x) { return __uint_as_float(__float_as_uint(x) - 1u); }
+
+__global__ void pack_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
+                            float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                            float4* __restrict__ P0, float4* __restrict__ P1, float* __restrict__ sstar) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    lgr_corr cr = corr[i];
+    P3 s = ldp(src, cr.index_query), t = ldp(tgt, cr.index_match);
+    float thr = cr.threshold;
+    // bins of calculateCorrespondenceUniformity (src/analysis.cpp:108-112); NaN/negative pinned to 0 like the oracle
+    float f0 = floorf((s.x - mnx) / (mxx - mnx) * 100), f1 = floorf((s.y - mny) / (mxy - mny) * 100), f2 = floorf((s.z - mnz) / (mxz - mnz) * 100);
+    f0 = (99.f < f0) ? 99.f : f0; f1 = (99.f < f1) ? 99.f : f1; f2 = (99.f < f2) ? 99.f : f2;   // std::min(f, 99.f)
+    int b0 = (f0 >= 0.f) ? (int) f0 : 0, b1 = (f1 >= 0.f) ? (int) f1 : 0, b2 = (f2 >= 0.f) ? (int) f2 : 0;
+    P0[i] = make_float4(s.x, s.y, s.z, thr);
+    P1[i] = make_float4(t.x, t.y, t.z, __int_as_float(b0 | (b1 << 8) | (b2 << 16)));
+    float ss;
+    if (!(thr > 0.f)) ss = 0.f;                           // nothing is < thr (NaN thr: nothing either)
+    else if (!(thr < 3.4028234663852886e38f)) ss = thr;   // inf: every finite s qualifies, s < inf
+    else {
+        float g = thr * thr;
+        if (!(g < 3.4028234663852886e38f)) g = 3.4028234663852886e38f;
+        if (g < 1.17549435e-38f) g = 1.17549435e-38f;
+        // walk to the boundary: smallest g with sqrt(g) >= thr
+        for (int it = 0; it < 8 && __builtin_sqrtf(g) >= thr && g > 0.f; ++it) g = next_down(g);
+        for (int it = 0; it < 16 && __builtin_sqrtf(g) < thr; ++it) g = next_up(g);
+        ss = g;
+    }
+    sstar[i] = ss;
+}
+
+// T (column-major) applied as Eigen's Matrix4f * Vector4f on SSE: ((c0*x + c1*y) + c2*z) + c3
+#define LGR_APPLY(T, sx, sy, sz, ox, oy, oz)                       \
+    float ox = ((T[0] * sx + T[4] * sy) + T[8] * sz) + T[12];      \
+    float oy = ((T[1] * sx + T[5] * sy) + T[9] * sz) + T[13];      \
+    float oz = ((T[2] * sx + T[6] * sy) + T[10] * sz) + T[14];
+
+// ---------------------------------------------------------------------------------------------------- phase 1
+// lane = hypothesis (T in registers), loop over a chunk of correspondences broadcast from LDS.
+// counts[h] = {inliers (4-norm rule, src/metric.cpp:141), support (3-norm rule, src/metric.cpp:111)}
+constexpr int CB = 64;        // hypotheses per workgroup
+constexpr int CCH = 2048;     // correspondences per workgroup
+__global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts, const int* __restrict__ list, int nh,
+                                                    const float4* __restrict__ P0, const float4* __restrict__ P1,
+                                                    const float* __restrict__ sstar, int c, int2* __restrict__ counts) {
+    __shared__ float4 s0[CB], s1[CB];
+    __shared__ float st[CB];
+    int h = blockIdx.x * CB + threadIdx.x;
+    bool act = h < nh;
+    float T[16];
+    {
+        const float4* tp = reinterpret_cast<const float4*>(Ts + (size_t) (act ? list[h] : 0) * 16);
+        float4 a = tp[0], b = tp[1], cc = tp[2], d = tp[3];
+        T[0] = a.x; T[1] = a.y; T[2] = a.z; T[3] = a.w; T[4] = b.x; T[5] = b.y; T[6] = b.z; T[7] = b.w;
+        T[8] = cc.x; T[9] = cc.y; T[10] = cc.z; T[11] = cc.w; T[12] = d.x; T[13] = d.y; T[14] = d.z; T[15] = d.w;
+    }
+    int ninl = 0, nsup = 0;
+    int c0 = blockIdx.y * CCH, c1 = min(c, c0 + CCH);
+    for (int base = c0; base < c1; base += CB) {
+        __syncthreads();
+        int i = base + threadIdx.x;
+        if (i < c1) { s0[threadIdx.x] = P0[i]; s1[threadIdx.x] = P1[i]; st[threadIdx.x] = sstar[i]; }
+        __syncthreads();
+        int nj = min(CB, c1 - base);
+        for (int j = 0; j < nj; ++j) {
+            float4 a = s0[j], b = s1[j];
+            float ss = st[j];
+            LGR_APPLY(T, a.x, a.y, a.z, ox, oy, oz)
+            float dx = ox - b.x, dy = oy - b.y, dz = oz - b.z;
+            float d4 = (dx * dx + dz * dz) + (dy * dy + 0.f);   // Eigen 4-vector squaredNorm reduction
+            float d3 = (dx * dx + dy * dy) + dz * dz;           // 3-vector block norm
+            ninl += d4 < ss ? 1 : 0;
+            nsup += d3 < ss ? 1 : 0;
+        }
+    }
+    if (act) { atomicAdd(&counts[h].x, ninl); atomicAdd(&counts[h].y, nsup); }
+}
+
+// ---------------------------------------------------------------------------------------------------- phase 2
+// one workgroup per hypothesis with >= MIN_NR_INLIERS inliers: metric in the reference's exact summation order.
+//   uniformity      : 3 x 100 x 100 int histogram of inlier source points (order-free), then
+//                     entropy_k = -(sum_b p log p) in bin order, /log(1e4), cbrt of the product (src/analysis.cpp:114-129)
+//   correspondences : score = sequential float sum over inliers in correspondence order (src/metric.cpp:55-81), /C
+// mask (optional) receives the inlier flags; rmse_out (optional) the rmse of src/metric.cpp:147-155.
+constexpr int MB = 256;
+__global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts, const int* __restrict__ list2, int nh2,
+                                                     const float4* __restrict__ P0, const float4* __restrict__ P1,
+                                                     const float* __restrict__ sstar, int c, int metric_id, int score_id,
+                                                     float* __restrict__ metric_out, int* __restrict__ ninl_out,
+                                                     float* __restrict__ rmse_out, uint8_t* __restrict__ mask,
+                                                     float2* __restrict__ scratch /* [gridDim.x][c] inlier (dist, thr) lists */) {
+    extern __shared__ int hist[];   // 30000 ints (uniformity) + 2*MB ints scan scratch
+    __shared__ float T[16];
+    __shared__ int s_count;
+    int hb = blockIdx.x;
+    if (hb >= nh2) return;
+    int hyp = list2 ? list2[hb] : hb;
+    if (threadIdx.x < 16) T[threadIdx.x] = Ts[(size_t) hyp * 16 + threadIdx.x];
+    const bool uni = metric_id == LGR_METRIC_UNIFORMITY;
+    if (uni) for (int i = threadIdx.x; i < 30000; i += MB) hist[i] = 0;
+    if (threadIdx.x == 0) s_count = 0;
+    int* scan = hist + 30000;
+    float2* lst = scratch ? scratch + (size_t) hb * c : nullptr;
+    __syncthreads();
+    for (int base = 0; base < c; base += MB) {
+        int i = base + threadIdx.x;
+        bool in = false;
+        float dist = 0.f, thr = 0.f;
+        int bins = 0;
+        if (i < c) {
+            float4 a = P0[i], b = P1[i];
+            LGR_APPLY(T, a.x, a.y, a.z, ox, oy, oz)
+            float dx = ox - b.x, dy = oy - b.y, dz = oz - b.z;
+            float d4 = (dx * dx + dz * dz) + (dy * dy + 0.f);
+            in = d4 < sstar[i];
+            dist = __builtin_sqrtf(d4); thr = a.w; bins = __float_as_int(b.w);
+            if (mask) mask[i] = in ? 1 : 0;
+        }
+        if (uni) {
+            if (in) {
+                int b0 = bins & 0xff, b1 = (bins >> 8) & 0xff, b2 = (bins >> 16) & 0xff;
+                atomicAdd(&hist[(0 * 100 + b1) * 100 + b2], 1);   // count[k][bin[(k+1)%3]][bin[(k+2)%3]]
+                atomicAdd(&hist[(1 * 100 + b2) * 100 + b0], 1);
+                atomicAdd(&hist[(2 * 100 + b0) * 100 + b1], 1);
+            }
+        }
+        if (lst || uni) {
+            // ordered compaction of the inliers of this tile (block-wide exclusive scan of the flags)
+            scan[threadIdx.x] = in ? 1 : 0;
+            __syncthreads();
+            for (int o = 1; o < MB; o <<= 1) {
+                int v = threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
+                __syncthreads();
+                scan[threadIdx.x] += v;
+                __syncthreads();
+            }
+            int pos = s_count + scan[threadIdx.x] - (in ? 1 : 0);
+            if (in && lst) lst[pos] = make_float2(dist, thr);
+            __syncthreads();
+            if (threadIdx.x == MB - 1) s_count += scan[MB - 1];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    int n_inl = s_count;
+    if (uni) {
+        __shared__ float ent[3];
+        if (threadIdx.x < 3) {
+            float e = 0.f;
+            float n = (float) n_inl;
+            const int* hk = hist + threadIdx.x * 10000;
+            for (int b = 0; b < 10000; ++b) {
+                int cnt = hk[b];
+                if (cnt == 0) continue;
+                float p = (float) cnt / n;
+                if (p == 0.f) continue;
+                e -= p * lgr_logf(p);
+            }
+            e /= 9.210340371976184f;
+            ent[threadIdx.x] = e;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = n_inl == 0 ? 0.f : lgr_cbrtf(ent[0] * ent[1] * ent[2]);
+            metric_out[hb] = m;
+            ninl_out[hb] = n_inl;
+        }
+    }
+    if (threadIdx.x == 0 && (!uni || rmse_out)) {
+        float score = 0.f, rm = 0.f;
+        if (lst) {
+            for (int j = 0; j < n_inl; ++j) {
+                float2 dt = lst[j];
+                float d = dt.x, t = dt.y;
+                rm += d * d;
+                float value = 1.f;
+                if (score_id == LGR_SCORE_MAE) value = fabsf(d - t) / t;
+                else if (score_id == LGR_SCORE_MSE) value = (d - t) * (d - t) / (t * t);
+                else if (score_id == LGR_SCORE_EXP) value = lgr_expf(-d * d / (2 * t * t));
+                score += value;
+            }
+        }
+        if (!uni) { metric_out[hb] = score / (float) c; ninl_out[hb] = n_inl; }
+        if (rmse_out) rmse_out[hb] = n_inl ? __builtin_sqrtf(rm / (float) n_inl) : 3.4028234663852886e38f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- batch reduce
+struct BatchStats {
+    unsigned long long best_key;   // (metric bits << 32) | (0xffffffff - batch offset); 0 = none
+    unsigned long long rec_key;    // (n_inl << 32) | (0xffffffff - batch offset); 0 = none
+    int n_ok, n_cand, rec_support, pad;
+};
+
+__global__ void flag_ge_kernel(const int2* __restrict__ counts, int nh, int* __restrict__ flags) {
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < nh) flags[h] = counts[h].x >= MIN_NR_INLIERS ? 1 : 0;
+}
+__global__ void compact_kernel(const int* __restrict__ flags, const int* __restrict__ pos, int n, const int* __restrict__ map,
+                               int* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) out[pos[i]] = map ? map[i] : i;
+}
+__global__ void reduce_kernel(const int* __restrict__ list2, int nh2, const float* __restrict__ metric, const int* __restrict__ ninl,
+                              const int* __restrict__ list, const int2* __restrict__ counts, int nh, BatchStats* __restrict__ st) {
+    // list2[j] = batch offset of candidate j; metric[j], ninl[j] its phase-2 results.  counts[] is indexed by the
+    // position in the ok-list `list` (needed for the support of the record holder).
+    unsigned long long bk = 0, rk = 0;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nh2; j += gridDim.x * blockDim.x) {
+        unsigned off = (unsigned) list2[j];
+        unsigned long long k1 = ((unsigned long long) __float_as_uint(metric[j]) << 32) | (0xffffffffu - off);
+        unsigned long long k2 = ((unsigned long long) (unsigned) ninl[j] << 32) | (0xffffffffu - off);
+        bk = k1 > bk ? k1 : bk; rk = k2 > rk ? k2 : rk;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long a = __shfl_xor(bk, o), b = __shfl_xor(rk, o);
+        bk = a > bk ? a : bk; rk = b > rk ? b : rk;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&st->best_key, bk); atomicMax(&st->rec_key, rk); }
+}
+__global__ void support_kernel(const int* __restrict__ list, const int2* __restrict__ counts, int nh, BatchStats* __restrict__ st) {
+    // find the support count of the record holder (its position in the ok-list)
+    unsigned long long rk = st->rec_key;
+    if (rk == 0) return;
+    int off = (int) (0xffffffffu - (unsigned) (rk & 0xffffffffu));
+    for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
+        if (list[h] == off) st->rec_support = counts[h].y;
+}
+
+// ---------------------------------------------------------------------------------------------------- refit
+// src/transformation.cpp:4-38: sequential float sums over the inliers in correspondence order.  Lanes 0..5 own the
+// six centroid accumulators, then lanes 0..8 the nine entries of H; the SVD and R, t follow on lane 0.
+__global__ void refit_kernel(const float4* __restrict__ P0, const float4* __restrict__ P1, const uint8_t* __restrict__ mask, int c,
+                             float* __restrict__ Tout) {
+    __shared__ float cen[6];
+    __shared__ float Hs[9];
+    __shared__ int sn;
+    int l = threadIdx.x;
+    if (l < 6) {
+        float acc = 0.f;
+        int n = 0;
+        for (int i = 0; i < c; ++i) {
+            if (mask && !mask[i]) continue;
+            float4 v = l < 3 ? P0[i] : P1[i];
+            int a = l % 3;
+            acc += a == 0 ? v.x : (a == 1 ? v.y : v.z);
+            ++n;
+        }
+        cen[l] = acc / (float) n;
+        if (l == 0) sn = n;
+    }
+    __syncthreads();
+    if (l < 9) {
+        int a = l / 3, b = l % 3;
+        float ca = cen[a], cb = cen[3 + b];
+        float acc = 0.f;
+        for (int i = 0; i < c; ++i) {
+            if (mask && !mask[i]) continue;
+            float4 p = P0[i], q = P1[i];
+            float pa = a == 0 ? p.x : (a == 1 ? p.y : p.z);
+            float qb = b == 0 ? q.x : (b == 1 ? q.y : q.z);
+            acc += (pa - ca) * (qb - cb);
+        }
+        Hs[l] = acc;
+    }
+    __syncthreads();
+    if (l == 0) {
+        float T[16];
+        if (sn == 0) {
+            for (int i = 0; i < 16; ++i) T[i] = __uint_as_float(0x7fc00000u);   // 0/0 centroids in the reference
+        } else {
+            float H[9], U[9], Sg[3], V[9], R[9];
+            for (int i = 0; i < 9; ++i) H[i] = Hs[i];
+            lgr_svd3(H, U, Sg, V);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    R[3 * i + j] = (V[3 * i + 0] * U[3 * j + 0] + V[3 * i + 1] * U[3 * j + 1]) + V[3 * i + 2] * U[3 * j + 2];
+            if (lgr_det3(R) < 0.f) {
+                V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j)
+                        R[3 * i + j] = (V[3 * i + 0] * U[3 * j + 0] + V[3 * i + 1] * U[3 * j + 1]) + V[3 * i + 2] * U[3 * j + 2];
+            }
+            float t[3];
+            for (int i = 0; i < 3; ++i) t[i] = cen[3 + i] - ((R[3 * i + 0] * cen[0] + R[3 * i + 1] * cen[1]) + R[3 * i + 2] * cen[2]);
+            for (int i = 0; i < 16; ++i) T[i] = 0.f;
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) T[4 * j + i] = R[3 * i + j];
+                T[12 + i] = t[i];
+            }
+            T[15] = 1.f;
+        }
+        for (int i = 0; i < 16; ++i) Tout[i] = T[i];
+    }
+}
+
+// include/utils.h:34-43 calculateCombinationOrMax<int>
+int comb_or_max(int n, int k) {
+    double result = 1.0;
+    for (int i = 0; i < k; ++i) { result *= n - i; result /= i + 1; }
+    int mx = INT_MAX;
+    return result > mx ? mx : (int) result;
+}
+
+// src/metric.cpp:116-122 given the support count
+int est_from_support(int count, int c, float confidence, int nr_samples) {
+    float frac = (float) count / (float) c;
+    frac /= 4.f;
+    if (frac <= 0.0 || std::log(1.0 - std::pow(frac, nr_samples)) >= 0.0) return INT_MAX;
+    double iterations = std::log(1.0 - confidence) / std::log(1.0 - std::pow(frac, nr_samples));
+    return static_cast<int>(std::min((double) INT_MAX, iterations));
+}
+
+struct Packed { float4* P0; float4* P1; float* sstar; };
+
+int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const lgr_corr* d_corr, int c, Packed* out) {
+    float bb[12];
+    LGR_TRY(lgr_bbox_host(ctx, d_src, ns, bb));   // UniformityMetricEstimator::setSourceCloud (src/metric.cpp:167-170)
+    float4* P;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_PACK, (size_t) c * 2 + (size_t) (c + 3) / 4 + 4, &P));
+    out->P0 = P; out->P1 = P + c; out->sstar = (float*) (P + 2 * (size_t) c);
+    if (c > 0)
+        pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bb[6], bb[7], bb[8], bb[9], bb[10], bb[11],
+                                                           out->P0, out->P1, out->sstar);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+size_t metric_smem() { return (size_t) (30000 + 2 * MB) * 4; }
+
+int metric_launch(lgr_ctx* ctx, const float* Ts, const int* list2, int nh2, const Packed& pk, int c, int metric_id, int score_id,
+                  float* metric_out, int* ninl_out, float* rmse_out, uint8_t* mask) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        LGR_HIP(ctx, hipFuncSetAttribute((const void*) metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
+        attr_set = true;
+    }
+    bool need_list = metric_id != LGR_METRIC_UNIFORMITY || rmse_out;
+    // hypotheses are processed in waves of at most `wave` workgroups so that the ordered inlier lists stay bounded
+    int wave = std::max(1, std::min(nh2, 512));
+    float2* scratch = nullptr;
+    if (need_list) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_LIST, (size_t) wave * std::max(c, 1), &scratch));
+    for (int h0 = 0; h0 < nh2; h0 += wave) {
+        int nh = std::min(wave, nh2 - h0);
+        metric_kernel<<<nh, MB, metric_smem(), ctx->stream>>>(Ts, list2 ? list2 + h0 : nullptr, nh, pk.P0, pk.P1, pk.sstar, c, metric_id,
+                                                              score_id, metric_out + h0, ninl_out + h0,
+                                                              rmse_out ? rmse_out + h0 : nullptr, mask, scratch);
+    }
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+struct EvalOut { int n_inl; float rmse; float metric; };
+// single transform (device pointer d_T to 16 floats): mask + stats
+int evaluate_one(lgr_ctx* ctx, const float* d_T, const Packed& pk, int c, int metric_id, int score_id, uint8_t* d_mask, EvalOut* out) {
+    float* res;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &res));
+    float* d_metric = res + 32; int* d_ninl = (int*) (res + 33); float* d_rmse = res + 34;
+    LGR_TRY(metric_launch(ctx, d_T, nullptr, 1, pk, c, metric_id, score_id, d_metric, d_ninl, d_rmse, d_mask));
+    float* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, d_metric, 12, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->metric = h[0]; memcpy(&out->n_inl, &h[1], 4); out->rmse = h[2];
+    return LGR_OK;
+}
+
+}  // namespace
+
+extern "C" int lgr_ransac_samples_dev(lgr_ctx* ctx, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, n >= 0 && n_corr >= 3 && (d_triples || n == 0) && first >= 0, LGR_ERR_INVALID_ARG);
+    if (n == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    samples_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(seed, first, n, n_corr, d_triples);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+extern "C" int lgr_evaluate_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                                const float T16[16], int metric_id, int score_id,
+                                uint8_t* d_mask, int* n_inliers, float* rmse, float* metric) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && T16 && c >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, metric_id == LGR_METRIC_UNIFORMITY || metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    Packed pk;
+    LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+    float* dT;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &dT));
+    LGR_HIP(ctx, hipMemcpyAsync(dT, T16, 64, hipMemcpyHostToDevice, ctx->stream));
+    EvalOut e;
+    LGR_TRY(evaluate_one(ctx, dT, pk, c, metric_id, score_id, d_mask, &e));
+    if (n_inliers) *n_inliers = e.n_inl;
+    if (rmse) *rmse = e.rmse;
+    if (metric) *metric = e.metric;
+    return LGR_OK;
+}
+
+// one batch: hypotheses -> ok-list -> counts -> candidate list -> metrics.  Returns device arrays + host counts.
+struct BatchBuffers {
+    float* Ts; int* ok; int* pos; int* list; int2* counts; int* flags2; int* pos2; int* list2; float* metric; int* ninl; BatchStats* st;
+};
+static int batch_buffers(lgr_ctx* ctx, int nb, BatchBuffers* b) {
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_T, (size_t) nb * 16, &b->Ts));
+    int* s;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_STATS, (size_t) nb * 12 + 64, &s));
+    b->ok = s; b->pos = s + nb; b->list = s + 2 * (size_t) nb; b->counts = (int2*) (s + 3 * (size_t) nb);
+    b->flags2 = s + 5 * (size_t) nb; b->pos2 = s + 6 * (size_t) nb; b->list2 = s + 7 * (size_t) nb;
+    b->metric = (float*) (s + 8 * (size_t) nb); b->ninl = s + 9 * (size_t) nb;
+    b->st = (BatchStats*) (s + 10 * (size_t) nb + ((10 * (size_t) nb) & 1));
+    return LGR_OK;
+}
+
+// runs one batch.  h_counts: [0] n_ok, [1] n_cand (hypotheses with >= MIN_NR_INLIERS inliers)
+static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c, const Packed& pk,
+                     const lgr_params* p, uint64_t seed, int first, int nb, const int32_t* d_triples, BatchBuffers& b,
+                     int* n_ok, int* n_cand) {
+    hypotheses_kernel<<<cdiv(nb, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, first, nb, d_triples,
+                                                              p->edge_thr_coef, b.Ts, b.ok);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, b.ok, b.pos, 0, (size_t) nb, rocprim::plus<int>(), ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
+    LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, b.ok, b.pos, 0, (size_t) nb, rocprim::plus<int>(), ctx->stream));
+    compact_kernel<<<cdiv(nb, 256), 256, 0, ctx->stream>>>(b.ok, b.pos, nb, nullptr, b.list);
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, b.pos + (nb - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 1, b.ok + (nb - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int nh = h[0] + h[1];
+    *n_ok = nh; *n_cand = 0;
+    if (nh == 0) return LGR_OK;
+    LGR_HIP(ctx, hipMemsetAsync(b.counts, 0, (size_t) nh * 8, ctx->stream));
+    dim3 g(cdiv(nh, CB), cdiv(c, CCH));
+    count_kernel<<<g, CB, 0, ctx->stream>>>(b.Ts, b.list, nh, pk.P0, pk.P1, pk.sstar, c, b.counts);
+    flag_ge_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.counts, nh, b.flags2);
+    LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, b.flags2, b.pos2, 0, (size_t) nh, rocprim::plus<int>(), ctx->stream));
+    compact_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.flags2, b.pos2, nh, b.list, b.list2);
+    LGR_HIP(ctx, hipMemcpyAsync(h, b.pos2 + (nh - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 1, b.flags2 + (nh - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int nh2 = h[0] + h[1];
+    *n_cand = nh2;
+    if (nh2 == 0) return LGR_OK;
+    LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr));
+    return LGR_OK;
+}
+
+static int check_params(lgr_ctx* ctx, const lgr_params* p) {
+    LGR_CHECK(ctx, p != nullptr, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, p->n_samples == 3, LGR_ERR_UNSUPPORTED);
+    LGR_CHECK(ctx, p->metric_id == LGR_METRIC_UNIFORMITY || p->metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);
+    LGR_CHECK(ctx, p->score_id >= 0 && p->score_id <= 3, LGR_ERR_INVALID_ARG);
+    return LGR_OK;
+}
+
+extern "C" int lgr_ransac_replay_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                                     const lgr_params* p, const int32_t* d_triples, int n,
+                                     uint8_t* d_ok, float* d_T16, int32_t* d_n_inliers, float* d_metric) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_TRY(check_params(ctx, p));
+    LGR_CHECK(ctx, d_src && d_tgt && d_corr && d_triples && d_ok && d_T16 && d_n_inliers && d_metric && c >= 3 && n >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
+    if (n == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    Packed pk;
+    LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+    BatchBuffers b;
+    LGR_TRY(batch_buffers(ctx, n, &b));
+    int n_ok = 0;
+    // every prerejection survivor gets its metric here (no MIN_NR_INLIERS gate): replay reports per hypothesis
+    hypotheses_kernel<<<cdiv(n, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0, 0, n, d_triples, p->edge_thr_coef, b.Ts, b.ok);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, b.ok, b.pos, 0, (size_t) n, rocprim::plus<int>(), ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
+    LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, b.ok, b.pos, 0, (size_t) n, rocprim::plus<int>(), ctx->stream));
+    compact_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(b.ok, b.pos, n, nullptr, b.list);
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, b.pos + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 1, b.ok + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    n_ok = h[0] + h[1];
+    LGR_HIP(ctx, hipMemsetAsync(d_n_inliers, 0, (size_t) n * 4, ctx->stream));
+    LGR_HIP(ctx, hipMemsetAsync(d_metric, 0, (size_t) n * 4, ctx->stream));
+    if (n_ok > 0) LGR_TRY(metric_launch(ctx, b.Ts, b.list, n_ok, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr));
+    // scatter back to iteration order
+    std::vector<int> hl(n_ok);
+    std::vector<float> hm(n_ok);
+    std::vector<int> hn(n_ok), hok(n);
+    if (n_ok) {
+        LGR_HIP(ctx, hipMemcpyAsync(hl.data(), b.list, (size_t) n_ok * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(hm.data(), b.metric, (size_t) n_ok * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(hn.data(), b.ninl, (size_t) n_ok * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    LGR_HIP(ctx, hipMemcpyAsync(hok.data(), b.ok, (size_t) n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<float> fm(n, 0.f);
+    std::vector<int> fn(n, 0);
+    std::vector<uint8_t> fo(n);
+    for (int i = 0; i < n; ++i) fo[i] = (uint8_t) hok[i];
+    for (int j = 0; j < n_ok; ++j) { fm[hl[j]] = hm[j]; fn[hl[j]] = hn[j]; }
+    LGR_HIP(ctx, hipMemcpyAsync(d_metric, fm.data(), (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(d_n_inliers, fn.data(), (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(d_ok, fo.data(), (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(d_T16, b.Ts, (size_t) n * 64, hipMemcpyDeviceToDevice, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LGR_OK;
+}
+
+extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                              const lgr_params* p, lgr_result* res, uint8_t* d_final_mask) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_TRY(check_params(ctx, p));
+    LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && res && c >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    auto t_start = std::chrono::steady_clock::now();
+    memset(res, 0, sizeof(*res));
+    for (int i = 0; i < 16; ++i) res->transformation[i] = (i % 5 == 0) ? 1.f : 0.f;
+    res->n_correspondences = c;
+    if (c < 3) return LGR_OK;   // selectCorrespondences refuses (src/sac_prerejective_omp.cpp:36-42); identity, not converged
+    uint64_t seed = p->fix_seed ? 566ull : p->seed;
+    Packed pk;
+    LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+    int max_iterations = std::min(comb_or_max(c, p->n_samples), p->max_iterations);
+    int batch = std::max(1, p->ransac_batch);
+    int bound = max_iterations, done = 0, largest = 0, num_rejections = 0, best_iter = -1;
+    float final_metric = 0.f;
+    float* d_best;   // device copy of the best transform so far
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &d_best));
+    {
+        float I[16];
+        for (int i = 0; i < 16; ++i) I[i] = (i % 5 == 0) ? 1.f : 0.f;
+        LGR_HIP(ctx, hipMemcpyAsync(d_best, I, 64, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    BatchBuffers b;
+    LGR_TRY(batch_buffers(ctx, std::min(batch, std::max(max_iterations, 1)), &b));
+    while (done < bound) {
+        int nb = std::min(batch, max_iterations - done);
+        int n_ok = 0, n_cand = 0;
+        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand));
+        num_rejections += nb - n_ok;
+        if (n_cand > 0) {
+            LGR_HIP(ctx, hipMemsetAsync(b.st, 0, sizeof(BatchStats), ctx->stream));
+            reduce_kernel<<<std::min(cdiv(n_cand, 256), 64), 256, 0, ctx->stream>>>(b.list2, n_cand, b.metric, b.ninl, b.list, b.counts, n_ok, b.st);
+            support_kernel<<<std::min(cdiv(n_ok, 256), 64), 256, 0, ctx->stream>>>(b.list, b.counts, n_ok, b.st);
+            BatchStats* hs;
+            LGR_TRY(lgr_pinned(ctx, sizeof(BatchStats), (void**) &hs));
+            LGR_HIP(ctx, hipMemcpyAsync(hs, b.st, sizeof(BatchStats), hipMemcpyDeviceToHost, ctx->stream));
+            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            BatchStats s = *hs;
+            if (s.best_key) {
+                unsigned mb = (unsigned) (s.best_key >> 32);
+                float m;
+                memcpy(&m, &mb, 4);
+                int off = (int) (0xffffffffu - (unsigned) (s.best_key & 0xffffffffu));
+                if (final_metric < m) {   // src/sac_prerejective_omp.cpp:232-235 / :251-254
+                    final_metric = m; best_iter = done + off;
+                    LGR_HIP(ctx, hipMemcpyAsync(d_best, b.Ts + (size_t) off * 16, 64, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+            }
+            if (s.rec_key) {
+                int rec_inl = (int) (s.rec_key >> 32);
+                if (rec_inl > largest) {   // :224-228
+                    largest = rec_inl;
+                    bound = std::min(bound, est_from_support(s.rec_support, c, p->confidence, p->n_samples));
+                }
+            }
+        }
+        done += nb;
+        if (done >= max_iterations) break;
+    }
+    // :265-296 final re-estimation
+    uint8_t* d_mask = d_final_mask;
+    if (!d_mask) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASK, (size_t) c + 16, &d_mask));
+    EvalOut e;
+    LGR_TRY(evaluate_one(ctx, d_best, pk, c, p->metric_id, p->score_id, d_mask, &e));
+    bool enough = e.n_inl > MIN_NR_FINAL_INLIERS || (float) e.n_inl > MIN_INLIER_RATE * (float) c;
+    float min_tol = p->metric_id == LGR_METRIC_UNIFORMITY ? 0.3f : 0.0f;   // include/metric.h:97-99 / 73-75
+    bool converged = enough && e.metric > min_tol;
+    float* d_Tn = d_best + 16;
+    refit_kernel<<<1, 64, 0, ctx->stream>>>(pk.P0, pk.P1, d_mask, c, d_Tn);
+    EvalOut e2;
+    LGR_TRY(evaluate_one(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, &e2));
+    float* hT;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &hT));
+    LGR_HIP(ctx, hipMemcpyAsync(hT, d_Tn, 64, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(res->transformation, hT, 64);
+    res->iterations = done;
+    res->converged = converged ? 1 : 0;
+    res->n_inliers = e2.n_inl;
+    res->metric = e2.metric;
+    res->best_metric_before_refit = final_metric;
+    res->best_iteration = best_iter;
+    res->num_rejections = num_rejections;
+    res->estimated_iters = bound;
+    res->time_te = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return LGR_OK;
+}
+
+extern "C" int lgr_ransac(lgr_ctx* ctx, const float* src, int ns, const float* tgt, int nt, const lgr_corr* corr, int c,
+                          const lgr_params* p, lgr_result* res, uint8_t* final_mask) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, src && tgt && (corr || c == 0) && res && ns > 0 && nt > 0 && c >= 0, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    float *ds, *dt;
+    lgr_corr* dc;
+    uint8_t* dm;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) ns * 12, &ds));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_B, (size_t) nt * 12, &dt));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_C, (size_t) c + 1, &dc));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_D, (size_t) c + 16, &dm));
+    LGR_HIP(ctx, hipMemcpyAsync(ds, src, (size_t) ns * 48, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(dt, tgt, (size_t) nt * 48, hipMemcpyHostToDevice, ctx->stream));
+    if (c) LGR_HIP(ctx, hipMemcpyAsync(dc, corr, (size_t) c * 16, hipMemcpyHostToDevice, ctx->stream));
+    LGR_TRY(lgr_ransac_dev(ctx, ds, ns, dt, nt, dc, c, p, res, dm));
+    if (final_mask && c >= 3) {
+        LGR_HIP(ctx, hipMemcpyAsync(final_mask, dm, (size_t) c, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (final_mask && c > 0) memset(final_mask, 0, c);
+    return LGR_OK;
+}
+
+extern "C" int lgr_refit_svd_dev(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c,
+                                 const uint8_t* d_mask, float T16[16]) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && T16 && c >= 0, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    float4* P;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_PACK, (size_t) c * 2 + (size_t) (c + 3) / 4 + 4, &P));
+    Packed pk{P, P + c, (float*) (P + 2 * (size_t) c)};
+    if (c > 0) pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, pk.P0, pk.P1, pk.sstar);
+    float* dT;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &dT));
+    refit_kernel<<<1, 64, 0, ctx->stream>>>(pk.P0, pk.P1, d_mask, c, dT);
+    float* hT;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &hT));
+    LGR_HIP(ctx, hipMemcpyAsync(hT, dT, 64, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(T16, hT, 64);
+    return LGR_OK;
+}
+
+extern "C" int lgr_refit_svd(lgr_ctx* ctx, const float* src, const float* tgt, int ns, int nt, const lgr_corr* inliers, int n, float T16[16]) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, src && tgt && (inliers || n == 0) && T16 && ns > 0 && nt > 0 && n >= 0, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    float *ds, *dt;
+    lgr_corr* dc;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) ns * 12, &ds));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_B, (size_t) nt * 12, &dt));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_C, (size_t) n + 1, &dc));
+    LGR_HIP(ctx, hipMemcpyAsync(ds, src, (size_t) ns * 48, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(dt, tgt, (size_t) nt * 48, hipMemcpyHostToDevice, ctx->stream));
+    if (n) LGR_HIP(ctx, hipMemcpyAsync(dc, inliers, (size_t) n * 16, hipMemcpyHostToDevice, ctx->stream));
+    return lgr_refit_svd_dev(ctx, ds, dt, dc, n, nullptr, T16);
+}
+
+// src/hypotheses.cpp:14-48 updateHypotheses: pure host bookkeeping (the call sites are compiled out in the reference,
+// SAVE_MULTIPLE_HYPOTHESES false, src/sac_prerejective_omp.cpp:11); tns16 = n column-major 4x4, capacity cap.
+extern "C" int lgr_update_hypotheses(float* tns16, float* metrics, int n, int cap, const float* new_T16, float new_metric, float distance_thr) {
+    if (!tns16 || !metrics || !new_T16 || n < 0 || cap < n) return LGR_ERR_INVALID_ARG;
+    auto diff = [](const float* T1, const float* T2, float& angle, float& td) {
+        // src/analysis.cpp:19-24: angle of R1^-1 R2, |t1 - t2|
+        double R[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += (double) T1[4 * i + k] * (double) T2[4 * j + k];
+                R[3 * i + j] = s;
+            }
+        double tr = R[0] + R[4] + R[8];
+        double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+        angle = (float) std::atan2(0.5 * std::sqrt(vx * vx + vy * vy + vz * vz), 0.5 * (tr - 1.0));
+        double dx = (double) T1[12] - T2[12], dy = (double) T1[13] - T2[13], dz = (double) T1[14] - T2[14];
+        td = (float) std::sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    std::vector<std::vector<float>> T(n, std::vector<float>(16));
+    std::vector<float> M(metrics, metrics + n);
+    for (int i = 0; i < n; ++i) memcpy(T[i].data(), tns16 + 16 * (size_t) i, 64);
+    float best = n == 0 ? 0.f : *std::max_element(M.begin(), M.end());
+    auto flush = [&]() {
+        int m = (int) T.size();
+        if (m > cap) return (int) LGR_ERR_INVALID_ARG;
+        for (int i = 0; i < m; ++i) { memcpy(tns16 + 16 * (size_t) i, T[i].data(), 64); metrics[i] = M[i]; }
+        return m;
+    };
+    if (new_metric < 0.1 * best) return flush();
+    std::vector<int> similar;
+    for (int i = (int) T.size() - 1; i >= 0; --i) {
+        float r, t;
+        diff(new_T16, T[i].data(), r, t);
+        bool is_similar = r < (M_PI / 9) && t < 20 * distance_thr;
+        if (is_similar) similar.push_back(i);
+        if (is_similar && M[i] > new_metric) return flush();
+    }
+    for (int idx : similar) { T.erase(T.begin() + idx); M.erase(M.begin() + idx); }
+    T.emplace_back(new_T16, new_T16 + 16);
+    M.push_back(new_metric);
+    if (new_metric > best)
+        for (int i = (int) T.size() - 1; i >= 0; --i)
+            if (M[i] < 0.1 * new_metric) { T.erase(T.begin() + i); M.erase(M.begin() + i); }
+    return flush();
+}

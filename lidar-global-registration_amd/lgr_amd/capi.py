@@ -205,3 +205,81 @@ class Context:
         out = np.zeros((kps.shape[0], 33), np.float32)
         self.check(_lib.lgr_fpfh(self.h, _ptr(kps), kps.shape[0], _ptr(surf), surf.shape[0], C.c_float(radius), _ptr(out)))
         return out
+
+    # ---- filters / correspondence search -------------------------------------------------------------------
+    def filter(self, matching_id, src, tgt, ij, dij, ji, dji, distance_thr, cluster_k=40):
+        out = self.empty((src.shape[0], 4), self.torch.int32)
+        n = C.c_int(0)
+        self.check(_lib.lgr_filter_dev(self.h, int(matching_id), _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0],
+                                       _ptr(ij), _ptr(dij), _ptr(ji), _ptr(dji), C.c_float(distance_thr), int(cluster_k),
+                                       _ptr(out), C.byref(n)))
+        return out[: n.value].cpu().numpy().view(CORR_DTYPE).reshape(-1)
+
+    def correspondences(self, src, tgt, params):
+        out = self.empty((src.shape[0], 4), self.torch.int32)
+        n = C.c_int(0)
+        self.check(_lib.lgr_correspondences_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], C.byref(params),
+                                                _ptr(out), C.byref(n)))
+        return out[: n.value]
+
+    def stage_ms(self):
+        out = (C.c_float * 12)()
+        _lib.lgr_ctx_stage_ms(self.h, out)
+        return list(out)
+
+    # ---- RANSAC ---------------------------------------------------------------------------------------------
+    def _corr_dev(self, corr):
+        if isinstance(corr, np.ndarray):
+            return self.torch.from_numpy(np.ascontiguousarray(corr).view(np.int32).reshape(-1, 4)).to(self._dev())
+        return corr
+
+    def ransac_samples(self, seed, first, n, n_corr):
+        out = self.empty((n, 3), self.torch.int32)
+        self.check(_lib.lgr_ransac_samples_dev(self.h, C.c_uint64(seed), int(first), int(n), int(n_corr), _ptr(out)))
+        return out
+
+    def evaluate(self, src, tgt, corr, T, metric_id=METRIC_UNIFORMITY, score_id=SCORE_MSE):
+        corr = self._corr_dev(corr)
+        c = corr.shape[0]
+        mask = self.empty((max(c, 1),), self.torch.uint8)
+        T16 = (C.c_float * 16)(*np.asarray(T, np.float32).T.reshape(16).tolist())
+        ni, rm, me = C.c_int(0), C.c_float(0), C.c_float(0)
+        self.check(_lib.lgr_evaluate_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), c, T16,
+                                         int(metric_id), int(score_id), _ptr(mask), C.byref(ni), C.byref(rm), C.byref(me)))
+        return mask[:c].cpu().numpy(), ni.value, rm.value, me.value
+
+    def ransac_replay(self, src, tgt, corr, params, triples):
+        torch = self.torch
+        corr = self._corr_dev(corr)
+        n = triples.shape[0]
+        ok = self.empty((n,), torch.uint8); Ts = self.empty((n, 16), torch.float32)
+        ninl = self.empty((n,), torch.int32); met = self.empty((n,), torch.float32)
+        self.check(_lib.lgr_ransac_replay_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), corr.shape[0],
+                                              C.byref(params), _ptr(triples), n, _ptr(ok), _ptr(Ts), _ptr(ninl), _ptr(met)))
+        return ok.cpu().numpy(), Ts.cpu().numpy(), ninl.cpu().numpy(), met.cpu().numpy()
+
+    def ransac(self, src, tgt, corr, params):
+        corr = self._corr_dev(corr)
+        c = corr.shape[0]
+        res = Result()
+        mask = self.empty((max(c, 1),), self.torch.uint8)
+        self.check(_lib.lgr_ransac_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), c,
+                                       C.byref(params), C.byref(res), _ptr(mask)))
+        return res, mask[:c].cpu().numpy()
+
+    def refit(self, src, tgt, corr, mask=None):
+        corr = self._corr_dev(corr)
+        T = (C.c_float * 16)()
+        self.check(_lib.lgr_refit_svd_dev(self.h, _ptr(src), _ptr(tgt), _ptr(corr), corr.shape[0], _ptr(mask), T))
+        return np.array(T, np.float32).reshape(4, 4).T.copy()
+
+    def align(self, src, tgt, params):
+        res = Result()
+        self.check(_lib.lgr_align_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], C.byref(params), C.byref(res)))
+        return res
+
+    def align_host(self, src, tgt, params):
+        src = np.ascontiguousarray(src, np.float32); tgt = np.ascontiguousarray(tgt, np.float32)
+        res = Result()
+        self.check(_lib.lgr_align(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], C.byref(params), C.byref(res)))
+        return res
