@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- scan-pair registrations/s on the BASELINE.json workload (synthetic 1M-point pair, 1xMI355X per rank).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one alignPointClouds-equivalent (lgr_align_dev: voxel downsample -> k-NN normals -> FPFH -> brute-force
+matching both ways -> match filter -> prerejective RANSAC -> SVD refit) over one synthetic scan pair whose clouds
+are already resident in HBM.  Scan pairs shard across ranks (one independent pair per rank, weak scaling); the only
+collective is one all-gather of the 96-byte per-pair result record per step (RCCL when N > 1).
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  "roofline"     : the dominant kernel (match_mfma, fp32 MFMA distance filter): algorithmic FLOP per launch
+                   (69 * Mq * Mt) / launch duration measured with hipEvents on the launch stream,
+                   against the dense fp32 MFMA peak of MI355X (157.3 TFLOP/s);
+  "cpu_baseline" : the CPU oracle ("port": the reference itself needs PCL/OpenCV and cannot be built here) timed on
+                   this host on a bounded sample of the same workload, extrapolated linearly where the stage is
+                   linear in the sampled dimension (the sample is stated in the object).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lidar-global-registration_amd"))
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=1_000_000, help="points per cloud (BASELINE config 2: 1e6)")
+    ap.add_argument("--matching", default="lr", choices=["lr", "cluster", "one_sided"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def make_params(capi, pair, matching):
+    mid = {"lr": capi.MATCH_LR, "cluster": capi.MATCH_CLUSTER, "one_sided": capi.MATCH_ONE_SIDED}[matching]
+    # SURVEY 8d / BASELINE.md config 2 profile (data/tests.yaml values where the yaml sets them)
+    return capi.default_params(matching_id=mid, metric_id=capi.METRIC_UNIFORMITY, score_id=capi.SCORE_MSE,
+                               feature_radius=0.25, feature_nr_points=352, normal_nr_points=30, bf_block_size=200000,
+                               edge_thr_coef=0.95, confidence=0.999, max_iterations=1000000, distance_thr=0.1,
+                               vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
+
+
+def cpu_baseline(pair, gpu_corr, args, matching):
+    """Oracle timed on the host cores on a bounded sample of the SAME 1M-point pair (see module docstring)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as o
+    o.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    o.set_num_threads(cores)
+    src, tgt = pair["src"], pair["tgt"]
+    n = src.shape[0]
+    budget = args.cpu_seconds
+    t = {}
+    # voxel / radius exactly as the pipeline derives them (include/matching.h:172,230-231)
+    r = 0.25
+    voxel = float(np.sqrt(np.pi * r * r / 352.0).astype(np.float32))
+    t0 = time.time(); ds = o.downsample(src, voxel); t["downsample"] = 2 * (time.time() - t0)
+    # normals: a prefix sample of the surface, searched in the full surface (linear in the number of queries)
+    ns = min(ds.shape[0], 40000)
+    t0 = time.time(); o.normals_knn(ds[:ns], 30, surf=ds, vp=pair["vp_src"]); t["normals"] = 2 * (time.time() - t0) * ds.shape[0] / ns
+    dsn = o.normals_knn(ds[: min(ds.shape[0], 60000)], 30, vp=pair["vp_src"])   # oriented normals for the FPFH sample
+    # FPFH on a spatially compact sub-scene (surface prefix is in (z,y,x) voxel order, so take a slab of keypoints)
+    nk = 20000
+    slab = dsn
+    kp_sel = src[:nk]
+    t0 = time.time(); f_s = o.fpfh(kp_sel, slab, r); dt = time.time() - t0
+    # cost model: SPFH is linear in surface points, weighting linear in keypoints; measured together on the slab
+    t["fpfh"] = 2 * dt * max(n / nk, ds.shape[0] / slab.shape[0])
+    # matching: S sampled queries against the full train set of real FPFH rows (O(M) per query), both directions
+    rng = np.random.default_rng(0)
+    feat_t = np.tile(f_s[~np.isnan(f_s).any(1)], (n // max(1, (~np.isnan(f_s).any(1)).sum()) + 1, 1))[:n]
+    feat_t = (feat_t + rng.normal(0, 0.5, feat_t.shape)).astype(np.float32)
+    S = 256
+    t0 = time.time(); o.match_bf_subset(feat_t, np.arange(S, dtype=np.int32), feat_t, 200000); dt = time.time() - t0
+    S2 = int(max(S, min(8192, S * (0.45 * budget) / max(dt, 1e-3))))
+    t0 = time.time(); o.match_bf_subset(feat_t, np.arange(S2, dtype=np.int32), feat_t, 200000); dt = time.time() - t0
+    n_dir = 1 if matching == "one_sided" else 2
+    t["match"] = n_dir * dt * n / S2
+    # filter thresholds (two k=2 density passes over 1M points): prefix sample
+    nd = 100000
+    t0 = time.time(); o.smoothed_densities(src[:nd], 2); t["filter"] = 2 * (time.time() - t0) * n / nd
+    # RANSAC on the correspondences the GPU produced for this pair, Philox schedule, first batches, scaled by iterations
+    corr = np.zeros(gpu_corr.shape[0], o.CORR_DTYPE)
+    corr["query"] = gpu_corr["index_query"]; corr["match"] = gpu_corr["index_match"]
+    corr["distance"] = gpu_corr["distance"]; corr["threshold"] = gpu_corr["threshold"]
+    it_sample = 16384
+    p = o.default_params(rng_mode=o.RNG_PHILOX, metric_id=o.METRIC_UNIFORMITY, max_iterations=it_sample, batch_size=16384)
+    t0 = time.time(); res, _ = o.ransac(src, tgt, corr, p); dt = time.time() - t0
+    t["ransac_sample_iters"] = res.iterations
+    t["ransac"] = dt
+    total = sum(v for k, v in t.items() if k not in ("ransac_sample_iters",))
+    return t, total, cores, S2
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the product and has no CPU fallback")
+    torch.cuda.set_device(local)
+    from lgr_amd import capi, synthetic
+    ctx = capi.Context(local)
+
+    pair = synthetic.make_pair(args.points, seed=synthetic.SEED + rank)
+    params = make_params(capi, pair, args.matching)
+    src = torch.from_numpy(pair["src"]).cuda(local)
+    tgt = torch.from_numpy(pair["tgt"]).cuda(local)
+    record = torch.zeros(24, dtype=torch.float32, device=f"cuda:{local}")   # 96-byte per-pair record
+    gathered = [torch.zeros_like(record) for _ in range(world)] if world > 1 else None
+
+    def step():
+        res = ctx.align(src, tgt, params)
+        rec = np.zeros(24, np.float32)
+        rec[:16] = np.array(res.transformation, np.float32)
+        rec[16:21] = [res.converged, res.iterations, res.n_inliers, res.time_cs, res.time_te]
+        record.copy_(torch.from_numpy(rec))
+        if world > 1:
+            dist.all_gather(gathered, record)     # the single RCCL collective of the path
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, stage_ms = [], []
+    for _ in range(args.steps):
+        res = step()
+        kernel_ms.append(ctx.match_kernel_ms())
+        mstats = ctx.match_stats()
+        stage_ms.append(list(res.stage_ms)[:7])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        n_dir = 1 if args.matching == "one_sided" else 2
+        m = args.points
+        # matching = 69 * Mq * Mt FLOP (2*33 MAC + 3 for norm add / compare); one launch serves both directions
+        alg_flop = 69.0 * m * m
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg_flop / (k_ms * 1e-3) / 1e12
+        T = res.matrix()
+        err = float(np.abs(T.astype(np.float64) - pair["T_gt"]).max())
+        out = {
+            "metric": "scan-pair registrations/sec", "value": world * args.steps / elapsed, "unit": "registrations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 1M-pt pair, random SE(3) + Gaussian noise (5 mm), FPFH r=0.25 m",
+                       "points_per_cloud": m, "pairs_per_step": world, "matching": args.matching, "metric_id": "uniformity",
+                       "bf_block_size": 200000, "max_iterations": 1000000, "parallelism": f"pairs sharded over {world} GPU(s)"},
+            "roofline": {"kernel": "match_mfma<both directions>", "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": k_ms, "rerank": mstats, "algorithmic_flop_per_launch": alg_flop, "directions_per_launch": n_dir},
+            "stage_ms": dict(zip(["downsample", "normals", "fpfh", "match", "filter", "ransac", "refit"],
+                                 [float(x) for x in np.mean(np.array(stage_ms), 0)])),
+            "result": {"converged": int(res.converged), "iterations": int(res.iterations), "n_correspondences": int(res.n_correspondences),
+                       "n_inliers": int(res.n_inliers), "max_abs_err_vs_gt": err},
+        }
+        if not args.no_cpu_baseline:
+            corr = ctx.correspondences(src, tgt, params).cpu().numpy().view(capi.CORR_DTYPE).reshape(-1)
+            t, total, cores, S2 = cpu_baseline(pair, corr, args, args.matching)
+            out["cpu_baseline"] = {
+                "value": 1.0 / total, "unit": "registrations/s", "cores": cores, "kind": "port",
+                "sample": (f"same 1M-pt pair; downsample full; normals 40k-query sample; FPFH 20k keypoints on a 60k-point slab; "
+                           f"matching {S2} sampled queries x 1M train rows x {n_dir} direction(s), scaled by M/S; density filter 100k prefix; "
+                           f"RANSAC first {t['ransac_sample_iters']} iterations (not scaled up)"),
+                "seconds_per_pair_estimate": total, "stage_seconds": {k: float(v) for k, v in t.items()},
+            }
+            out["speedup_vs_cpu_baseline"] = out["value"] / (world * out["cpu_baseline"]["value"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,11 @@ int lgr_match_bf_dev(lgr_ctx*, const float* d_q33, int mq, const float* d_t33, i
 int lgr_match_bf2_dev(lgr_ctx*, const float* d_a33, int ma, const float* d_b33, int mb, int block,
                       int32_t* d_ab_idx, float* d_ab_dist, int32_t* d_ba_idx, float* d_ba_dist);
 
+/* diagnostics of the last match call: [items_ab, dense_ab, items_ba, dense_ba, sub_cols, rg_rows] and the duration of
+ * its MFMA filter kernel (hipEvents on the ctx stream) -- what bench.py's roofline object is computed from */
+int lgr_match_last_stats(unsigned* out6);
+int lgr_match_last_kernel_ms(lgr_ctx*, float* ms);
+
 /* ---- src/common.cpp:531-547 calculateSmoothedDensities(pcd, k) / :202-208 calculatePointCloudDensity ---- */
 int lgr_smoothed_densities(lgr_ctx*, const float* pts, int n, int k, float* out);
 int lgr_smoothed_densities_dev(lgr_ctx*, const float* d_pts, int n, int k, float* d_out);

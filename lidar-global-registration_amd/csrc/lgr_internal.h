@@ -29,6 +29,7 @@ struct lgr_ctx {
     hipEvent_t ev[16];
     float stage_ms[12];
     int n_cu = 256;
+    int mfma_timed = 0;
 };
 
 int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line);

@@ -8,6 +8,11 @@ import os
 
 import numpy as np
 
+try:   # torch ships its own HIP runtime: it must be loaded BEFORE liblgr_hip.so pulls in libamdhip64
+    import torch as _torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    _torch = None
+
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
 LIB_PATH = os.path.join(_CSRC, "liblgr_hip.so")
 
@@ -157,6 +162,11 @@ class Context:
         out = (C.c_uint * 6)()
         _lib.lgr_match_last_stats(out)
         return dict(items_ab=out[0], dense_ab=out[1], items_ba=out[2], dense_ba=out[3], sub_cols=out[4], rg_rows=out[5])
+
+    def match_kernel_ms(self):
+        ms = C.c_float(0)
+        self.check(_lib.lgr_match_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
 
     # ---- geometry stages ------------------------------------------------------------------------------------
     def bbox(self, pts):

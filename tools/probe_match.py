@@ -18,4 +18,4 @@ for m in [int(a) for a in sys.argv[1:]] or [100000, 400000]:
         torch.cuda.synchronize(); t = time.time()
         r = ctx.match_bf2(a, b, 200000); ctx.sync()
         dt = time.time() - t
-        print(f"m={m} it={it} bf2 {dt*1e3:.1f} ms  {69.0*m*m/dt/1e12:.1f} TFLOP/s(alg)  stats={ctx.match_stats()}", flush=True)
+        print(f"m={m} it={it} bf2 {dt*1e3:.1f} ms  {69.0*m*m/dt/1e12:.1f} TFLOP/s(alg)  stats={ctx.match_stats()} kernel_ms={ctx.match_kernel_ms():.1f}", flush=True)
