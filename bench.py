@@ -121,24 +121,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the product and has no CPU fallback")
     torch.cuda.set_device(local)
-    from lgr_amd import capi, synthetic
+    from lgr_amd import capi, synthetic, distributed
     ctx = capi.Context(local)
 
     pair = synthetic.make_pair(args.points, seed=synthetic.SEED + rank)
     params = make_params(capi, pair, args.matching)
     src = torch.from_numpy(pair["src"]).cuda(local)
     tgt = torch.from_numpy(pair["tgt"]).cuda(local)
-    record = torch.zeros(24, dtype=torch.float32, device=f"cuda:{local}")   # 96-byte per-pair record
-    gathered = [torch.zeros_like(record) for _ in range(world)] if world > 1 else None
+    record = torch.zeros((1, distributed.RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{local}")   # 96-byte per-pair record
 
     def step():
         res = ctx.align(src, tgt, params)
-        rec = np.zeros(24, np.float32)
-        rec[:16] = np.array(res.transformation, np.float32)
-        rec[16:21] = [res.converged, res.iterations, res.n_inliers, res.time_cs, res.time_te]
-        record.copy_(torch.from_numpy(rec))
-        if world > 1:
-            dist.all_gather(gathered, record)     # the single RCCL collective of the path
+        rec = distributed.pack_record(rank, res.transformation, res.converged, res.iterations, res.n_inliers, res.time_cs, res.time_te)
+        record.copy_(torch.from_numpy(rec)[None])
+        distributed.gather_records(record, world)     # the single collective of the path (RCCL all-gather when N > 1)
         return res
 
     def barrier():

@@ -1,0 +1,91 @@
+"""Host-side logic that needs no GPU: synthetic generator, pair sharding, record packing, and the N > 1 path
+(world_size 2 over gloo): shard -> per-pair record -> ONE all_gather -> every rank holds every pair's record."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lidar-global-registration_amd"))
+from lgr_amd import distributed, synthetic  # noqa: E402
+
+
+def test_synthetic_pair_is_deterministic_and_consistent():
+    a = synthetic.make_pair(5000, seed=9)
+    b = synthetic.make_pair(5000, seed=9)
+    np.testing.assert_array_equal(a["src"], b["src"])
+    np.testing.assert_array_equal(a["tgt"], b["tgt"])
+    assert a["src"].shape == (5000, 12) and a["src"].dtype == np.float32
+    assert (a["src"][:, 3] == 1).all() and (a["src"][:, 8] == 1).all() and (a["src"][:, 4:8] == 0).all()
+    T = a["T_gt"]
+    assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12) and np.linalg.det(T[:3, :3]) > 0
+    # the overlap really overlaps: tgt mapped back to the scene frame shares the x range [1/3, 2/3] with src
+    back = (a["tgt"][:, :3].astype(np.float64) - T[:3, 3]) @ T[:3, :3]
+    lx = 24.0 * a["scale"]
+    assert back[:, 0].min() < 0.4 * lx and a["src"][:, 0].max() > 0.6 * lx
+
+
+def test_correspondence_problem_inlier_fraction():
+    pr = synthetic.make_correspondence_problem(n_pts=4000, c=1000, inlier_frac=0.4, sigma=0.001, thr=0.05, seed=2)
+    s = pr["src"][pr["corr"]["index_query"], :3].astype(np.float64)
+    t = pr["tgt"][pr["corr"]["index_match"], :3].astype(np.float64)
+    d = np.linalg.norm(s @ pr["T_gt"][:3, :3].T + pr["T_gt"][:3, 3] - t, axis=1)
+    assert abs((d < 0.05).mean() - 0.4) < 0.03
+
+
+@pytest.mark.parametrize("n,world", [(156, 8), (7, 2), (3, 4), (0, 2)])
+def test_shard_pairs_partition(n, world):
+    shards = [distributed.shard_pairs(n, world, r) for r in range(world)]
+    flat = sorted(x for s in shards for x in s)
+    assert flat == list(range(n))
+    assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+def test_record_roundtrip():
+    T = synthetic.random_se3(np.random.default_rng(0)).astype(np.float32)
+    rec = distributed.pack_record(17, T.T.reshape(16), 1, 123456, 789, 0.5, 0.25)
+    assert rec.nbytes == 96
+    u = distributed.unpack_record(rec)
+    np.testing.assert_array_equal(u["T"], T)
+    assert (u["converged"], u["iterations"], u["n_inliers"], u["pair_id"]) == (1, 123456, 789, 17)
+
+
+def _fake_align(pair_id):
+    T = synthetic.random_se3(np.random.default_rng(1000 + pair_id)).astype(np.float32)
+    return distributed.pack_record(pair_id, T.T.reshape(16), pair_id % 2, 10 * pair_id, pair_id + 5, 0.1, 0.2)
+
+
+def _worker(rank, world, port, n_pairs, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = distributed.run_pairs(n_pairs, world, rank, _fake_align)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_allgather():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_pairs, world = 7, 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([_fake_align(i) for i in range(n_pairs)])
+    for r in range(world):
+        np.testing.assert_array_equal(got[r], want)      # every rank holds every pair's record, ordered by pair id
+
+
+def test_single_rank_run_pairs():
+    out = distributed.run_pairs(5, 1, 0, _fake_align)
+    np.testing.assert_array_equal(out, np.stack([_fake_align(i) for i in range(5)]))
