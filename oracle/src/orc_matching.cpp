@@ -47,33 +47,43 @@ inline bool row_valid(const float* r) { for (int j = 0; j < 33; ++j) if (!std::i
 //   include/matching.h:594-634 matchBF: for each train block j: cv::batchDistance K=1 keeps the first minimum with a
 //   strict '<' on the int bit pattern of sqrt(d2) (NaN never enters) -> lowest index wins inside a block;
 //   src/common.cpp:517-529 updateMultivaluedCorrespondence inserts BEFORE an equal distance -> a later block wins ties.
-inline void match_one(const float* q, const float* t33, int mt, int block, int& best_idx, float& best_dist) {
-    best_idx = -1; best_dist = 0.f;
-    for (int j0 = 0; j0 < mt; j0 += block) {
-        int j1 = std::min(mt, j0 + block);
-        int bi = -1; float bd = std::numeric_limits<float>::max();   // batchDistance init: FLT_MAX / -1
-        for (int j = j0; j < j1; ++j) {
-            float d = std::sqrt(l2sqr33(q, t33 + 33 * (size_t) j));
-            if (d < bd) { bd = d; bi = j; }   // NaN compares false; for non-negative floats int-bit compare == float compare
-        }
-        if (bi < 0) continue;                 // matches[l] empty / queryIdx == -1
-        if (best_idx < 0 || !(best_dist < bd)) { best_idx = bi; best_dist = bd; }   // insert before >= entries, keep k=1
+// best match of one query inside one train block [j0, j1): cv::batchDistance K=1 keeps the first minimum with a
+// strict '<' on the int bit pattern of sqrt(d2) (NaN never enters) -> lowest index wins inside a block
+inline void block_best(const float* q, const float* t33, int j0, int j1, int& bi, float& bd) {
+    bi = -1; bd = std::numeric_limits<float>::max();   // batchDistance init: FLT_MAX / -1
+    for (int j = j0; j < j1; ++j) {
+        float d = std::sqrt(l2sqr33(q, t33 + 33 * (size_t) j));
+        if (d < bd) { bd = d; bi = j; }   // NaN compares false; for non-negative floats int-bit compare == float compare
     }
+}
+// src/common.cpp:517-529 updateMultivaluedCorrespondence with k = 1: inserts BEFORE an equal distance -> a later
+// block wins ties
+inline void merge_block(int bi, float bd, int& best_idx, float& best_dist) {
+    if (bi < 0) return;                   // matches[l] empty / queryIdx == -1
+    if (best_idx < 0 || !(best_dist < bd)) { best_idx = bi; best_dist = bd; }
 }
 }  // namespace
 
-extern "C" int orc_match_bf(const float* q33, int mq, const float* t33, int mt, int block, int* idx, float* dist) {
+// include/matching.h:594-634 matchBF: the reference loops train blocks INSIDE query blocks and lets OpenCV
+// parallelise over the query rows of one knnMatch call; the same loop order is kept here (one train block, 26 MB at
+// block_size 200000, stays cache resident while all queries visit it), results are independent of the query blocking.
+extern "C" int orc_match_bf_subset(const float* q33, const int* qsel, int nsel, const float* t33, int mt, int block, int* idx, float* dist) {
     if (block <= 0) return -1;
-#pragma omp parallel for schedule(dynamic, 16)
-    for (int i = 0; i < mq; ++i) match_one(q33 + 33 * (size_t) i, t33, mt, block, idx[i], dist[i]);
+    for (int s = 0; s < nsel; ++s) { idx[s] = -1; dist[s] = 0.f; }
+    for (int j0 = 0; j0 < mt; j0 += block) {
+        int j1 = std::min(mt, j0 + block);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int s = 0; s < nsel; ++s) {
+            int bi; float bd;
+            block_best(q33 + 33 * (size_t) (qsel ? qsel[s] : s), t33, j0, j1, bi, bd);
+            merge_block(bi, bd, idx[s], dist[s]);
+        }
+    }
     return 0;
 }
 
-extern "C" int orc_match_bf_subset(const float* q33, const int* qsel, int nsel, const float* t33, int mt, int block, int* idx, float* dist) {
-    if (block <= 0) return -1;
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int s = 0; s < nsel; ++s) match_one(q33 + 33 * (size_t) qsel[s], t33, mt, block, idx[s], dist[s]);
-    return 0;
+extern "C" int orc_match_bf(const float* q33, int mq, const float* t33, int mt, int block, int* idx, float* dist) {
+    return orc_match_bf_subset(q33, nullptr, mq, t33, mt, block, idx, dist);
 }
 
 // src/common.cpp:531-547 calculateSmoothedDensities: k-NN of point i (itself included, sorted by (d2, index));
