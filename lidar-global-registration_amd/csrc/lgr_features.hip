@@ -437,10 +437,9 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     float r2 = radius * radius;
     float* spfh;
     LGR_TRY(lgr_ws_t(ctx, WS_SPFH, (size_t) n * 33 + 64 + (size_t) n, &spfh));
-    uint8_t* need = (uint8_t*) (spfh + (size_t) n * 33 + 16);
-    LGR_HIP(ctx, hipMemsetAsync(need, 0, (size_t) n + 1, ctx->stream));
-    need_kernel<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, m, r2, need);
-    if (g.n > 0) spfh_kernel<<<cdiv(g.n, SB), SB, 0, ctx->stream>>>(g, r2, need, spfh);
+    // PCL computes SPFH only for surface points within r of some keypoint (spfh_indices); rows outside that set are
+    // never read by the weighting step, so computing all rows gives the same FPFH output and saves the marking pass.
+    if (g.n > 0) spfh_kernel<<<cdiv(g.n, SB), SB, 0, ctx->stream>>>(g, r2, nullptr, spfh);
     // keypoints in grid-cell order (locality of the SPFH row gathers)
     unsigned *keys, *keys2;
     int *vals, *vals2;

@@ -39,6 +39,8 @@ __global__ void bbox_kernel(const float* __restrict__ pts, int n, unsigned* __re
             qmx[a] = (qmx[a] < p[a]) ? p[a] : qmx[a];   // std::max(mx, p)
         }
     }
+    // wave reduce, then one LDS stage per block, then 12 atomics per BLOCK (the grid is small)
+    __shared__ float sh[4][12];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int o = 32; o > 0; o >>= 1) {
@@ -46,9 +48,17 @@ __global__ void bbox_kernel(const float* __restrict__ pts, int n, unsigned* __re
             qmn[a] = fminf(qmn[a], __shfl_xor(qmn[a], o)); qmx[a] = fmaxf(qmx[a], __shfl_xor(qmx[a], o));
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&out[a], fkey(tmn[a])); atomicMax(&out[3 + a], fkey(tmx[a]));
-            atomicMin(&out[6 + a], fkey(qmn[a])); atomicMax(&out[9 + a], fkey(qmx[a]));
+            int w = threadIdx.x >> 6;
+            sh[w][a] = tmn[a]; sh[w][3 + a] = tmx[a]; sh[w][6 + a] = qmn[a]; sh[w][9 + a] = qmx[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        int k = threadIdx.x;
+        bool is_min = (k < 3) || (k >= 6 && k < 9);
+        float v = sh[0][k];
+        for (int w = 1; w < (int) (blockDim.x >> 6); ++w) v = is_min ? fminf(v, sh[w][k]) : fmaxf(v, sh[w][k]);
+        if (is_min) atomicMin(&out[k], fkey(v)); else atomicMax(&out[k], fkey(v));
     }
 }
 
@@ -65,14 +75,17 @@ __global__ void cell_keys(const float* __restrict__ pts, int n, float ox, float 
     keys[i] = k; vals[i] = i;
 }
 
-// cell_start[c] = first sorted position whose key >= c  (keys sorted ascending; invalid keys == ncell at the end)
-__global__ void cell_starts(const unsigned* __restrict__ keys, int n, int ncell, int* __restrict__ start) {
+// counts[c] = number of sorted entries with key c (written once, by the thread at the run's first element);
+// cell_start = exclusive scan of counts (rocPRIM), so empty cells cost nothing
+__global__ void cell_counts(const unsigned* __restrict__ keys, int n, int ncell, int* __restrict__ counts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    unsigned k = i < n ? min(keys[i], (unsigned) ncell) : (unsigned) ncell;
-    unsigned kp = i > 0 ? min(keys[i - 1], (unsigned) ncell) : 0u;
-    unsigned lo = i > 0 ? kp + 1 : 0u;
-    for (unsigned c = lo; c <= k; ++c) start[c] = i;
+    if (i >= n) return;
+    unsigned k = keys[i];
+    if (k >= (unsigned) ncell) return;                  // invalid points (sorted last)
+    if (i > 0 && keys[i - 1] == k) return;              // not the head of its run
+    int j = i + 1;
+    while (j < n && keys[j] == k) ++j;
+    counts[k] = j - i;
 }
 
 __global__ void gather_points(const float* __restrict__ pts, const int* __restrict__ vals, int nvalid,
@@ -133,7 +146,7 @@ int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12) {
     memcpy(&kfmn, &fmn, 4); kfmn |= 0x80000000u;
     for (int a = 0; a < 3; ++a) { init[a] = pinf; init[3 + a] = ninf; init[6 + a] = kfmx; init[9 + a] = kfmn; }
     LGR_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
-    if (n > 0) bbox_kernel<<<std::min(cdiv(n, 256), ctx->n_cu * 8), 256, 0, ctx->stream>>>(d_pts, n, d);
+    if (n > 0) bbox_kernel<<<std::min(cdiv(n, 256), ctx->n_cu), 256, 0, ctx->stream>>>(d_pts, n, d);
     unsigned* h;
     LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
     LGR_HIP(ctx, hipMemcpyAsync(h, d, 48, hipMemcpyDeviceToHost, ctx->stream));
@@ -179,7 +192,7 @@ int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, flo
     unsigned *keys, *keys2;
     int *vals, *vals2, *start;
     float4 *pxyz, *pnrm;
-    LGR_TRY(lgr_ws_t(ctx, sb + 0, (size_t) n + 1, &keys));
+    LGR_TRY(lgr_ws_t(ctx, sb + 0, (size_t) std::max(n, ncell + 1) + 1, &keys));
     LGR_TRY(lgr_ws_t(ctx, sb + 1, (size_t) n + 1, &vals));
     LGR_TRY(lgr_ws_t(ctx, sb + 2, (size_t) n + 1, &keys2));
     LGR_TRY(lgr_ws_t(ctx, sb + 3, (size_t) n + 1, &vals2));
@@ -196,7 +209,14 @@ int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, flo
         void* tmp;
         LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tmp_bytes, &tmp));
         LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, bits, ctx->stream));
-        cell_starts<<<cdiv(n + 1, 256), 256, 0, ctx->stream>>>(keys2, n, ncell, start);
+        int* counts = (int*) keys;    // the unsorted key buffer is free again; ncell + 1 <= capacity is ensured below
+        LGR_HIP(ctx, hipMemsetAsync(counts, 0, ((size_t) ncell + 1) * 4, ctx->stream));
+        cell_counts<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys2, n, ncell, counts);
+        size_t sb = 0;
+        LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, sb, counts, start, 0, (size_t) ncell + 1, rocprim::plus<int>(), ctx->stream));
+        void* stmp;
+        LGR_TRY(lgr_ws(ctx, WS_GRID_MISC, std::max<size_t>(sb, 256) + 256, &stmp));
+        LGR_HIP(ctx, rocprim::exclusive_scan((char*) stmp + 256, sb, counts, start, 0, (size_t) ncell + 1, rocprim::plus<int>(), ctx->stream));
         int* h_n;
         LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_n));
         LGR_HIP(ctx, hipMemcpyAsync(h_n, start + ncell, 4, hipMemcpyDeviceToHost, ctx->stream));

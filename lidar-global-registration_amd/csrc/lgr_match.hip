@@ -180,6 +180,15 @@ __global__ void pack_kernel(const float* __restrict__ X, const int* __restrict__
     }
 }
 
+// original rows in padded (cluster-sorted) order, contiguous, for the exact rerank (padding rows are never read)
+__global__ void gather_rows_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, float* __restrict__ out) {
+    size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t) n_pad * 33) return;
+    int pos = (int) (e / 33), k = (int) (e % 33);
+    int o = perm[pos];
+    out[e] = o >= 0 ? X[(size_t) o * 33 + k] : 0.f;
+}
+
 // per-group maxima of sqrt(norm) (finite entries only): out[set][g]
 __global__ void group_max_kernel(const float* __restrict__ nrm, int n_pad, int group, float* __restrict__ out) {
     int g = blockIdx.x, set = blockIdx.y, n_groups = gridDim.x;
@@ -453,7 +462,7 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
 
 // 4b. one wave per (query position, train group) item: exact distances to the group's train rows (original arrays).
 __global__ __launch_bounds__(256) void rerank_items(const float* __restrict__ Q, const int* __restrict__ permQ,
-                                                    const float* __restrict__ T, const int* __restrict__ permT, int t_pad,
+                                                    const float* __restrict__ Tsorted, const int* __restrict__ permT, int t_pad,
                                                     int group_size, int block, int nblocks, const uint2* __restrict__ items,
                                                     unsigned n_items, unsigned long long* __restrict__ best) {
     int lane = threadIdx.x & 63;
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(256) void rerank_items(const float* __restrict__ Q,
             int to = permT[j];
             if (to < 0) continue;                // padding
             float t[33];
-            const float* tp = T + (size_t) to * 33;
+            const float* tp = Tsorted + (size_t) j * 33;   // same values as T[to], contiguous in padded order
 #pragma unroll
             for (int k = 0; k < 33; ++k) t[k] = tp[k];
             float d = exact_l2(q, t);
@@ -604,7 +613,7 @@ int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, int unit
 template <bool ROWDIR>
 int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, const float* Q, const Side& qs,
                const float* nQ, const float* nQ_sets, const float* gmax, const int* cl_of_group,
-               const float* T, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
+               const float* T, const float* Tsorted, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
                unsigned* stat_items, unsigned* stat_dense) {
     const int q_pad = qs.n_pad;
     unsigned* dense;
@@ -640,7 +649,7 @@ int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, c
         rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, 0, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
                                                                       thr, counts, offs, items);
         int grid = (int) std::min<unsigned>((n_items + 3) / 4, (unsigned) ctx->n_cu * 16);
-        rerank_items<<<grid, 256, 0, ctx->stream>>>(Q, qs.perm, T, ts.perm, ts.n_pad, group_size, block, nblocks, items, n_items, best);
+        rerank_items<<<grid, 256, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, block, nblocks, items, n_items, best);
     }
     if (n_dense) {
         dim3 g(std::min(cdiv(n_dense, 256), 64), cdiv(ts.m, DENSE_CHUNK));
@@ -694,9 +703,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     }
 
     // ---- 2. assign / sort / place, group sizes
-    auto pick_group = [](size_t q_count, size_t t_count) {   // table [t/g][q] floats kept under ~3 GB
+    auto pick_group = [](size_t q_count, size_t t_count) {   // table [t/g][q] floats kept under ~6 GB
         int g = 1024;
-        while (g < 4096 && (t_count / g + 1) * q_count * 4 > ((size_t) 3 << 30)) g *= 2;
+        while (g < 4096 && (t_count / g + 1) * q_count * 4 > ((size_t) 6 << 30)) g *= 2;
         return g;
     };
     int rg_rows = both ? pick_group((size_t) mb, (size_t) ma) : BLOCK_ROWS;   // row groups (column direction table)
@@ -753,10 +762,17 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_HIP(ctx, hipGetLastError());
 
     // ---- 5. exact rerank
-    LGR_TRY((run_rerank<true>(ctx, rowmin, n_sub, sub_cols, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, B, block, bestA,
+    float *sortedA = nullptr, *sortedB;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_B, (size_t) mb_pad * 33, &sortedB));
+    gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, sortedB);
+    if (both) {
+        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_A, (size_t) ma_pad * 33, &sortedA));
+        gather_rows_kernel<<<cdiv((long long) ma_pad * 33, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, sortedA);
+    }
+    LGR_TRY((run_rerank<true>(ctx, rowmin, n_sub, sub_cols, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
                               d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab)));
     if (both)
-        LGR_TRY((run_rerank<false>(ctx, colmin, n_rg, rg_rows, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, A, block, bestB,
+        LGR_TRY((run_rerank<false>(ctx, colmin, n_rg, rg_rows, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
                                    d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba)));
     return LGR_OK;
 }

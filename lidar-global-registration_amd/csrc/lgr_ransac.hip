@@ -291,7 +291,10 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
                 atomicAdd(&hist[(2 * 100 + b0) * 100 + b1], 1);
             }
         }
-        if (lst || uni) {
+        if (!lst) {
+            // uniformity without an ordered list: only the inlier count is needed (order-free)
+            if (in) atomicAdd(&s_count, 1);
+        } else {
             // ordered compaction of the inliers of this tile (block-wide exclusive scan of the flags)
             scan[threadIdx.x] = in ? 1 : 0;
             __syncthreads();
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
                 __syncthreads();
             }
             int pos = s_count + scan[threadIdx.x] - (in ? 1 : 0);
-            if (in && lst) lst[pos] = make_float2(dist, thr);
+            if (in) lst[pos] = make_float2(dist, thr);
             __syncthreads();
             if (threadIdx.x == MB - 1) s_count += scan[MB - 1];
             __syncthreads();
@@ -392,6 +395,17 @@ __global__ void support_kernel(const int* __restrict__ list, const int2* __restr
     int off = (int) (0xffffffffu - (unsigned) (rk & 0xffffffffu));
     for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
         if (list[h] == off) st->rec_support = counts[h].y;
+}
+
+// ordered compaction of the inlier pairs (mask -> flags -> exclusive scan -> scatter) ahead of the sequential refit
+__global__ void mask_flags_kernel(const uint8_t* __restrict__ mask, int c, int* __restrict__ flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) flags[i] = mask[i] ? 1 : 0;
+}
+__global__ void compact_pairs_kernel(const float4* __restrict__ P0, const float4* __restrict__ P1, const int* __restrict__ flags,
+                                     const int* __restrict__ pos, int c, float4* __restrict__ Q0, float4* __restrict__ Q1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c && flags[i]) { Q0[pos[i]] = P0[i]; Q1[pos[i]] = P1[i]; }
 }
 
 // ---------------------------------------------------------------------------------------------------- refit
@@ -489,6 +503,37 @@ int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const lgr
     if (c > 0)
         pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bb[6], bb[7], bb[8], bb[9], bb[10], bb[11],
                                                            out->P0, out->P1, out->sstar);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+// refit over the inliers flagged in d_mask (NULL: all pairs): compaction in correspondence order, then refit_kernel
+int refit_launch(lgr_ctx* ctx, const Packed& pk, int c, const uint8_t* d_mask, float* d_Tout) {
+    if (!d_mask || c == 0) {
+        refit_kernel<<<1, 64, 0, ctx->stream>>>(pk.P0, pk.P1, nullptr, c, d_Tout);
+        LGR_HIP(ctx, hipGetLastError());
+        return LGR_OK;
+    }
+    int* flags;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_HIST, (size_t) 2 * c + 16 + 8 * ((size_t) c + 4), &flags));
+    int* pos = flags + c;
+    float4* Q0 = (float4*) (flags + 2 * (size_t) c + 16 - ((2 * (size_t) c) & 3));
+    Q0 = (float4*) (((uintptr_t) (flags + 2 * (size_t) c) + 15) & ~(uintptr_t) 15);
+    float4* Q1 = Q0 + c;
+    mask_flags_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_mask, c, flags);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, flags, pos, 0, (size_t) c, rocprim::plus<int>(), ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
+    LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, flags, pos, 0, (size_t) c, rocprim::plus<int>(), ctx->stream));
+    compact_pairs_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(pk.P0, pk.P1, flags, pos, c, Q0, Q1);
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, pos + (c - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 1, flags + (c - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int n = h[0] + h[1];
+    refit_kernel<<<1, 64, 0, ctx->stream>>>(Q0, Q1, nullptr, n, d_Tout);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
@@ -749,7 +794,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     float min_tol = p->metric_id == LGR_METRIC_UNIFORMITY ? 0.3f : 0.0f;   // include/metric.h:97-99 / 73-75
     bool converged = enough && e.metric > min_tol;
     float* d_Tn = d_best + 16;
-    refit_kernel<<<1, 64, 0, ctx->stream>>>(pk.P0, pk.P1, d_mask, c, d_Tn);
+    LGR_TRY(refit_launch(ctx, pk, c, d_mask, d_Tn));
     EvalOut e2;
     LGR_TRY(evaluate_one(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, &e2));
     float* hT;
@@ -803,7 +848,7 @@ extern "C" int lgr_refit_svd_dev(lgr_ctx* ctx, const float* d_src, const float* 
     if (c > 0) pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, pk.P0, pk.P1, pk.sstar);
     float* dT;
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &dT));
-    refit_kernel<<<1, 64, 0, ctx->stream>>>(pk.P0, pk.P1, d_mask, c, dT);
+    LGR_TRY(refit_launch(ctx, pk, c, d_mask, dT));
     float* hT;
     LGR_TRY(lgr_pinned(ctx, 64, (void**) &hT));
     LGR_HIP(ctx, hipMemcpyAsync(hT, dT, 64, hipMemcpyDeviceToHost, ctx->stream));
