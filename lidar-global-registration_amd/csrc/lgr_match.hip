@@ -14,7 +14,8 @@
 //                     scales with (|a - c_p| + |b - c_p|)^2, i.e. it is tiny exactly for the near pairs that matter
 //                     (FPFH data is full of near-duplicate "flat surface" rows far from the global mean).
 //   3. match_mfma   : the brute-force contraction on v_mfma_f32_32x32x2_f32 with a fused epilogue that keeps only
-//                     min_b S per (row, column group) and min_a (S + |a'|^2) per (column, row group).  FILTER only.
+//                     min_b d2~ per (row, column group) and min_a d2~ per (column, row group), d2~ = S + |a'|^2.
+//                     FILTER only.
 //   4. rerank_*     : per query, a group is a candidate when its lower bound (value - proven error) does not exceed
 //                     the smallest upper bound; candidate groups are rescanned with the exact canonical distance and
 //                     a packed 64-bit atomicMin applies the reference's tie rules (order independent).
@@ -30,8 +31,9 @@ namespace {
 
 constexpr int KK = 17;              // K = 34 -> 17 MFMA steps of k = 2
 constexpr int TILE = 32;
-constexpr int RW = 2;               // row tiles per wave
-constexpr int WAVES = 4;
+constexpr int RW = 1;               // row tiles per wave
+constexpr int WAVES = 8;
+constexpr int NTHR = WAVES * 64;    // threads per workgroup of the MFMA kernel
 constexpr int BLOCK_ROWS = TILE * RW * WAVES;   // 256
 constexpr int RB_PER_SUPER = 16;
 constexpr int SUPER_ROWS = BLOCK_ROWS * RB_PER_SUPER;   // 4096
@@ -212,13 +214,15 @@ __global__ void group_max_kernel(const float* __restrict__ nrm, int n_pad, int g
 //    wave w of row block rb owns row tiles (rb*8 + 2w, +1); all waves share the column stage staged in LDS.
 //    The column operand set is chosen per row block: Bp + blkcl[rb] * bset_stride.
 template <bool COLDIR>
-__global__ __launch_bounds__(256) void match_mfma(const float* __restrict__ Ap, const float* __restrict__ Bp, size_t bset_stride,
-                                                  const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
-                                                  int sub_cols, int rg_rows,
-                                                  float* __restrict__ rowmin /* [mb_pad/sub_cols][ma_pad] */,
-                                                  float* __restrict__ colmin /* [ma_pad/rg_rows][mb_pad] */,
-                                                  int n_cc, int n_sr) {
-    __shared__ float Bs[STAGE_FLOATS];
+__global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ Ap, const float* __restrict__ Bp, size_t bset_stride,
+                                                     const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
+                                                     int sub_cols, int rg_rows,
+                                                     float* __restrict__ rowmin /* [mb_pad/sub_cols][ma_pad] */,
+                                                     float* __restrict__ colmin /* [ma_pad/rg_rows][mb_pad] */,
+                                                     int n_cc, int n_sr) {
+    // column stage double buffered in LDS: the next stage is prefetched into registers while the current one is
+    // consumed and written to the other buffer afterwards -> one barrier per stage, global latency hidden
+    __shared__ float Bs[2][STAGE_FLOATS];
     __shared__ unsigned cmin_s[CHUNK_COLS];
 
     // XCD-aware remap: workgroups that share a column chunk (the B operand) are placed on one XCD (speed only).
@@ -237,15 +241,16 @@ __global__ __launch_bounds__(256) void match_mfma(const float* __restrict__ Ap, 
     const int n_rb = min(RB_PER_SUPER, ma_pad / BLOCK_ROWS - rb0);
     const int rg_blocks = rg_rows / BLOCK_ROWS;
     const float INF = __uint_as_float(0x7f800000u);
+    constexpr int NPRE = (STAGE_FLOATS / 4 + NTHR - 1) / NTHR;   // float4 per thread per stage (5, the last one partial)
 
     if (COLDIR) {
-        for (int i = tid; i < CHUNK_COLS; i += 256) cmin_s[i] = 0xffffffffu;
+        for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = 0xffffffffu;
     }
 
     for (int rbi = 0; rbi < n_rb; ++rbi) {
         const int rb = rb0 + rbi;
         const int row_tile = rb * (BLOCK_ROWS / TILE) + wave * RW;
-        const float* Bset = Bp + (size_t) blkcl[rb] * bset_stride;
+        const float* Bset = Bp + (size_t) blkcl[rb] * bset_stride + (size_t) col_tile0 * KK * 64;
         // A fragments (coalesced 256-B loads) and the |a'|^2 of the 16 rows each lane's accumulators cover
         float a[RW][KK];
         float na[RW][16];
@@ -253,11 +258,9 @@ __global__ __launch_bounds__(256) void match_mfma(const float* __restrict__ Ap, 
         for (int r = 0; r < RW; ++r) {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) a[r][kk] = Ap[((size_t) (row_tile + r) * KK + kk) * 64 + lane];
-            if (COLDIR) {
 #pragma unroll
-                for (int g = 0; g < 16; ++g)
-                    na[r][g] = nA[(row_tile + r) * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
-            }
+            for (int g = 0; g < 16; ++g)
+                na[r][g] = nA[(row_tile + r) * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
         }
         float rmin[RW][16];
 #pragma unroll
@@ -265,45 +268,62 @@ __global__ __launch_bounds__(256) void match_mfma(const float* __restrict__ Ap, 
 #pragma unroll
             for (int g = 0; g < 16; ++g) rmin[r][g] = INF;
 
+        // stage 0 of this row block (barrier first: every wave is past the previous row block's LDS reads)
+        __syncthreads();
+        {
+            const float4* src = reinterpret_cast<const float4*>(Bset);
+            float4* dst = reinterpret_cast<float4*>(Bs[0]);
+            for (int i = tid; i < STAGE_FLOATS / 4; i += NTHR) dst[i] = src[i];
+        }
+        __syncthreads();
+
         for (int st = 0; st < n_stages; ++st) {
-            __syncthreads();
-            {
-                const float4* src = reinterpret_cast<const float4*>(Bset + ((size_t) (col_tile0 + st * STAGE_TILES)) * KK * 64);
-                float4* dst = reinterpret_cast<float4*>(Bs);
-                for (int i = tid; i < STAGE_FLOATS / 4; i += 256) dst[i] = src[i];
+            const int buf = st & 1;
+            const bool more = st + 1 < n_stages;
+            float4 pre[NPRE];
+            if (more) {
+                const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) (st + 1) * STAGE_FLOATS);
+#pragma unroll
+                for (int j = 0; j < NPRE; ++j) {
+                    int i = tid + NTHR * j;
+                    if (i < STAGE_FLOATS / 4) pre[j] = src[i];
+                }
             }
-            __syncthreads();
+            // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
+            // measured: removing the epilogue saved exactly its VALU time), so the epilogue is kept minimal:
+            // one add gives d2~ = S + |a'|^2 for both directions (a known-quiet value: no canonicalising v_max), one
+            // v_min per row slot, v_min3 pairs for the column chain, a VALU lane swap instead of an LDS shuffle.
+            // The B fragment of the next tile is fetched from LDS before the epilogue runs.
+            float b[KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
 #pragma unroll 1
             for (int ct = 0; ct < STAGE_TILES; ++ct) {
-                float b[KK];
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], b[0], zero, 0, 0, 0);
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[(ct * KK + kk) * 64 + lane];
-                f32x16 acc[RW];
+                for (int kk = 1; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b[kk], acc, 0, 0, 0);
+                if (ct + 1 < STAGE_TILES) {
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
+                    for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][((ct + 1) * KK + kk) * 64 + lane];
+                }
+                float v[16];
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) acc[r][g] = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                    for (int r = 0; r < RW; ++r)
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][kk], b[kk], acc[r], 0, 0, 0);
-                float cm = INF;
-#pragma unroll
-                for (int r = 0; r < RW; ++r)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        float s = acc[r][g];
-                        rmin[r][g] = __builtin_fminf(rmin[r][g], s);
-                        if (COLDIR) cm = __builtin_fminf(cm, s + na[r][g]);
-                    }
+                for (int g = 0; g < 16; ++g) { v[g] = acc[g] + na[0][g]; rmin[0][g] = __builtin_fminf(rmin[0][g], v[g]); }
                 if (COLDIR) {
-                    cm = __builtin_fminf(cm, __shfl_xor(cm, 32));
+                    float cm = __builtin_fminf(v[0], v[1]);
+#pragma unroll
+                    for (int g = 2; g < 16; g += 2) cm = __builtin_fminf(__builtin_fminf(cm, v[g]), v[g + 1]);
+                    // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
+                    unsigned ci = __float_as_uint(cm);
+                    auto sw = __builtin_amdgcn_permlane32_swap(ci, ci, false, false);
+                    float other = __uint_as_float(half ? sw[0] : sw[1]);
+                    cm = __builtin_fminf(cm, other);
                     if (lane < 32) atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + lane], f2key(cm));
                 }
             }
             // flush the row minima of this column group
-            if (((st + 1) % sub_stages) == 0 || st + 1 == n_stages) {
+            if (((st + 1) % sub_stages) == 0 || !more) {
                 int sub = (col_tile0 * TILE + st * STAGE_COLS) / sub_cols;
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
@@ -320,16 +340,25 @@ __global__ __launch_bounds__(256) void match_mfma(const float* __restrict__ Ap, 
                         rmin[r][g] = INF;
                     }
             }
+            if (more) {
+                float4* dst = reinterpret_cast<float4*>(Bs[buf ^ 1]);
+#pragma unroll
+                for (int j = 0; j < NPRE; ++j) {
+                    int i = tid + NTHR * j;
+                    if (i < STAGE_FLOATS / 4) dst[i] = pre[j];
+                }
+                __syncthreads();   // next buffer visible; all waves done with the buffer that is refilled next
+            }
         }
         if (COLDIR && (((rbi + 1) % rg_blocks) == 0 || rbi + 1 == n_rb)) {
             __syncthreads();
             int rg = (rb * BLOCK_ROWS) / rg_rows;
             int ncols = n_coltiles * TILE;
-            for (int i = tid; i < ncols; i += 256) {
+            for (int i = tid; i < ncols; i += NTHR) {
                 colmin[(size_t) rg * mb_pad + col_tile0 * TILE + i] = key2f(cmin_s[i]);
                 cmin_s[i] = 0xffffffffu;
             }
-            // the next iteration's first __syncthreads() orders these resets before any new atomicMin
+            // the next row block's first __syncthreads() orders these resets before any new atomicMin
         }
     }
 }
@@ -371,7 +400,7 @@ __device__ __forceinline__ unsigned tie_rank(int j, int block, int nblocks) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // 4a. candidate groups per query.  table[g][q_pad] holds, for padded query position i and train group g, the
-// filtered minimum v (row direction: S = d2 - |q'|^2; column direction: d2).  Proven bound of |filtered - true| for
+// filtered minimum v of d2~ = S + |a'|^2.  Proven bound of |filtered - true| for
 // every pair of (query i, group g)  (DESIGN.md "matcher margin"): centring (2 roundings) + fma chain of 34 products
 // + norm rounding + the column-direction add:  eps = 4 g40 (x + y)^2, g40 = 40u/(1-40u), u = 2^-24, where x, y are
 // |q - c| and the group's max |t - c| for the centre c the pair was computed with.
@@ -422,7 +451,7 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
         ub = fminf(ub, v + e);
     }
     if (!(ub < FLT_BIG)) return;     // no valid train row at all
-    double d2 = fmax(ROWDIR ? (double) ub + (double) nq : (double) ub, 0.0);
+    double d2 = fmax((double) ub, 0.0);   // both tables hold d2~ = S + |a'|^2
     float thr = (float) ((double) ub + 1e-5 * d2 + 8.0 * 5.9604644775390625e-8 * fabs((double) ub) + 1e-30);
     if (thr < ub) thr = ub;
     int nc = 0;
@@ -754,9 +783,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int n_cc = cdiv(mb_pad, CHUNK_COLS), n_sr = cdiv(ma_pad, SUPER_ROWS);
     (void) hipEventRecord(ctx->ev[9], ctx->stream);
     if (both)
-        match_mfma<true><<<n_cc * n_sr, 256, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, sub_cols, rg_rows, rowmin, colmin, n_cc, n_sr);
+        match_mfma<true><<<n_cc * n_sr, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, sub_cols, rg_rows, rowmin, colmin, n_cc, n_sr);
     else
-        match_mfma<false><<<n_cc * n_sr, 256, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, sub_cols, rg_rows, rowmin, colmin, n_cc, n_sr);
+        match_mfma<false><<<n_cc * n_sr, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, sub_cols, rg_rows, rowmin, colmin, n_cc, n_sr);
     (void) hipEventRecord(ctx->ev[10], ctx->stream);
     ctx->mfma_timed = 1;
     LGR_HIP(ctx, hipGetLastError());
