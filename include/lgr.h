@@ -67,7 +67,7 @@ typedef struct {
     int32_t fix_seed;            /* 1: seed = 566 (SEED include/common.h:25); 0: seed field below */
     int32_t has_vp_src, has_vp_tgt;
     float   vp_src[3], vp_tgt[3];
-    int32_t ransac_batch;        /* iterations per device batch (deterministic schedule), default 16384 */
+    int32_t ransac_batch;        /* iterations per device batch (deterministic schedule), default 65536 */
     uint64_t seed;
 } lgr_params;
 

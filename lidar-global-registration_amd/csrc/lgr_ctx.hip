@@ -118,6 +118,6 @@ extern "C" void lgr_default_params(lgr_params* p) {
     p->max_iterations = 2147483647;
     p->normals_available = 0;
     p->fix_seed = 1;
-    p->ransac_batch = 16384;
+    p->ransac_batch = 65536;
     p->seed = 566;
 }

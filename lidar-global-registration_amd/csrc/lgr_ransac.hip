@@ -249,28 +249,46 @@ __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts,
 //                     entropy_k = -(sum_b p log p) in bin order, /log(1e4), cbrt of the product (src/analysis.cpp:114-129)
 //   correspondences : score = sequential float sum over inliers in correspondence order (src/metric.cpp:55-81), /C
 // mask (optional) receives the inlier flags; rmse_out (optional) the rmse of src/metric.cpp:147-155.
-constexpr int MB = 256;
+constexpr int MB = 1024;
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* scan /* [MB] */, int tid, int* total) {
+    // wave-level inclusive scan by shuffles, then a scan over the 16 wave totals
+    int lane = tid & 63, w = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) scan[w] = x;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int i = 0; i < MB / 64; ++i) { int t = scan[i]; scan[i] = acc; acc += t; } scan[MB / 64] = acc; }
+    __syncthreads();
+    int base = scan[w];
+    *total = scan[MB / 64];
+    __syncthreads();
+    return base + x - v;
+}
+
 __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts, const int* __restrict__ list2, int nh2,
                                                      const float4* __restrict__ P0, const float4* __restrict__ P1,
                                                      const float* __restrict__ sstar, int c, int metric_id, int score_id,
                                                      float* __restrict__ metric_out, int* __restrict__ ninl_out,
                                                      float* __restrict__ rmse_out, uint8_t* __restrict__ mask,
                                                      float2* __restrict__ scratch /* [gridDim.x][c] inlier (dist, thr) lists */) {
-    extern __shared__ int hist[];   // 30000 ints (uniformity) + 2*MB ints scan scratch
+    extern __shared__ int hist[];   // 30000 ints (uniformity) + 64 ints scan scratch
     __shared__ float T[16];
     __shared__ int s_count;
+    __shared__ int s_nnz[3];
     int hb = blockIdx.x;
     if (hb >= nh2) return;
+    const int tid = threadIdx.x;
     int hyp = list2 ? list2[hb] : hb;
-    if (threadIdx.x < 16) T[threadIdx.x] = Ts[(size_t) hyp * 16 + threadIdx.x];
+    if (tid < 16) T[tid] = Ts[(size_t) hyp * 16 + tid];
     const bool uni = metric_id == LGR_METRIC_UNIFORMITY;
-    if (uni) for (int i = threadIdx.x; i < 30000; i += MB) hist[i] = 0;
-    if (threadIdx.x == 0) s_count = 0;
+    if (uni) for (int i = tid; i < 30000; i += MB) hist[i] = 0;
+    if (tid == 0) s_count = 0;
     int* scan = hist + 30000;
     float2* lst = scratch ? scratch + (size_t) hb * c : nullptr;
     __syncthreads();
     for (int base = 0; base < c; base += MB) {
-        int i = base + threadIdx.x;
+        int i = base + tid;
         bool in = false;
         float dist = 0.f, thr = 0.f;
         int bins = 0;
@@ -280,63 +298,76 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
             float dx = ox - b.x, dy = oy - b.y, dz = oz - b.z;
             float d4 = (dx * dx + dz * dz) + (dy * dy + 0.f);
             in = d4 < sstar[i];
-            dist = __builtin_sqrtf(d4); thr = a.w; bins = __float_as_int(b.w);
+            thr = a.w; bins = __float_as_int(b.w);
+            if (in && lst) dist = __builtin_sqrtf(d4);
             if (mask) mask[i] = in ? 1 : 0;
         }
-        if (uni) {
-            if (in) {
-                int b0 = bins & 0xff, b1 = (bins >> 8) & 0xff, b2 = (bins >> 16) & 0xff;
-                atomicAdd(&hist[(0 * 100 + b1) * 100 + b2], 1);   // count[k][bin[(k+1)%3]][bin[(k+2)%3]]
-                atomicAdd(&hist[(1 * 100 + b2) * 100 + b0], 1);
-                atomicAdd(&hist[(2 * 100 + b0) * 100 + b1], 1);
-            }
+        if (uni && in) {
+            int b0 = bins & 0xff, b1 = (bins >> 8) & 0xff, b2 = (bins >> 16) & 0xff;
+            atomicAdd(&hist[(0 * 100 + b1) * 100 + b2], 1);   // count[k][bin[(k+1)%3]][bin[(k+2)%3]]
+            atomicAdd(&hist[(1 * 100 + b2) * 100 + b0], 1);
+            atomicAdd(&hist[(2 * 100 + b0) * 100 + b1], 1);
         }
         if (!lst) {
             // uniformity without an ordered list: only the inlier count is needed (order-free)
-            if (in) atomicAdd(&s_count, 1);
+            unsigned long long m = __ballot(in);
+            if ((tid & 63) == 0 && m) atomicAdd(&s_count, __popcll(m));
         } else {
-            // ordered compaction of the inliers of this tile (block-wide exclusive scan of the flags)
-            scan[threadIdx.x] = in ? 1 : 0;
+            // ordered compaction of the inliers of this tile
+            int tot;
+            int pos = block_excl_scan_1024(in ? 1 : 0, scan, tid, &tot);
+            if (in) lst[s_count + pos] = make_float2(dist, thr);
             __syncthreads();
-            for (int o = 1; o < MB; o <<= 1) {
-                int v = threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
-                __syncthreads();
-                scan[threadIdx.x] += v;
-                __syncthreads();
-            }
-            int pos = s_count + scan[threadIdx.x] - (in ? 1 : 0);
-            if (in) lst[pos] = make_float2(dist, thr);
-            __syncthreads();
-            if (threadIdx.x == MB - 1) s_count += scan[MB - 1];
+            if (tid == 0) s_count += tot;
             __syncthreads();
         }
     }
     __syncthreads();
     int n_inl = s_count;
     if (uni) {
+        // entropy_k = -(sum over bins in ascending order of p log p) / log(1e4)   (src/analysis.cpp:114-127).
+        // The terms are computed in parallel, compacted IN BIN ORDER over the (dead) histogram slab, then summed
+        // sequentially by one lane per projection: the reference's summation order, without 10^4 serial steps.
         __shared__ float ent[3];
-        if (threadIdx.x < 3) {
-            float e = 0.f;
-            float n = (float) n_inl;
-            const int* hk = hist + threadIdx.x * 10000;
-            for (int b = 0; b < 10000; ++b) {
-                int cnt = hk[b];
-                if (cnt == 0) continue;
-                float p = (float) cnt / n;
-                if (p == 0.f) continue;
-                e -= p * lgr_logf(p);
+        float n = (float) n_inl;
+        for (int k = 0; k < 3; ++k) {
+            int* hk = hist + k * 10000;
+            int cntv[10];
+            int nz = 0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                cntv[j] = tid < 1000 ? hk[tid * 10 + j] : 0;
+                float p = (float) cntv[j] / n;
+                nz += (cntv[j] != 0 && p != 0.f) ? 1 : 0;
             }
+            int tot;
+            int pos = block_excl_scan_1024(nz, scan, tid, &tot);   // its barriers retire every read of hk before the writes below
+            float* tk = reinterpret_cast<float*>(hk);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                float p = (float) cntv[j] / n;
+                if (cntv[j] != 0 && p != 0.f) { tk[pos] = p * lgr_logf(p); ++pos; }
+            }
+            if (tid == 0) s_nnz[k] = tot;
+            __syncthreads();
+        }
+        if (tid == 0 || tid == 64 || tid == 128) {
+            int k = tid >> 6;
+            const float* tk = reinterpret_cast<const float*>(hist + k * 10000);
+            float e = 0.f;
+            int nn = s_nnz[k];
+            for (int j = 0; j < nn; ++j) e -= tk[j];
             e /= 9.210340371976184f;
-            ent[threadIdx.x] = e;
+            ent[k] = e;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             float m = n_inl == 0 ? 0.f : lgr_cbrtf(ent[0] * ent[1] * ent[2]);
             metric_out[hb] = m;
             ninl_out[hb] = n_inl;
         }
     }
-    if (threadIdx.x == 0 && (!uni || rmse_out)) {
+    if (tid == 0 && (!uni || rmse_out)) {
         float score = 0.f, rm = 0.f;
         if (lst) {
             for (int j = 0; j < n_inl; ++j) {
@@ -538,7 +569,7 @@ int refit_launch(lgr_ctx* ctx, const Packed& pk, int c, const uint8_t* d_mask, f
     return LGR_OK;
 }
 
-size_t metric_smem() { return (size_t) (30000 + 2 * MB) * 4; }
+size_t metric_smem() { return (size_t) (30000 + 64) * 4; }
 
 int metric_launch(lgr_ctx* ctx, const float* Ts, const int* list2, int nh2, const Packed& pk, int c, int metric_id, int score_id,
                   float* metric_out, int* ninl_out, float* rmse_out, uint8_t* mask) {

@@ -34,7 +34,7 @@ extern "C" void orc_default_params(lgr_orc_params* p) {
     p->max_iterations = INT_MAX;
     p->rng_mode = ORC_RNG_PHILOX;
     p->n_threads = 8;
-    p->batch_size = 16384;
+    p->batch_size = 65536;
     p->seed = 566;                // SEED include/common.h:25
 }
 
