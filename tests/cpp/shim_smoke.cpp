@@ -1,0 +1,38 @@
+// Compiles against the header-only shim exactly like a reference call site would (tests/point2plane_distance.cpp:81
+// style): build two clouds, alignPointClouds, check the transform.  Run by tests/test_host_shim.py on the GPU box.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "../../lidar-global-registration_amd/host/lgr_compat.hpp"
+
+using namespace lgr;
+
+int main() {
+    std::mt19937 gen(566);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    auto src = std::make_shared<PointNCloud>(), tgt = std::make_shared<PointNCloud>();
+    // bumpy surface patch 3 m x 2 m; tgt = src region shifted, then rotated about z by 30 degrees and translated
+    auto h = [](float x, float y) { return 0.25f * std::sin(2.1f * x + 0.4f * y) + 0.2f * std::cos(1.3f * y - 0.7f * x) + 0.1f * std::sin(5.f * x * y * 0.2f); };
+    const float c = std::cos(0.5235988f), s = std::sin(0.5235988f);
+    for (int i = 0; i < 12000; ++i) {
+        float x = 3.f * U(gen), y = 2.f * U(gen);
+        src->points.emplace_back(x, y, h(x, y), 1.f);
+        float x2 = 3.f * U(gen), y2 = 2.f * U(gen), z2 = h(x2, y2);
+        tgt->points.emplace_back(c * x2 - s * y2 + 1.f, s * x2 + c * y2 - 2.f, z2 + 0.5f, 1.f);
+    }
+    AlignmentParameters p;
+    p.distance_thr = 0.1f; p.feature_radius = 0.25f; p.bf_block_size = 200000; p.max_iterations = 50000;
+    p.keypoint_id = "any"; p.descriptor_id = "fpfh"; p.matching_id = "lr"; p.metric_id = "uniformity";
+    p.vp_src = std::array<float, 3>{0.f, 0.f, 10.f}; p.vp_tgt = std::array<float, 3>{1.f, -2.f, 10.5f};
+    AlignmentResult r = alignPointClouds(src, tgt, p);
+    const Matrix4f& T = r.transformation;
+    float err = std::fabs(T(0, 0) - c) + std::fabs(T(1, 0) - s) + std::fabs(T(0, 3) - 1.f) + std::fabs(T(1, 3) + 2.f) + std::fabs(T(2, 3) - 0.5f);
+    std::printf("converged=%d iterations=%d correspondences=%zu err=%g\n", (int) r.converged, r.iterations, r.correspondences->size(), err);
+    // stand-alone entry points of the surface
+    auto down = std::make_shared<PointNCloud>();
+    downsamplePointCloud(src, down, 0.05f);
+    std::vector<float> dens = calculateSmoothedDensities(src);
+    std::printf("downsampled %zu -> %zu, density[0]=%g\n", src->size(), down->size(), dens[0]);
+    return (r.converged && err < 0.05f && down->size() > 100 && down->size() < src->size()) ? 0 : 1;
+}
