@@ -175,6 +175,20 @@ int lgr_refit_svd_dev(lgr_ctx*, const float* d_src, const float* d_tgt, const lg
 int lgr_align(lgr_ctx*, const float* src, int ns, const float* tgt, int nt, const lgr_params*, lgr_result*);
 int lgr_align_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params*, lgr_result* /* host */);
 
+/* ---- alignGror(src, tgt, correspondences, parameters) (src/alignment.cpp:21-35) =
+ *      pcl::registration::GRORInitialAlignment::computeTransformation (include/gror/ia_gror.hpp:367-415) with
+ *      setResolution(distance_thr), setOptimalSelectionNumber(800).  Result: transformation, iterations = 1,
+ *      converged = 1 (as alignGror reports), n_inliers = inliers of the refinement (:261-293), metric = size of the
+ *      maximum consistent set (best_count_), best_iteration = rows that reached the tight-constraint stage,
+ *      estimated_iters = K.  inlier_mask (c bytes) optional.  Tie orders of the three std::sort calls: DESIGN.md. ---- */
+int lgr_gror(lgr_ctx*, const float* src, int ns, const float* tgt, int nt, const lgr_corr* corr, int c,
+             float resolution, int k_optimal, lgr_result* res, uint8_t* inlier_mask /* host, or NULL */);
+int lgr_gror_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                 float resolution, int k_optimal, lgr_result* res /* host */, uint8_t* d_inlier_mask /* or NULL */);
+/* node degrees of optimalSelectionBasedOnNodeReliability (include/gror/ia_gror.hpp:126-170), c int32 on the device */
+int lgr_gror_node_degree_dev(lgr_ctx*, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c,
+                             float resolution, int32_t* d_degree);
+
 /* ---- include/hypotheses.h:10-16 (host bookkeeping; compiled out in the reference, SAVE_MULTIPLE_HYPOTHESES false) ---- */
 int lgr_update_hypotheses(float* tns16, float* metrics, int n, int cap, const float* new_T16, float new_metric, float distance_thr);
 

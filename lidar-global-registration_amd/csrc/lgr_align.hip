@@ -208,8 +208,8 @@ extern "C" int lgr_correspondences(lgr_ctx* ctx, const float* src, int ns, const
 extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params* p, lgr_result* res) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && p && res && ns > 1 && nt > 1, LGR_ERR_INVALID_ARG);
-    // alignTeaser throws in the reference (src/alignment.cpp:40); GROR is SURVEY row a23 (config 5), not built yet
-    LGR_CHECK(ctx, p->alignment_id == LGR_ALIGN_RANSAC, LGR_ERR_UNSUPPORTED);
+    // alignTeaser throws in the reference (src/alignment.cpp:40)
+    LGR_CHECK(ctx, p->alignment_id == LGR_ALIGN_RANSAC || p->alignment_id == LGR_ALIGN_GROR, LGR_ERR_UNSUPPORTED);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     auto t0 = std::chrono::steady_clock::now();
     lgr_corr* dc;
@@ -219,7 +219,11 @@ extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const flo
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double time_cs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     tick(ctx, 7);
-    LGR_TRY(lgr_ransac_dev(ctx, d_src, ns, d_tgt, nt, dc, c, p, res, nullptr));
+    if (p->alignment_id == LGR_ALIGN_GROR) {   // src/alignment.cpp:21-35: resolution = distance_thr, K_optimal = 800
+        LGR_TRY(lgr_gror_dev(ctx, d_src, ns, d_tgt, nt, dc, c, p->distance_thr, 800, res, nullptr));
+    } else {
+        LGR_TRY(lgr_ransac_dev(ctx, d_src, ns, d_tgt, nt, dc, c, p, res, nullptr));
+    }
     tick(ctx, 8);
     LGR_HIP(ctx, hipEventSynchronize(ctx->ev[8]));
     float t;

@@ -303,8 +303,18 @@ inline AlignmentResult alignRansac(const PointNCloud::ConstPtr& src, const Point
     SampleConsensusPrerejectiveOMP ransac(src, tgt, correspondences, parameters);
     return ransac.align();
 }
-inline AlignmentResult alignGror(const PointNCloud::ConstPtr&, const PointNCloud::ConstPtr&, const CorrespondencesPtr&, const AlignmentParameters&) {
-    throw std::runtime_error("lgr: GROR (SURVEY row a23) is not built yet");
+// src/alignment.cpp:21-35: resolution = distance_thr, K_optimal = 800, iterations = 1, converged = true
+inline AlignmentResult alignGror(const PointNCloud::ConstPtr& src, const PointNCloud::ConstPtr& tgt, const CorrespondencesPtr& correspondences,
+                                 const AlignmentParameters& parameters) {
+    lgr_result r;
+    check(lgr_gror(context(), raw(*src), (int) src->size(), raw(*tgt), (int) tgt->size(),
+                   reinterpret_cast<const lgr_corr*>(correspondences->data()), (int) correspondences->size(), parameters.distance_thr, 800, &r, nullptr),
+          "alignGror");
+    AlignmentResult out;
+    out.src = src; out.tgt = tgt; out.correspondences = correspondences;
+    std::memcpy(out.transformation.data(), r.transformation, 64);
+    out.iterations = 1; out.converged = true; out.time_te = r.time_te;
+    return out;
 }
 inline AlignmentResult alignTeaser(const PointNCloud::ConstPtr&, const PointNCloud::ConstPtr&, const CorrespondencesPtr&, const AlignmentParameters&) {
     throw std::runtime_error("Not implemented: support TEASER");   // src/alignment.cpp:40

@@ -277,6 +277,22 @@ class Context:
                                        C.byref(params), C.byref(res), _ptr(mask)))
         return res, mask[:c].cpu().numpy()
 
+    def gror(self, src, tgt, corr, resolution, k_optimal=800):
+        corr = self._corr_dev(corr)
+        c = corr.shape[0]
+        res = Result()
+        mask = self.empty((max(c, 1),), self.torch.uint8)
+        self.check(_lib.lgr_gror_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), c,
+                                     C.c_float(resolution), int(k_optimal), C.byref(res), _ptr(mask)))
+        return res, mask[:c].cpu().numpy()
+
+    def gror_node_degree(self, src, tgt, corr, resolution):
+        corr = self._corr_dev(corr)
+        c = corr.shape[0]
+        deg = self.empty((max(c, 1),), self.torch.int32)
+        self.check(_lib.lgr_gror_node_degree_dev(self.h, _ptr(src), _ptr(tgt), _ptr(corr), c, C.c_float(resolution), _ptr(deg)))
+        return deg[:c].cpu().numpy()
+
     def refit(self, src, tgt, corr, mask=None):
         corr = self._corr_dev(corr)
         T = (C.c_float * 16)()

@@ -146,6 +146,11 @@ int orc_ransac(const float* src, int ns, const float* tgt, int nt, const lgr_orc
 int orc_align(const float* src, int ns, const float* tgt, int nt, const lgr_orc_params* p,
               lgr_orc_result* res, lgr_orc_corr* corr_out, int* n_corr_out, double* stage_seconds);
 
+/* include/gror/ia_gror.hpp (BASELINE config 5), driven like alignGror (src/alignment.cpp:21-35) */
+int orc_gror_node_degree(const float* src, const float* tgt, const lgr_orc_corr* corr, int c, float resolution, int* degree);
+int orc_gror(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
+             float resolution, int K_optimal, float T16[16], int* diag8, float* best_angle);
+
 /* src/hypotheses.cpp:14-48.  tns: n*16 (col-major) in/out, capacity cap. returns new n */
 int orc_update_hypotheses(float* tns, float* metrics, int n, int cap, const float* new_T, float new_metric, float distance_thr);
 /* src/analysis.cpp:19-24 */

@@ -379,3 +379,23 @@ def cbrtf(x):
 
 def expf(x):
     return lib().orc_expf(C.c_float(x))
+
+
+def gror_node_degree(src, tgt, corr, resolution):
+    src, tgt = _pts(src), _pts(tgt)
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    deg = np.zeros(corr.shape[0], np.int32)
+    lib().orc_gror_node_degree(_p(src), _p(tgt), _p(corr), corr.shape[0], C.c_float(resolution), _p(deg))
+    return deg
+
+
+def gror(src, tgt, corr, resolution, K=800):
+    src, tgt = _pts(src), _pts(tgt)
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    T = np.zeros(16, np.float32)
+    diag = np.zeros(8, np.int32)
+    ang = C.c_float(0)
+    rc = lib().orc_gror(_p(src), src.shape[0], _p(tgt), tgt.shape[0], _p(corr), corr.shape[0], C.c_float(resolution), int(K),
+                        _p(T), _p(diag), C.byref(ang))
+    assert rc == 0
+    return T.reshape(4, 4).T.copy(), dict(K=int(diag[0]), best_count=int(diag[1]), tcfs_rows=int(diag[2]), n_inliers=int(diag[3]), best_angle=ang.value)

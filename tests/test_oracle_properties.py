@@ -220,3 +220,53 @@ def test_end_to_end_small(oracle):
     assert res.converged == 1 and len(corr) > 100
     assert np.abs(res.matrix() - pair["T_gt"]).max() < 5e-2
     assert (np.diff(corr["query"]) > 0).all()                       # correspondences ascend in the source index
+
+
+# ---------------------------------------------------------------------------------------------- GROR (config 5)
+def _gror_problem(c, frac, seed):
+    from lgr_amd import synthetic
+    pr = synthetic.make_correspondence_problem(n_pts=5000, c=c, inlier_frac=frac, seed=seed)
+    import oracle as o
+    corr = np.zeros(c, o.CORR_DTYPE)
+    corr["query"] = pr["corr"]["index_query"]; corr["match"] = pr["corr"]["index_match"]
+    corr["distance"] = pr["corr"]["distance"]; corr["threshold"] = pr["corr"]["threshold"]
+    return pr, corr
+
+
+def test_gror_node_degree_vs_numpy(oracle):
+    """ia_gror.hpp:126-170 against a dense numpy restatement (float32 ops in the same order)."""
+    pr, corr = _gror_problem(400, 0.3, 2)
+    S = pr["src"][corr["query"], :3].astype(np.float32); T = pr["tgt"][corr["match"], :3].astype(np.float32)
+
+    def edge(P):
+        d = P[:, None, :] - P[None, :, :]
+        return np.sqrt(((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)).astype(np.float32)
+    delta = np.abs(edge(S) - edge(T)).astype(np.float32)
+    hit = delta.astype(np.float64) < 2.0 * float(np.float32(0.05))
+    np.fill_diagonal(hit, False)
+    assert np.array_equal(oracle.gror_node_degree(pr["src"], pr["tgt"], corr, 0.05), hit.sum(1).astype(np.int32))
+
+
+@pytest.mark.parametrize("c,frac", [(3000, 0.3), (3000, 0.05), (500, 0.4)])
+def test_gror_recovers_ground_truth(oracle, c, frac):
+    pr, corr = _gror_problem(c, frac, 9)
+    T, d = oracle.gror(pr["src"], pr["tgt"], corr, 0.05, 800)
+    n_true = int(round(frac * c))
+    assert d["K"] == min(800, c)
+    assert d["best_count"] >= min(0.5 * n_true, 0.4 * d["K"])
+    assert abs(d["n_inliers"] - n_true) <= 0.1 * n_true + 5
+    assert np.abs(T[:3, :3] - pr["T_gt"][:3, :3]).max() < 1e-3 and np.abs(T[:3, 3] - pr["T_gt"][:3, 3]).max() < 1e-2
+    R = T[:3, :3].astype(np.float64)
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5 and np.linalg.det(R) > 0.999
+    assert np.array_equal(T[3], np.array([0, 0, 0, 1], np.float32))
+
+
+def test_gror_selection_keeps_input_order_below_k(oracle):
+    """Below K_optimal the input is used as is (ia_gror.hpp:183-185): shuffling the outliers' positions among
+    themselves must not change K; above K_optimal only the K best-voted correspondences reach the edge stage."""
+    pr, corr = _gror_problem(600, 0.5, 4)
+    T1, d1 = oracle.gror(pr["src"], pr["tgt"], corr, 0.05, 800)
+    T2, d2 = oracle.gror(pr["src"], pr["tgt"], corr, 0.05, 200)
+    assert d1["K"] == 600 and d2["K"] == 200
+    assert d2["best_count"] <= 200 and d2["best_count"] > 150      # the top-voted 200 are almost all true pairs
+    assert np.abs(T1 - T2).max() < 5e-3
