@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
     // column stage double buffered in LDS: the next stage is prefetched into registers while the current one is
     // consumed and written to the other buffer afterwards -> one barrier per stage, global latency hidden
     __shared__ float Bs[2][STAGE_FLOATS];
-    __shared__ unsigned cmin_s[CHUNK_COLS];
+    __shared__ int cmin_s[CHUNK_COLS];
 
     // XCD-aware remap: workgroups that share a column chunk (the B operand) are placed on one XCD (speed only).
     int nwg = n_cc * n_sr;
@@ -240,11 +240,11 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
     const int rb0 = sr * RB_PER_SUPER;
     const int n_rb = min(RB_PER_SUPER, ma_pad / BLOCK_ROWS - rb0);
     const int rg_blocks = rg_rows / BLOCK_ROWS;
-    const float INF = __uint_as_float(0x7f800000u);
+    constexpr int IINF = 0x7f800000;   // +inf as bits
     constexpr int NPRE = (STAGE_FLOATS / 4 + NTHR - 1) / NTHR;   // float4 per thread per stage (5, the last one partial)
 
     if (COLDIR) {
-        for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = 0xffffffffu;
+        for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = IINF;
     }
 
     for (int rbi = 0; rbi < n_rb; ++rbi) {
@@ -262,11 +262,14 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
             for (int g = 0; g < 16; ++g)
                 na[r][g] = nA[(row_tile + r) * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
         }
-        float rmin[RW][16];
+        f32x16 nav;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) nav[g] = na[0][g];
+        int rmin[RW][16];   // float bit patterns, see the epilogue note
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) rmin[r][g] = INF;
+            for (int g = 0; g < 16; ++g) rmin[r][g] = IINF;
 
         // stage 0 of this row block (barrier first: every wave is past the previous row block's LDS reads)
         __syncthreads();
@@ -291,35 +294,37 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
             }
             // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
             // measured: removing the epilogue saved exactly its VALU time), so the epilogue is kept minimal:
-            // one add gives d2~ = S + |a'|^2 for both directions (a known-quiet value: no canonicalising v_max), one
-            // v_min per row slot, v_min3 pairs for the column chain, a VALU lane swap instead of an LDS shuffle.
+            //  * |a'|^2 enters through the accumulator input of the first MFMA step, so d2~ = S + |a'|^2 costs nothing;
+            //  * minima are taken on the bit patterns with v_min_i32 / v_min3_i32 (one instruction per slot, no
+            //    canonicalising v_max pair as a float min of raw MFMA output needs).  Signed-int order equals float
+            //    order except among negative values, where it keeps the one closest to zero; d2~ < 0 only within the
+            //    proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
+            //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
             // The B fragment of the next tile is fetched from LDS before the epilogue runs.
             float b[KK];
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
 #pragma unroll 1
             for (int ct = 0; ct < STAGE_TILES; ++ct) {
-                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], b[0], zero, 0, 0, 0);
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], b[0], nav, 0, 0, 0);
 #pragma unroll
                 for (int kk = 1; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b[kk], acc, 0, 0, 0);
                 if (ct + 1 < STAGE_TILES) {
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][((ct + 1) * KK + kk) * 64 + lane];
                 }
-                float v[16];
+                int v[16];
 #pragma unroll
-                for (int g = 0; g < 16; ++g) { v[g] = acc[g] + na[0][g]; rmin[0][g] = __builtin_fminf(rmin[0][g], v[g]); }
+                for (int g = 0; g < 16; ++g) { v[g] = __float_as_int(acc[g]); rmin[0][g] = min(rmin[0][g], v[g]); }
                 if (COLDIR) {
-                    float cm = __builtin_fminf(v[0], v[1]);
+                    int cm = min(v[0], v[1]);
 #pragma unroll
-                    for (int g = 2; g < 16; g += 2) cm = __builtin_fminf(__builtin_fminf(cm, v[g]), v[g + 1]);
+                    for (int g = 2; g < 16; g += 2) cm = min(min(cm, v[g]), v[g + 1]);
                     // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
-                    unsigned ci = __float_as_uint(cm);
-                    auto sw = __builtin_amdgcn_permlane32_swap(ci, ci, false, false);
-                    float other = __uint_as_float(half ? sw[0] : sw[1]);
-                    cm = __builtin_fminf(cm, other);
-                    if (lane < 32) atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + lane], f2key(cm));
+                    auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
+                    int other = (int) (half ? sw[0] : sw[1]);
+                    cm = min(cm, other);
+                    if (lane < 32) atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + lane], cm);
                 }
             }
             // flush the row minima of this column group
@@ -329,15 +334,15 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
                 for (int r = 0; r < RW; ++r)
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
-                        float v = rmin[r][g];
-                        v = __builtin_fminf(v, __shfl_xor(v, 1));
-                        v = __builtin_fminf(v, __shfl_xor(v, 2));
-                        v = __builtin_fminf(v, __shfl_xor(v, 4));
-                        v = __builtin_fminf(v, __shfl_xor(v, 8));
-                        v = __builtin_fminf(v, __shfl_xor(v, 16));
+                        int v = rmin[r][g];
+                        v = min(v, __shfl_xor(v, 1));
+                        v = min(v, __shfl_xor(v, 2));
+                        v = min(v, __shfl_xor(v, 4));
+                        v = min(v, __shfl_xor(v, 8));
+                        v = min(v, __shfl_xor(v, 16));
                         if ((lane & 31) == 0)
-                            rowmin[(size_t) sub * ma_pad + (row_tile + r) * TILE + (g & 3) + 8 * (g >> 2) + 4 * half] = v;
-                        rmin[r][g] = INF;
+                            rowmin[(size_t) sub * ma_pad + (row_tile + r) * TILE + (g & 3) + 8 * (g >> 2) + 4 * half] = __int_as_float(v);
+                        rmin[r][g] = IINF;
                     }
             }
             if (more) {
@@ -355,8 +360,8 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
             int rg = (rb * BLOCK_ROWS) / rg_rows;
             int ncols = n_coltiles * TILE;
             for (int i = tid; i < ncols; i += NTHR) {
-                colmin[(size_t) rg * mb_pad + col_tile0 * TILE + i] = key2f(cmin_s[i]);
-                cmin_s[i] = 0xffffffffu;
+                colmin[(size_t) rg * mb_pad + col_tile0 * TILE + i] = __int_as_float(cmin_s[i]);
+                cmin_s[i] = IINF;
             }
             // the next row block's first __syncthreads() orders these resets before any new atomicMin
         }
