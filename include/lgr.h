@@ -133,6 +133,9 @@ int lgr_match_bf2_dev(lgr_ctx*, const float* d_a33, int ma, const float* d_b33, 
  * its MFMA filter kernel (hipEvents on the ctx stream) -- what bench.py's roofline object is computed from */
 int lgr_match_last_stats(unsigned* out6);
 int lgr_match_last_kernel_ms(lgr_ctx*, float* ms);
+/* fraction of the (256-row block x 128-column stage) tiles the MFMA passes of the last match call computed; the exact
+ * bound-based skipping leaves the rest out.  1.0 = dense. */
+int lgr_match_last_work(double* executed_fraction);
 
 /* ---- src/common.cpp:531-547 calculateSmoothedDensities(pcd, k) / :202-208 calculatePointCloudDensity ---- */
 int lgr_smoothed_densities(lgr_ctx*, const float* pts, int n, int k, float* out);

@@ -35,16 +35,19 @@ constexpr int RW = 1;               // row tiles per wave
 constexpr int WAVES = 8;
 constexpr int NTHR = WAVES * 64;    // threads per workgroup of the MFMA kernel
 constexpr int BLOCK_ROWS = TILE * RW * WAVES;   // 256
-constexpr int RB_PER_SUPER = 16;
-constexpr int SUPER_ROWS = BLOCK_ROWS * RB_PER_SUPER;   // 4096
 constexpr int STAGE_TILES = 4;
 constexpr int STAGE_COLS = STAGE_TILES * TILE;  // 128
 constexpr int CHUNK_COLS = 4096;
 constexpr int STAGE_FLOATS = STAGE_TILES * KK * 64;   // 4352
 constexpr int PAD = 256;
-constexpr int KCL = 16;             // k-means centres
-constexpr int KM_SAMPLE = 8192;     // sample rows per side
+constexpr int KCL = 16;             // k-means centres (operand centring)
+constexpr int SUBMAX = 64;          // second-level centres per cluster ("leaves": sort order + skip bounds)
+constexpr int MAXLEAF = KCL * SUBMAX;
+constexpr int KM_SAMPLE = 16384;    // sample rows per side
 constexpr int KM_ITERS = 6;
+constexpr int KM2_ITERS = 4;
+constexpr int NEAR_T = 4;           // pass 1 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf
+constexpr int STAGES_PER_CHUNK = CHUNK_COLS / STAGE_COLS;   // 32 -> one 32-bit stage mask per (row block, chunk)
 constexpr float FLT_BIG = 3.4028234663852886e38f;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -104,14 +107,21 @@ __device__ __forceinline__ int nearest_centre(const float* v, const float* __res
 }
 __global__ void km_accum(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, const float* __restrict__ cen,
                          float* __restrict__ sums /* [KCL][34] */) {
+    __shared__ float ls[KCL * 34];
+    for (int i = threadIdx.x; i < KCL * 34; i += blockDim.x) ls[i] = 0.f;
+    __syncthreads();
     int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ns || !smp_ok[s]) return;
-    float v[33], d;
+    if (s < ns && smp_ok[s]) {
+        float v[33], d;
 #pragma unroll
-    for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
-    int c = nearest_centre(v, cen, d);
-    for (int k = 0; k < 33; ++k) atomicAdd(&sums[c * 34 + k], v[k]);
-    atomicAdd(&sums[c * 34 + 33], 1.0f);
+        for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
+        int c = nearest_centre(v, cen, d);
+        for (int k = 0; k < 33; ++k) atomicAdd(&ls[c * 34 + k], v[k]);
+        atomicAdd(&ls[c * 34 + 33], 1.0f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KCL * 34; i += blockDim.x)
+        if (ls[i] != 0.f) atomicAdd(&sums[i], ls[i]);
 }
 __global__ void km_update(float* __restrict__ cen, float* __restrict__ sums) {
     int c = threadIdx.x;
@@ -120,32 +130,126 @@ __global__ void km_update(float* __restrict__ cen, float* __restrict__ sums) {
     for (int k = 0; k < 33; ++k) { if (n > 0.f) cen[c * 33 + k] = sums[c * 34 + k] / n; sums[c * 34 + k] = 0.f; }
     sums[c * 34 + 33] = 0.f;
 }
-
-// key = (cluster << 27) | (bits(r2) >> 5): sort by cluster, then by distance to the centre.  Invalid rows: 0xffffffff.
-__global__ void assign_kernel(const float* __restrict__ X, int m, const float* __restrict__ cen, unsigned* __restrict__ keys,
-                              int* __restrict__ vals, uint8_t* __restrict__ valid, int* __restrict__ counts /* [KCL+1] */) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    float v[33], r2;
-    bool ok = row_finite(X + (size_t) i * 33, v);
-    unsigned key = 0xffffffffu;
-    if (ok) {
-        int c = nearest_centre(v, cen, r2);
-        if (r2 < FLT_BIG) { key = ((unsigned) c << 27) | (__float_as_uint(r2) >> 5); atomicAdd(&counts[c], 1); }
-        else ok = false;
+// second level: `sub` centres inside every cluster, seeded with evenly spaced sample members of the cluster
+__global__ void km_label(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, const float* __restrict__ cen,
+                         int* __restrict__ label) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    int c = -1;
+    if (smp_ok[s]) {
+        float v[33], d;
+#pragma unroll
+        for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
+        c = nearest_centre(v, cen, d);
     }
-    if (!ok) atomicAdd(&counts[KCL], 1);
-    keys[i] = key; vals[i] = i; valid[i] = ok ? 1 : 0;
+    label[s] = c;
+}
+__global__ void km2_init(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen, int sub,
+                         float* __restrict__ cen2) {
+    const int p = blockIdx.x, lane = threadIdx.x;   // one wave per cluster
+    for (int e = lane; e < sub * 33; e += 64) cen2[(size_t) p * sub * 33 + e] = cen[p * 33 + e % 33];
+    __threadfence_block();
+    __syncthreads();
+    int cnt = 0;
+    for (int base = 0; base < ns; base += 64) {
+        int s = base + lane;
+        bool m = s < ns && label[s] == p;
+        cnt += __popcll(__ballot(m));
+    }
+    if (cnt == 0) return;
+    int rank0 = 0;
+    for (int base = 0; base < ns; base += 64) {
+        int s = base + lane;
+        bool m = s < ns && label[s] == p;
+        unsigned long long bal = __ballot(m);
+        if (m) {
+            int r = rank0 + __popcll(bal & ((1ull << lane) - 1ull));
+            int j = (int) ((long long) r * sub / cnt);
+            bool first = r == 0 || (int) ((long long) (r - 1) * sub / cnt) != j;
+            if (first)
+                for (int k = 0; k < 33; ++k) cen2[((size_t) p * sub + j) * 33 + k] = smp[(size_t) s * 33 + k];
+        }
+        rank0 += __popcll(bal);
+    }
+}
+__device__ __forceinline__ int nearest_sub(const float* v, const float* __restrict__ c2 /* [sub][33] of the row's cluster */, int sub, float& best) {
+    int bj = 0;
+    best = __uint_as_float(0x7f800000u);
+#pragma unroll 1
+    for (int j = 0; j < sub; ++j) {
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 33; ++k) { float t = v[k] - c2[j * 33 + k]; d = d + t * t; }
+        if (d < best) { best = d; bj = j; }
+    }
+    return bj;
+}
+__global__ void km2_accum(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen2, int sub,
+                          float* __restrict__ sums2 /* [KCL*sub][34] */) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    int p = label[s];
+    if (p < 0) return;
+    float v[33], d;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
+    int j = nearest_sub(v, cen2 + (size_t) p * sub * 33, sub, d);
+    float* dst = sums2 + ((size_t) p * sub + j) * 34;
+    for (int k = 0; k < 33; ++k) atomicAdd(&dst[k], v[k]);
+    atomicAdd(&dst[33], 1.0f);
+}
+__global__ void km2_update(float* __restrict__ cen2, float* __restrict__ sums2, int n_leaves) {
+    int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_leaves) return;
+    float n = sums2[(size_t) l * 34 + 33];
+    for (int k = 0; k < 33; ++k) { if (n > 0.f) cen2[(size_t) l * 33 + k] = sums2[(size_t) l * 34 + k] / n; sums2[(size_t) l * 34 + k] = 0.f; }
+    sums2[(size_t) l * 34 + 33] = 0.f;
 }
 
-// sorted position s -> padded position (every cluster starts at a multiple of the pad unit)
+// key = (leaf << 22) | (bits(r2) >> 9), leaf = cluster * sub + sub-centre: sort by cluster, leaf, then distance to the
+// cluster centre.  Invalid rows: 0xffffffff.  counts[leaf] / counts[MAXLEAF] (invalid) and the squared leaf radii
+// rmax[leaf] = max |x - c_leaf|^2 (float bits) are accumulated through LDS.
+__global__ void assign_kernel(const float* __restrict__ X, int m, const float* __restrict__ cen, const float* __restrict__ cen2, int sub,
+                              unsigned* __restrict__ keys, int* __restrict__ vals, uint8_t* __restrict__ valid,
+                              int* __restrict__ counts /* [MAXLEAF+1] */, unsigned* __restrict__ rmax /* [MAXLEAF] */) {
+    __shared__ int lc[MAXLEAF + 1];
+    __shared__ unsigned lr[MAXLEAF];
+    for (int i = threadIdx.x; i <= MAXLEAF; i += blockDim.x) { lc[i] = 0; if (i < MAXLEAF) lr[i] = 0u; }
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        float v[33], r2;
+        bool ok = row_finite(X + (size_t) i * 33, v);
+        unsigned key = 0xffffffffu;
+        if (ok) {
+            int c = nearest_centre(v, cen, r2);
+            if (r2 < FLT_BIG) {
+                float rl2;
+                int j = nearest_sub(v, cen2 + (size_t) c * sub * 33, sub, rl2);
+                int leaf = c * sub + j;
+                key = ((unsigned) leaf << 22) | (__float_as_uint(r2) >> 9);
+                atomicAdd(&lc[leaf], 1);
+                atomicMax(&lr[leaf], __float_as_uint(rl2));
+            } else ok = false;
+        }
+        if (!ok) atomicAdd(&lc[MAXLEAF], 1);
+        keys[i] = key; vals[i] = i; valid[i] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l <= MAXLEAF; l += blockDim.x) {
+        if (lc[l]) atomicAdd(&counts[l], lc[l]);
+        if (l < MAXLEAF && lr[l]) atomicMax(&rmax[l], lr[l]);
+    }
+}
+
+// sorted position s -> padded position (leaves / clusters start at multiples of their pad units)
 __global__ void place_kernel(const unsigned* __restrict__ keys_sorted, const int* __restrict__ vals_sorted, int n_valid,
-                             const int* __restrict__ sorted_start /* [KCL] */, const int* __restrict__ pad_start /* [KCL] */,
+                             const int* __restrict__ sorted_start /* [leaf] */, const int* __restrict__ pad_start /* [leaf] */,
                              int* __restrict__ perm) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_valid) return;
-    int c = (int) (keys_sorted[s] >> 27);
-    perm[pad_start[c] + (s - sorted_start[c])] = vals_sorted[s];
+    int l = (int) (keys_sorted[s] >> 22);
+    perm[pad_start[l] + (s - sorted_start[l])] = vals_sorted[s];
 }
 
 // 2. pack.  P layout: [tile][kk][half][i] floats (tile = 32 rows): MFMA lane l of step kk reads P[(tile*KK+kk)*64 + l].
@@ -191,13 +295,15 @@ __global__ void gather_rows_kernel(const float* __restrict__ X, const int* __res
     out[e] = o >= 0 ? X[(size_t) o * 33 + k] : 0.f;
 }
 
-// per-group maxima of sqrt(norm) (finite entries only): out[set][g]
-__global__ void group_max_kernel(const float* __restrict__ nrm, int n_pad, int group, float* __restrict__ out) {
+// per-group maxima of sqrt(norm) (finite entries only): out[set][g]; groups are [starts[g], starts[g+1]) or, with
+// starts == nullptr, fixed windows of `group` positions
+__global__ void group_max_kernel(const float* __restrict__ nrm, int n_pad, int group, const int* __restrict__ starts, float* __restrict__ out) {
     int g = blockIdx.x, set = blockIdx.y, n_groups = gridDim.x;
     float m = 0.f;
-    for (int i = threadIdx.x; i < group; i += blockDim.x) {
-        int pos = g * group + i;
-        if (pos < n_pad) { float v = nrm[(size_t) set * n_pad + pos]; if (v < FLT_BIG) m = fmaxf(m, v); }
+    int p0 = starts ? starts[g] : g * group, p1 = starts ? starts[g + 1] : min(n_pad, (g + 1) * group);
+    for (int pos = p0 + threadIdx.x; pos < p1; pos += blockDim.x) {
+        float v = nrm[(size_t) set * n_pad + pos];
+        if (v < FLT_BIG) m = fmaxf(m, v);
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     __shared__ float sh[4];
@@ -210,142 +316,198 @@ __global__ void group_max_kernel(const float* __restrict__ nrm, int n_pad, int g
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3. MFMA filter kernel.  One workgroup = 4096 rows (16 row blocks of 256) x 4096 columns.
-//    wave w of row block rb owns row tiles (rb*8 + 2w, +1); all waves share the column stage staged in LDS.
+// 3. MFMA filter kernel.  One work item = one row group (item_rb row blocks of 256) x one 4096-column chunk (32 stages of 128).
+//    Wave w of row block rb owns row tile rb*8 + w; all waves share the column stage staged in LDS.
 //    The column operand set is chosen per row block: Bp + blkcl[rb] * bset_stride.
+//    stage_mask[rb][chunk] (optional) selects the stages to compute: bound-based skipping, section 3b.
+//    Row minima are flushed per column group (tile_group[tile], a leaf of the train side) with an integer atomicMin
+//    on the float bits; column minima per row group with a read-modify-write (one owner per entry).  Both tables must
+//    be initialised to +inf bits, so several masked passes accumulate into the same tables.
+#ifdef EXP_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_T(var) unsigned long long var = wall_clock64()
+#define PROF_ADD(slot, a, b) do { if (tid == 0) atomicAdd(&g_prof[slot], (b) - (a)); } while (0)
+#define PROF_CNT(slot) do { if (tid == 0) atomicAdd(&g_prof[slot], 1ull); } while (0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, a, b)
+#define PROF_CNT(slot)
+#endif
 template <bool COLDIR>
 __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ Ap, const float* __restrict__ Bp, size_t bset_stride,
                                                      const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
-                                                     int sub_cols, int rg_rows,
-                                                     float* __restrict__ rowmin /* [mb_pad/sub_cols][ma_pad] */,
-                                                     float* __restrict__ colmin /* [ma_pad/rg_rows][mb_pad] */,
-                                                     int n_cc, int n_sr) {
+                                                     int rg_rows, const int* __restrict__ tile_group, const unsigned* __restrict__ stage_mask,
+                                                     int* __restrict__ rowmin /* [n_groups][ma_pad] */,
+                                                     int* __restrict__ colmin /* [ma_pad/rg_rows][mb_pad] */,
+                                                     int n_cc, int item_rb, const int2* __restrict__ items, const int* __restrict__ xcd_start,
+                                                     int* __restrict__ xcd_ctr) {
     // column stage double buffered in LDS: the next stage is prefetched into registers while the current one is
     // consumed and written to the other buffer afterwards -> one barrier per stage, global latency hidden
     __shared__ float Bs[2][STAGE_FLOATS];
     __shared__ int cmin_s[CHUNK_COLS];
+    __shared__ int tg_s[CHUNK_COLS / TILE];
+    __shared__ int item_s;
 
-    // XCD-aware remap: workgroups that share a column chunk (the B operand) are placed on one XCD (speed only).
-    int nwg = n_cc * n_sr;
-    int orig = blockIdx.x;
-    int q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
-    int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
-    int cc = wgid / n_sr, sr = wgid % n_sr;
-
+    // Persistent workgroups over a compacted work list.  An item is (column chunk, item_rb row blocks) with at least
+    // one stage to compute.  Hardware places workgroup i on XCD i % 8; the list is partitioned per XCD (XCD x owns the
+    // chunks x, x + 8, ...; items ordered by chunk, then rows), and the workgroups of an XCD pull items in order from
+    // a shared counter: a chunk's B operand stays in one L2 while its items run, chunks of different cost interleave
+    // across the XCDs, and nobody idles behind a static partition.  (Speed only: any item order gives the same tables.)
+    const int xcd = blockIdx.x % 8;
+    const int item0 = xcd_start[xcd], n_items = xcd_start[xcd + 1] - item0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int col_tile0 = cc * (CHUNK_COLS / TILE);
-    const int n_coltiles = min(CHUNK_COLS / TILE, mb_pad / TILE - col_tile0);
-    const int n_stages = n_coltiles / STAGE_TILES;
-    const int sub_stages = sub_cols / STAGE_COLS;
-    const int rb0 = sr * RB_PER_SUPER;
-    const int n_rb = min(RB_PER_SUPER, ma_pad / BLOCK_ROWS - rb0);
     const int rg_blocks = rg_rows / BLOCK_ROWS;
+    const int n_rb_total = ma_pad / BLOCK_ROWS;
     constexpr int IINF = 0x7f800000;   // +inf as bits
     constexpr int NPRE = (STAGE_FLOATS / 4 + NTHR - 1) / NTHR;   // float4 per thread per stage (5, the last one partial)
-
     if (COLDIR) {
-        for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = IINF;
+        for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = IINF;   // every flush leaves the array at +inf again
     }
+    int cur_cc = -1, col_tile0 = 0, n_coltiles = 0;
+    unsigned full = 0u;
+    unsigned tend[STAGE_TILES] = {0u, 0u, 0u, 0u};
+    PROF_T(t_wg0);
+    PROF_CNT(8);
+
+  for (;;) {
+    __syncthreads();   // all waves are done with the previous item (tg_s, item_s, cmin_s)
+    if (tid == 0) item_s = atomicAdd(&xcd_ctr[xcd], 1);
+    __syncthreads();
+    const int it = item_s;
+    if (it >= n_items) break;
+    const int2 item = items[item0 + it];
+    const int cc = item.x, rb0 = item.y;
+    const int n_rb = min(item_rb, n_rb_total - rb0);
+    if (cc != cur_cc) {
+        cur_cc = cc;
+        col_tile0 = cc * (CHUNK_COLS / TILE);
+        n_coltiles = min(CHUNK_COLS / TILE, mb_pad / TILE - col_tile0);
+        const int n_stages = n_coltiles / STAGE_TILES;
+        full = n_stages >= 32 ? 0xffffffffu : ((1u << n_stages) - 1u);
+        // column group (train leaf) of every 32-column tile of this chunk; tend[ct] bit st = tile ct of stage st is
+        // the last tile of its group (uniform registers: nothing is loaded between the MFMA chains)
+        if (tid < CHUNK_COLS / TILE) tg_s[tid] = tid < n_coltiles ? tile_group[col_tile0 + tid] : -1;
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < STAGE_TILES; ++ct) {
+            int t = (lane & 31) * STAGE_TILES + ct;
+            bool e = t < n_coltiles && (t == n_coltiles - 1 || tg_s[t + 1] != tg_s[t]);
+            tend[ct] = __builtin_amdgcn_readfirstlane((unsigned) (__ballot(e) & 0xffffffffull));
+        }
+    }
+    // the stage masks of the item's row blocks, fetched once (lane rbi holds the mask of row block rb0 + rbi)
+    unsigned my_mask = full;
+    if (stage_mask) my_mask = lane < n_rb ? (stage_mask[(size_t) (rb0 + lane) * n_cc + cc] & full) : 0u;
+    bool col_dirty = false;
 
     for (int rbi = 0; rbi < n_rb; ++rbi) {
         const int rb = rb0 + rbi;
-        const int row_tile = rb * (BLOCK_ROWS / TILE) + wave * RW;
-        const float* Bset = Bp + (size_t) blkcl[rb] * bset_stride + (size_t) col_tile0 * KK * 64;
-        // A fragments (coalesced 256-B loads) and the |a'|^2 of the 16 rows each lane's accumulators cover
-        float a[RW][KK];
-        float na[RW][16];
+        unsigned mask = stage_mask ? __builtin_amdgcn_readlane(my_mask, rbi) : full;   // uniform over the workgroup
+        if (mask) {
+            PROF_T(t_v0);
+            PROF_CNT(9);
+            col_dirty = true;
+            const int row_tile = rb * (BLOCK_ROWS / TILE) + wave * RW;
+            const float* Bset = Bp + (size_t) blkcl[rb] * bset_stride + (size_t) col_tile0 * KK * 64;
+            // A fragments (coalesced 256-B loads) and the |a'|^2 of the 16 rows each lane's accumulators cover
+            float a[KK];
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
+            for (int kk = 0; kk < KK; ++kk) a[kk] = Ap[((size_t) row_tile * KK + kk) * 64 + lane];
+            f32x16 nav;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) a[r][kk] = Ap[((size_t) (row_tile + r) * KK + kk) * 64 + lane];
+            for (int g = 0; g < 16; ++g) nav[g] = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
+            int rmin[16];   // float bit patterns, see the epilogue note
 #pragma unroll
-            for (int g = 0; g < 16; ++g)
-                na[r][g] = nA[(row_tile + r) * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
-        }
-        f32x16 nav;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) nav[g] = na[0][g];
-        int rmin[RW][16];   // float bit patterns, see the epilogue note
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) rmin[r][g] = IINF;
+            for (int g = 0; g < 16; ++g) rmin[g] = IINF;
 
-        // stage 0 of this row block (barrier first: every wave is past the previous row block's LDS reads)
-        __syncthreads();
-        {
-            const float4* src = reinterpret_cast<const float4*>(Bset);
-            float4* dst = reinterpret_cast<float4*>(Bs[0]);
-            for (int i = tid; i < STAGE_FLOATS / 4; i += NTHR) dst[i] = src[i];
-        }
-        __syncthreads();
-
-        for (int st = 0; st < n_stages; ++st) {
-            const int buf = st & 1;
-            const bool more = st + 1 < n_stages;
-            float4 pre[NPRE];
-            if (more) {
-                const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) (st + 1) * STAGE_FLOATS);
-#pragma unroll
-                for (int j = 0; j < NPRE; ++j) {
-                    int i = tid + NTHR * j;
-                    if (i < STAGE_FLOATS / 4) pre[j] = src[i];
-                }
+            // first active stage of this row block (barrier first: every wave is past the previous row block's LDS reads)
+            int st = __builtin_ctz(mask);
+            __syncthreads();
+            {
+                const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) st * STAGE_FLOATS);
+                float4* dst = reinterpret_cast<float4*>(Bs[0]);
+                for (int i = tid; i < STAGE_FLOATS / 4; i += NTHR) dst[i] = src[i];
             }
-            // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
-            // measured: removing the epilogue saved exactly its VALU time), so the epilogue is kept minimal:
-            //  * |a'|^2 enters through the accumulator input of the first MFMA step, so d2~ = S + |a'|^2 costs nothing;
-            //  * minima are taken on the bit patterns with v_min_i32 / v_min3_i32 (one instruction per slot, no
-            //    canonicalising v_max pair as a float min of raw MFMA output needs).  Signed-int order equals float
-            //    order except among negative values, where it keeps the one closest to zero; d2~ < 0 only within the
-            //    proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
-            //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
-            // The B fragment of the next tile is fetched from LDS before the epilogue runs.
-            float b[KK];
+            __syncthreads();
+            PROF_T(t_v1);
+            PROF_ADD(0, t_v0, t_v1);
+            int buf = 0;
+            while (true) {
+                mask &= mask - 1u;
+                const int nxt = mask ? __builtin_ctz(mask) : -1;
+                float4 pre[NPRE];
+                if (nxt >= 0) {
+                    const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) nxt * STAGE_FLOATS);
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
-#pragma unroll 1
-            for (int ct = 0; ct < STAGE_TILES; ++ct) {
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], b[0], nav, 0, 0, 0);
-#pragma unroll
-                for (int kk = 1; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b[kk], acc, 0, 0, 0);
-                if (ct + 1 < STAGE_TILES) {
-#pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][((ct + 1) * KK + kk) * 64 + lane];
-                }
-                int v[16];
-#pragma unroll
-                for (int g = 0; g < 16; ++g) { v[g] = __float_as_int(acc[g]); rmin[0][g] = min(rmin[0][g], v[g]); }
-                if (COLDIR) {
-                    int cm = min(v[0], v[1]);
-#pragma unroll
-                    for (int g = 2; g < 16; g += 2) cm = min(min(cm, v[g]), v[g + 1]);
-                    // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
-                    auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
-                    int other = (int) (half ? sw[0] : sw[1]);
-                    cm = min(cm, other);
-                    if (lane < 32) atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + lane], cm);
-                }
-            }
-            // flush the row minima of this column group
-            if (((st + 1) % sub_stages) == 0 || !more) {
-                int sub = (col_tile0 * TILE + st * STAGE_COLS) / sub_cols;
-#pragma unroll
-                for (int r = 0; r < RW; ++r)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        int v = rmin[r][g];
-                        v = min(v, __shfl_xor(v, 1));
-                        v = min(v, __shfl_xor(v, 2));
-                        v = min(v, __shfl_xor(v, 4));
-                        v = min(v, __shfl_xor(v, 8));
-                        v = min(v, __shfl_xor(v, 16));
-                        if ((lane & 31) == 0)
-                            rowmin[(size_t) sub * ma_pad + (row_tile + r) * TILE + (g & 3) + 8 * (g >> 2) + 4 * half] = __int_as_float(v);
-                        rmin[r][g] = IINF;
+                    for (int j = 0; j < NPRE; ++j) {
+                        int i = tid + NTHR * j;
+                        if (i < STAGE_FLOATS / 4) pre[j] = src[i];
                     }
-            }
-            if (more) {
+                }
+                // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
+                // measured: removing the epilogue saved exactly its VALU time), so the epilogue is kept minimal:
+                //  * |a'|^2 enters through the accumulator input of the first MFMA step: d2~ = S + |a'|^2 costs nothing;
+                //  * minima are taken on the bit patterns with v_min_i32 / v_min3_i32 (one instruction per slot, no
+                //    canonicalising v_max pair as a float min of raw MFMA output needs).  Signed-int order equals float
+                //    order except among negative values, where it keeps the one closest to zero; d2~ < 0 only within
+                //    the proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
+                //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
+                // The B fragment of the next tile is fetched from LDS before the epilogue runs.
+                float b[KK];
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
+#pragma unroll 1
+                for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], nav, 0, 0, 0);
+#pragma unroll
+                    for (int kk = 1; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+                    if (ct + 1 < STAGE_TILES) {
+#pragma unroll
+                        for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][((ct + 1) * KK + kk) * 64 + lane];
+                    }
+                    int v[16];
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) { v[g] = __float_as_int(acc[g]); rmin[g] = min(rmin[g], v[g]); }
+                    if (COLDIR) {
+                        int cm = min(v[0], v[1]);
+#pragma unroll
+                        for (int g = 2; g < 16; g += 2) cm = min(min(cm, v[g]), v[g + 1]);
+                        // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
+                        auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
+                        int other = (int) (half ? sw[0] : sw[1]);
+                        cm = min(cm, other);
+                        if (lane < 32) atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + lane], cm);
+                    }
+                    // flush the row minima when the column group (train leaf) ends, or before skipped stages
+                    const unsigned te = ct == 0 ? tend[0] : ct == 1 ? tend[1] : ct == 2 ? tend[2] : tend[3];
+#ifdef EXP_NOFLUSHTILE
+                    if (ct == STAGE_TILES - 1 && ((((tend[0] | tend[1] | tend[2] | tend[3]) >> st) & 1u) || nxt != st + 1)) {
+#else
+                    if (((te >> st) & 1u) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
+#endif
+                        PROF_CNT(10);
+                        const int grp = tg_s[st * STAGE_TILES + ct];
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            int v = rmin[g];
+                            v = min(v, __shfl_xor(v, 1));
+                            v = min(v, __shfl_xor(v, 2));
+                            v = min(v, __shfl_xor(v, 4));
+                            v = min(v, __shfl_xor(v, 8));
+                            v = min(v, __shfl_xor(v, 16));
+#ifdef EXP_STORE
+                            if ((lane & 31) == 0 && v != IINF)
+                                rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half] = v;
+#else
+                            if ((lane & 31) == 0 && v != IINF)
+                                atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], v);
+#endif
+                            rmin[g] = IINF;
+                        }
+                    }
+                }
+                if (nxt < 0) break;
+                PROF_T(t_s0);
                 float4* dst = reinterpret_cast<float4*>(Bs[buf ^ 1]);
 #pragma unroll
                 for (int j = 0; j < NPRE; ++j) {
@@ -353,21 +515,145 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
                     if (i < STAGE_FLOATS / 4) dst[i] = pre[j];
                 }
                 __syncthreads();   // next buffer visible; all waves done with the buffer that is refilled next
+                PROF_T(t_s1);
+                PROF_ADD(2, t_s0, t_s1);
+                buf ^= 1;
+                st = nxt;
             }
+            PROF_T(t_v2);
+            PROF_ADD(1, t_v1, t_v2);
         }
-        if (COLDIR && (((rbi + 1) % rg_blocks) == 0 || rbi + 1 == n_rb)) {
-            __syncthreads();
-            int rg = (rb * BLOCK_ROWS) / rg_rows;
-            int ncols = n_coltiles * TILE;
-            for (int i = tid; i < ncols; i += NTHR) {
-                colmin[(size_t) rg * mb_pad + col_tile0 * TILE + i] = __int_as_float(cmin_s[i]);
+    }
+    // column minima of this item -> table (the item covers exactly one row group: single owner, plain read-modify-write)
+    if (COLDIR && col_dirty) {
+        PROF_T(t_c0);
+        __syncthreads();
+        int rg = rb0 / rg_blocks;
+        int ncols = n_coltiles * TILE;
+        int* dst = colmin + (size_t) rg * mb_pad + col_tile0 * TILE;
+        constexpr int NCM = CHUNK_COLS / NTHR;   // 8 columns per thread: all loads in flight before the merge
+        int cur[NCM], old[NCM];
+#pragma unroll
+        for (int j = 0; j < NCM; ++j) {
+            int i = tid + NTHR * j;
+            cur[j] = i < ncols ? cmin_s[i] : IINF;
+            old[j] = cur[j] != IINF ? dst[i] : IINF;
+        }
+#pragma unroll
+        for (int j = 0; j < NCM; ++j) {
+            int i = tid + NTHR * j;
+            if (cur[j] != IINF) {
+                if (cur[j] < old[j]) dst[i] = cur[j];
                 cmin_s[i] = IINF;
             }
-            // the next row block's first __syncthreads() orders these resets before any new atomicMin
         }
+        PROF_T(t_c1);
+        PROF_ADD(3, t_c0, t_c1);
+    }
+  }
+    PROF_T(t_wg1);
+    PROF_ADD(4, t_wg0, t_wg1);
+}
+
+// work list of match_mfma: flag every (XCD-major chunk, item row) that has something to compute, scan, emit
+__global__ void items_flag_kernel(const unsigned* __restrict__ mask, int n_rb, int n_cc, int item_rb, int n_ir, int ccx, int* __restrict__ flags) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 8 * ccx * n_ir) return;
+    int xcd = j / (ccx * n_ir), rem = j % (ccx * n_ir);
+    int cc = (rem / n_ir) * 8 + xcd, ir = rem % n_ir;
+    int f = 0;
+    if (cc < n_cc) {
+        if (!mask) f = 1;
+        else
+            for (int r = ir * item_rb; r < min(n_rb, (ir + 1) * item_rb); ++r) f |= mask[(size_t) r * n_cc + cc] != 0u ? 1 : 0;
+    }
+    flags[j] = f;
+}
+__global__ void items_emit_kernel(const int* __restrict__ flags, const int* __restrict__ pos, int item_rb, int n_ir, int ccx,
+                                  int2* __restrict__ items, int* __restrict__ xcd_start /* [9] */) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_xcd = ccx * n_ir;
+    if (j >= 8 * per_xcd) return;
+    int xcd = j / per_xcd, rem = j % per_xcd;
+    if (flags[j]) items[pos[j]] = make_int2((rem / n_ir) * 8 + xcd, (rem % n_ir) * item_rb);
+    if (rem == 0) xcd_start[xcd] = pos[j];
+    if (j == 8 * per_xcd - 1) xcd_start[8] = pos[j] + flags[j];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3b. bound-based stage skipping (exact).  Train rows are sorted by leaf (two-level k-means), so a column group g is a
+// ball (centre c_g, radius r_g).  For a 256-row block rb,  LB(rb, g) = max(0, min_i |a_i - c_g| - r_g)  is a lower bound
+// of every distance in the tile rb x g.  Pass 1 computes the NEAR_T nearest groups of each row block and the NEAR_T
+// nearest row blocks of each group; from its minima every row / column gets an upper bound U of its nearest-neighbour
+// distance.  Pass 2 computes the remaining tiles with LB <= max U of the block's rows or of the group's columns.  A
+// skipped tile holds only pairs with d >= LB > U >= (nearest distance), so it can contain neither the nearest
+// neighbour nor a tie of any row or column.  All comparisons carry relative slack far above float rounding.
+constexpr float LB_SHRINK = 0.99999f, LB_GROW = 1.00001f;
+
+// LBsq[rb][g]; +inf when the row block has no valid row or the leaf is empty
+__global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asorted, const int* __restrict__ permA, const float* __restrict__ cen2,
+                                                 const unsigned* __restrict__ r2max, const int* __restrict__ leaf_count, int n_leaves,
+                                                 float* __restrict__ LBsq) {
+    __shared__ float rows[BLOCK_ROWS * 33];
+    __shared__ int okr[BLOCK_ROWS];
+    const int rb = blockIdx.x;
+    for (int e = threadIdx.x; e < BLOCK_ROWS * 33; e += 256) rows[e] = Asorted[(size_t) rb * BLOCK_ROWS * 33 + e];
+    okr[threadIdx.x] = permA[rb * BLOCK_ROWS + threadIdx.x] >= 0;
+    __syncthreads();
+    for (int g = threadIdx.x; g < n_leaves; g += 256) {
+        float out = __uint_as_float(0x7f800000u);
+        if (leaf_count[g] > 0) {
+            float c[33];
+#pragma unroll
+            for (int k = 0; k < 33; ++k) c[k] = cen2[(size_t) g * 33 + k];
+            float dmin = __uint_as_float(0x7f800000u);
+            for (int i = 0; i < BLOCK_ROWS; ++i) {
+                if (!okr[i]) continue;
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < 33; ++k) { float t = rows[i * 33 + k] - c[k]; d = d + t * t; }
+                dmin = fminf(dmin, d);
+            }
+            if (dmin < FLT_BIG) {
+                float lb = sqrtf(dmin) * LB_SHRINK - sqrtf(__uint_as_float(r2max[g])) * LB_GROW;
+                lb = lb > 0.f ? lb : 0.f;
+                out = lb * lb * LB_SHRINK;
+            }
+        }
+        LBsq[(size_t) rb * n_leaves + g] = out;
     }
 }
 
+// the NEAR_T smallest finite entries of a strided vector -> need1 = 1   (one wave per vector)
+__global__ void near_kernel(const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
+                            uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride) {
+    const int vec = blockIdx.x, lane = threadIdx.x;
+    if (vec >= n_vec) return;
+    int chosen[NEAR_T];
+#pragma unroll
+    for (int t = 0; t < NEAR_T; ++t) chosen[t] = -1;
+#pragma unroll
+    for (int t = 0; t < NEAR_T; ++t) {
+        float bv = __uint_as_float(0x7f800000u);
+        int bi = -1;
+        for (int e = lane; e < len; e += 64) {
+            bool taken = false;
+#pragma unroll
+            for (int u = 0; u < NEAR_T; ++u) taken = taken || chosen[u] == e;
+            if (taken) continue;
+            float v = LBsq[vec * vec_stride + e * elem_stride];
+            if (v < bv) { bv = v; bi = e; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(bv, o);
+            int oi = __shfl_xor(bi, o);
+            if (ov < bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
+        }
+        if (bi < 0) break;
+        chosen[t] = bi;
+        if (lane == 0) need1[vec * need_vec_stride + bi * need_elem_stride] = 1;
+    }
+}
 // ---------------------------------------------------------------------------------------------------------------
 // exact canonical distance: cv::hal::normL2Sqr_ (OpenCV 4.5.1, SSE baseline: 4 lanes x 4 accumulators over blocks
 // of 16 floats, mul then add, reduce ((acc0+acc1)+acc2)+acc3 then (s0+s2)+(s1+s3), scalar tail) followed by sqrt.
@@ -431,6 +717,84 @@ __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* 
     const double g40 = 40 * u / (1 - 40 * u);
     double s = x + y;
     return (float) (4.0 * g40 * s * s * 1.000001 + 1e-30);
+}
+
+// upper bounds after a masked pass (section 3b): largest over the row block / the leaf of  min_g (filtered + eps)
+__global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
+                                                            const float* __restrict__ nQ, const int* __restrict__ blkclQ,
+                                                            const float* __restrict__ gmax, float* __restrict__ u_rb) {
+    const int i = blockIdx.x * BLOCK_ROWS + threadIdx.x;
+    float ub = -1.f;   // padding rows need nothing
+    if (i < q_pad && permQ[i] >= 0) {
+        int p = blkclQ[blockIdx.x];
+        float xq = sqrtf(nQ[i]) * 1.0000002f;
+        ub = __uint_as_float(0x7f800000u);
+        for (int g = 0; g < n_groups; ++g) {
+            float v = table[(size_t) g * q_pad + i];
+            if (!(v < FLT_BIG)) continue;
+            float e = group_eps<true>(i, g, xq, nullptr, gmax, n_groups, p, nullptr, q_pad);
+            ub = fminf(ub, v + e);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
+    __shared__ float sh[BLOCK_ROWS / 64];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ub;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLOCK_ROWS / 64; ++w) ub = fmaxf(ub, sh[w]);
+        u_rb[blockIdx.x] = ub;
+    }
+}
+__global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pad, const int* __restrict__ permT,
+                             const float* __restrict__ nT_sets, const float* __restrict__ gmaxA, const int* __restrict__ cl_of_rg,
+                             const int* __restrict__ tile_group, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= t_pad || permT[j] < 0) return;
+    float ub = __uint_as_float(0x7f800000u);
+    for (int g = 0; g < n_rg; ++g) {
+        float v = table[(size_t) g * t_pad + j];
+        if (!(v < FLT_BIG)) continue;
+        float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad);
+        ub = fminf(ub, v + e);
+    }
+    ub = ub > 0.f ? ub : 0.f;
+    atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
+}
+// stage masks of one pass: mode 1 = need1; mode 2 = not need1 and LB <= U of the rows or (both directions) of the leaf
+struct MaskStats { unsigned long long stages[2]; };
+__global__ void mask_kernel(int mode, int both, const uint8_t* __restrict__ need1, const float* __restrict__ LBsq,
+                            const float* __restrict__ u_rb, const unsigned* __restrict__ u_leaf, const int* __restrict__ tile_group,
+                            int n_rb, int n_cc, int n_leaves, int n_stage_total, unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned m = 0u;
+    if (idx < n_rb * n_cc) {
+        const int rb = idx / n_cc, cc = idx % n_cc;
+        const float urb = mode == 2 ? u_rb[rb] : 0.f;
+        for (int s = 0; s < STAGES_PER_CHUNK; ++s) {
+            int gst = cc * STAGES_PER_CHUNK + s;
+            if (gst >= n_stage_total) break;
+            bool on = false;   // a stage is computed when any leaf it overlaps needs it
+            int gprev = -1;
+            for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                int g = tile_group[gst * STAGE_TILES + ct];
+                if (g == gprev) continue;
+                gprev = g;
+                bool n1 = need1[(size_t) rb * n_leaves + g] != 0;
+                if (mode == 1) on = on || n1;
+                else {
+                    float lb = LBsq[(size_t) rb * n_leaves + g];
+                    bool need = urb >= 0.f && lb <= urb * LB_GROW + 1e-12f;
+                    if (both) { float ug = __uint_as_float(u_leaf[g]); need = need || lb <= ug * LB_GROW + 1e-12f; }
+                    on = on || (!n1 && need);
+                }
+            }
+            if (on) m |= 1u << s;
+        }
+        mask[idx] = m;
+    }
+    unsigned c = __popc(m);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats->stages[mode - 1], (unsigned long long) c);
 }
 
 template <bool ROWDIR>
@@ -497,7 +861,8 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
 // 4b. one wave per (query position, train group) item: exact distances to the group's train rows (original arrays).
 __global__ __launch_bounds__(256) void rerank_items(const float* __restrict__ Q, const int* __restrict__ permQ,
                                                     const float* __restrict__ Tsorted, const int* __restrict__ permT, int t_pad,
-                                                    int group_size, int block, int nblocks, const uint2* __restrict__ items,
+                                                    int group_size, const int* __restrict__ starts /* variable groups, or nullptr */,
+                                                    int block, int nblocks, const uint2* __restrict__ items,
                                                     unsigned n_items, unsigned long long* __restrict__ best) {
     int lane = threadIdx.x & 63;
     for (unsigned it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += gridDim.x * 4) {
@@ -507,7 +872,7 @@ __global__ __launch_bounds__(256) void rerank_items(const float* __restrict__ Q,
         const float* qp = Q + (size_t) qo * 33;
 #pragma unroll
         for (int k = 0; k < 33; ++k) q[k] = qp[k];
-        int j0 = (int) w.y * group_size, j1 = min(t_pad, j0 + group_size);
+        int j0 = starts ? starts[w.y] : (int) w.y * group_size, j1 = starts ? starts[w.y + 1] : min(t_pad, j0 + group_size);
         unsigned long long bk = ~0ull;
         for (int j = j0 + lane; j < j1; j += 64) {
             int to = permT[j];
@@ -591,61 +956,79 @@ int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 // one side (A or B) after clustering
 struct Side {
-    int m = 0, n_valid = 0, n_pad = 0, unit = PAD;
+    int m = 0, n_valid = 0, n_pad = 0;
     int* perm = nullptr;          // [n_pad] padded position -> original row or -1
     uint8_t* valid = nullptr;     // [m]
     int* blkcl = nullptr;         // [n_pad / 256] cluster of each 256-row block (device)
-    std::vector<int> h_blkcl;     // host copy
+    int* leaf_start = nullptr;    // [n_leaves + 1] padded start of every leaf (device); leaf l covers [start[l], start[l+1])
+    int* leaf_count = nullptr;    // [MAXLEAF + 1] valid rows per leaf (device; [MAXLEAF] = invalid rows)
+    unsigned* r2max = nullptr;    // [MAXLEAF] squared leaf radius bits (device)
+    std::vector<int> h_blkcl;     // host copies
+    std::vector<int> h_leaf_start;
 };
 
-// assign + sort + place one side
-int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, int unit, int ws_keys, int ws_perm, Side* s) {
-    s->m = m; s->unit = unit;
+// assign + sort + place one side.  Leaves start at multiples of leaf_unit, clusters at multiples of cluster_unit
+// (a multiple of 256 and of leaf_unit); padding positions carry perm = -1.
+int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const float* cen2, int sub, int leaf_unit, int cluster_unit,
+               int ws_keys, int ws_perm, Side* s) {
+    s->m = m;
+    const int n_leaves = KCL * sub;
     unsigned *keys, *keys2;
     int *vals, *vals2;
     char* kbuf;
     size_t body = (((size_t) m * 17 + 255) & ~(size_t) 255);
-    LGR_TRY(lgr_ws_t(ctx, ws_keys, body + 1024, &kbuf));
+    LGR_TRY(lgr_ws_t(ctx, ws_keys, body + 16384, &kbuf));
     keys = (unsigned*) kbuf; keys2 = keys + m; vals = (int*) (keys2 + m); vals2 = vals + m;
     s->valid = (uint8_t*) (vals2 + m);
-    int* counts = (int*) (kbuf + body);
-    LGR_HIP(ctx, hipMemsetAsync(counts, 0, 256, ctx->stream));
-    assign_kernel<<<cdiv(m, 128), 128, 0, ctx->stream>>>(d_x, m, cen, keys, vals, s->valid, counts);
+    int* counts = (int*) (kbuf + body);               // [MAXLEAF + 1]
+    unsigned* rmax = (unsigned*) (kbuf + body + 8192);   // [MAXLEAF]
+    s->leaf_count = counts; s->r2max = rmax;
+    LGR_HIP(ctx, hipMemsetAsync(counts, 0, 16384, ctx->stream));
+    assign_kernel<<<cdiv(m, 256), 256, 0, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax);
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
     void* tmp;
     LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
     LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
     int* h;
-    LGR_TRY(lgr_pinned(ctx, 256, (void**) &h));
-    LGR_HIP(ctx, hipMemcpyAsync(h, counts, (KCL + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_TRY(lgr_pinned(ctx, 8192, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, counts, (MAXLEAF + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int starts[2 * KCL];
+    std::vector<int> starts(2 * (size_t) MAXLEAF + 2, 0);   // [0..MAXLEAF): sorted start, [MAXLEAF..2*MAXLEAF]: padded start
     int acc = 0, pacc = 0;
     s->h_blkcl.clear();
+    s->h_leaf_start.assign(n_leaves + 1, 0);
     for (int c = 0; c < KCL; ++c) {
-        starts[c] = acc; starts[KCL + c] = pacc;
-        acc += h[c];
-        int padded = pad_to(h[c], unit);
-        for (int b = 0; b < padded / BLOCK_ROWS; ++b) s->h_blkcl.push_back(c);
-        pacc += padded;
+        int cluster_begin = pacc;
+        for (int j = 0; j < sub; ++j) {
+            int l = c * sub + j;
+            starts[l] = acc; starts[MAXLEAF + l] = pacc;
+            s->h_leaf_start[l] = pacc;
+            acc += h[l];
+            pacc += pad_to(h[l], leaf_unit);
+        }
+        pacc = pad_to(pacc, cluster_unit);
+        for (int b = 0; b < (pacc - cluster_begin) / BLOCK_ROWS; ++b) s->h_blkcl.push_back(c);
     }
+    s->h_leaf_start[n_leaves] = pacc;
+    starts[MAXLEAF + n_leaves] = pacc;
     s->n_valid = acc; s->n_pad = pacc;
     if (s->n_pad == 0) return LGR_OK;
     int* pbuf;
-    LGR_TRY(lgr_ws_t(ctx, ws_perm, (size_t) s->n_pad + s->h_blkcl.size() + 2 * KCL + 64, &pbuf));
+    LGR_TRY(lgr_ws_t(ctx, ws_perm, (size_t) s->n_pad + s->h_blkcl.size() + starts.size() + 64, &pbuf));
     s->perm = pbuf; s->blkcl = pbuf + s->n_pad;
     int* d_starts = s->blkcl + s->h_blkcl.size();
+    s->leaf_start = d_starts + MAXLEAF;
     LGR_HIP(ctx, hipMemsetAsync(s->perm, 0xff, (size_t) s->n_pad * 4, ctx->stream));
     LGR_HIP(ctx, hipMemcpyAsync(s->blkcl, s->h_blkcl.data(), s->h_blkcl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    LGR_HIP(ctx, hipMemcpyAsync(d_starts, starts, sizeof starts, hipMemcpyHostToDevice, ctx->stream));
-    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `starts` is a stack buffer
-    if (s->n_valid) place_kernel<<<cdiv(s->n_valid, 256), 256, 0, ctx->stream>>>(keys2, vals2, s->n_valid, d_starts, d_starts + KCL, s->perm);
+    LGR_HIP(ctx, hipMemcpyAsync(d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging buffers go out of scope
+    if (s->n_valid) place_kernel<<<cdiv(s->n_valid, 256), 256, 0, ctx->stream>>>(keys2, vals2, s->n_valid, d_starts, d_starts + MAXLEAF, s->perm);
     return LGR_OK;
 }
 
 template <bool ROWDIR>
-int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, const float* Q, const Side& qs,
+int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
                const float* nQ, const float* nQ_sets, const float* gmax, const int* cl_of_group,
                const float* T, const float* Tsorted, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
                unsigned* stat_items, unsigned* stat_dense) {
@@ -683,7 +1066,7 @@ int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, c
         rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, 0, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
                                                                       thr, counts, offs, items);
         int grid = (int) std::min<unsigned>((n_items + 3) / 4, (unsigned) ctx->n_cu * 16);
-        rerank_items<<<grid, 256, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, block, nblocks, items, n_items, best);
+        rerank_items<<<grid, 256, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, starts, block, nblocks, items, n_items, best);
     }
     if (n_dense) {
         dim3 g(std::min(cdiv(n_dense, 256), 64), cdiv(ts.m, DENSE_CHUNK));
@@ -697,13 +1080,24 @@ int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, c
 }  // namespace
 
 // statistics of the last match call (bench/diagnostics): candidate (query, group) items and dense-fallback queries
-// per direction, group sizes
-struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; };
+// per direction, group counts, and the column stages the MFMA passes executed out of all (row block, stage) pairs
+struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; };
 static lgr_match_stats g_last_stats;
 extern "C" int lgr_match_last_stats(unsigned* out6) {
     out6[0] = g_last_stats.items_ab; out6[1] = g_last_stats.dense_ab; out6[2] = g_last_stats.items_ba;
     out6[3] = g_last_stats.dense_ba; out6[4] = (unsigned) g_last_stats.sub_cols; out6[5] = (unsigned) g_last_stats.rg_rows;
     return LGR_OK;
+}
+// fraction of the (row block x column stage) tiles of the last match call that the MFMA passes computed (1 = dense)
+extern "C" int lgr_match_last_work(double* executed_fraction) {
+    if (!executed_fraction) return LGR_ERR_INVALID_ARG;
+    *executed_fraction = g_last_stats.stages_all > 0 ? g_last_stats.stages_done / g_last_stats.stages_all : 1.0;
+    return LGR_OK;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
 }
 
 static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, int mb, int block,
@@ -714,29 +1108,54 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     if (d_ba_idx) LGR_CHECK(ctx, d_ba_dist != nullptr, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     memset(&g_last_stats, 0, sizeof g_last_stats);
+    ctx->mfma_timed = 0;
     // default result: unmatched
     if (ma) { LGR_HIP(ctx, hipMemsetAsync(d_ab_idx, 0xff, (size_t) ma * 4, ctx->stream)); LGR_HIP(ctx, hipMemsetAsync(d_ab_dist, 0, (size_t) ma * 4, ctx->stream)); }
     if (mb && d_ba_idx) { LGR_HIP(ctx, hipMemsetAsync(d_ba_idx, 0xff, (size_t) mb * 4, ctx->stream)); LGR_HIP(ctx, hipMemsetAsync(d_ba_dist, 0, (size_t) mb * 4, ctx->stream)); }
     if (ma == 0 || mb == 0) return LGR_OK;
 
-    // ---- 1. k-means centres on a sample
+    // leaves per cluster: about 1024 rows per leaf on the larger side.  LGR_MATCH_SUB / LGR_MATCH_PRUNE override the
+    // automatic choices (tests force the skipping path on small inputs); results never depend on them.
+    int sub = 1;
+    while (sub < SUBMAX && (long long) KCL * sub * 1024 < std::max(ma, mb)) sub *= 2;
+    sub = std::min(SUBMAX, std::max(1, env_int("LGR_MATCH_SUB", sub)));
+    const int n_leaves = KCL * sub;
+    const int prune_mode = env_int("LGR_MATCH_PRUNE", -1);   // -1 auto, 0 off, 1 on
+    const bool prune = prune_mode == 1 || (prune_mode != 0 && (double) ma * mb >= 65536.0 * 65536.0);
+
+    // ---- 1. k-means centres on a sample: KCL clusters, then `sub` leaves inside every cluster
+    const int ns = 2 * KM_SAMPLE;
     char* misc;
-    const size_t misc_bytes = 8192 + (size_t) 2 * KM_SAMPLE * 34 * 4;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, misc_bytes, &misc));
+    size_t off = 8192;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
+    const size_t o_cen2 = carve((size_t) MAXLEAF * 33 * 4), o_sums2 = carve((size_t) MAXLEAF * 34 * 4);
+    const size_t o_smp = carve((size_t) ns * 33 * 4), o_ok = carve((size_t) ns * 4), o_label = carve((size_t) ns * 4);
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, off, &misc));
     float* cen = (float*) (misc + 256);                 // [KCL][33]
     float* sums = (float*) (misc + 4096);               // [KCL][34]
-    float* smp = (float*) (misc + 8192);
-    int* smp_ok = (int*) (smp + (size_t) 2 * KM_SAMPLE * 33);
-    const int ns = 2 * KM_SAMPLE;
+    float* cen2 = (float*) (misc + o_cen2);             // [n_leaves][33]
+    float* sums2 = (float*) (misc + o_sums2);
+    float* smp = (float*) (misc + o_smp);
+    int* smp_ok = (int*) (misc + o_ok);
+    int* label = (int*) (misc + o_label);
     km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok);
     km_init<<<1, 64, 0, ctx->stream>>>(smp, smp_ok, ns, cen);
     LGR_HIP(ctx, hipMemsetAsync(sums, 0, KCL * 34 * 4, ctx->stream));
     for (int it = 0; it < KM_ITERS; ++it) {
-        km_accum<<<cdiv(ns, 128), 128, 0, ctx->stream>>>(smp, smp_ok, ns, cen, sums);
+        km_accum<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, cen, sums);
         km_update<<<1, 64, 0, ctx->stream>>>(cen, sums);
     }
+    km_label<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, cen, label);
+    km2_init<<<KCL, 64, 0, ctx->stream>>>(smp, label, ns, cen, sub, cen2);
+    if (sub > 1) {
+        LGR_HIP(ctx, hipMemsetAsync(sums2, 0, (size_t) n_leaves * 34 * 4, ctx->stream));
+        for (int it = 0; it < KM2_ITERS; ++it) {
+            km2_accum<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, label, ns, cen2, sub, sums2);
+            km2_update<<<cdiv(n_leaves, 64), 64, 0, ctx->stream>>>(cen2, sums2, n_leaves);
+        }
+    }
 
-    // ---- 2. assign / sort / place, group sizes
+    // ---- 2. assign / sort / place
     auto pick_group = [](size_t q_count, size_t t_count) {   // table [t/g][q] floats kept under ~6 GB
         int g = 1024;
         while (g < 4096 && (t_count / g + 1) * q_count * 4 > ((size_t) 6 << 30)) g *= 2;
@@ -745,15 +1164,15 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int rg_rows = both ? pick_group((size_t) mb, (size_t) ma) : BLOCK_ROWS;   // row groups (column direction table)
     if (ma <= 65536) rg_rows = BLOCK_ROWS;                                     // small inputs: keep the cluster padding small
     Side A, B;
-    LGR_TRY(build_side(ctx, d_a, ma, cen, rg_rows, WS_MATCH_NA, WS_MATCH_AP, &A));
-    LGR_TRY(build_side(ctx, d_b, mb, cen, PAD, WS_MATCH_NB, WS_MATCH_BP, &B));
+    LGR_TRY(build_side(ctx, d_a, ma, cen, cen2, sub, 1, rg_rows, WS_MATCH_NA, WS_MATCH_AP, &A));
+    LGR_TRY(build_side(ctx, d_b, mb, cen, cen2, sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B));
     if (A.n_valid == 0 || B.n_valid == 0) return LGR_OK;
     const int ma_pad = A.n_pad, mb_pad = B.n_pad;
-    const int sub_cols = pick_group((size_t) ma_pad, (size_t) mb_pad);
-    g_last_stats.sub_cols = sub_cols; g_last_stats.rg_rows = rg_rows;
+    g_last_stats.sub_cols = n_leaves; g_last_stats.rg_rows = rg_rows;
     const int ta = ma_pad / TILE, tb = mb_pad / TILE;
+    const int n_rb = ma_pad / BLOCK_ROWS, n_stage_total = mb_pad / STAGE_COLS;
 
-    // ---- 3. pack operands
+    // ---- 3. pack operands, group maxima, stage -> leaf map
     float *Ap, *Bp, *nAp, *nBp;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ROWMIN, (size_t) ta * KK * 64 + ma_pad, &Ap));
     nAp = Ap + (size_t) ta * KK * 64;
@@ -762,62 +1181,148 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     nBp = Bp + KCL * bset_stride;
     pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, Ap, nAp);
     pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, Bp, nBp);
-    const int n_sub = cdiv(mb_pad, sub_cols), n_rg = cdiv(ma_pad, rg_rows);
+    const int n_rg = cdiv(ma_pad, rg_rows);
     float *gmaxB, *gmaxA;
-    int* cl_of_rg;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_B, (size_t) KCL * n_sub + 2 * (size_t) n_rg + 64, &gmaxB));
-    gmaxA = gmaxB + (size_t) KCL * n_sub;
+    int *cl_of_rg, *tile_group;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_B, (size_t) KCL * n_leaves + 2 * (size_t) n_rg + tb + 64, &gmaxB));
+    gmaxA = gmaxB + (size_t) KCL * n_leaves;
     cl_of_rg = (int*) (gmaxA + n_rg);
-    group_max_kernel<<<dim3(n_sub, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, sub_cols, gmaxB);
-    group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, gmaxA);
+    tile_group = cl_of_rg + n_rg;
+    group_max_kernel<<<dim3(n_leaves, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, 0, B.leaf_start, gmaxB);
+    group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
     {
-        std::vector<int> h(n_rg);
+        std::vector<int> h(n_rg + tb);
         for (int g = 0; g < n_rg; ++g) h[g] = A.h_blkcl[(size_t) g * (rg_rows / BLOCK_ROWS)];
-        LGR_HIP(ctx, hipMemcpyAsync(cl_of_rg, h.data(), (size_t) n_rg * 4, hipMemcpyHostToDevice, ctx->stream));
+        for (int l = 0; l < n_leaves; ++l)
+            for (int t = B.h_leaf_start[l] / TILE; t < B.h_leaf_start[l + 1] / TILE; ++t) h[n_rg + t] = l;
+        LGR_HIP(ctx, hipMemcpyAsync(cl_of_rg, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-
-    // ---- 4. MFMA pass
-    float *rowmin, *colmin = nullptr;
-    const size_t tab_floats = (size_t) n_sub * ma_pad + (both ? (size_t) n_rg * mb_pad : 0);
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_A, tab_floats + 2 * ((size_t) ma + mb) + 64, &rowmin));
-    if (both) colmin = rowmin + (size_t) n_sub * ma_pad;
-    unsigned long long* bestA = (unsigned long long*) (rowmin + tab_floats + (tab_floats & 1));
-    unsigned long long* bestB = bestA + ma;
-    fill_u64<<<cdiv(ma + mb, 256), 256, 0, ctx->stream>>>(bestA, ma + mb, ~0ull);
-    int n_cc = cdiv(mb_pad, CHUNK_COLS), n_sr = cdiv(ma_pad, SUPER_ROWS);
-    (void) hipEventRecord(ctx->ev[9], ctx->stream);
-    if (both)
-        match_mfma<true><<<n_cc * n_sr, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, sub_cols, rg_rows, rowmin, colmin, n_cc, n_sr);
-    else
-        match_mfma<false><<<n_cc * n_sr, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, sub_cols, rg_rows, rowmin, colmin, n_cc, n_sr);
-    (void) hipEventRecord(ctx->ev[10], ctx->stream);
-    ctx->mfma_timed = 1;
-    LGR_HIP(ctx, hipGetLastError());
-
-    // ---- 5. exact rerank
     float *sortedA = nullptr, *sortedB;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_B, (size_t) mb_pad * 33, &sortedB));
     gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, sortedB);
-    if (both) {
+    if (both || prune) {
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_A, (size_t) ma_pad * 33, &sortedA));
         gather_rows_kernel<<<cdiv((long long) ma_pad * 33, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, sortedA);
     }
-    LGR_TRY((run_rerank<true>(ctx, rowmin, n_sub, sub_cols, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
+
+    // ---- 4. MFMA passes into the two minimum tables (+inf initialised)
+    int *rowmin, *colmin = nullptr;
+    const size_t tab_floats = (size_t) n_leaves * ma_pad + (both ? (size_t) n_rg * mb_pad : 0);
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_A, tab_floats + 2 * ((size_t) ma + mb) + 64, &rowmin));
+    if (both) colmin = rowmin + (size_t) n_leaves * ma_pad;
+    unsigned long long* bestA = (unsigned long long*) (rowmin + tab_floats + (tab_floats & 1));
+    unsigned long long* bestB = bestA + ma;
+    fill_u64<<<cdiv(ma + mb, 256), 256, 0, ctx->stream>>>(bestA, ma + mb, ~0ull);
+    LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
+    const int n_cc = cdiv(mb_pad, CHUNK_COLS);
+    // work items of the persistent MFMA kernel: one row group (the owner of its column minima) x one column chunk
+    const int item_rb = both ? std::min(rg_rows / BLOCK_ROWS, 16) : 4;
+    const int n_ir = cdiv(n_rb, item_rb), ccx = cdiv(n_cc, 8), n_flags = 8 * ccx * n_ir;
+    int* ibuf;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS2, (size_t) 4 * n_flags + 64, &ibuf));
+    int *iflags = ibuf, *ipos = ibuf + n_flags;
+    int2* ilist = (int2*) (ibuf + 2 * (size_t) n_flags);
+    int* xcd_start = ibuf + 4 * (size_t) n_flags;   // [9]
+    int* xcd_ctr = xcd_start + 16;                   // [8]
+    const int mfma_grid = 8 * 2 * std::max(1, ctx->n_cu / 8);   // two resident workgroups per CU
+    auto launch_mfma = [&](const unsigned* mask) -> int {
+        items_flag_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(mask, n_rb, n_cc, item_rb, n_ir, ccx, iflags);
+        size_t sb = 0;
+        LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, sb, iflags, ipos, 0, (size_t) n_flags, rocprim::plus<int>(), ctx->stream));
+        void* stmp;
+        LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, sb, &stmp));
+        LGR_HIP(ctx, rocprim::exclusive_scan(stmp, sb, iflags, ipos, 0, (size_t) n_flags, rocprim::plus<int>(), ctx->stream));
+        items_emit_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(iflags, ipos, item_rb, n_ir, ccx, ilist, xcd_start);
+        LGR_HIP(ctx, hipMemsetAsync(xcd_ctr, 0, 32, ctx->stream));
+        (void) hipEventRecord(ctx->ev[ctx->mfma_timed ? 11 : 9], ctx->stream);
+        if (both)
+            match_mfma<true><<<mfma_grid, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin,
+                                                               n_cc, item_rb, ilist, xcd_start, xcd_ctr);
+        else
+            match_mfma<false><<<mfma_grid, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin,
+                                                                n_cc, item_rb, ilist, xcd_start, xcd_ctr);
+        (void) hipEventRecord(ctx->ev[ctx->mfma_timed ? 12 : 10], ctx->stream);
+        ctx->mfma_timed += 1;
+        LGR_HIP(ctx, hipGetLastError());
+        return LGR_OK;
+    };
+    g_last_stats.stages_all = (double) n_rb * n_stage_total;
+    if (!prune) {
+        LGR_TRY(launch_mfma(nullptr));
+        g_last_stats.stages_done = g_last_stats.stages_all;
+    } else {
+        // section 3b: lower bounds, pass 1 (nearest tiles), upper bounds, pass 2 (everything the bounds cannot exclude)
+        char* pb;
+        size_t poff = 0;
+        auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
+        const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_need = pcarve((size_t) n_rb * n_leaves);
+        const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
+        const size_t o_stats = pcarve(sizeof(MaskStats));
+        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
+        float* LBsq = (float*) (pb + o_lb);
+        uint8_t* need1 = (uint8_t*) (pb + o_need);
+        unsigned* mask = (unsigned*) (pb + o_mask);
+        float* u_rb = (float*) (pb + o_urb);
+        unsigned* u_leaf = (unsigned*) (pb + o_ul);
+        MaskStats* mstats = (MaskStats*) (pb + o_stats);
+        LGR_HIP(ctx, hipMemsetAsync(pb + o_need, 0, poff - o_need, ctx->stream));   // need1, masks, bounds, stats
+        lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
+        near_kernel<<<n_rb, 64, 0, ctx->stream>>>(LBsq, n_rb, n_leaves, (size_t) n_leaves, 1, need1, (size_t) n_leaves, 1);
+        near_kernel<<<n_leaves, 64, 0, ctx->stream>>>(LBsq, n_leaves, n_rb, 1, (size_t) n_leaves, need1, 1, (size_t) n_leaves);
+        mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(1, both ? 1 : 0, need1, LBsq, u_rb, u_leaf, tile_group, n_rb, n_cc,
+                                                                                n_leaves, n_stage_total, mask, mstats);
+        LGR_TRY(launch_mfma(mask));
+        row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_leaves, ma_pad, A.perm, nAp, A.blkcl, gmaxB, u_rb);
+        if (both)
+            col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_group, u_leaf);
+        mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(2, both ? 1 : 0, need1, LBsq, u_rb, u_leaf, tile_group, n_rb, n_cc,
+                                                                                n_leaves, n_stage_total, mask, mstats);
+        LGR_TRY(launch_mfma(mask));
+        MaskStats* hs;
+        LGR_TRY(lgr_pinned(ctx, 256, (void**) &hs));
+        LGR_HIP(ctx, hipMemcpyAsync(hs, mstats, sizeof(MaskStats), hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        g_last_stats.stages_done = (double) hs->stages[0] + (double) hs->stages[1];
+#ifdef EXP_PROF
+        {
+            unsigned long long hp[16];
+            (void) hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof hp);
+            fprintf(stderr, "[lgr] prof (100 MHz ticks): prologue %llu stages %llu (store+barrier %llu) colflush %llu wg_total %llu | wgs %llu visits %llu rowflush %llu\n",
+                    hp[0], hp[1], hp[2], hp[3], hp[4], hp[8], hp[9], hp[10]);
+            unsigned long long z[16] = {0};
+            (void) hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
+        }
+#endif
+        if (env_int("LGR_MATCH_DEBUG", 0))
+            fprintf(stderr, "[lgr] stages pass 1 %llu pass 2 %llu of %.0f (n_rb %d n_cc %d item_rb %d leaves %d)\n", hs->stages[0], hs->stages[1],
+                    g_last_stats.stages_all, n_rb, n_cc, item_rb, n_leaves);
+    }
+    LGR_HIP(ctx, hipGetLastError());
+
+    // ---- 5. exact rerank
+    LGR_TRY((run_rerank<true>(ctx, (const float*) rowmin, n_leaves, 0, B.leaf_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
                               d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab)));
     if (both)
-        LGR_TRY((run_rerank<false>(ctx, colmin, n_rg, rg_rows, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
+        LGR_TRY((run_rerank<false>(ctx, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
                                    d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba)));
     return LGR_OK;
 }
 
-// duration of the last match_mfma launch in ms (hipEvents on the ctx stream); -1 if none
+// duration of the match_mfma launch(es) of the last match call in ms (hipEvents on the ctx stream); -1 if none
 extern "C" int lgr_match_last_kernel_ms(lgr_ctx* ctx, float* ms) {
     if (!ctx || !ms) return LGR_ERR_INVALID_ARG;
     *ms = -1.f;
     if (!ctx->mfma_timed) return LGR_OK;
     LGR_HIP(ctx, hipEventSynchronize(ctx->ev[10]));
     LGR_HIP(ctx, hipEventElapsedTime(ms, ctx->ev[9], ctx->ev[10]));
+    if (ctx->mfma_timed == 2) {   // two masked passes
+        float ms2 = 0.f;
+        LGR_HIP(ctx, hipEventSynchronize(ctx->ev[12]));
+        LGR_HIP(ctx, hipEventElapsedTime(&ms2, ctx->ev[11], ctx->ev[12]));
+        if (env_int("LGR_MATCH_DEBUG", 0)) fprintf(stderr, "[lgr] match_mfma pass 1 %.2f ms, pass 2 %.2f ms\n", *ms, ms2);
+        *ms += ms2;
+    }
     return LGR_OK;
 }
 

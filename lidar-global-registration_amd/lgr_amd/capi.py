@@ -163,6 +163,12 @@ class Context:
         _lib.lgr_match_last_stats(out)
         return dict(items_ab=out[0], dense_ab=out[1], items_ba=out[2], dense_ba=out[3], sub_cols=out[4], rg_rows=out[5])
 
+    def match_work(self):
+        """fraction of the (row block x column stage) tiles the MFMA passes of the last match call computed"""
+        f = C.c_double(1.0)
+        self.check(_lib.lgr_match_last_work(C.byref(f)))
+        return f.value
+
     def match_kernel_ms(self):
         ms = C.c_float(0)
         self.check(_lib.lgr_match_last_kernel_ms(self.h, C.byref(ms)))

@@ -11,6 +11,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64"])
+def matcher_mode(request, monkeypatch):
+    """Every test runs on the automatic path and with the bound-based stage skipping forced on (it is only
+    automatic for >= 65536 x 65536 inputs) with 1, 4 and 64 leaves per cluster; results must not depend on it."""
+    if request.param != "auto":
+        monkeypatch.setenv("LGR_MATCH_PRUNE", "1")
+        monkeypatch.setenv("LGR_MATCH_SUB", request.param.replace("prune_sub", ""))
+    return request.param
+
+
 def fpfh_like(rng, m, spread=1.0):
     """rows shaped like FPFH: three 11-bin blocks, each summing to 100."""
     x = rng.gamma(0.6 * spread, 1.0, (m, 3, 11)).astype(np.float64) + 1e-3
@@ -102,3 +112,28 @@ def test_match_large_property(lgr):
     inv = np.empty(m, np.int64); inv[perm] = np.arange(m)
     assert (ab_i.cpu().numpy() == inv).mean() > 0.999
     assert (ba_i.cpu().numpy() == perm).mean() > 0.999
+
+
+def clustered(rng, m, n_modes=40, spread=1.5):
+    """FPFH-like rows around a few dozen modes: the structure the leaf bounds exploit."""
+    modes = fpfh_like(rng, n_modes)
+    x = modes[rng.integers(0, n_modes, m)] + rng.normal(0, spread, (m, 33))
+    return np.abs(x).astype(np.float32)
+
+
+@pytest.mark.parametrize("ma,mb", [(20000, 24000), (9000, 30000)])
+def test_match_clustered_parity_and_skipping(lgr, oracle, matcher_mode, ma, mb):
+    """Clustered data at a size where whole tiles can be skipped: results stay bit-identical to the oracle, and the
+    forced skipping path really leaves tiles out."""
+    rng = np.random.default_rng(ma)
+    a, b = clustered(rng, ma), clustered(rng, mb)
+    a[17] = b[5]; b[9000] = b[5]          # exact ties across bf blocks survive the skipping
+    run_both(lgr, oracle, a, b, 7000)
+    import torch
+    lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 7000)
+    lgr.sync()
+    w = lgr.match_work()
+    if matcher_mode in ("prune_sub4", "prune_sub64"):
+        assert w < 1.0, w
+    if matcher_mode == "auto":
+        assert w == 1.0
