@@ -843,7 +843,8 @@ template <bool ROWDIR>
 __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q_pad, const float* __restrict__ nQ,
                             const int* __restrict__ blkclQ, const float* __restrict__ nQ_sets, const float* __restrict__ gmax,
                             const int* __restrict__ cl_of_group, const float* __restrict__ thr_in,
-                            const int* __restrict__ counts, const int* __restrict__ offs, uint2* __restrict__ items) {
+                            const int* __restrict__ counts, const int* __restrict__ offs, unsigned* __restrict__ item_q,
+                            unsigned* __restrict__ item_g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q_pad || counts[i] == 0) return;
     int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
@@ -854,45 +855,63 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
         float v = table[(size_t) g * q_pad + i];
         if (!(v < FLT_BIG)) continue;
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad);
-        if (v - e <= thr) items[pos++] = make_uint2((unsigned) i, (unsigned) g);
+        if (v - e <= thr) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) g; ++pos; }
     }
 }
 
-// 4b. one wave per (query position, train group) item: exact distances to the group's train rows (original arrays).
-__global__ __launch_bounds__(256) void rerank_items(const float* __restrict__ Q, const int* __restrict__ permQ,
-                                                    const float* __restrict__ Tsorted, const int* __restrict__ permT, int t_pad,
-                                                    int group_size, const int* __restrict__ starts /* variable groups, or nullptr */,
-                                                    int block, int nblocks, const uint2* __restrict__ items,
-                                                    unsigned n_items, unsigned long long* __restrict__ best) {
-    int lane = threadIdx.x & 63;
-    for (unsigned it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_items; it += gridDim.x * 4) {
-        uint2 w = items[it];
-        int qo = permQ[w.x];
-        float q[33];
-        const float* qp = Q + (size_t) qo * 33;
+// 4b. exact distances of the (query position, train group) items, sorted by group: a workgroup takes 256 consecutive
+// items (almost always one group), streams the group's train rows through LDS once and every thread scans them for its
+// own query with the canonical distance -- the group is read once per 256 queries instead of once per query.
+constexpr int RQ_THREADS = 256;
+constexpr int RQ_ROWS = 64;
+constexpr int RQ_STRIDE = 36;   // floats per staged row (16-byte aligned rows)
+__global__ __launch_bounds__(RQ_THREADS) void rerank_grouped(const float* __restrict__ Q, const int* __restrict__ permQ,
+                                                             const float* __restrict__ Tsorted, const int* __restrict__ permT, int t_pad,
+                                                             int group_size, const int* __restrict__ starts /* variable groups, or nullptr */,
+                                                             int block, int nblocks, const unsigned* __restrict__ item_g,
+                                                             const unsigned* __restrict__ item_q, unsigned n_items,
+                                                             unsigned long long* __restrict__ best) {
+    __shared__ __attribute__((aligned(16))) float Ts[RQ_ROWS * RQ_STRIDE];
+    __shared__ int To[RQ_ROWS];
+    __shared__ unsigned next_g;
+    const int tid = threadIdx.x;
+    const unsigned idx = blockIdx.x * RQ_THREADS + tid;
+    const bool act = idx < n_items;
+    const unsigned g = act ? item_g[idx] : 0xffffffffu;
+    const int qo = act ? permQ[item_q[idx]] : -1;
+    float q[33];
 #pragma unroll
-        for (int k = 0; k < 33; ++k) q[k] = qp[k];
-        int j0 = starts ? starts[w.y] : (int) w.y * group_size, j1 = starts ? starts[w.y + 1] : min(t_pad, j0 + group_size);
-        unsigned long long bk = ~0ull;
-        for (int j = j0 + lane; j < j1; j += 64) {
-            int to = permT[j];
-            if (to < 0) continue;                // padding
-            float t[33];
-            const float* tp = Tsorted + (size_t) j * 33;   // same values as T[to], contiguous in padded order
-#pragma unroll
-            for (int k = 0; k < 33; ++k) t[k] = tp[k];
-            float d = exact_l2(q, t);
-            if (!(d < FLT_BIG)) continue;        // batchDistance keeps only d < FLT_MAX
-            unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | tie_rank(to, block, nblocks);
-            bk = key < bk ? key : bk;
+    for (int k = 0; k < 33; ++k) q[k] = act ? Q[(size_t) qo * 33 + k] : 0.f;
+    unsigned long long bk = ~0ull;
+    unsigned cur = item_g[blockIdx.x * RQ_THREADS];   // items are sorted: the first one has the smallest group
+    while (cur != 0xffffffffu) {
+        const int j0 = starts ? starts[cur] : (int) cur * group_size;
+        const int j1 = starts ? starts[cur + 1] : min(t_pad, j0 + group_size);
+        for (int jb = j0; jb < j1; jb += RQ_ROWS) {
+            const int nj = min(RQ_ROWS, j1 - jb);
+            __syncthreads();
+            for (int e = tid; e < nj * 33; e += RQ_THREADS) Ts[(e / 33) * RQ_STRIDE + e % 33] = Tsorted[(size_t) jb * 33 + e];
+            if (tid < nj) To[tid] = permT[jb + tid];
+            __syncthreads();
+            if (act && g == cur) {
+                for (int jj = 0; jj < nj; ++jj) {
+                    int to = To[jj];
+                    if (to < 0) continue;                // padding
+                    float d = exact_l2(q, Ts + jj * RQ_STRIDE);
+                    if (!(d < FLT_BIG)) continue;        // batchDistance keeps only d < FLT_MAX
+                    unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | tie_rank(to, block, nblocks);
+                    bk = key < bk ? key : bk;
+                }
+            }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            unsigned long long ok = __shfl_xor(bk, o);
-            bk = ok < bk ? ok : bk;
-        }
-        if (lane == 0 && bk != ~0ull) atomicMin(&best[qo], bk);
+        __syncthreads();
+        if (tid == 0) next_g = 0xffffffffu;
+        __syncthreads();
+        if (act && g > cur) atomicMin(&next_g, g);
+        __syncthreads();
+        cur = next_g;
     }
+    if (act && bk != ~0ull) atomicMin(&best[qo], bk);
 }
 
 // 4c. dense fallback (degenerate data: more than half of all groups qualify, e.g. huge sets of identical rows):
@@ -1061,12 +1080,20 @@ int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, c
     unsigned n_dense = ((RerankCounters*) (h + 2))->n_dense;
     *stat_items = n_items; *stat_dense = n_dense;
     if (n_items) {
-        uint2* items;
-        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS, (size_t) n_items, &items));
+        unsigned* ib;
+        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS, (size_t) 4 * n_items + 64, &ib));
+        unsigned *item_q = ib, *item_g = ib + n_items, *item_q2 = ib + 2 * (size_t) n_items, *item_g2 = ib + 3 * (size_t) n_items;
         rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, 0, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
-                                                                      thr, counts, offs, items);
-        int grid = (int) std::min<unsigned>((n_items + 3) / 4, (unsigned) ctx->n_cu * 16);
-        rerank_items<<<grid, 256, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, starts, block, nblocks, items, n_items, best);
+                                                                      thr, counts, offs, item_q, item_g);
+        int bits = 1;
+        while ((1 << bits) < n_groups) ++bits;
+        size_t sb = 0;
+        LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sb, item_g, item_g2, item_q, item_q2, (size_t) n_items, 0, bits, ctx->stream));
+        void* stmp;
+        LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, sb, &stmp));
+        LGR_HIP(ctx, rocprim::radix_sort_pairs(stmp, sb, item_g, item_g2, item_q, item_q2, (size_t) n_items, 0, bits, ctx->stream));
+        rerank_grouped<<<cdiv(n_items, RQ_THREADS), RQ_THREADS, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, starts, block, nblocks,
+                                                                                 item_g2, item_q2, n_items, best);
     }
     if (n_dense) {
         dim3 g(std::min(cdiv(n_dense, 256), 64), cdiv(ts.m, DENSE_CHUNK));
