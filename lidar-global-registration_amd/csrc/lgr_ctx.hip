@@ -61,7 +61,7 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LGR_ERR_HIP; }
         c->own_stream = true;
     }
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < 32; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return LGR_ERR_HIP; }
     for (int i = 0; i < 12; ++i) c->stage_ms[i] = 0.f;
     hipDeviceProp_t prop;
@@ -77,7 +77,7 @@ extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i].p) (void) hipFree(ctx->ws[i].p);
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
-    for (int i = 0; i < 16; ++i) (void) hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 32; ++i) (void) hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
     return LGR_OK;

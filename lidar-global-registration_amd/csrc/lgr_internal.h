@@ -26,7 +26,7 @@ struct lgr_ctx {
     lgr_buf ws[96];
     void* pinned = nullptr;  // small pinned host scratch for read-backs
     size_t pinned_cap = 0;
-    hipEvent_t ev[16];
+    hipEvent_t ev[32];       // 0..8 stage timers (lgr_align), 9.. pairs around the match_mfma passes
     float stage_ms[12];
     int n_cu = 256;
     int mfma_timed = 0;

@@ -46,7 +46,10 @@ constexpr int MAXLEAF = KCL * SUBMAX;
 constexpr int KM_SAMPLE = 16384;    // sample rows per side
 constexpr int KM_ITERS = 6;
 constexpr int KM2_ITERS = 4;
-constexpr int NEAR_T = 4;           // pass 1 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf
+constexpr int NEAR_T = 64;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured optimum at 1M)
+#ifndef LGR_PRUNE_BETAS
+#define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
+#endif
 constexpr int STAGES_PER_CHUNK = CHUNK_COLS / STAGE_COLS;   // 32 -> one 32-bit stage mask per (row block, chunk)
 constexpr float FLT_BIG = 3.4028234663852886e38f;
 
@@ -624,23 +627,19 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
     }
 }
 
-// the NEAR_T smallest finite entries of a strided vector -> need1 = 1   (one wave per vector)
-__global__ void near_kernel(const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
+// the near_t smallest finite entries of a strided vector -> sched = 1   (one wave per vector; dynamic LDS: len bits)
+__global__ void near_kernel(int near_t, const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
                             uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride) {
+    extern __shared__ unsigned taken[];
     const int vec = blockIdx.x, lane = threadIdx.x;
     if (vec >= n_vec) return;
-    int chosen[NEAR_T];
-#pragma unroll
-    for (int t = 0; t < NEAR_T; ++t) chosen[t] = -1;
-#pragma unroll
-    for (int t = 0; t < NEAR_T; ++t) {
+    for (int w = lane; w < (len + 31) / 32; w += 64) taken[w] = 0u;
+    __syncthreads();
+    for (int t = 0; t < near_t; ++t) {
         float bv = __uint_as_float(0x7f800000u);
         int bi = -1;
         for (int e = lane; e < len; e += 64) {
-            bool taken = false;
-#pragma unroll
-            for (int u = 0; u < NEAR_T; ++u) taken = taken || chosen[u] == e;
-            if (taken) continue;
+            if ((taken[e >> 5] >> (e & 31)) & 1u) continue;
             float v = LBsq[vec * vec_stride + e * elem_stride];
             if (v < bv) { bv = v; bi = e; }
         }
@@ -650,10 +649,11 @@ __global__ void near_kernel(const float* __restrict__ LBsq, int n_vec, int len, 
             if (ov < bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
         }
         if (bi < 0) break;
-        chosen[t] = bi;
-        if (lane == 0) need1[vec * need_vec_stride + bi * need_elem_stride] = 1;
+        if (lane == 0) { taken[bi >> 5] |= 1u << (bi & 31); need1[vec * need_vec_stride + bi * need_elem_stride] = 1; }
+        __syncthreads();
     }
 }
+
 // ---------------------------------------------------------------------------------------------------------------
 // exact canonical distance: cv::hal::normL2Sqr_ (OpenCV 4.5.1, SSE baseline: 4 lanes x 4 accumulators over blocks
 // of 16 floats, mul then add, reduce ((acc0+acc1)+acc2)+acc3 then (s0+s2)+(s1+s3), scalar tail) followed by sqrt.
@@ -760,33 +760,42 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
     ub = ub > 0.f ? ub : 0.f;
     atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
 }
-// stage masks of one pass: mode 1 = need1; mode 2 = not need1 and LB <= U of the rows or (both directions) of the leaf
-struct MaskStats { unsigned long long stages[2]; };
-__global__ void mask_kernel(int mode, int both, const uint8_t* __restrict__ need1, const float* __restrict__ LBsq,
-                            const float* __restrict__ u_rb, const unsigned* __restrict__ u_leaf, const int* __restrict__ tile_group,
+// tile scheduling of one pass (section 3b).  sched_kernel: tiles of the previous pass become done; a tile not yet
+// done is scheduled when  LBsq <= beta_sq * U  of its row block or (both directions) of its leaf.  mask_kernel turns the
+// scheduled (row block, leaf) tiles into stage masks: a stage is computed when any leaf it overlaps is scheduled.
+struct MaskStats { unsigned long long stages[8]; };
+__global__ void sched_kernel(int both, float beta_sq, const float* __restrict__ LBsq, const float* __restrict__ u_rb,
+                             const unsigned* __restrict__ u_leaf, int n_rb, int n_leaves, uint8_t* __restrict__ done, uint8_t* __restrict__ sched) {
+    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t) n_rb * n_leaves) return;
+    const int rb = (int) (idx / n_leaves), g = (int) (idx % n_leaves);
+    uint8_t d = done[idx] | sched[idx];
+    done[idx] = d;
+    uint8_t s = 0;
+    if (!d) {
+        float lb = LBsq[idx], urb = u_rb[rb];
+        bool need = urb >= 0.f && lb <= beta_sq * (urb * LB_GROW + 1e-12f);
+        if (both) { float ug = __uint_as_float(u_leaf[g]); need = need || lb <= beta_sq * (ug * LB_GROW + 1e-12f); }
+        s = need ? 1 : 0;
+    }
+    sched[idx] = s;
+}
+__global__ void mask_kernel(int pass, const uint8_t* __restrict__ sched, const int* __restrict__ tile_group,
                             int n_rb, int n_cc, int n_leaves, int n_stage_total, unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned m = 0u;
     if (idx < n_rb * n_cc) {
         const int rb = idx / n_cc, cc = idx % n_cc;
-        const float urb = mode == 2 ? u_rb[rb] : 0.f;
         for (int s = 0; s < STAGES_PER_CHUNK; ++s) {
             int gst = cc * STAGES_PER_CHUNK + s;
             if (gst >= n_stage_total) break;
-            bool on = false;   // a stage is computed when any leaf it overlaps needs it
+            bool on = false;
             int gprev = -1;
             for (int ct = 0; ct < STAGE_TILES; ++ct) {
                 int g = tile_group[gst * STAGE_TILES + ct];
                 if (g == gprev) continue;
                 gprev = g;
-                bool n1 = need1[(size_t) rb * n_leaves + g] != 0;
-                if (mode == 1) on = on || n1;
-                else {
-                    float lb = LBsq[(size_t) rb * n_leaves + g];
-                    bool need = urb >= 0.f && lb <= urb * LB_GROW + 1e-12f;
-                    if (both) { float ug = __uint_as_float(u_leaf[g]); need = need || lb <= ug * LB_GROW + 1e-12f; }
-                    on = on || (!n1 && need);
-                }
+                on = on || sched[(size_t) rb * n_leaves + g] != 0;
             }
             if (on) m |= 1u << s;
         }
@@ -794,7 +803,7 @@ __global__ void mask_kernel(int mode, int both, const uint8_t* __restrict__ need
     }
     unsigned c = __popc(m);
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats->stages[mode - 1], (unsigned long long) c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats->stages[pass], (unsigned long long) c);
 }
 
 template <bool ROWDIR>
@@ -1142,12 +1151,14 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     if (ma == 0 || mb == 0) return LGR_OK;
 
     // leaves per cluster: about 1024 rows per leaf on the larger side.  LGR_MATCH_SUB / LGR_MATCH_PRUNE override the
-    // automatic choices (tests force the skipping path on small inputs); results never depend on them.
+    // automatic choices, LGR_MATCH_NEAR the pass-0 width (tests force the skipping path on small inputs); results never
+    // depend on them.
     int sub = 1;
     while (sub < SUBMAX && (long long) KCL * sub * 1024 < std::max(ma, mb)) sub *= 2;
     sub = std::min(SUBMAX, std::max(1, env_int("LGR_MATCH_SUB", sub)));
     const int n_leaves = KCL * sub;
     const int prune_mode = env_int("LGR_MATCH_PRUNE", -1);   // -1 auto, 0 off, 1 on
+    const int near_t = std::max(1, env_int("LGR_MATCH_NEAR", NEAR_T));
     const bool prune = prune_mode == 1 || (prune_mode != 0 && (double) ma * mb >= 65536.0 * 65536.0);
 
     // ---- 1. k-means centres on a sample: KCL clusters, then `sub` leaves inside every cluster
@@ -1262,14 +1273,15 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_HIP(ctx, rocprim::exclusive_scan(stmp, sb, iflags, ipos, 0, (size_t) n_flags, rocprim::plus<int>(), ctx->stream));
         items_emit_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(iflags, ipos, item_rb, n_ir, ccx, ilist, xcd_start);
         LGR_HIP(ctx, hipMemsetAsync(xcd_ctr, 0, 32, ctx->stream));
-        (void) hipEventRecord(ctx->ev[ctx->mfma_timed ? 11 : 9], ctx->stream);
+        LGR_CHECK(ctx, ctx->mfma_timed < 8, LGR_ERR_INVALID_ARG);
+        (void) hipEventRecord(ctx->ev[9 + 2 * ctx->mfma_timed], ctx->stream);
         if (both)
             match_mfma<true><<<mfma_grid, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin,
                                                                n_cc, item_rb, ilist, xcd_start, xcd_ctr);
         else
             match_mfma<false><<<mfma_grid, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin,
                                                                 n_cc, item_rb, ilist, xcd_start, xcd_ctr);
-        (void) hipEventRecord(ctx->ev[ctx->mfma_timed ? 12 : 10], ctx->stream);
+        (void) hipEventRecord(ctx->ev[10 + 2 * ctx->mfma_timed], ctx->stream);
         ctx->mfma_timed += 1;
         LGR_HIP(ctx, hipGetLastError());
         return LGR_OK;
@@ -1283,47 +1295,50 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         char* pb;
         size_t poff = 0;
         auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
-        const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_need = pcarve((size_t) n_rb * n_leaves);
+        const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
-        uint8_t* need1 = (uint8_t*) (pb + o_need);
+        uint8_t* done = (uint8_t*) (pb + o_done);
+        uint8_t* sched = (uint8_t*) (pb + o_sched);
         unsigned* mask = (unsigned*) (pb + o_mask);
         float* u_rb = (float*) (pb + o_urb);
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
-        LGR_HIP(ctx, hipMemsetAsync(pb + o_need, 0, poff - o_need, ctx->stream));   // need1, masks, bounds, stats
+        LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, poff - o_done, ctx->stream));   // done, sched, masks, bounds, stats
         lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
-        near_kernel<<<n_rb, 64, 0, ctx->stream>>>(LBsq, n_rb, n_leaves, (size_t) n_leaves, 1, need1, (size_t) n_leaves, 1);
-        near_kernel<<<n_leaves, 64, 0, ctx->stream>>>(LBsq, n_leaves, n_rb, 1, (size_t) n_leaves, need1, 1, (size_t) n_leaves);
-        mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(1, both ? 1 : 0, need1, LBsq, u_rb, u_leaf, tile_group, n_rb, n_cc,
-                                                                                n_leaves, n_stage_total, mask, mstats);
-        LGR_TRY(launch_mfma(mask));
-        row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_leaves, ma_pad, A.perm, nAp, A.blkcl, gmaxB, u_rb);
-        if (both)
-            col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_group, u_leaf);
-        mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(2, both ? 1 : 0, need1, LBsq, u_rb, u_leaf, tile_group, n_rb, n_cc,
-                                                                                n_leaves, n_stage_total, mask, mstats);
-        LGR_TRY(launch_mfma(mask));
+        // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
+        near_kernel<<<n_rb, 64, (size_t) (n_leaves + 31) / 32 * 4, ctx->stream>>>(near_t, LBsq, n_rb, n_leaves, (size_t) n_leaves, 1, sched, (size_t) n_leaves, 1);
+        near_kernel<<<n_leaves, 64, (size_t) (n_rb + 31) / 32 * 4, ctx->stream>>>(near_t, LBsq, n_leaves, n_rb, 1, (size_t) n_leaves, sched, 1, (size_t) n_leaves);
+        // passes 1..: tiles within beta * U of the bounds known so far; the last pass (beta = 1) takes everything the
+        // bounds cannot exclude
+        static const float betas[] = {LGR_PRUNE_BETAS};
+        const int n_beta = (int) (sizeof betas / sizeof betas[0]);
+        for (int pass = 0; pass <= n_beta; ++pass) {
+            if (pass > 0) {
+                row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_leaves, ma_pad, A.perm, nAp, A.blkcl, gmaxB, u_rb);
+                if (both) {
+                    LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
+                    col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_group, u_leaf);
+                }
+                float bsq = betas[pass - 1] * betas[pass - 1];
+                sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves, done, sched);
+            }
+            mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_group, n_rb, n_cc, n_leaves, n_stage_total, mask, mstats);
+            LGR_TRY(launch_mfma(mask));
+        }
         MaskStats* hs;
         LGR_TRY(lgr_pinned(ctx, 256, (void**) &hs));
         LGR_HIP(ctx, hipMemcpyAsync(hs, mstats, sizeof(MaskStats), hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        g_last_stats.stages_done = (double) hs->stages[0] + (double) hs->stages[1];
-#ifdef EXP_PROF
-        {
-            unsigned long long hp[16];
-            (void) hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof hp);
-            fprintf(stderr, "[lgr] prof (100 MHz ticks): prologue %llu stages %llu (store+barrier %llu) colflush %llu wg_total %llu | wgs %llu visits %llu rowflush %llu\n",
-                    hp[0], hp[1], hp[2], hp[3], hp[4], hp[8], hp[9], hp[10]);
-            unsigned long long z[16] = {0};
-            (void) hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
+        g_last_stats.stages_done = 0;
+        for (int k = 0; k <= n_beta; ++k) g_last_stats.stages_done += (double) hs->stages[k];
+        if (env_int("LGR_MATCH_DEBUG", 0)) {
+            fprintf(stderr, "[lgr] stages per pass:");
+            for (int k = 0; k <= n_beta; ++k) fprintf(stderr, " %llu", hs->stages[k]);
+            fprintf(stderr, " of %.0f (n_rb %d n_cc %d item_rb %d leaves %d)\n", g_last_stats.stages_all, n_rb, n_cc, item_rb, n_leaves);
         }
-#endif
-        if (env_int("LGR_MATCH_DEBUG", 0))
-            fprintf(stderr, "[lgr] stages pass 1 %llu pass 2 %llu of %.0f (n_rb %d n_cc %d item_rb %d leaves %d)\n", hs->stages[0], hs->stages[1],
-                    g_last_stats.stages_all, n_rb, n_cc, item_rb, n_leaves);
     }
     LGR_HIP(ctx, hipGetLastError());
 
@@ -1341,14 +1356,13 @@ extern "C" int lgr_match_last_kernel_ms(lgr_ctx* ctx, float* ms) {
     if (!ctx || !ms) return LGR_ERR_INVALID_ARG;
     *ms = -1.f;
     if (!ctx->mfma_timed) return LGR_OK;
-    LGR_HIP(ctx, hipEventSynchronize(ctx->ev[10]));
-    LGR_HIP(ctx, hipEventElapsedTime(ms, ctx->ev[9], ctx->ev[10]));
-    if (ctx->mfma_timed == 2) {   // two masked passes
-        float ms2 = 0.f;
-        LGR_HIP(ctx, hipEventSynchronize(ctx->ev[12]));
-        LGR_HIP(ctx, hipEventElapsedTime(&ms2, ctx->ev[11], ctx->ev[12]));
-        if (env_int("LGR_MATCH_DEBUG", 0)) fprintf(stderr, "[lgr] match_mfma pass 1 %.2f ms, pass 2 %.2f ms\n", *ms, ms2);
-        *ms += ms2;
+    *ms = 0.f;
+    for (int k = 0; k < ctx->mfma_timed; ++k) {   // one event pair per masked pass
+        float t = 0.f;
+        LGR_HIP(ctx, hipEventSynchronize(ctx->ev[10 + 2 * k]));
+        LGR_HIP(ctx, hipEventElapsedTime(&t, ctx->ev[9 + 2 * k], ctx->ev[10 + 2 * k]));
+        if (env_int("LGR_MATCH_DEBUG", 0)) fprintf(stderr, "[lgr] match_mfma pass %d: %.2f ms\n", k, t);
+        *ms += t;
     }
     return LGR_OK;
 }

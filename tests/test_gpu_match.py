@@ -17,6 +17,7 @@ def matcher_mode(request, monkeypatch):
     automatic for >= 65536 x 65536 inputs) with 1, 4 and 64 leaves per cluster; results must not depend on it."""
     if request.param != "auto":
         monkeypatch.setenv("LGR_MATCH_PRUNE", "1")
+        monkeypatch.setenv("LGR_MATCH_NEAR", "2")       # narrow first pass, so that tiles really are skipped at test sizes
         monkeypatch.setenv("LGR_MATCH_SUB", request.param.replace("prune_sub", ""))
     return request.param
 
