@@ -38,7 +38,6 @@ constexpr int BLOCK_ROWS = TILE * RW * WAVES;   // 256
 constexpr int STAGE_TILES = 4;
 constexpr int STAGE_COLS = STAGE_TILES * TILE;  // 128
 constexpr int CHUNK_COLS = 4096;
-constexpr int STAGE_FLOATS = STAGE_TILES * KK * 64;   // 4352
 constexpr int PAD = 256;
 constexpr int KCL = 16;             // k-means centres (operand centring)
 constexpr int SUBMAX = 64;          // second-level centres per cluster ("leaves": sort order + skip bounds)
@@ -54,6 +53,17 @@ constexpr int STAGES_PER_CHUNK = CHUNK_COLS / STAGE_COLS;   // 32 -> one 32-bit 
 constexpr float FLT_BIG = 3.4028234663852886e38f;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// MFMA operand formats.  F32: v_mfma_f32_32x32x2_f32, K = 34 (33 dims + norm slot) -> 17 steps, fragment = 1 float.
+// F16: v_mfma_f32_32x32x16_f16 (16x the f32 rate) on two-term f16 splits of the scaled f32 operands,
+//      x * 2^s = h1 + h2 (+ residual <= 2^-22 |x|):  a.b ~ a1.b1 + a1.b2 + a2.b1  -> concatenated K = 3 * 33 + 3 norm slots
+//      = 102, padded to 112 = 7 steps, fragment = 8 halves (lane l: row l & 31, k = 16 * step + 8 * (l >> 5) + j).
+template <bool F16> struct OpFmt;
+template <> struct OpFmt<false> { typedef float frag; static constexpr int KS = 17; };
+template <> struct OpFmt<true> { typedef f16x8 frag; static constexpr int KS = 7; };
+constexpr int KCAT16 = 112;
+struct F16Scale { float s_mul; float inv_s2; float a_norm[3]; };   // 2^s, 2^-2s, the three a-side norm-slot constants
 
 __device__ __forceinline__ unsigned f2key(float f) {
     unsigned b = __float_as_uint(f);
@@ -289,6 +299,72 @@ __global__ void pack_kernel(const float* __restrict__ X, const int* __restrict__
     }
 }
 
+// f16-split operands (OpFmt<true>).  Same roles / sets / nrm output as pack_kernel; P holds f16x8 fragments:
+// fragment (tile, step, lane) at ((set * tiles + tile) * 7 + step) * 64 + lane, lane = row | (khalf << 5).
+// Concatenated K index c: [0,33) a1.b1, [33,66) a1.b2, [66,99) a2.b1, 99..101 norm slots, rest 0.
+// rows: h = split(-2 x' 2^s), norm slots = constants A1..A3;  cols: h = split(x' 2^s), norm slots = the three-term
+// f16 expansion of N = |x'|^2 2^2s against A1..A3 (N = A1 B1 + A2 B2 + A3 B3 up to 2^-33 N or the f16 flush limit).
+__global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
+                              const float* __restrict__ cen, const int* __restrict__ blkcl, F16Scale sc,
+                              _Float16* __restrict__ P, float* __restrict__ nrm) {
+    int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n_pad) return;
+    int set = role == 1 ? blockIdx.y : 0;
+    int o = perm[pos];
+    int c = role == 1 ? set : blkcl[pos / BLOCK_ROWS];
+    float v[33];
+    float n2 = 0.f;
+    if (o >= 0) {
+#pragma unroll
+        for (int k = 0; k < 33; ++k) { v[k] = X[(size_t) o * 33 + k] - cen[c * 33 + k]; n2 = n2 + v[k] * v[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 33; ++k) v[k] = 0.f;
+        n2 = __uint_as_float(0x7f800000u);
+    }
+    nrm[(size_t) set * n_pad + pos] = n2;
+    if (!P) return;   // norms only (first pass: the scale is chosen from the largest norm)
+    int tile = pos >> 5, r = pos & 31;
+    _Float16* base = P + ((size_t) set * (n_pad / TILE) + tile) * OpFmt<true>::KS * 64 * 8;
+    auto put = [&](int cidx, _Float16 h) {
+        int step = cidx >> 4, khalf = (cidx >> 3) & 1, j = cidx & 7;
+        base[((size_t) step * 64 + (khalf << 5) + r) * 8 + j] = h;
+    };
+    const float mul = role == 0 ? -2.0f * sc.s_mul : sc.s_mul;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) {
+        float x = v[k] * mul;                 // exact (power of two)
+        _Float16 h1 = (_Float16) x;           // round to nearest
+        _Float16 h2 = (_Float16) (x - (float) h1);
+        if (role == 0) { put(k, h1); put(33 + k, h1); put(66 + k, h2); }
+        else { put(k, h1); put(33 + k, h2); put(66 + k, h1); }
+    }
+    if (role == 0) {
+        put(99, (_Float16) sc.a_norm[0]); put(100, (_Float16) sc.a_norm[1]); put(101, (_Float16) sc.a_norm[2]);
+    } else if (o >= 0) {
+        float N = n2 * (sc.s_mul * sc.s_mul);
+        _Float16 b1 = (_Float16) (N / sc.a_norm[0]);
+        float r1 = __builtin_fmaf(-sc.a_norm[0], (float) b1, N);
+        _Float16 b2 = (_Float16) (r1 / sc.a_norm[1]);
+        float r2 = __builtin_fmaf(-sc.a_norm[1], (float) b2, r1);
+        _Float16 b3 = (_Float16) (r2 / sc.a_norm[2]);
+        put(99, b1); put(100, b2); put(101, b3);
+    } else {
+        put(99, (_Float16) __uint_as_float(0x7f800000u)); put(100, (_Float16) 0.f); put(101, (_Float16) 0.f);   // padding column: +inf
+    }
+#pragma unroll
+    for (int cidx = 102; cidx < KCAT16; ++cidx) put(cidx, (_Float16) 0.f);
+}
+
+// largest finite |x - c|^2 over all rows and sets (float bits through atomicMax; values are >= 0)
+__global__ void norm_max_kernel(const float* __restrict__ nrm, size_t n, unsigned* __restrict__ out) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (i < n) { float t = nrm[i]; if (t < FLT_BIG) v = t; }
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(out, __float_as_uint(v));
+}
+
 // original rows in padded (cluster-sorted) order, contiguous, for the exact rerank (padding rows are never read)
 __global__ void gather_rows_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, float* __restrict__ out) {
     size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,8 +412,12 @@ __device__ unsigned long long g_prof[16];
 #define PROF_ADD(slot, a, b)
 #define PROF_CNT(slot)
 #endif
-template <bool COLDIR>
-__global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ Ap, const float* __restrict__ Bp, size_t bset_stride,
+__device__ __forceinline__ f32x16 mfma_step(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma_step(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <bool COLDIR, bool F16>
+__global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>::frag* __restrict__ Ap, const typename OpFmt<F16>::frag* __restrict__ Bp,
+                                                     size_t bset_stride /* fragments */, float c_scale /* 2^2s, F16 only */, float out_scale /* 2^-2s */,
                                                      const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
                                                      int rg_rows, const int* __restrict__ tile_group, const unsigned* __restrict__ stage_mask,
                                                      int* __restrict__ rowmin /* [n_groups][ma_pad] */,
@@ -346,7 +426,11 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
                                                      int* __restrict__ xcd_ctr) {
     // column stage double buffered in LDS: the next stage is prefetched into registers while the current one is
     // consumed and written to the other buffer afterwards -> one barrier per stage, global latency hidden
-    __shared__ float Bs[2][STAGE_FLOATS];
+    typedef typename OpFmt<F16>::frag frag;
+    constexpr int KS = OpFmt<F16>::KS;
+    constexpr int STAGE_FRAGS = STAGE_TILES * KS * 64;
+    constexpr int STAGE_VEC4 = STAGE_FRAGS * (int) sizeof(frag) / 16;   // 16-byte pieces per stage
+    __shared__ __attribute__((aligned(16))) frag Bs[2][STAGE_FRAGS];
     __shared__ int cmin_s[CHUNK_COLS];
     __shared__ int tg_s[CHUNK_COLS / TILE];
     __shared__ int item_s;
@@ -362,7 +446,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
     const int rg_blocks = rg_rows / BLOCK_ROWS;
     const int n_rb_total = ma_pad / BLOCK_ROWS;
     constexpr int IINF = 0x7f800000;   // +inf as bits
-    constexpr int NPRE = (STAGE_FLOATS / 4 + NTHR - 1) / NTHR;   // float4 per thread per stage (5, the last one partial)
+    constexpr int NPRE = (STAGE_VEC4 + NTHR - 1) / NTHR;   // 16-byte pieces per thread per stage (the last one partial)
     if (COLDIR) {
         for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = IINF;   // every flush leaves the array at +inf again
     }
@@ -411,14 +495,17 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
             PROF_CNT(9);
             col_dirty = true;
             const int row_tile = rb * (BLOCK_ROWS / TILE) + wave * RW;
-            const float* Bset = Bp + (size_t) blkcl[rb] * bset_stride + (size_t) col_tile0 * KK * 64;
+            const frag* Bset = Bp + (size_t) blkcl[rb] * bset_stride + (size_t) col_tile0 * KS * 64;
             // A fragments (coalesced 256-B loads) and the |a'|^2 of the 16 rows each lane's accumulators cover
-            float a[KK];
+            frag a[KS];
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) a[kk] = Ap[((size_t) row_tile * KK + kk) * 64 + lane];
+            for (int kk = 0; kk < KS; ++kk) a[kk] = Ap[((size_t) row_tile * KS + kk) * 64 + lane];
             f32x16 nav;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) nav[g] = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
+            for (int g = 0; g < 16; ++g) {
+                float n = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
+                nav[g] = F16 ? n * c_scale : n;   // the f16 operands are scaled by 2^s: d2~ 2^2s comes out of the chain
+            }
             int rmin[16];   // float bit patterns, see the epilogue note
 #pragma unroll
             for (int g = 0; g < 16; ++g) rmin[g] = IINF;
@@ -427,9 +514,9 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
             int st = __builtin_ctz(mask);
             __syncthreads();
             {
-                const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) st * STAGE_FLOATS);
+                const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) st * STAGE_FRAGS);
                 float4* dst = reinterpret_cast<float4*>(Bs[0]);
-                for (int i = tid; i < STAGE_FLOATS / 4; i += NTHR) dst[i] = src[i];
+                for (int i = tid; i < STAGE_VEC4; i += NTHR) dst[i] = src[i];
             }
             __syncthreads();
             PROF_T(t_v1);
@@ -440,11 +527,11 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
                 const int nxt = mask ? __builtin_ctz(mask) : -1;
                 float4 pre[NPRE];
                 if (nxt >= 0) {
-                    const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) nxt * STAGE_FLOATS);
+                    const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) nxt * STAGE_FRAGS);
 #pragma unroll
                     for (int j = 0; j < NPRE; ++j) {
                         int i = tid + NTHR * j;
-                        if (i < STAGE_FLOATS / 4) pre[j] = src[i];
+                        if (i < STAGE_VEC4) pre[j] = src[i];
                     }
                 }
                 // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
@@ -456,17 +543,17 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
                 //    the proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
                 //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
                 // The B fragment of the next tile is fetched from LDS before the epilogue runs.
-                float b[KK];
+                frag b[KS];
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
+                for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
 #pragma unroll 1
                 for (int ct = 0; ct < STAGE_TILES; ++ct) {
-                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], nav, 0, 0, 0);
+                    f32x16 acc = mfma_step(a[0], b[0], nav);
 #pragma unroll
-                    for (int kk = 1; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+                    for (int kk = 1; kk < KS; ++kk) acc = mfma_step(a[kk], b[kk], acc);
                     if (ct + 1 < STAGE_TILES) {
 #pragma unroll
-                        for (int kk = 0; kk < KK; ++kk) b[kk] = Bs[buf][((ct + 1) * KK + kk) * 64 + lane];
+                        for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][((ct + 1) * KS + kk) * 64 + lane];
                     }
                     int v[16];
 #pragma unroll
@@ -502,6 +589,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
                             if ((lane & 31) == 0 && v != IINF)
                                 rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half] = v;
 #else
+                            if (F16) v = __float_as_int(__int_as_float(v) * out_scale);   // back to d2~ (monotonic)
                             if ((lane & 31) == 0 && v != IINF)
                                 atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], v);
 #endif
@@ -515,7 +603,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < NPRE; ++j) {
                     int i = tid + NTHR * j;
-                    if (i < STAGE_FLOATS / 4) dst[i] = pre[j];
+                    if (i < STAGE_VEC4) dst[i] = pre[j];
                 }
                 __syncthreads();   // next buffer visible; all waves done with the buffer that is refilled next
                 PROF_T(t_s1);
@@ -546,7 +634,8 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const float* __restrict__ 
         for (int j = 0; j < NCM; ++j) {
             int i = tid + NTHR * j;
             if (cur[j] != IINF) {
-                if (cur[j] < old[j]) dst[i] = cur[j];
+                int v = F16 ? __float_as_int(__int_as_float(cur[j]) * out_scale) : cur[j];
+                if (v < old[j]) dst[i] = v;
                 cmin_s[i] = IINF;
             }
         }
@@ -700,9 +789,12 @@ __device__ __forceinline__ unsigned tie_rank(int j, int block, int nblocks) {
 //         + float rounding of the comparison.
 struct RerankCounters { unsigned n_items; unsigned n_dense; unsigned pad0; unsigned pad1; };
 
+// extra terms of the f16-split operand path (0 on the f32 path): eps += lin * (x + y) + abs
+struct EpsExtra { float lin, abs, quad; };   // quad: multiplier of the 4 g40 (x + y)^2 term (1 on the f32 path)
+
 template <bool ROWDIR>
 __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* __restrict__ nT_sets, const float* __restrict__ gmax,
-                                           int n_groups, int p_of_query, const int* __restrict__ cl_of_group, int t_pad) {
+                                           int n_groups, int p_of_query, const int* __restrict__ cl_of_group, int t_pad, EpsExtra ex) {
     // ROWDIR: query = row i of cluster p (xq = |a'|), train group g of columns: y = gmaxB[p][g]
     // COLDIR: query = column i, train group g = row group of cluster p(g): x = gmaxA[g], y = |b - c_p(g)| (per set)
     double x, y;
@@ -716,13 +808,13 @@ __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* 
     const double u = 5.9604644775390625e-8;
     const double g40 = 40 * u / (1 - 40 * u);
     double s = x + y;
-    return (float) (4.0 * g40 * s * s * 1.000001 + 1e-30);
+    return (float) ((4.0 * (double) ex.quad * g40 * s * s + (double) ex.lin * s + (double) ex.abs) * 1.000001 + 1e-30);
 }
 
 // upper bounds after a masked pass (section 3b): largest over the row block / the leaf of  min_g (filtered + eps)
 __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                                                             const float* __restrict__ nQ, const int* __restrict__ blkclQ,
-                                                            const float* __restrict__ gmax, float* __restrict__ u_rb) {
+                                                            const float* __restrict__ gmax, EpsExtra ex, float* __restrict__ u_rb) {
     const int i = blockIdx.x * BLOCK_ROWS + threadIdx.x;
     float ub = -1.f;   // padding rows need nothing
     if (i < q_pad && permQ[i] >= 0) {
@@ -732,7 +824,7 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
         for (int g = 0; g < n_groups; ++g) {
             float v = table[(size_t) g * q_pad + i];
             if (!(v < FLT_BIG)) continue;
-            float e = group_eps<true>(i, g, xq, nullptr, gmax, n_groups, p, nullptr, q_pad);
+            float e = group_eps<true>(i, g, xq, nullptr, gmax, n_groups, p, nullptr, q_pad, ex);
             ub = fminf(ub, v + e);
         }
     }
@@ -747,14 +839,14 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
 }
 __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pad, const int* __restrict__ permT,
                              const float* __restrict__ nT_sets, const float* __restrict__ gmaxA, const int* __restrict__ cl_of_rg,
-                             const int* __restrict__ tile_group, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
+                             const int* __restrict__ tile_group, EpsExtra ex, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= t_pad || permT[j] < 0) return;
     float ub = __uint_as_float(0x7f800000u);
     for (int g = 0; g < n_rg; ++g) {
         float v = table[(size_t) g * t_pad + j];
         if (!(v < FLT_BIG)) continue;
-        float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad);
+        float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad, ex);
         ub = fminf(ub, v + e);
     }
     ub = ub > 0.f ? ub : 0.f;
@@ -810,7 +902,7 @@ template <bool ROWDIR>
 __global__ void rerank_count(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                              const float* __restrict__ nQ /* ROWDIR: |a'|^2 per padded row */, const int* __restrict__ blkclQ,
                              const float* __restrict__ nQ_sets /* COLDIR: |b - c_p|^2 [KCL][q_pad] */, const float* __restrict__ gmax,
-                             const int* __restrict__ cl_of_group, int dense_limit,
+                             const int* __restrict__ cl_of_group, int dense_limit, EpsExtra ex,
                              float* __restrict__ thr_out, int* __restrict__ counts, unsigned* __restrict__ dense,
                              RerankCounters* __restrict__ cnt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -825,7 +917,7 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     for (int g = 0; g < n_groups; ++g) {
         float v = table[(size_t) g * q_pad + i];
         if (!(v < FLT_BIG)) continue;
-        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad);
+        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
         ub = fminf(ub, v + e);
     }
     if (!(ub < FLT_BIG)) return;     // no valid train row at all
@@ -836,7 +928,7 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     for (int g = 0; g < n_groups; ++g) {
         float v = table[(size_t) g * q_pad + i];
         if (!(v < FLT_BIG)) continue;
-        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad);
+        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
         nc += (v - e <= thr) ? 1 : 0;
     }
     if (nc > dense_limit) {
@@ -851,7 +943,7 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
 template <bool ROWDIR>
 __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q_pad, const float* __restrict__ nQ,
                             const int* __restrict__ blkclQ, const float* __restrict__ nQ_sets, const float* __restrict__ gmax,
-                            const int* __restrict__ cl_of_group, const float* __restrict__ thr_in,
+                            const int* __restrict__ cl_of_group, EpsExtra ex, const float* __restrict__ thr_in,
                             const int* __restrict__ counts, const int* __restrict__ offs, unsigned* __restrict__ item_q,
                             unsigned* __restrict__ item_g) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -863,7 +955,7 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
     for (int g = 0; g < n_groups; ++g) {
         float v = table[(size_t) g * q_pad + i];
         if (!(v < FLT_BIG)) continue;
-        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad);
+        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
         if (v - e <= thr) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) g; ++pos; }
     }
 }
@@ -1056,7 +1148,7 @@ int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const fl
 }
 
 template <bool ROWDIR>
-int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
+int run_rerank(lgr_ctx* ctx, EpsExtra ex, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
                const float* nQ, const float* nQ_sets, const float* gmax, const int* cl_of_group,
                const float* T, const float* Tsorted, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
                unsigned* stat_items, unsigned* stat_dense) {
@@ -1073,7 +1165,7 @@ int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, c
     int nblocks = (ts.m + block - 1) / block;
     int dense_limit = std::max(64, n_groups / 2);
     rerank_count<ROWDIR><<<cdiv(q_pad, 256), 256, 0, ctx->stream>>>(table, n_groups, q_pad, qs.perm, nQ, qs.blkcl, nQ_sets, gmax,
-                                                                   cl_of_group, dense_limit, thr, counts, dense, cnt);
+                                                                   cl_of_group, dense_limit, ex, thr, counts, dense, cnt);
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, counts, offs, 0, (size_t) q_pad, rocprim::plus<int>(), ctx->stream));
     void* tmp;
@@ -1093,7 +1185,7 @@ int run_rerank(lgr_ctx* ctx, const float* table, int n_groups, int group_size, c
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS, (size_t) 4 * n_items + 64, &ib));
         unsigned *item_q = ib, *item_g = ib + n_items, *item_q2 = ib + 2 * (size_t) n_items, *item_g2 = ib + 3 * (size_t) n_items;
         rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, 0, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
-                                                                      thr, counts, offs, item_q, item_g);
+                                                                      ex, thr, counts, offs, item_q, item_g);
         int bits = 1;
         while ((1 << bits) < n_groups) ++bits;
         size_t sb = 0;
@@ -1211,14 +1303,61 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const int n_rb = ma_pad / BLOCK_ROWS, n_stage_total = mb_pad / STAGE_COLS;
 
     // ---- 3. pack operands, group maxima, stage -> leaf map
-    float *Ap, *Bp, *nAp, *nBp;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ROWMIN, (size_t) ta * KK * 64 + ma_pad, &Ap));
-    nAp = Ap + (size_t) ta * KK * 64;
-    const size_t bset_stride = (size_t) tb * KK * 64;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_COLMIN, KCL * bset_stride + (size_t) KCL * mb_pad, &Bp));
-    nBp = Bp + KCL * bset_stride;
-    pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, Ap, nAp);
-    pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, Bp, nBp);
+    const bool f16 = env_int("LGR_MATCH_F16", 1) != 0;
+    const int KS = f16 ? OpFmt<true>::KS : OpFmt<false>::KS;
+    const size_t frag_bytes = f16 ? sizeof(f16x8) : sizeof(float);
+    const size_t a_op_bytes = (size_t) ta * KS * 64 * frag_bytes;
+    const size_t bset_stride = (size_t) tb * KS * 64;   // fragments per column set
+    char *Aop, *Bop;
+    float *nAp, *nBp;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ROWMIN, a_op_bytes + (size_t) ma_pad * 4 + 256, &Aop));
+    nAp = (float*) (Aop + ((a_op_bytes + 255) & ~(size_t) 255));
+    const size_t b_op_bytes = KCL * bset_stride * frag_bytes;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_COLMIN, b_op_bytes + (size_t) KCL * mb_pad * 4 + 256, &Bop));
+    nBp = (float*) (Bop + ((b_op_bytes + 255) & ~(size_t) 255));
+    EpsExtra ex{0.f, 0.f, 1.f};
+    float c_scale = 1.f, out_scale = 1.f;
+    if (!f16) {
+        pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, (float*) Aop, nAp);
+        pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, (float*) Bop, nBp);
+    } else {
+        // norms first: the power-of-two scale 2^s puts the largest operand (2 |a'| 2^s, |b'| 2^s) just under 2^15
+        F16Scale sc{1.f, 1.f, {1.f, 1.f, 1.f}};
+        pack16_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, nullptr, nAp);
+        pack16_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp);
+        unsigned* d_max = (unsigned*) (misc + 128);
+        LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
+        norm_max_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(nAp, (size_t) ma_pad, d_max);
+        norm_max_kernel<<<cdiv((long long) KCL * mb_pad, 256), 256, 0, ctx->stream>>>(nBp, (size_t) KCL * mb_pad, d_max);
+        unsigned* h_max;
+        LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_max));
+        LGR_HIP(ctx, hipMemcpyAsync(h_max, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float r2;
+        memcpy(&r2, h_max, 4);
+        double R = std::sqrt((double) r2);
+        int sexp = R > 0 ? (int) std::floor(std::log2(16384.0 / R)) : 14;
+        sexp = std::max(-40, std::min(14, sexp));
+        double N_max = (double) r2 * std::ldexp(1.0, 2 * sexp);
+        int e1 = N_max > 32768.0 ? (int) std::ceil(std::log2(N_max / 32768.0)) : 0;
+        e1 = std::min(15, std::max(0, e1));
+        sc.s_mul = (float) std::ldexp(1.0, sexp);
+        sc.inv_s2 = (float) std::ldexp(1.0, -2 * sexp);
+        sc.a_norm[0] = (float) std::ldexp(1.0, e1);
+        sc.a_norm[1] = (float) std::ldexp(1.0, std::max(0, e1 - 11));
+        sc.a_norm[2] = (float) std::ldexp(1.0, std::max(0, e1 - 22));
+        c_scale = (float) std::ldexp(1.0, 2 * sexp);
+        out_scale = sc.inv_s2;
+        // error terms of the split: elements whose second half would be an f16 subnormal may be flushed
+        // (tau per element, linear term); three-term norm expansion (absolute term); the 112-product f32 accumulation
+        // chain and the 2^-22 split residual are covered by doubling the quadratic term
+        const double tau = std::ldexp(1.0, -14 - sexp);
+        ex.lin = (float) (12.0 * tau);
+        ex.abs = (float) (std::ldexp(1.0, -14) * (sc.a_norm[2] + sc.a_norm[1] / 2048.0 + sc.a_norm[0] / 4194304.0) * (double) sc.inv_s2 * 1.01);
+        ex.quad = 2.f;
+        pack16_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
+        pack16_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
+    }
     const int n_rg = cdiv(ma_pad, rg_rows);
     float *gmaxB, *gmaxA;
     int *cl_of_rg, *tile_group;
@@ -1275,15 +1414,32 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_HIP(ctx, hipMemsetAsync(xcd_ctr, 0, 32, ctx->stream));
         LGR_CHECK(ctx, ctx->mfma_timed < 8, LGR_ERR_INVALID_ARG);
         (void) hipEventRecord(ctx->ev[9 + 2 * ctx->mfma_timed], ctx->stream);
-        if (both)
-            match_mfma<true><<<mfma_grid, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin,
-                                                               n_cc, item_rb, ilist, xcd_start, xcd_ctr);
-        else
-            match_mfma<false><<<mfma_grid, NTHR, 0, ctx->stream>>>(Ap, Bp, bset_stride, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin,
-                                                                n_cc, item_rb, ilist, xcd_start, xcd_ctr);
+#define LGR_MFMA_ARGS bset_stride, c_scale, out_scale, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin, n_cc, item_rb, ilist, xcd_start, xcd_ctr
+        if (f16) {
+            if (both) match_mfma<true, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+        } else {
+            if (both) match_mfma<true, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
+        }
+#undef LGR_MFMA_ARGS
         (void) hipEventRecord(ctx->ev[10 + 2 * ctx->mfma_timed], ctx->stream);
         ctx->mfma_timed += 1;
         LGR_HIP(ctx, hipGetLastError());
+#ifdef EXP_PROF
+        {
+            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            unsigned long long hp[16];
+            (void) hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof hp);
+            int hx[9];
+            (void) hipMemcpy(hx, xcd_start, sizeof hx, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[lgr] prof launch %d (10 ns ticks): prologue %llu stages %llu (store+barrier %llu) colflush %llu wg_total %llu | wgs %llu visits %llu rowflush %llu | items %d (per xcd %d %d %d %d %d %d %d %d)\n",
+                    ctx->mfma_timed - 1, hp[0], hp[1], hp[2], hp[3], hp[4], hp[8], hp[9], hp[10], hx[8], hx[1] - hx[0], hx[2] - hx[1], hx[3] - hx[2],
+                    hx[4] - hx[3], hx[5] - hx[4], hx[6] - hx[5], hx[7] - hx[6], hx[8] - hx[7]);
+            unsigned long long z[16] = {0};
+            (void) hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
+        }
+#endif
         return LGR_OK;
     };
     g_last_stats.stages_all = (double) n_rb * n_stage_total;
@@ -1317,10 +1473,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const int n_beta = (int) (sizeof betas / sizeof betas[0]);
         for (int pass = 0; pass <= n_beta; ++pass) {
             if (pass > 0) {
-                row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_leaves, ma_pad, A.perm, nAp, A.blkcl, gmaxB, u_rb);
+                row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_leaves, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, u_rb);
                 if (both) {
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
-                    col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_group, u_leaf);
+                    col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_group, ex, u_leaf);
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves, done, sched);
@@ -1343,10 +1499,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_HIP(ctx, hipGetLastError());
 
     // ---- 5. exact rerank
-    LGR_TRY((run_rerank<true>(ctx, (const float*) rowmin, n_leaves, 0, B.leaf_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
+    LGR_TRY((run_rerank<true>(ctx, ex, (const float*) rowmin, n_leaves, 0, B.leaf_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
                               d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab)));
     if (both)
-        LGR_TRY((run_rerank<false>(ctx, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
+        LGR_TRY((run_rerank<false>(ctx, ex, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
                                    d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba)));
     return LGR_OK;
 }
