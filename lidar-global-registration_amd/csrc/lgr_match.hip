@@ -57,8 +57,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // MFMA operand formats.  F32: v_mfma_f32_32x32x2_f32, K = 34 (33 dims + norm slot) -> 17 steps, fragment = 1 float.
 // F16: v_mfma_f32_32x32x16_f16 (16x the f32 rate) on two-term f16 splits of the scaled f32 operands,
-//      x * 2^s = h1 + h2 (+ residual <= 2^-22 |x|):  a.b ~ a1.b1 + a1.b2 + a2.b1  -> concatenated K = 3 * 33 + 3 norm slots
-//      = 102, padded to 112 = 7 steps, fragment = 8 halves (lane l: row l & 31, k = 16 * step + 8 * (l >> 5) + j).
+//      x * 2^s = h1 + h2 (+ residual <= 2^-22 |x|):  a.b ~ a1.b1 + a1.b2 + a2.b1  -> concatenated K = 3 * 33 + 6 norm slots
+//      = 105, padded to 112 = 7 steps, fragment = 8 halves (lane l: row l & 31, k = 16 * step + 8 * (l >> 5) + j).
 template <bool F16> struct OpFmt;
 template <> struct OpFmt<false> { typedef float frag; static constexpr int KS = 17; };
 template <> struct OpFmt<true> { typedef f16x8 frag; static constexpr int KS = 7; };
@@ -301,9 +301,10 @@ __global__ void pack_kernel(const float* __restrict__ X, const int* __restrict__
 
 // f16-split operands (OpFmt<true>).  Same roles / sets / nrm output as pack_kernel; P holds f16x8 fragments:
 // fragment (tile, step, lane) at ((set * tiles + tile) * 7 + step) * 64 + lane, lane = row | (khalf << 5).
-// Concatenated K index c: [0,33) a1.b1, [33,66) a1.b2, [66,99) a2.b1, 99..101 norm slots, rest 0.
-// rows: h = split(-2 x' 2^s), norm slots = constants A1..A3;  cols: h = split(x' 2^s), norm slots = the three-term
-// f16 expansion of N = |x'|^2 2^2s against A1..A3 (N = A1 B1 + A2 B2 + A3 B3 up to 2^-33 N or the f16 flush limit).
+// Concatenated K index c: [0,33) a1.b1, [33,66) a1.b2, [66,99) a2.b1, 99..104 norm slots, rest 0.
+// rows: h = split(-2 x' 2^s);  cols: h = split(x' 2^s);  a norm enters as the three-term f16 expansion of
+// N = |x'|^2 2^2s against the constants A1..A3 on the other side (N = A1 B1 + A2 B2 + A3 B3 up to 2^-33 N or the f16
+// flush limit).
 __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
                               const float* __restrict__ cen, const int* __restrict__ blkcl, F16Scale sc,
                               _Float16* __restrict__ P, float* __restrict__ nrm) {
@@ -339,21 +340,23 @@ __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict
         if (role == 0) { put(k, h1); put(33 + k, h1); put(66 + k, h2); }
         else { put(k, h1); put(33 + k, h2); put(66 + k, h1); }
     }
-    if (role == 0) {
-        put(99, (_Float16) sc.a_norm[0]); put(100, (_Float16) sc.a_norm[1]); put(101, (_Float16) sc.a_norm[2]);
-    } else if (o >= 0) {
+    // norm slots: 99..101 carry |b'|^2 (expansion on the column side, constants on the row side), 102..104 carry
+    // |a'|^2 the other way round, so d2~ 2^2s = |b'|^2 - 2 a'.b' + |a'|^2 comes out of the MFMA chain with C = 0
+    const int mine = role == 0 ? 102 : 99, other = role == 0 ? 99 : 102;
+    put(other, (_Float16) sc.a_norm[0]); put(other + 1, (_Float16) sc.a_norm[1]); put(other + 2, (_Float16) sc.a_norm[2]);
+    if (o >= 0) {
         float N = n2 * (sc.s_mul * sc.s_mul);
         _Float16 b1 = (_Float16) (N / sc.a_norm[0]);
         float r1 = __builtin_fmaf(-sc.a_norm[0], (float) b1, N);
         _Float16 b2 = (_Float16) (r1 / sc.a_norm[1]);
         float r2 = __builtin_fmaf(-sc.a_norm[1], (float) b2, r1);
         _Float16 b3 = (_Float16) (r2 / sc.a_norm[2]);
-        put(99, b1); put(100, b2); put(101, b3);
+        put(mine, b1); put(mine + 1, b2); put(mine + 2, b3);
     } else {
-        put(99, (_Float16) __uint_as_float(0x7f800000u)); put(100, (_Float16) 0.f); put(101, (_Float16) 0.f);   // padding column: +inf
+        put(mine, (_Float16) __uint_as_float(0x7f800000u)); put(mine + 1, (_Float16) 0.f); put(mine + 2, (_Float16) 0.f);   // padding: +inf
     }
 #pragma unroll
-    for (int cidx = 102; cidx < KCAT16; ++cidx) put(cidx, (_Float16) 0.f);
+    for (int cidx = 105; cidx < KCAT16; ++cidx) put(cidx, (_Float16) 0.f);
 }
 
 // largest finite |x - c|^2 over all rows and sets (float bits through atomicMax; values are >= 0)
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
     const int rg_blocks = rg_rows / BLOCK_ROWS;
     const int n_rb_total = ma_pad / BLOCK_ROWS;
     constexpr int IINF = 0x7f800000;   // +inf as bits
-    constexpr int NPRE = (STAGE_VEC4 + NTHR - 1) / NTHR;   // 16-byte pieces per thread per stage (the last one partial)
+    static_assert(STAGE_VEC4 % 64 == 0, "a stage is a whole number of 1 KB DMA pieces");
     if (COLDIR) {
         for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = IINF;   // every flush leaves the array at +inf again
     }
@@ -500,49 +503,45 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
             frag a[KS];
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) a[kk] = Ap[((size_t) row_tile * KS + kk) * 64 + lane];
-            f32x16 nav;
+            f32x16 nav = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (!F16) {   // f32 operands: |a'|^2 through the accumulator input (the f16 format carries it in K slots)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                float n = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
-                nav[g] = F16 ? n * c_scale : n;   // the f16 operands are scaled by 2^s: d2~ 2^2s comes out of the chain
+                for (int g = 0; g < 16; ++g) nav[g] = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
             }
             int rmin[16];   // float bit patterns, see the epilogue note
 #pragma unroll
             for (int g = 0; g < 16; ++g) rmin[g] = IINF;
 
+            // Column stages go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers; each wave
+            // instruction copies one contiguous 1 KB piece, the stage image has the same order in memory and in LDS).
+            auto stage_dma = [&](int stage, int to_buf) {
+                const char* src = reinterpret_cast<const char*>(Bset + (size_t) stage * STAGE_FRAGS);
+                char* dst = reinterpret_cast<char*>(Bs[to_buf]);
+#pragma unroll
+                for (int piece = wave; piece < STAGE_VEC4 / 64; piece += WAVES)
+                    __builtin_amdgcn_global_load_lds((const void*) (src + piece * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*) (dst + piece * 1024), 16, 0, 0);
+            };
             // first active stage of this row block (barrier first: every wave is past the previous row block's LDS reads)
             int st = __builtin_ctz(mask);
             __syncthreads();
-            {
-                const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) st * STAGE_FRAGS);
-                float4* dst = reinterpret_cast<float4*>(Bs[0]);
-                for (int i = tid; i < STAGE_VEC4; i += NTHR) dst[i] = src[i];
-            }
-            __syncthreads();
+            stage_dma(st, 0);
+            __syncthreads();   // waits for the DMA (vmcnt(0)) and makes the stage visible
             PROF_T(t_v1);
             PROF_ADD(0, t_v0, t_v1);
-            int buf = 0;
-            while (true) {
-                mask &= mask - 1u;
-                const int nxt = mask ? __builtin_ctz(mask) : -1;
-                float4 pre[NPRE];
-                if (nxt >= 0) {
-                    const float4* src = reinterpret_cast<const float4*>(Bset + (size_t) nxt * STAGE_FRAGS);
-#pragma unroll
-                    for (int j = 0; j < NPRE; ++j) {
-                        int i = tid + NTHR * j;
-                        if (i < STAGE_VEC4) pre[j] = src[i];
-                    }
-                }
-                // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
-                // measured: removing the epilogue saved exactly its VALU time), so the epilogue is kept minimal:
-                //  * |a'|^2 enters through the accumulator input of the first MFMA step: d2~ = S + |a'|^2 costs nothing;
-                //  * minima are taken on the bit patterns with v_min_i32 / v_min3_i32 (one instruction per slot, no
-                //    canonicalising v_max pair as a float min of raw MFMA output needs).  Signed-int order equals float
-                //    order except among negative values, where it keeps the one closest to zero; d2~ < 0 only within
-                //    the proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
-                //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
-                // The B fragment of the next tile is fetched from LDS before the epilogue runs.
+            // Stage loop: the DMA of the next active stage into the other buffer is issued before the current stage is
+            // consumed; the barrier at the end of the stage waits for it.
+            // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
+            // measured: removing the epilogue saved exactly its VALU time), so the epilogue is kept minimal:
+            //  * |a'|^2 enters through the accumulator input of the first MFMA step (f32) or through spare K slots
+            //    (f16): d2~ = S + |a'|^2 costs nothing;
+            //  * minima are taken on the bit patterns with v_min_i32 / v_min3_i32 (one instruction per slot, no
+            //    canonicalising v_max pair as a float min of raw MFMA output needs).  Signed-int order equals float
+            //    order except among negative values, where it keeps the one closest to zero; d2~ < 0 only within
+            //    the proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
+            //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
+            // The B fragment of the next tile is fetched from LDS before the epilogue runs.
+            auto compute = [&](int st, int buf, int nxt) {
                 frag b[KS];
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
@@ -570,11 +569,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
                     }
                     // flush the row minima when the column group (train leaf) ends, or before skipped stages
                     const unsigned te = ct == 0 ? tend[0] : ct == 1 ? tend[1] : ct == 2 ? tend[2] : tend[3];
-#ifdef EXP_NOFLUSHTILE
-                    if (ct == STAGE_TILES - 1 && ((((tend[0] | tend[1] | tend[2] | tend[3]) >> st) & 1u) || nxt != st + 1)) {
-#else
                     if (((te >> st) & 1u) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
-#endif
                         PROF_CNT(10);
                         const int grp = tg_s[st * STAGE_TILES + ct];
 #pragma unroll
@@ -585,27 +580,24 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
                             v = min(v, __shfl_xor(v, 4));
                             v = min(v, __shfl_xor(v, 8));
                             v = min(v, __shfl_xor(v, 16));
-#ifdef EXP_STORE
-                            if ((lane & 31) == 0 && v != IINF)
-                                rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half] = v;
-#else
                             if (F16) v = __float_as_int(__int_as_float(v) * out_scale);   // back to d2~ (monotonic)
                             if ((lane & 31) == 0 && v != IINF)
                                 atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], v);
-#endif
                             rmin[g] = IINF;
                         }
                     }
                 }
+            };
+            mask &= mask - 1u;   // st is taken
+            int buf = 0;
+            while (true) {
+                int nxt = -1;
+                if (mask) { nxt = __builtin_ctz(mask); mask &= mask - 1u; }
+                if (nxt >= 0) stage_dma(nxt, buf ^ 1);
+                compute(st, buf, nxt);
                 if (nxt < 0) break;
                 PROF_T(t_s0);
-                float4* dst = reinterpret_cast<float4*>(Bs[buf ^ 1]);
-#pragma unroll
-                for (int j = 0; j < NPRE; ++j) {
-                    int i = tid + NTHR * j;
-                    if (i < STAGE_VEC4) dst[i] = pre[j];
-                }
-                __syncthreads();   // next buffer visible; all waves done with the buffer that is refilled next
+                __syncthreads();   // DMA landed (vmcnt(0)) and visible; all waves done with the buffer refilled next
                 PROF_T(t_s1);
                 PROF_ADD(2, t_s0, t_s1);
                 buf ^= 1;
@@ -1353,7 +1345,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         // chain and the 2^-22 split residual are covered by doubling the quadratic term
         const double tau = std::ldexp(1.0, -14 - sexp);
         ex.lin = (float) (12.0 * tau);
-        ex.abs = (float) (std::ldexp(1.0, -14) * (sc.a_norm[2] + sc.a_norm[1] / 2048.0 + sc.a_norm[0] / 4194304.0) * (double) sc.inv_s2 * 1.01);
+        ex.abs = (float) (2.0 * std::ldexp(1.0, -14) * (sc.a_norm[2] + sc.a_norm[1] / 2048.0 + sc.a_norm[0] / 4194304.0) * (double) sc.inv_s2 * 1.01);   // both norms
         ex.quad = 2.f;
         pack16_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
         pack16_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
@@ -1433,8 +1425,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             (void) hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof hp);
             int hx[9];
             (void) hipMemcpy(hx, xcd_start, sizeof hx, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[lgr] prof launch %d (10 ns ticks): prologue %llu stages %llu (store+barrier %llu) colflush %llu wg_total %llu | wgs %llu visits %llu rowflush %llu | items %d (per xcd %d %d %d %d %d %d %d %d)\n",
-                    ctx->mfma_timed - 1, hp[0], hp[1], hp[2], hp[3], hp[4], hp[8], hp[9], hp[10], hx[8], hx[1] - hx[0], hx[2] - hx[1], hx[3] - hx[2],
+            fprintf(stderr, "[lgr] prof launch %d (10 ns ticks): prologue %llu stages %llu (barrier+dma wait %llu, - %llu) colflush %llu wg_total %llu | wgs %llu visits %llu rowflush %llu | items %d (per xcd %d %d %d %d %d %d %d %d)\n",
+                    ctx->mfma_timed - 1, hp[0], hp[1], hp[2], hp[5], hp[3], hp[4], hp[8], hp[9], hp[10], hx[8], hx[1] - hx[0], hx[2] - hx[1], hx[3] - hx[2],
                     hx[4] - hx[3], hx[5] - hx[4], hx[6] - hx[5], hx[7] - hx[6], hx[8] - hx[7]);
             unsigned long long z[16] = {0};
             (void) hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
