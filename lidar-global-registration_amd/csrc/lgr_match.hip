@@ -572,19 +572,49 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
                     if (((te >> st) & 1u) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
                         PROF_CNT(10);
                         const int grp = tg_s[st * STAGE_TILES + ct];
+                        // Halving butterfly over the 32 lanes of each half wave: at every step a lane keeps half of
+                        // its registers and receives the partner's copy of them, so 16 registers x 32 lanes reduce to
+                        // one value per lane with 16 + 8 + 4 + 2 + 1 exchanges instead of 16 x 5; lane bits 4..1 then
+                        // select the register (= row) the lane ends up holding, and one atomic instruction with 16
+                        // active lanes per half wave writes all rows.
+                        int w8[8], w4[4], w2[2], w1;
+                        {
+                            const bool up = (lane & 16) != 0;
 #pragma unroll
-                        for (int g = 0; g < 16; ++g) {
-                            int v = rmin[g];
-                            v = min(v, __shfl_xor(v, 1));
-                            v = min(v, __shfl_xor(v, 2));
-                            v = min(v, __shfl_xor(v, 4));
-                            v = min(v, __shfl_xor(v, 8));
-                            v = min(v, __shfl_xor(v, 16));
-                            if (F16) v = __float_as_int(__int_as_float(v) * out_scale);   // back to d2~ (monotonic)
-                            if ((lane & 31) == 0 && v != IINF)
-                                atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], v);
-                            rmin[g] = IINF;
+                            for (int j = 0; j < 8; ++j) {
+                                int keep = up ? rmin[8 + j] : rmin[j], send = up ? rmin[j] : rmin[8 + j];
+                                w8[j] = min(keep, __shfl_xor(send, 16));
+                            }
                         }
+                        {
+                            const bool up = (lane & 8) != 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                int keep = up ? w8[4 + j] : w8[j], send = up ? w8[j] : w8[4 + j];
+                                w4[j] = min(keep, __shfl_xor(send, 8));
+                            }
+                        }
+                        {
+                            const bool up = (lane & 4) != 0;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                int keep = up ? w4[2 + j] : w4[j], send = up ? w4[j] : w4[2 + j];
+                                w2[j] = min(keep, __shfl_xor(send, 4));
+                            }
+                        }
+                        {
+                            const bool up = (lane & 2) != 0;
+                            int keep = up ? w2[1] : w2[0], send = up ? w2[0] : w2[1];
+                            w1 = min(keep, __shfl_xor(send, 2));
+                        }
+                        w1 = min(w1, __shfl_xor(w1, 1));
+                        // register index held by this lane: bit 3 <- lane bit 4, bit 2 <- bit 3, bit 1 <- bit 2, bit 0 <- bit 1
+                        const int g = (lane >> 1) & 15;
+                        if (F16) w1 = __float_as_int(__int_as_float(w1) * out_scale);   // back to d2~ (monotonic)
+                        if ((lane & 1) == 0 && w1 != IINF)
+                            atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], w1);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rmin[r] = IINF;
                     }
                 }
             };
