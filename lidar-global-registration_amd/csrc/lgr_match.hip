@@ -49,6 +49,7 @@ constexpr int NEAR_T = 64;          // pass 0 visits the NEAR_T nearest leaves o
 #ifndef LGR_PRUNE_BETAS
 #define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
 #endif
+constexpr int GROUP_COLS = 1024;     // largest column group of the row-minimum table (leaves are cut into such pieces)
 constexpr int STAGES_PER_CHUNK = CHUNK_COLS / STAGE_COLS;   // 32 -> one 32-bit stage mask per (row block, chunk)
 constexpr float FLT_BIG = 3.4028234663852886e38f;
 
@@ -359,13 +360,21 @@ __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict
     for (int cidx = 105; cidx < KCAT16; ++cidx) put(cidx, (_Float16) 0.f);
 }
 
-// largest finite |x - c|^2 over all rows and sets (float bits through atomicMax; values are >= 0)
-__global__ void norm_max_kernel(const float* __restrict__ nrm, size_t n, unsigned* __restrict__ out) {
-    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+// largest finite |x - c|^2 over all rows and sets (float bits through atomicMax; values are >= 0): one atomic per block
+__global__ __launch_bounds__(256) void norm_max_kernel(const float* __restrict__ nrm, size_t n, unsigned* __restrict__ out) {
     float v = 0.f;
-    if (i < n) { float t = nrm[i]; if (t < FLT_BIG) v = t; }
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) {
+        float t = nrm[i];
+        if (t < FLT_BIG) v = fmaxf(v, t);
+    }
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(out, __float_as_uint(v));
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        if (v > 0.f) atomicMax(out, __float_as_uint(v));
+    }
 }
 
 // original rows in padded (cluster-sorted) order, contiguous, for the exact rerank (padding rows are never read)
@@ -983,19 +992,16 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
 }
 
 // 4b. exact distances of the (query position, train group) items, sorted by group: a workgroup takes 256 consecutive
-// items (almost always one group), streams the group's train rows through LDS once and every thread scans them for its
-// own query with the canonical distance -- the group is read once per 256 queries instead of once per query.
+// items (almost always one group) and every thread scans the group's train rows for its own query with the canonical
+// distance.  The train row address is wave uniform (made explicit with readfirstlane), so the rows arrive through the
+// scalar cache as SGPR operands of the VALU ops: no vector loads, no LDS in the inner loop.
 constexpr int RQ_THREADS = 256;
-constexpr int RQ_ROWS = 64;
-constexpr int RQ_STRIDE = 36;   // floats per staged row (16-byte aligned rows)
 __global__ __launch_bounds__(RQ_THREADS) void rerank_grouped(const float* __restrict__ Q, const int* __restrict__ permQ,
                                                              const float* __restrict__ Tsorted, const int* __restrict__ permT, int t_pad,
                                                              int group_size, const int* __restrict__ starts /* variable groups, or nullptr */,
                                                              int block, int nblocks, const unsigned* __restrict__ item_g,
                                                              const unsigned* __restrict__ item_q, unsigned n_items,
                                                              unsigned long long* __restrict__ best) {
-    __shared__ __attribute__((aligned(16))) float Ts[RQ_ROWS * RQ_STRIDE];
-    __shared__ int To[RQ_ROWS];
     __shared__ unsigned next_g;
     const int tid = threadIdx.x;
     const unsigned idx = blockIdx.x * RQ_THREADS + tid;
@@ -1008,20 +1014,19 @@ __global__ __launch_bounds__(RQ_THREADS) void rerank_grouped(const float* __rest
     unsigned long long bk = ~0ull;
     unsigned cur = item_g[blockIdx.x * RQ_THREADS];   // items are sorted: the first one has the smallest group
     while (cur != 0xffffffffu) {
-        const int j0 = starts ? starts[cur] : (int) cur * group_size;
-        const int j1 = starts ? starts[cur + 1] : min(t_pad, j0 + group_size);
-        for (int jb = j0; jb < j1; jb += RQ_ROWS) {
-            const int nj = min(RQ_ROWS, j1 - jb);
-            __syncthreads();
-            for (int e = tid; e < nj * 33; e += RQ_THREADS) Ts[(e / 33) * RQ_STRIDE + e % 33] = Tsorted[(size_t) jb * 33 + e];
-            if (tid < nj) To[tid] = permT[jb + tid];
-            __syncthreads();
-            if (act && g == cur) {
-                for (int jj = 0; jj < nj; ++jj) {
-                    int to = To[jj];
-                    if (to < 0) continue;                // padding
-                    float d = exact_l2(q, Ts + jj * RQ_STRIDE);
-                    if (!(d < FLT_BIG)) continue;        // batchDistance keeps only d < FLT_MAX
+        const int j0 = __builtin_amdgcn_readfirstlane(starts ? starts[cur] : (int) cur * group_size);
+        const int j1 = __builtin_amdgcn_readfirstlane(starts ? starts[cur + 1] : min(t_pad, j0 + group_size));
+        // waves without an item of this group skip it (wave-uniform branch)
+        if (__ballot(act && g == cur) != 0ull) {
+            for (int j = j0; j < j1; ++j) {
+                const int to = __builtin_amdgcn_readfirstlane(permT[j]);
+                if (to < 0) continue;                // padding
+                const float* __restrict__ tp = Tsorted + (size_t) j * 33;   // wave-uniform address -> scalar loads
+                float t[33];
+#pragma unroll
+                for (int k = 0; k < 33; ++k) t[k] = tp[k];
+                float d = exact_l2(q, t);
+                if (act && g == cur && d < FLT_BIG) {   // batchDistance keeps only d < FLT_MAX
                     unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | tie_rank(to, block, nblocks);
                     bk = key < bk ? key : bk;
                 }
@@ -1320,7 +1325,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_TRY(build_side(ctx, d_b, mb, cen, cen2, sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B));
     if (A.n_valid == 0 || B.n_valid == 0) return LGR_OK;
     const int ma_pad = A.n_pad, mb_pad = B.n_pad;
-    g_last_stats.sub_cols = n_leaves; g_last_stats.rg_rows = rg_rows;
+    g_last_stats.rg_rows = rg_rows;
     const int ta = ma_pad / TILE, tb = mb_pad / TILE;
     const int n_rb = ma_pad / BLOCK_ROWS, n_stage_total = mb_pad / STAGE_COLS;
 
@@ -1349,8 +1354,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         pack16_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp);
         unsigned* d_max = (unsigned*) (misc + 128);
         LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
-        norm_max_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(nAp, (size_t) ma_pad, d_max);
-        norm_max_kernel<<<cdiv((long long) KCL * mb_pad, 256), 256, 0, ctx->stream>>>(nBp, (size_t) KCL * mb_pad, d_max);
+        norm_max_kernel<<<std::min(cdiv(ma_pad, 256), 2048), 256, 0, ctx->stream>>>(nAp, (size_t) ma_pad, d_max);
+        norm_max_kernel<<<std::min(cdiv((long long) KCL * mb_pad, 256), 2048), 256, 0, ctx->stream>>>(nBp, (size_t) KCL * mb_pad, d_max);
         unsigned* h_max;
         LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_max));
         LGR_HIP(ctx, hipMemcpyAsync(h_max, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1381,22 +1386,36 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         pack16_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
     }
     const int n_rg = cdiv(ma_pad, rg_rows);
+    // column groups of the row-minimum table: a leaf, cut into pieces of at most GROUP_COLS columns (k-means leaves of
+    // near-duplicate descriptors can hold tens of thousands of rows; the exact rerank scans a whole group per item)
+    std::vector<int> h_group_start, h_tiles(2 * (size_t) tb);   // [tile] -> group, [tb + tile] -> leaf
+    for (int l = 0; l < n_leaves; ++l)
+        for (int s0 = B.h_leaf_start[l]; s0 < B.h_leaf_start[l + 1]; s0 += GROUP_COLS) {
+            int s1 = std::min(B.h_leaf_start[l + 1], s0 + GROUP_COLS), g = (int) h_group_start.size();
+            h_group_start.push_back(s0);
+            for (int t = s0 / TILE; t < s1 / TILE; ++t) { h_tiles[t] = g; h_tiles[tb + t] = l; }
+        }
+    const int n_groups = (int) h_group_start.size();
+    g_last_stats.sub_cols = n_groups;
+    h_group_start.push_back(mb_pad);
     float *gmaxB, *gmaxA;
-    int *cl_of_rg, *tile_group;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_B, (size_t) KCL * n_leaves + 2 * (size_t) n_rg + tb + 64, &gmaxB));
-    gmaxA = gmaxB + (size_t) KCL * n_leaves;
+    int *cl_of_rg, *tile_group, *tile_leaf, *group_start;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_B, (size_t) KCL * n_groups + 2 * (size_t) n_rg + 2 * (size_t) tb + n_groups + 65, &gmaxB));
+    gmaxA = gmaxB + (size_t) KCL * n_groups;
     cl_of_rg = (int*) (gmaxA + n_rg);
     tile_group = cl_of_rg + n_rg;
-    group_max_kernel<<<dim3(n_leaves, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, 0, B.leaf_start, gmaxB);
-    group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
+    tile_leaf = tile_group + tb;
+    group_start = tile_leaf + tb;
     {
-        std::vector<int> h(n_rg + tb);
+        std::vector<int> h(n_rg);
         for (int g = 0; g < n_rg; ++g) h[g] = A.h_blkcl[(size_t) g * (rg_rows / BLOCK_ROWS)];
-        for (int l = 0; l < n_leaves; ++l)
-            for (int t = B.h_leaf_start[l] / TILE; t < B.h_leaf_start[l + 1] / TILE; ++t) h[n_rg + t] = l;
         LGR_HIP(ctx, hipMemcpyAsync(cl_of_rg, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(tile_group, h_tiles.data(), h_tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(group_start, h_group_start.data(), h_group_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    group_max_kernel<<<dim3(n_groups, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, 0, group_start, gmaxB);
+    group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
     float *sortedA = nullptr, *sortedB;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_B, (size_t) mb_pad * 33, &sortedB));
     gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, sortedB);
@@ -1407,9 +1426,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
 
     // ---- 4. MFMA passes into the two minimum tables (+inf initialised)
     int *rowmin, *colmin = nullptr;
-    const size_t tab_floats = (size_t) n_leaves * ma_pad + (both ? (size_t) n_rg * mb_pad : 0);
+    const size_t tab_floats = (size_t) n_groups * ma_pad + (both ? (size_t) n_rg * mb_pad : 0);
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_A, tab_floats + 2 * ((size_t) ma + mb) + 64, &rowmin));
-    if (both) colmin = rowmin + (size_t) n_leaves * ma_pad;
+    if (both) colmin = rowmin + (size_t) n_groups * ma_pad;
     unsigned long long* bestA = (unsigned long long*) (rowmin + tab_floats + (tab_floats & 1));
     unsigned long long* bestB = bestA + ma;
     fill_u64<<<cdiv(ma + mb, 256), 256, 0, ctx->stream>>>(bestA, ma + mb, ~0ull);
@@ -1495,15 +1514,15 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const int n_beta = (int) (sizeof betas / sizeof betas[0]);
         for (int pass = 0; pass <= n_beta; ++pass) {
             if (pass > 0) {
-                row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_leaves, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, u_rb);
+                row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, u_rb);
                 if (both) {
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
-                    col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_group, ex, u_leaf);
+                    col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, u_leaf);
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves, done, sched);
             }
-            mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_group, n_rb, n_cc, n_leaves, n_stage_total, mask, mstats);
+            mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, mask, mstats);
             LGR_TRY(launch_mfma(mask));
         }
         MaskStats* hs;
@@ -1521,7 +1540,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_HIP(ctx, hipGetLastError());
 
     // ---- 5. exact rerank
-    LGR_TRY((run_rerank<true>(ctx, ex, (const float*) rowmin, n_leaves, 0, B.leaf_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
+    LGR_TRY((run_rerank<true>(ctx, ex, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
                               d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab)));
     if (both)
         LGR_TRY((run_rerank<false>(ctx, ex, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
