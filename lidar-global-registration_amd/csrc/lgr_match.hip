@@ -842,17 +842,66 @@ __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* 
     return (float) ((4.0 * (double) ex.quad * g40 * s * s + (double) ex.lin * s + (double) ex.abs) * 1.000001 + 1e-30);
 }
 
+// Which table entries were computed at all (skipping leaves most of them at +inf): byte matrices derived from the
+// done | scheduled tiles, so the table scans below read only the entries that can be finite.
+//   rows:  comp_r[row block][column group]      cols:  comp_c[leaf][row group]
+struct CompView { const uint8_t* m; int stride; const int* row_of_tile; };   // m == nullptr: everything was computed
+__device__ __forceinline__ const uint8_t* comp_row(const CompView& c, int i, int block_row) {
+    if (!c.m) return nullptr;
+    int r = c.row_of_tile ? c.row_of_tile[i / TILE] : block_row;
+    return c.m + (size_t) r * c.stride;
+}
+// compact list (dynamic LDS) of the groups computed for any query of this block; returns its length, or -1 when
+// nothing was skipped (iterate all groups).  Every thread of the block must call it.
+__device__ __forceinline__ int comp_list(const CompView& c, int i0, int n_i, int n_groups, int* list_s) {
+    __shared__ int cnt_s;
+    if (!c.m) return -1;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    const int t0 = i0 / TILE, t1 = (min(i0 + (int) blockDim.x, n_i) - 1) / TILE;
+    for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        uint8_t f = 0;
+        if (c.row_of_tile) {
+            int prev = -1;
+            for (int t = t0; t <= t1; ++t) { int r = c.row_of_tile[t]; if (r != prev) { f |= c.m[(size_t) r * c.stride + g]; prev = r; } }
+        } else f = c.m[(size_t) (i0 / BLOCK_ROWS) * c.stride + g];
+        if (f) list_s[atomicAdd(&cnt_s, 1)] = g;
+    }
+    __syncthreads();
+    return cnt_s;
+}
+__global__ void comp_rows_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched, const int* __restrict__ group_leaf,
+                                 int n_rb, int n_leaves, int n_groups, uint8_t* __restrict__ comp_r) {
+    size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t) n_rb * n_groups) return;
+    int rb = (int) (idx / n_groups), g = (int) (idx % n_groups);
+    size_t t = (size_t) rb * n_leaves + group_leaf[g];
+    comp_r[idx] = done[t] | sched[t];
+}
+__global__ void comp_cols_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched, int n_rb, int n_leaves, int n_rg,
+                                 int rg_blocks, uint8_t* __restrict__ comp_c) {
+    size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t) n_leaves * n_rg) return;
+    int l = (int) (idx / n_rg), rg = (int) (idx % n_rg);
+    uint8_t v = 0;
+    for (int rb = rg * rg_blocks; rb < min(n_rb, (rg + 1) * rg_blocks); ++rb) v |= done[(size_t) rb * n_leaves + l] | sched[(size_t) rb * n_leaves + l];
+    comp_c[idx] = v;
+}
+
 // upper bounds after a masked pass (section 3b): largest over the row block / the leaf of  min_g (filtered + eps)
 __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                                                             const float* __restrict__ nQ, const int* __restrict__ blkclQ,
-                                                            const float* __restrict__ gmax, EpsExtra ex, float* __restrict__ u_rb) {
+                                                            const float* __restrict__ gmax, EpsExtra ex, CompView comp, float* __restrict__ u_rb) {
+    extern __shared__ int list_s[];
     const int i = blockIdx.x * BLOCK_ROWS + threadIdx.x;
+    const int n_list = comp_list(comp, blockIdx.x * BLOCK_ROWS, q_pad, n_groups, list_s);
     float ub = -1.f;   // padding rows need nothing
     if (i < q_pad && permQ[i] >= 0) {
         int p = blkclQ[blockIdx.x];
         float xq = sqrtf(nQ[i]) * 1.0000002f;
         ub = __uint_as_float(0x7f800000u);
-        for (int g = 0; g < n_groups; ++g) {
+        for (int k = 0; k < (n_list < 0 ? n_groups : n_list); ++k) {
+            const int g = n_list < 0 ? k : list_s[k];
             float v = table[(size_t) g * q_pad + i];
             if (!(v < FLT_BIG)) continue;
             float e = group_eps<true>(i, g, xq, nullptr, gmax, n_groups, p, nullptr, q_pad, ex);
@@ -870,11 +919,14 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
 }
 __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pad, const int* __restrict__ permT,
                              const float* __restrict__ nT_sets, const float* __restrict__ gmaxA, const int* __restrict__ cl_of_rg,
-                             const int* __restrict__ tile_group, EpsExtra ex, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
+                             const int* __restrict__ tile_group, EpsExtra ex, CompView comp, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
+    extern __shared__ int list_s[];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, t_pad, n_rg, list_s);
     if (j >= t_pad || permT[j] < 0) return;
     float ub = __uint_as_float(0x7f800000u);
-    for (int g = 0; g < n_rg; ++g) {
+    for (int k = 0; k < (n_list < 0 ? n_rg : n_list); ++k) {
+        const int g = n_list < 0 ? k : list_s[k];
         float v = table[(size_t) g * t_pad + j];
         if (!(v < FLT_BIG)) continue;
         float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad, ex);
@@ -933,10 +985,13 @@ template <bool ROWDIR>
 __global__ void rerank_count(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                              const float* __restrict__ nQ /* ROWDIR: |a'|^2 per padded row */, const int* __restrict__ blkclQ,
                              const float* __restrict__ nQ_sets /* COLDIR: |b - c_p|^2 [KCL][q_pad] */, const float* __restrict__ gmax,
-                             const int* __restrict__ cl_of_group, int dense_limit, EpsExtra ex,
+                             const int* __restrict__ cl_of_group, int dense_limit, EpsExtra ex, CompView comp,
                              float* __restrict__ thr_out, int* __restrict__ counts, unsigned* __restrict__ dense,
                              RerankCounters* __restrict__ cnt) {
+    extern __shared__ int list_s[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s);
+    const int n_it = n_list < 0 ? n_groups : n_list;
     if (i >= q_pad) return;
     counts[i] = 0;
     int o = permQ[i];
@@ -945,7 +1000,8 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     float nq = ROWDIR ? nQ[i] : 0.f;
     float xq = ROWDIR ? sqrtf(nq) * 1.0000002f : 0.f;
     float ub = __uint_as_float(0x7f800000u);
-    for (int g = 0; g < n_groups; ++g) {
+    for (int k = 0; k < n_it; ++k) {
+        const int g = n_list < 0 ? k : list_s[k];
         float v = table[(size_t) g * q_pad + i];
         if (!(v < FLT_BIG)) continue;
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
@@ -956,7 +1012,8 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     float thr = (float) ((double) ub + 1e-5 * d2 + 8.0 * 5.9604644775390625e-8 * fabs((double) ub) + 1e-30);
     if (thr < ub) thr = ub;
     int nc = 0;
-    for (int g = 0; g < n_groups; ++g) {
+    for (int k = 0; k < n_it; ++k) {
+        const int g = n_list < 0 ? k : list_s[k];
         float v = table[(size_t) g * q_pad + i];
         if (!(v < FLT_BIG)) continue;
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
@@ -974,16 +1031,19 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
 template <bool ROWDIR>
 __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q_pad, const float* __restrict__ nQ,
                             const int* __restrict__ blkclQ, const float* __restrict__ nQ_sets, const float* __restrict__ gmax,
-                            const int* __restrict__ cl_of_group, EpsExtra ex, const float* __restrict__ thr_in,
+                            const int* __restrict__ cl_of_group, EpsExtra ex, CompView comp, const float* __restrict__ thr_in,
                             const int* __restrict__ counts, const int* __restrict__ offs, unsigned* __restrict__ item_q,
                             unsigned* __restrict__ item_g) {
+    extern __shared__ int list_s[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s);
     if (i >= q_pad || counts[i] == 0) return;
     int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
     float xq = ROWDIR ? sqrtf(nQ[i]) * 1.0000002f : 0.f;
     float thr = thr_in[i];
     int pos = offs[i];
-    for (int g = 0; g < n_groups; ++g) {
+    for (int k = 0; k < (n_list < 0 ? n_groups : n_list); ++k) {
+        const int g = n_list < 0 ? k : list_s[k];
         float v = table[(size_t) g * q_pad + i];
         if (!(v < FLT_BIG)) continue;
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
@@ -1175,7 +1235,7 @@ int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const fl
 }
 
 template <bool ROWDIR>
-int run_rerank(lgr_ctx* ctx, EpsExtra ex, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
+int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
                const float* nQ, const float* nQ_sets, const float* gmax, const int* cl_of_group,
                const float* T, const float* Tsorted, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
                unsigned* stat_items, unsigned* stat_dense) {
@@ -1191,8 +1251,8 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, const float* table, int n_groups, int 
     LGR_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(RerankCounters), ctx->stream));
     int nblocks = (ts.m + block - 1) / block;
     int dense_limit = std::max(64, n_groups / 2);
-    rerank_count<ROWDIR><<<cdiv(q_pad, 256), 256, 0, ctx->stream>>>(table, n_groups, q_pad, qs.perm, nQ, qs.blkcl, nQ_sets, gmax,
-                                                                   cl_of_group, dense_limit, ex, thr, counts, dense, cnt);
+    rerank_count<ROWDIR><<<cdiv(q_pad, 256), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(table, n_groups, q_pad, qs.perm, nQ, qs.blkcl, nQ_sets, gmax,
+                                                                   cl_of_group, dense_limit, ex, comp, thr, counts, dense, cnt);
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, counts, offs, 0, (size_t) q_pad, rocprim::plus<int>(), ctx->stream));
     void* tmp;
@@ -1211,8 +1271,8 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, const float* table, int n_groups, int 
         unsigned* ib;
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS, (size_t) 4 * n_items + 64, &ib));
         unsigned *item_q = ib, *item_g = ib + n_items, *item_q2 = ib + 2 * (size_t) n_items, *item_g2 = ib + 3 * (size_t) n_items;
-        rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, 0, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
-                                                                      ex, thr, counts, offs, item_q, item_g);
+        rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
+                                                                      ex, comp, thr, counts, offs, item_q, item_g);
         int bits = 1;
         while ((1 << bits) < n_groups) ++bits;
         size_t sb = 0;
@@ -1484,6 +1544,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         return LGR_OK;
     };
     g_last_stats.stages_all = (double) n_rb * n_stage_total;
+    CompView comp_rows{nullptr, 0, nullptr}, comp_cols{nullptr, 0, nullptr};
     if (!prune) {
         LGR_TRY(launch_mfma(nullptr));
         g_last_stats.stages_done = g_last_stats.stages_all;
@@ -1495,6 +1556,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
+        const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
@@ -1503,7 +1565,22 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         float* u_rb = (float*) (pb + o_urb);
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
-        LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, poff - o_done, ctx->stream));   // done, sched, masks, bounds, stats
+        uint8_t* comp_r = (uint8_t*) (pb + o_cr);
+        uint8_t* comp_c = (uint8_t*) (pb + o_cc);
+        int* group_leaf = (int*) (pb + o_gl);
+        LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, o_cr - o_done, ctx->stream));   // done, sched, masks, bounds, stats
+        {
+            std::vector<int> h(n_groups);
+            for (int g = 0; g < n_groups; ++g) h[g] = h_tiles[tb + h_group_start[g] / TILE];
+            LGR_HIP(ctx, hipMemcpyAsync(group_leaf, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        auto build_comp = [&]() {
+            comp_rows_kernel<<<cdiv((long long) n_rb * n_groups, 256), 256, 0, ctx->stream>>>(done, sched, group_leaf, n_rb, n_leaves, n_groups, comp_r);
+            if (both) comp_cols_kernel<<<cdiv((long long) n_leaves * n_rg, 256), 256, 0, ctx->stream>>>(done, sched, n_rb, n_leaves, n_rg, rg_rows / BLOCK_ROWS, comp_c);
+        };
+        comp_rows = CompView{comp_r, n_groups, nullptr};
+        comp_cols = CompView{comp_c, n_rg, tile_leaf};
         lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
         near_kernel<<<n_rb, 64, (size_t) (n_leaves + 31) / 32 * 4, ctx->stream>>>(near_t, LBsq, n_rb, n_leaves, (size_t) n_leaves, 1, sched, (size_t) n_leaves, 1);
@@ -1514,10 +1591,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const int n_beta = (int) (sizeof betas / sizeof betas[0]);
         for (int pass = 0; pass <= n_beta; ++pass) {
             if (pass > 0) {
-                row_u_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, u_rb);
+                build_comp();
+                row_u_kernel<<<n_rb, BLOCK_ROWS, (size_t) (n_groups + 8) * 4, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, comp_rows, u_rb);
                 if (both) {
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
-                    col_u_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, u_leaf);
+                    col_u_kernel<<<cdiv(mb_pad, 256), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, comp_cols, u_leaf);
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves, done, sched);
@@ -1525,6 +1603,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, mask, mstats);
             LGR_TRY(launch_mfma(mask));
         }
+        build_comp();   // final state for the rerank scans
         MaskStats* hs;
         LGR_TRY(lgr_pinned(ctx, 256, (void**) &hs));
         LGR_HIP(ctx, hipMemcpyAsync(hs, mstats, sizeof(MaskStats), hipMemcpyDeviceToHost, ctx->stream));
@@ -1540,10 +1619,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_HIP(ctx, hipGetLastError());
 
     // ---- 5. exact rerank
-    LGR_TRY((run_rerank<true>(ctx, ex, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
+    LGR_TRY((run_rerank<true>(ctx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
                               d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab)));
     if (both)
-        LGR_TRY((run_rerank<false>(ctx, ex, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
+        LGR_TRY((run_rerank<false>(ctx, ex, comp_cols, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
                                    d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba)));
     return LGR_OK;
 }
