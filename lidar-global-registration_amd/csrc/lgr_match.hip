@@ -853,12 +853,12 @@ __device__ __forceinline__ const uint8_t* comp_row(const CompView& c, int i, int
 }
 // compact list (dynamic LDS) of the groups computed for any query of this block; returns its length, or -1 when
 // nothing was skipped (iterate all groups).  Every thread of the block must call it.
-__device__ __forceinline__ int comp_list(const CompView& c, int i0, int n_i, int n_groups, int* list_s) {
+__device__ __forceinline__ int comp_list(const CompView& c, int i0, int n_i, int n_groups, int* list_s, int span = 0) {
     __shared__ int cnt_s;
     if (!c.m) return -1;
     if (threadIdx.x == 0) cnt_s = 0;
     __syncthreads();
-    const int t0 = i0 / TILE, t1 = (min(i0 + (int) blockDim.x, n_i) - 1) / TILE;
+    const int t0 = i0 / TILE, t1 = (min(i0 + (span ? span : (int) blockDim.x), n_i) - 1) / TILE;
     for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
         uint8_t f = 0;
         if (c.row_of_tile) {
@@ -979,6 +979,58 @@ __global__ void mask_kernel(int pass, const uint8_t* __restrict__ sched, const i
     unsigned c = __popc(m);
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats->stages[pass], (unsigned long long) c);
+}
+
+// Self-check of the filter bound (LGR_MATCH_CHECK=1, test sizes only): for sampled queries and every computed group,
+// |filtered minimum - exact minimum of the squared distance (double)| / eps, maximised through atomicMax on the float
+// bits.  eps is a proven bound, so the ratio must stay <= 1; tests assert it on both operand formats.
+template <bool ROWDIR>
+__global__ void check_kernel(const float* __restrict__ table, int n_groups, int q_pad, int group_size, const int* __restrict__ starts,
+                             const float* __restrict__ Qsorted, const int* __restrict__ permQ, const float* __restrict__ Tsorted,
+                             const int* __restrict__ permT, int t_pad, const float* __restrict__ nQ, const int* __restrict__ blkclQ,
+                             const float* __restrict__ nQ_sets, const float* __restrict__ gmax, const int* __restrict__ cl_of_group,
+                             EpsExtra ex, CompView comp, int stride, const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched,
+                             int n_leaves, unsigned* __restrict__ worst) {
+    extern __shared__ int list_s[];
+    const int i = blockIdx.x * stride;   // sampled padded query position
+    // the computed groups of the row block (rows) / of the leaf (columns) this query lives in
+    const int n_list = comp_list(comp, ROWDIR ? (i / BLOCK_ROWS) * BLOCK_ROWS : (i / TILE) * TILE, q_pad, n_groups, list_s, ROWDIR ? BLOCK_ROWS : TILE);
+    // columns: a row group is computed row block by row block; the table holds the minimum over the computed ones only
+    const int my_leaf = (!ROWDIR && done && i < q_pad) ? comp.row_of_tile[i / TILE] : -1;
+    if (i >= q_pad || permQ[i] < 0) return;
+    const int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
+    const float xq = ROWDIR ? sqrtf(nQ[i]) * 1.0000002f : 0.f;
+    float q[33];
+    for (int k = 0; k < 33; ++k) q[k] = Qsorted[(size_t) i * 33 + k];
+    for (int kk = 0; kk < (n_list < 0 ? n_groups : n_list); ++kk) {
+        const int g = n_list < 0 ? kk : list_s[kk];
+        const float v = table[(size_t) g * q_pad + i];
+        const int j0 = starts ? starts[g] : g * group_size, j1 = starts ? starts[g + 1] : min(t_pad, j0 + group_size);
+        double best = 1e300;
+        for (int j = j0 + (int) threadIdx.x; j < j1; j += blockDim.x) {
+            if (permT[j] < 0) continue;
+            if (my_leaf >= 0) {
+                size_t t = (size_t) (j / BLOCK_ROWS) * n_leaves + my_leaf;
+                if (!(done[t] | sched[t])) continue;
+            }
+            double d = 0;
+            for (int k = 0; k < 33; ++k) { double t = (double) q[k] - (double) Tsorted[(size_t) j * 33 + k]; d += t * t; }
+            best = d < best ? d : best;
+        }
+        for (int o = 32; o > 0; o >>= 1) { double other = __shfl_xor(best, o); best = other < best ? other : best; }
+        __shared__ double sh[4];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int) (blockDim.x >> 6); ++w) best = sh[w] < best ? sh[w] : best;
+            if (best < 1e299) {   // the group has valid rows: the table entry must be finite and within eps
+                float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
+                float ratio = (v < FLT_BIG) ? (float) (fabs((double) v - best) / (double) e) : 1e30f;
+                atomicMax(worst, __float_as_uint(ratio));
+            }
+        }
+    }
 }
 
 template <bool ROWDIR>
@@ -1298,6 +1350,7 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
 // per direction, group counts, and the column stages the MFMA passes executed out of all (row block, stage) pairs
 struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; };
 static lgr_match_stats g_last_stats;
+static double g_last_check[2] = {-1, -1};
 extern "C" int lgr_match_last_stats(unsigned* out6) {
     out6[0] = g_last_stats.items_ab; out6[1] = g_last_stats.dense_ab; out6[2] = g_last_stats.items_ba;
     out6[3] = g_last_stats.dense_ba; out6[4] = (unsigned) g_last_stats.sub_cols; out6[5] = (unsigned) g_last_stats.rg_rows;
@@ -1307,6 +1360,14 @@ extern "C" int lgr_match_last_stats(unsigned* out6) {
 extern "C" int lgr_match_last_work(double* executed_fraction) {
     if (!executed_fraction) return LGR_ERR_INVALID_ARG;
     *executed_fraction = g_last_stats.stages_all > 0 ? g_last_stats.stages_done / g_last_stats.stages_all : 1.0;
+    return LGR_OK;
+}
+
+// LGR_MATCH_CHECK=1 (tests): worst |filtered - exact| / eps over the sampled table entries of the last call, per direction
+// (rows, columns); -1 when the check did not run.  A proven bound: must be <= 1.
+extern "C" int lgr_match_last_check(double* out2) {
+    if (!out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = g_last_check[0]; out2[1] = g_last_check[1];
     return LGR_OK;
 }
 
@@ -1323,6 +1384,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     if (d_ba_idx) LGR_CHECK(ctx, d_ba_dist != nullptr, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     memset(&g_last_stats, 0, sizeof g_last_stats);
+    g_last_check[0] = g_last_check[1] = -1;
     ctx->mfma_timed = 0;
     // default result: unmatched
     if (ma) { LGR_HIP(ctx, hipMemsetAsync(d_ab_idx, 0xff, (size_t) ma * 4, ctx->stream)); LGR_HIP(ctx, hipMemsetAsync(d_ab_dist, 0, (size_t) ma * 4, ctx->stream)); }
@@ -1545,6 +1607,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     };
     g_last_stats.stages_all = (double) n_rb * n_stage_total;
     CompView comp_rows{nullptr, 0, nullptr}, comp_cols{nullptr, 0, nullptr};
+    const uint8_t *chk_done = nullptr, *chk_sched = nullptr;
     if (!prune) {
         LGR_TRY(launch_mfma(nullptr));
         g_last_stats.stages_done = g_last_stats.stages_all;
@@ -1579,6 +1642,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             comp_rows_kernel<<<cdiv((long long) n_rb * n_groups, 256), 256, 0, ctx->stream>>>(done, sched, group_leaf, n_rb, n_leaves, n_groups, comp_r);
             if (both) comp_cols_kernel<<<cdiv((long long) n_leaves * n_rg, 256), 256, 0, ctx->stream>>>(done, sched, n_rb, n_leaves, n_rg, rg_rows / BLOCK_ROWS, comp_c);
         };
+        chk_done = done; chk_sched = sched;
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
         lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
@@ -1617,6 +1681,26 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         }
     }
     LGR_HIP(ctx, hipGetLastError());
+
+    if (env_int("LGR_MATCH_CHECK", 0) && sortedA) {
+        unsigned* d_worst = (unsigned*) (misc + 192);
+        LGR_HIP(ctx, hipMemsetAsync(d_worst, 0, 8, ctx->stream));
+        const int stride = 37;
+        check_kernel<true><<<cdiv(ma_pad, stride), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(
+            (const float*) rowmin, n_groups, ma_pad, 0, group_start, sortedA, A.perm, sortedB, B.perm, mb_pad, nAp, A.blkcl, nullptr, gmaxB, nullptr,
+            ex, comp_rows, stride, nullptr, nullptr, 0, d_worst);
+        if (both)
+            check_kernel<false><<<cdiv(mb_pad, stride), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>(
+                (const float*) colmin, n_rg, mb_pad, rg_rows, nullptr, sortedB, B.perm, sortedA, A.perm, ma_pad, nullptr, nullptr, nBp, gmaxA, cl_of_rg,
+                ex, comp_cols, stride, chk_done, chk_sched, n_leaves, d_worst + 1);
+        unsigned* hw;
+        LGR_TRY(lgr_pinned(ctx, 64, (void**) &hw));
+        LGR_HIP(ctx, hipMemcpyAsync(hw, d_worst, 8, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        float r0, r1;
+        memcpy(&r0, hw, 4); memcpy(&r1, hw + 1, 4);
+        g_last_check[0] = r0; g_last_check[1] = r1;
+    }
 
     // ---- 5. exact rerank
     LGR_TRY((run_rerank<true>(ctx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,

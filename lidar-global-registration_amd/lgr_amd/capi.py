@@ -169,6 +169,12 @@ class Context:
         self.check(_lib.lgr_match_last_work(C.byref(f)))
         return f.value
 
+    def match_check(self):
+        """(rows, cols) worst |filtered - exact| / eps of the last match call run with LGR_MATCH_CHECK=1, or -1"""
+        out = (C.c_double * 2)()
+        self.check(_lib.lgr_match_last_check(out))
+        return out[0], out[1]
+
     def match_kernel_ms(self):
         ms = C.c_float(0)
         self.check(_lib.lgr_match_last_kernel_ms(self.h, C.byref(ms)))

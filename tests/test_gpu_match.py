@@ -138,3 +138,39 @@ def test_match_clustered_parity_and_skipping(lgr, oracle, matcher_mode, ma, mb):
         assert w < 1.0, w
     if matcher_mode == "auto":
         assert w == 1.0
+
+
+@pytest.mark.parametrize("fmt", ["f16", "f32"])
+@pytest.mark.parametrize("kind", ["fpfh", "clustered", "tiny", "wide", "duplicates"])
+def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, kind):
+    """The MFMA filter value of every computed (query, group) entry must lie within the proven eps of the exact group
+    minimum (computed in double on the device, LGR_MATCH_CHECK=1) -- on the f16-split operand format and on f32, for
+    FPFH-like rows, tight clusters, tiny and wide dynamic ranges and exact duplicates; results stay oracle-exact."""
+    import torch
+    if matcher_mode == "prune_sub1":
+        pytest.skip("same code path as prune_sub4")
+    monkeypatch.setenv("LGR_MATCH_CHECK", "1")
+    monkeypatch.setenv("LGR_MATCH_F16", "1" if fmt == "f16" else "0")
+    rng = np.random.default_rng(77)
+    ma, mb = 6000, 9000
+    if kind == "fpfh":
+        a, b = fpfh_like(rng, ma), fpfh_like(rng, mb)
+    elif kind == "clustered":
+        a, b = clustered(rng, ma, spread=0.3), clustered(rng, mb, spread=0.3)
+    elif kind == "tiny":            # values ~1e-3 around a common offset: small centred norms, f16 subnormal halves
+        a = (50.0 + 1e-3 * rng.normal(size=(ma, 33))).astype(np.float32)
+        b = (50.0 + 1e-3 * rng.normal(size=(mb, 33))).astype(np.float32)
+    elif kind == "wide":            # six decades of magnitudes in one set
+        sa = 10.0 ** rng.uniform(-3, 3, (ma, 1)); sb = 10.0 ** rng.uniform(-3, 3, (mb, 1))
+        a = (sa * rng.normal(size=(ma, 33))).astype(np.float32)
+        b = (sb * rng.normal(size=(mb, 33))).astype(np.float32)
+    else:
+        base = fpfh_like(rng, 50)
+        a = base[rng.integers(0, 50, ma)].copy(); b = base[rng.integers(0, 50, mb)].copy()
+        a[::3] += rng.normal(0, 1e-4, (len(a[::3]), 33)).astype(np.float32)
+    run_both(lgr, oracle, a, b, 2500)
+    lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 2500)
+    lgr.sync()
+    r_rows, r_cols = lgr.match_check()
+    assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
+    print(f"filter bound ratio [{fmt} {kind} {matcher_mode}]: rows {r_rows:.3g} cols {r_cols:.3g}")
