@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
                 frag b[KS];
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
-#pragma unroll 1
+#pragma unroll
                 for (int ct = 0; ct < STAGE_TILES; ++ct) {
                     f32x16 acc = mfma_step(a[0], b[0], nav);
 #pragma unroll
