@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "lidar-global-registration_amd"))
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+MFMA_F16_PEAK_TFLOPS = 2516.8    # same guide: BF16/FP16 MFMA "~2.5 PF dense" = 16 x the f32-input MFMA rate
 
 
 def parse():
@@ -167,11 +168,16 @@ def main():
         # matching = 69 * Mq * Mt FLOP (2*33 MAC + 3 for norm add / compare); one launch serves both directions
         alg_flop = 69.0 * m * m
         k_ms = float(np.mean(kernel_ms))
-        # the exact bound-based skipping computes only a fraction of the M x M tiles: `achieved` counts the
-        # FLOP the MFMA passes really issued (hardware rate against the MFMA peak); the algorithmic 69 M^2 over the same
-        # time is reported beside it as the effective rate
+        # Roofline of the dominant kernel (both masked MFMA launches of a step).  `achieved` counts the MFMA FLOP really
+        # issued: the exact bound-based skipping computes only `executed` of the M x M tiles, and per (query, train) pair
+        # the kernel issues 7 x v_mfma_f32_32x32x16_f16 steps on two-term f16 splits of the f32 operands (K = 112:
+        # 224 FLOP) or 17 x v_mfma_f32_32x32x2_f32 (K = 34: 68 FLOP); `peak` is the dense MFMA peak of that operand
+        # type.  The algorithmic 69 FLOP per pair over the same time is reported beside it.
         executed = float(np.mean(work))
-        achieved = alg_flop * executed / (k_ms * 1e-3) / 1e12
+        fmt = ctx.match_format()
+        flop_per_pair = 224.0 if fmt == "f16" else 68.0
+        peak = MFMA_F16_PEAK_TFLOPS if fmt == "f16" else MFMA_F32_PEAK_TFLOPS
+        achieved = flop_per_pair * m * m * executed / (k_ms * 1e-3) / 1e12
         effective = alg_flop / (k_ms * 1e-3) / 1e12
         T = res.matrix()
         err = float(np.abs(T.astype(np.float64) - pair["T_gt"]).max())
@@ -183,8 +189,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic 1M-pt pair, random SE(3) + Gaussian noise (5 mm), FPFH r=0.25 m",
                        "points_per_cloud": m, "pairs_per_step": world, "matching": args.matching, "metric_id": "uniformity",
                        "bf_block_size": 200000, "max_iterations": 1000000, "parallelism": f"pairs sharded over {world} GPU(s)"},
-            "roofline": {"kernel": "match_mfma<both directions> (all masked passes of one step)", "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "roofline": {"kernel": "match_mfma<both directions> (all masked passes of one step)", "bound": "mfma", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "operand_format": "f16 two-term splits, f32 accumulate (224 MFMA FLOP/pair)" if fmt == "f16" else "f32 (68 MFMA FLOP/pair)",
                          "kernel_ms": k_ms, "executed_tile_fraction": executed, "effective_tflops_algorithmic": effective,
                          "rerank": mstats, "algorithmic_flop_per_launch": alg_flop, "directions_per_launch": n_dir},
             "stage_ms": dict(zip(["downsample", "normals", "fpfh", "match", "filter", "ransac", "refit"],

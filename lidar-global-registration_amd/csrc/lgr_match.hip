@@ -1348,7 +1348,7 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
 
 // statistics of the last match call (bench/diagnostics): candidate (query, group) items and dense-fallback queries
 // per direction, group counts, and the column stages the MFMA passes executed out of all (row block, stage) pairs
-struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; };
+struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; };
 static lgr_match_stats g_last_stats;
 static double g_last_check[2] = {-1, -1};
 extern "C" int lgr_match_last_stats(unsigned* out6) {
@@ -1360,6 +1360,14 @@ extern "C" int lgr_match_last_stats(unsigned* out6) {
 extern "C" int lgr_match_last_work(double* executed_fraction) {
     if (!executed_fraction) return LGR_ERR_INVALID_ARG;
     *executed_fraction = g_last_stats.stages_all > 0 ? g_last_stats.stages_done / g_last_stats.stages_all : 1.0;
+    return LGR_OK;
+}
+
+// MFMA operand format of the last match call: 1 = f16-split operands on v_mfma_f32_32x32x16_f16 (224 FLOP per pair),
+// 0 = f32 operands on v_mfma_f32_32x32x2_f32 (68 FLOP per pair)
+extern "C" int lgr_match_last_format(int* f16) {
+    if (!f16) return LGR_ERR_INVALID_ARG;
+    *f16 = g_last_stats.f16;
     return LGR_OK;
 }
 
@@ -1453,6 +1461,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
 
     // ---- 3. pack operands, group maxima, stage -> leaf map
     const bool f16 = env_int("LGR_MATCH_F16", 1) != 0;
+    g_last_stats.f16 = f16 ? 1 : 0;
     const int KS = f16 ? OpFmt<true>::KS : OpFmt<false>::KS;
     const size_t frag_bytes = f16 ? sizeof(f16x8) : sizeof(float);
     const size_t a_op_bytes = (size_t) ta * KS * 64 * frag_bytes;

@@ -169,6 +169,12 @@ class Context:
         self.check(_lib.lgr_match_last_work(C.byref(f)))
         return f.value
 
+    def match_format(self):
+        """'f16' (split operands on the f16 MFMA) or 'f32' for the last match call"""
+        v = C.c_int(0)
+        self.check(_lib.lgr_match_last_format(C.byref(v)))
+        return "f16" if v.value else "f32"
+
     def match_check(self):
         """(rows, cols) worst |filtered - exact| / eps of the last match call run with LGR_MATCH_CHECK=1, or -1"""
         out = (C.c_double * 2)()
