@@ -44,6 +44,7 @@ enum { LGR_MATCH_LR = 0, LGR_MATCH_ONE_SIDED = 1, LGR_MATCH_CLUSTER = 2 };      
 enum { LGR_METRIC_CORRESPONDENCES = 0, LGR_METRIC_UNIFORMITY = 1 };             /* src/metric.cpp:272-301 */
 enum { LGR_SCORE_CONSTANT = 0, LGR_SCORE_MAE = 1, LGR_SCORE_MSE = 2, LGR_SCORE_EXP = 3 };
 enum { LGR_ALIGN_RANSAC = 0, LGR_ALIGN_GROR = 1 };                              /* src/alignment.cpp:92-101 */
+enum { LGR_KEYPOINT_ANY = 0, LGR_KEYPOINT_ISS = 1 };                            /* src/common.cpp:657-691 */
 enum { LGR_ORDER_REFERENCE = 0, LGR_ORDER_CANONICAL = 1 };                      /* downsample output order */
 
 typedef struct { int32_t index_query, index_match; float distance, threshold; } lgr_corr;
@@ -69,6 +70,9 @@ typedef struct {
     float   vp_src[3], vp_tgt[3];
     int32_t ransac_batch;        /* iterations per device batch (deterministic schedule), default 65536 */
     uint64_t seed;
+    int32_t keypoint_id;         /* LGR_KEYPOINT_ANY (every point, BASELINE configs) or LGR_KEYPOINT_ISS */
+    float   iss_radius_src, iss_radius_tgt;   /* include/common.h:139; salient = non-maxima radius */
+    int32_t reserved0;
 } lgr_params;
 
 /* mirrors AlignmentResult (include/common.h:165-174) + diagnostics */
@@ -104,6 +108,15 @@ int  lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12);
 
 /* ---- include/common.h:266-280 calculateBoundingBox ---- */
 int lgr_bbox_dev(lgr_ctx*, const float* d_pts, int n, float* d_min3_max3 /* 6 floats */);
+
+/* ---- include/common.h:304-310 detectKeyPoints(pcd, parameters, iss_radius) with keypoint_id = iss
+ *      (src/common.cpp:657-691: pcl::ISSKeypoint3D, salient = non-max radius = iss_radius, thresholds 0.975,
+ *      min_neighbors 4; the reference passes gamma/min_neighbors as constants, they are arguments here).
+ *      idx must hold n entries; ascending point indices. ---- */
+int lgr_iss_keypoints(lgr_ctx*, const float* pts, int n, float radius, float gamma21, float gamma32, int min_neighbors,
+                      int32_t* idx, int* n_out);
+int lgr_iss_keypoints_dev(lgr_ctx*, const float* d_pts, int n, float radius, float gamma21, float gamma32, int min_neighbors,
+                          int32_t* d_idx, int* n_out /* host */);
 
 /* ---- include/downsample.h:32 downsamplePointCloud(pcd, pcd_down, voxel_size)  (src/downsample.cpp:5-41) ----
  * out may alias the input (the reference passes the same cloud, src/common.cpp:455-456).  n_out <= n.

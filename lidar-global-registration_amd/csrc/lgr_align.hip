@@ -129,6 +129,20 @@ extern "C" int lgr_filter_dev(lgr_ctx* ctx, int matching_id, const float* d_src,
 
 static void tick(lgr_ctx* ctx, int i) { (void) hipEventRecord(ctx->ev[i], ctx->stream); }
 
+// key-point cloud = pcd[kps_indices] (pcl::copyPointCloud, include/matching.h:167); 12 floats per point
+__global__ void gather_points_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int m, float* __restrict__ out) {
+    size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t) m * 12) return;
+    out[e] = pts[(size_t) idx[e / 12] * 12 + e % 12];
+}
+// finalize (include/matching.h:150-160): local key-point indices -> indices of the clouds
+__global__ void finalize_kernel(lgr_corr* __restrict__ corr, int n, const int32_t* __restrict__ ks, const int32_t* __restrict__ kt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    corr[i].index_query = ks[corr[i].index_query];
+    corr[i].index_match = kt[corr[i].index_match];
+}
+
 extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params* p,
                                        lgr_corr* d_out, int* n_out) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
@@ -145,12 +159,35 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     float voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
     const float* clouds[2] = {d_src, d_tgt};
     int sizes[2] = {ns, nt};
+    // key points (src/correspondence_search.cpp:8-11): every point, or the ISS detections.  kps = pcd[kps_indices]
+    // (include/matching.h:167); every later stage works on the key-point clouds and the indices are mapped back at the
+    // end (finalize, include/matching.h:150-160).
+    const bool iss = p->keypoint_id == LGR_KEYPOINT_ISS;
+    LGR_CHECK(ctx, p->keypoint_id == LGR_KEYPOINT_ANY || iss, LGR_ERR_UNSUPPORTED);
+    const float* kclouds[2] = {d_src, d_tgt};
+    int ksizes[2] = {ns, nt};
+    int32_t* kidx[2] = {nullptr, nullptr};
+    if (iss) {
+        for (int c = 0; c < 2; ++c) {
+            float* kp;
+            LGR_TRY(lgr_ws_t(ctx, c == 0 ? WS_PIPE_KIDX_S : WS_PIPE_KIDX_T, (size_t) sizes[c] + 1, &kidx[c]));
+            int m = 0;
+            LGR_TRY(lgr_iss_keypoints_dev(ctx, clouds[c], sizes[c], c == 0 ? p->iss_radius_src : p->iss_radius_tgt, 0.975f, 0.975f, 4, kidx[c], &m));
+            LGR_TRY(lgr_ws_t(ctx, c == 0 ? WS_PIPE_KPS_S : WS_PIPE_KPS_T, (size_t) std::max(m, 1) * 12, &kp));
+            if (m) gather_points_kernel<<<cdiv((long long) m * 12, 256), 256, 0, ctx->stream>>>(clouds[c], kidx[c], m, kp);
+            kclouds[c] = kp; ksizes[c] = m;
+        }
+        if (ksizes[0] == 0 || ksizes[1] == 0) return LGR_OK;
+    }
+    const int ns_all = ns, nt_all = nt;
+    (void) ns_all; (void) nt_all;
+    ns = ksizes[0]; nt = ksizes[1];
     float* feat[2];
     float* surf[2];
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_FEAT_S, (size_t) ns * 33, &feat[0]));
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_FEAT_T, (size_t) nt * 33, &feat[1]));
-    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_SURF_S, (size_t) ns * 12, &surf[0]));
-    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_SURF_T, (size_t) nt * 12, &surf[1]));
+    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_SURF_S, (size_t) sizes[0] * 12, &surf[0]));
+    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_SURF_T, (size_t) sizes[1] * 12, &surf[1]));
     float ms[3] = {0, 0, 0};
     for (int c = 0; c < 2; ++c) {
         int nd = 0;
@@ -162,7 +199,7 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
         tick(ctx, 2);
         // :243-246 re-estimates the normals of the key-point COPY; FPFH reads only the surface normals
         // (include/common.h:329), so that step has no observable effect and is not executed.
-        LGR_TRY(lgr_fpfh_dev(ctx, clouds[c], sizes[c], surf[c], nd, search_radius, feat[c]));              // :248
+        LGR_TRY(lgr_fpfh_dev(ctx, kclouds[c], ksizes[c], surf[c], nd, search_radius, feat[c]));            // :248
         tick(ctx, 3);
         LGR_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
         float t;
@@ -178,7 +215,8 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     if (p->matching_id == LGR_MATCH_ONE_SIDED) LGR_TRY(lgr_match_bf_dev(ctx, feat[0], ns, feat[1], nt, p->bf_block_size, ij, dij));
     else LGR_TRY(lgr_match_bf2_dev(ctx, feat[0], ns, feat[1], nt, p->bf_block_size, ij, dij, ji, dji));
     tick(ctx, 5);
-    LGR_TRY(lgr_filter_dev(ctx, p->matching_id, d_src, ns, d_tgt, nt, ij, dij, ji, dji, p->distance_thr, p->cluster_k, d_out, n_out));
+    LGR_TRY(lgr_filter_dev(ctx, p->matching_id, kclouds[0], ns, kclouds[1], nt, ij, dij, ji, dji, p->distance_thr, p->cluster_k, d_out, n_out));
+    if (iss && *n_out) finalize_kernel<<<cdiv(*n_out, 256), 256, 0, ctx->stream>>>(d_out, *n_out, kidx[0], kidx[1]);
     tick(ctx, 6);
     LGR_HIP(ctx, hipEventSynchronize(ctx->ev[6]));
     float t;

@@ -112,6 +112,7 @@ extern "C" void lgr_default_params(lgr_params* p) {
     p->randomness = 1;
     p->n_samples = 3;
     p->alignment_id = LGR_ALIGN_RANSAC;
+    p->keypoint_id = LGR_KEYPOINT_ANY;   // BASELINE configs; the reference's struct default is iss (include/common.h:148)
     p->matching_id = LGR_MATCH_CLUSTER;
     p->metric_id = LGR_METRIC_UNIFORMITY;
     p->score_id = LGR_SCORE_MSE;

@@ -23,7 +23,7 @@ struct lgr_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    lgr_buf ws[96];
+    lgr_buf ws[112];
     void* pinned = nullptr;  // small pinned host scratch for read-backs
     size_t pinned_cap = 0;
     hipEvent_t ev[32];       // 0..8 stage timers (lgr_align), 9.. pairs around the match_mfma passes
@@ -65,11 +65,11 @@ enum {
     WS_SPFH, WS_KP_ORDER, WS_DENS_A, WS_DENS_B, WS_DENS_C,
     WS_RANSAC_T, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK,
     WS_PIPE_SURF_S, WS_PIPE_SURF_T, WS_PIPE_FEAT_S, WS_PIPE_FEAT_T, WS_PIPE_IJ, WS_PIPE_JI, WS_PIPE_DIJ, WS_PIPE_DJI,
-    WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_FLAGS, WS_PIPE_MISC,
+    WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_FLAGS, WS_PIPE_MISC, WS_PIPE_KIDX_S, WS_PIPE_KIDX_T, WS_PIPE_KPS_S, WS_PIPE_KPS_T,
     WS_HOST_A, WS_HOST_B, WS_HOST_C, WS_HOST_D, WS_HOST_E, WS_HOST_F,
     WS_COUNT
 };
-static_assert(WS_COUNT <= 96, "grow lgr_ctx::ws");
+static_assert(WS_COUNT <= 112, "grow lgr_ctx::ws");
 
 // returns device pointer of at least `bytes` (contents undefined unless kept); grows with 25% slack
 int lgr_ws(lgr_ctx* ctx, int slot, size_t bytes, void** out);

@@ -1520,9 +1520,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // column groups of the row-minimum table: a leaf, cut into pieces of at most GROUP_COLS columns (k-means leaves of
     // near-duplicate descriptors can hold tens of thousands of rows; the exact rerank scans a whole group per item)
     std::vector<int> h_group_start, h_tiles(2 * (size_t) tb);   // [tile] -> group, [tb + tile] -> leaf
+    int group_cols = GROUP_COLS;   // larger pieces for very large inputs: keep the table [groups][ma_pad] under ~24 GB
+    while (group_cols < 65536 && ((size_t) mb_pad / group_cols + n_leaves) * (size_t) ma_pad * 4 > ((size_t) 24 << 30)) group_cols *= 2;
     for (int l = 0; l < n_leaves; ++l)
-        for (int s0 = B.h_leaf_start[l]; s0 < B.h_leaf_start[l + 1]; s0 += GROUP_COLS) {
-            int s1 = std::min(B.h_leaf_start[l + 1], s0 + GROUP_COLS), g = (int) h_group_start.size();
+        for (int s0 = B.h_leaf_start[l]; s0 < B.h_leaf_start[l + 1]; s0 += group_cols) {
+            int s1 = std::min(B.h_leaf_start[l + 1], s0 + group_cols), g = (int) h_group_start.size();
             h_group_start.push_back(s0);
             for (int t = s0 / TILE; t < s1 / TILE; ++t) { h_tiles[t] = g; h_tiles[tb + t] = l; }
         }

@@ -173,3 +173,35 @@ __device__ __forceinline__ void lgr_svd3(const float* A, float* U, float* S, flo
 #pragma unroll
         for (int i = 0; i < 3; ++i) U[3 * i + j] = Uc[j][i];
 }
+
+// eigenvalues of a symmetric 3x3 in double (a00 a01 a02 a11 a12 a22), ascending: cyclic Jacobi, 10 fixed sweeps.
+// Op for op the sequence of c_eigvals3d (oracle/src/orc_iss.cpp).
+__device__ __forceinline__ void lgr_eigvals3d(const double* S, double* ev) {
+    double a[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+    for (int sweep = 0; sweep < 10; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = a[p][q];
+                if (apq == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                double t = 1.0 / (fabs(theta) + __builtin_sqrt(theta * theta + 1.0));
+                if (theta < 0.0) t = -t;
+                double c = 1.0 / __builtin_sqrt(t * t + 1.0), s = t * c;
+                const int r = 3 - p - q;
+                double app = a[p][p], aqq = a[q][q], arp = a[r][p], arq = a[r][q];
+                a[p][p] = app - t * apq;
+                a[q][q] = aqq + t * apq;
+                a[p][q] = a[q][p] = 0.0;
+                a[r][p] = a[p][r] = c * arp - s * arq;
+                a[r][q] = a[q][r] = s * arp + c * arq;
+            }
+    }
+    double x = a[0][0], y = a[1][1], z = a[2][2], tmp;
+    if (x > y) { tmp = x; x = y; y = tmp; }
+    if (y > z) { tmp = y; y = z; z = tmp; }
+    if (x > y) { tmp = x; x = y; y = tmp; }
+    ev[0] = x; ev[1] = y; ev[2] = z;
+}
+

@@ -152,6 +152,9 @@ inline lgr_params to_abi(const AlignmentParameters& p) {
     a.scale_factor = p.scale_factor; a.confidence = p.confidence; a.bf_block_size = p.bf_block_size;
     a.cluster_k = p.cluster_k; a.randomness = p.randomness; a.n_samples = p.n_samples;
     a.alignment_id = p.alignment_id == "gror" ? LGR_ALIGN_GROR : LGR_ALIGN_RANSAC;
+    // detectKeyPoints (src/common.cpp:657-691): "iss" -> ISS, anything else -> every point (with a warning there)
+    a.keypoint_id = p.keypoint_id == "iss" ? LGR_KEYPOINT_ISS : LGR_KEYPOINT_ANY;
+    a.iss_radius_src = p.iss_radius_src; a.iss_radius_tgt = p.iss_radius_tgt;
     a.matching_id = p.matching_id == "cluster" ? LGR_MATCH_CLUSTER : (p.matching_id == "one_sided" ? LGR_MATCH_ONE_SIDED : LGR_MATCH_LR);
     a.metric_id = p.metric_id == "uniformity" ? LGR_METRIC_UNIFORMITY : LGR_METRIC_CORRESPONDENCES;
     a.score_id = p.score_id == "mae" ? LGR_SCORE_MAE : (p.score_id == "mse" ? LGR_SCORE_MSE : (p.score_id == "exp" ? LGR_SCORE_EXP : LGR_SCORE_CONSTANT));
@@ -255,8 +258,7 @@ public:
     FeatureBasedCorrespondenceSearch(PointNCloud::ConstPtr src, PointNCloud::ConstPtr tgt, AlignmentParameters parameters)
         : src_(std::move(src)), tgt_(std::move(tgt)), parameters_(std::move(parameters)) {}
     CorrespondencesPtr calculateCorrespondences() override {
-        // keypoint "any" (src/common.cpp:680-689); ISS is SURVEY 8f "next" and reported as unsupported here
-        if (parameters_.keypoint_id != "any") throw std::runtime_error("lgr: only keypoint 'any' is built on the device path");
+        // key points: "iss" or every point (src/common.cpp:657-691; other ids fall back to every point there too)
         if (parameters_.descriptor_id != "fpfh") throw std::runtime_error("lgr: only descriptor 'fpfh' is built on the device path");
         lgr_params a = to_abi(parameters_);
         auto out = std::make_shared<Correspondences>(src_->size());

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_CSRC, "liblgr_hip.so")
 
 MATCH_LR, MATCH_ONE_SIDED, MATCH_CLUSTER = 0, 1, 2
 METRIC_CORRESPONDENCES, METRIC_UNIFORMITY = 0, 1
+KEYPOINT_ANY, KEYPOINT_ISS = 0, 1
 SCORE_CONSTANT, SCORE_MAE, SCORE_MSE, SCORE_EXP = 0, 1, 2, 3
 ALIGN_RANSAC, ALIGN_GROR = 0, 1
 ORDER_REFERENCE, ORDER_CANONICAL = 0, 1
@@ -35,6 +36,7 @@ class Params(C.Structure):
         ("max_iterations", C.c_int32), ("normals_available", C.c_int32), ("fix_seed", C.c_int32),
         ("has_vp_src", C.c_int32), ("has_vp_tgt", C.c_int32), ("vp_src", C.c_float * 3), ("vp_tgt", C.c_float * 3),
         ("ransac_batch", C.c_int32), ("seed", C.c_uint64),
+        ("keypoint_id", C.c_int32), ("iss_radius_src", C.c_float), ("iss_radius_tgt", C.c_float), ("reserved0", C.c_int32),
     ]
 
 
@@ -202,6 +204,13 @@ class Context:
         out = self.empty((pts.shape[0],), self.torch.float32)
         self.check(_lib.lgr_smoothed_densities_dev(self.h, _ptr(pts), pts.shape[0], int(k), _ptr(out)))
         return out
+
+    def iss_keypoints(self, pts, radius, gamma21=0.975, gamma32=0.975, min_neighbors=4):
+        idx = self.empty((max(pts.shape[0], 1),), self.torch.int32)
+        n = C.c_int(0)
+        self.check(_lib.lgr_iss_keypoints_dev(self.h, _ptr(pts), pts.shape[0], C.c_float(radius), C.c_float(gamma21), C.c_float(gamma32),
+                                              int(min_neighbors), _ptr(idx), C.byref(n)))
+        return idx[: n.value]
 
     def downsample(self, pts, voxel):
         out = self.empty((pts.shape[0], 12), self.torch.float32)

@@ -33,6 +33,7 @@ enum { ORC_METRIC_CORRESPONDENCES = 0, ORC_METRIC_UNIFORMITY = 1 };
 enum { ORC_SCORE_CONSTANT = 0, ORC_SCORE_MAE = 1, ORC_SCORE_MSE = 2, ORC_SCORE_EXP = 3 };
 enum { ORC_MATCH_LR = 0, ORC_MATCH_ONE_SIDED = 1, ORC_MATCH_CLUSTER = 2 };
 enum { ORC_RNG_MT19937_LEMIRE = 0, ORC_RNG_MT19937_REJECT = 1, ORC_RNG_PHILOX = 2 };
+enum { ORC_KEYPOINT_ANY = 0, ORC_KEYPOINT_ISS = 1 };
 
 typedef struct {
     /* mirrors AlignmentParameters (include/common.h:135-163), enum ids instead of strings */
@@ -54,6 +55,8 @@ typedef struct {
     int   has_vp_src, has_vp_tgt;
     float vp_src[3], vp_tgt[3];
     /* RANSAC schedule */
+    int   keypoint_id;         /* ORC_KEYPOINT_* (0 = any: every point is a key point) */
+    float iss_radius_src, iss_radius_tgt;
     int   rng_mode;            /* ORC_RNG_* */
     int   n_threads;           /* reference schedule (mt19937 modes): emulated OpenMP team size */
     int   batch_size;          /* philox schedule: iterations per batch */
@@ -110,7 +113,13 @@ int orc_filter(int matching_id, const float* src, int ns, const float* tgt, int 
                const int* ij_idx, const float* ij_dist, const int* ji_idx, const float* ji_dist,
                float distance_thr, int cluster_k, lgr_orc_corr* out, int* n_out);
 
-/* src/correspondence_search.cpp:4-15 with keypoint 'any': whole correspondence search */
+/* src/common.cpp:657-691 detectKeyPoints with keypoint_id = iss (pcl::ISSKeypoint3D, salient = non-max radius,
+ * thresholds 0.975, min_neighbors 4): ascending indices.  out_idx holds n ints; third (optional) n doubles */
+int orc_iss_keypoints(const float* pts, int n, float radius, float gamma21, float gamma32, int min_neighbors,
+                      int* out_idx, int* n_out, double* third);
+void orc_eigvals3d(const double S6[6] /* a00 a01 a02 a11 a12 a22 */, double ev3[3] /* ascending */);
+
+/* src/correspondence_search.cpp:4-15 (keypoint 'any' or 'iss'): whole correspondence search */
 int orc_correspondences(const float* src, int ns, const float* tgt, int nt, const lgr_orc_params* p,
                         lgr_orc_corr* out, int* n_out, double* stage_seconds /* 8 doubles or NULL */);
 

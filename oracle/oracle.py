@@ -17,6 +17,7 @@ METRIC_CORRESPONDENCES, METRIC_UNIFORMITY = 0, 1
 SCORE_CONSTANT, SCORE_MAE, SCORE_MSE, SCORE_EXP = 0, 1, 2, 3
 MATCH_LR, MATCH_ONE_SIDED, MATCH_CLUSTER = 0, 1, 2
 RNG_MT19937_LEMIRE, RNG_MT19937_REJECT, RNG_PHILOX = 0, 1, 2
+KEYPOINT_ANY, KEYPOINT_ISS = 0, 1
 
 CORR_DTYPE = np.dtype([("query", "<i4"), ("match", "<i4"), ("distance", "<f4"), ("threshold", "<f4")])
 
@@ -29,6 +30,7 @@ class Params(C.Structure):
         ("matching_id", C.c_int), ("metric_id", C.c_int), ("score_id", C.c_int), ("max_iterations", C.c_int),
         ("normals_available", C.c_int), ("has_vp_src", C.c_int), ("has_vp_tgt", C.c_int),
         ("vp_src", C.c_float * 3), ("vp_tgt", C.c_float * 3),
+        ("keypoint_id", C.c_int), ("iss_radius_src", C.c_float), ("iss_radius_tgt", C.c_float),
         ("rng_mode", C.c_int), ("n_threads", C.c_int), ("batch_size", C.c_int), ("seed", C.c_uint64),
     ]
 
@@ -399,3 +401,21 @@ def gror(src, tgt, corr, resolution, K=800):
                         _p(T), _p(diag), C.byref(ang))
     assert rc == 0
     return T.reshape(4, 4).T.copy(), dict(K=int(diag[0]), best_count=int(diag[1]), tcfs_rows=int(diag[2]), n_inliers=int(diag[3]), best_angle=ang.value)
+
+
+def iss_keypoints(pts, radius, gamma21=0.975, gamma32=0.975, min_neighbors=4, with_third=False):
+    pts = _pts(pts)
+    idx = np.zeros(pts.shape[0], np.int32)
+    n = C.c_int(0)
+    third = np.zeros(pts.shape[0], np.float64) if with_third else None
+    rc = lib().orc_iss_keypoints(_p(pts), pts.shape[0], C.c_float(radius), C.c_float(gamma21), C.c_float(gamma32), int(min_neighbors),
+                                 _p(idx), C.byref(n), _p(third))
+    assert rc == 0, rc
+    return (idx[: n.value].copy(), third) if with_third else idx[: n.value].copy()
+
+
+def eigvals3d(S6):
+    S6 = np.ascontiguousarray(S6, np.float64)
+    ev = np.zeros(3, np.float64)
+    lib().orc_eigvals3d(_p(S6), _p(ev))
+    return ev

@@ -198,7 +198,7 @@ extern "C" int orc_filter(int matching_id, const float* src, int ns, const float
 //   downsample (:234) -> normals k (:235) -> [kps normals re-estimate :243-246: no observable effect for FPFH,
 //   skipped] -> FPFH (:248) -> 1-NN both ways (:306) -> filter.  The surface is kept in ORC_ORDER_CANONICAL.
 // stage_seconds: [0] downsample [1] normals [2] fpfh [3] match [4] filter
-extern "C" int orc_correspondences(const float* src, int ns, const float* tgt, int nt, const lgr_orc_params* p,
+extern "C" int orc_correspondences(const float* src_all, int ns_all, const float* tgt_all, int nt_all, const lgr_orc_params* p,
                                    lgr_orc_corr* out, int* n_out, double* st) {
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!(p->feature_radius > 0.f)) return -3;
@@ -206,8 +206,33 @@ extern "C" int orc_correspondences(const float* src, int ns, const float* tgt, i
     float search_radius = powf(p->scale_factor, (float) log2_radius);
     float voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
     std::vector<float> feat[2];
-    const float* clouds[2] = {src, tgt};
-    int sizes[2] = {ns, nt};
+    const float* clouds[2] = {src_all, tgt_all};
+    int sizes[2] = {ns_all, nt_all};
+    // key points (src/correspondence_search.cpp:8-11): every point, or the ISS detections; kps = pcd[kps_indices]
+    // (include/matching.h:167), all later stages work on the key-point clouds and finalize() maps indices back
+    std::vector<int> kidx[2];
+    std::vector<float> kps[2];
+    for (int c = 0; c < 2; ++c) {
+        if (p->keypoint_id == ORC_KEYPOINT_ISS) {
+            double t0 = now_s();
+            kidx[c].resize(sizes[c]);
+            int m = 0;
+            float r = c == 0 ? p->iss_radius_src : p->iss_radius_tgt;
+            if (orc_iss_keypoints(clouds[c], sizes[c], r, 0.975f, 0.975f, 4, kidx[c].data(), &m, nullptr)) return -5;
+            kidx[c].resize(m);
+            kps[c].resize((size_t) m * 12);
+            for (int i = 0; i < m; ++i) memcpy(kps[c].data() + 12 * (size_t) i, clouds[c] + 12 * (size_t) kidx[c][i], 48);
+            t[5] += now_s() - t0;
+        }
+    }
+    const bool iss = p->keypoint_id == ORC_KEYPOINT_ISS;
+    const float* src = iss ? kps[0].data() : src_all;
+    const float* tgt = iss ? kps[1].data() : tgt_all;
+    const int ns = iss ? (int) kidx[0].size() : ns_all, nt = iss ? (int) kidx[1].size() : nt_all;
+    const float* kclouds[2] = {src, tgt};
+    const int ksizes[2] = {ns, nt};
+    *n_out = 0;
+    if (ns == 0 || nt == 0) { if (st) for (int i = 0; i < 8; ++i) st[i] = t[i]; return 0; }
     for (int c = 0; c < 2; ++c) {
         double t0 = now_s();
         std::vector<float> ds((size_t) sizes[c] * 12);
@@ -217,8 +242,8 @@ extern "C" int orc_correspondences(const float* src, int ns, const float* tgt, i
         const float* vp = c == 0 ? (p->has_vp_src ? p->vp_src : nullptr) : (p->has_vp_tgt ? p->vp_tgt : nullptr);
         orc_normals_knn(ds.data(), nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available);
         double t2 = now_s();
-        feat[c].resize((size_t) sizes[c] * 33);
-        orc_fpfh(clouds[c], sizes[c], ds.data(), nd, search_radius, feat[c].data(), 0);
+        feat[c].resize((size_t) ksizes[c] * 33);
+        orc_fpfh(kclouds[c], ksizes[c], ds.data(), nd, search_radius, feat[c].data(), 0);
         double t3 = now_s();
         t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2;
     }
@@ -236,6 +261,8 @@ extern "C" int orc_correspondences(const float* src, int ns, const float* tgt, i
                         p->distance_thr, p->cluster_k, out, n_out);
     double t2 = now_s();
     t[3] = t1 - t0; t[4] = t2 - t1;
+    if (iss && rc == 0)   // finalize(): local key-point indices -> cloud indices
+        for (int i = 0; i < *n_out; ++i) { out[i].query = kidx[0][out[i].query]; out[i].match = kidx[1][out[i].match]; }
     if (st) for (int i = 0; i < 8; ++i) st[i] = t[i];
     return rc;
 }

@@ -270,3 +270,43 @@ def test_gror_selection_keeps_input_order_below_k(oracle):
     assert d1["K"] == 600 and d2["K"] == 200
     assert d2["best_count"] <= 200 and d2["best_count"] > 150      # the top-voted 200 are almost all true pairs
     assert np.abs(T1 - T2).max() < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------- ISS key points (8f)
+def test_eigvals3d_vs_numpy(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        A = rng.normal(size=(3, 3)) * 10.0 ** rng.uniform(-3, 3)
+        M = A @ A.T
+        ev = oracle.eigvals3d([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+        ref = np.linalg.eigvalsh(M)
+        assert np.all(np.diff(ev) >= 0)
+        assert np.allclose(ev, ref, rtol=1e-12, atol=1e-12 * abs(ref).max())
+    assert np.array_equal(oracle.eigvals3d([0, 0, 0, 0, 0, 0]), np.zeros(3))
+    assert np.allclose(oracle.eigvals3d([3, 0, 0, 1, 0, 2]), [1, 2, 3])
+
+
+def test_iss_definition(oracle):
+    """Key points are exactly the points that pass the eigenvalue-ratio test, have enough neighbours and carry the
+    largest third eigenvalue of their radius neighbourhood (brute-force numpy restatement on a small cloud)."""
+    rng = np.random.default_rng(8)
+    xyz = rng.uniform(-1, 1, (1500, 3)).astype(np.float32)
+    xyz[:, 2] *= 0.15
+    pts = synthetic.make_points(xyz)
+    r = np.float32(0.18)
+    idx, third = oracle.iss_keypoints(pts, float(r), with_third=True)
+    d = xyz[:, None, :] - xyz[None, :, :]
+    d2 = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+    nb = d2 < r * r
+    expect = []
+    for i in range(len(xyz)):
+        if not (third[i] > 0) or nb[i].sum() < 4:
+            continue
+        if not np.any(third[nb[i]] > third[i]):
+            expect.append(i)
+    assert np.array_equal(idx, np.array(expect, np.int32))
+    # the third eigenvalue is the smallest eigenvalue of the scatter matrix where the ratio test passes
+    i = int(idx[0])
+    q = xyz[nb[i]].astype(np.float64) - xyz[i].astype(np.float64)
+    ev = np.linalg.eigvalsh(q.T @ q)
+    assert abs(ev[0] - third[i]) <= 1e-9 * ev[2] and ev[1] / ev[2] < 0.975 and ev[0] / ev[1] < 0.975

@@ -1,0 +1,55 @@
+"""GPU measurements of the other BASELINE configs (not the bench line): config 4 (5M-point feature stage, RANSAC
+stress with C = 200k at 60 % outliers, 1e5 fixed iterations) and config 5 (GROR, C = 50k at 60 % outliers)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lidar-global-registration_amd"))
+import numpy as np, torch
+from lgr_amd import capi, synthetic
+
+ctx = capi.Context(0)
+
+
+def timed(f, n=3):
+    f(); ctx.sync(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        r = f()
+    ctx.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3, r
+
+
+which = sys.argv[1:] or ["ransac", "gror", "features5m"]
+if "ransac" in which:
+    pr = synthetic.make_correspondence_problem(n_pts=1_000_000, c=200_000, inlier_frac=0.4, sigma=0.01, thr=0.05, seed=566)
+    src, tgt = torch.from_numpy(pr["src"]).cuda(), torch.from_numpy(pr["tgt"]).cuda()
+    p = capi.default_params(max_iterations=100000, confidence=1.0, metric_id=capi.METRIC_UNIFORMITY, distance_thr=0.05)
+    ms, (res, mask) = timed(lambda: ctx.ransac(src, tgt, pr["corr"], p))
+    print(f"config 4 RANSAC stress: C=200000, 60% outliers, iterations run {res.iterations}, inliers {res.n_inliers}, "
+          f"{ms:.1f} ms -> {res.iterations / ms * 1e3 / 1e6:.2f} M hypotheses/s, err {np.abs(res.matrix() - pr['T_gt']).max():.2e}", flush=True)
+    p2 = capi.default_params(max_iterations=100000, metric_id=capi.METRIC_UNIFORMITY, distance_thr=0.05)
+    ms, (res, mask) = timed(lambda: ctx.ransac(src, tgt, pr["corr"], p2))
+    print(f"config 4 RANSAC latency (adaptive early-out): iterations {res.iterations}, {ms:.1f} ms", flush=True)
+if "gror" in which:
+    pr = synthetic.make_correspondence_problem(n_pts=2_000_000, c=50_000, inlier_frac=0.4, sigma=0.01, thr=0.05, seed=567)
+    src, tgt = torch.from_numpy(pr["src"]).cuda(), torch.from_numpy(pr["tgt"]).cuda()
+    ms, (res, mask) = timed(lambda: ctx.gror(src, tgt, pr["corr"], 0.05))
+    print(f"config 5 GROR: C=50000, 60% outliers, K=800: {ms:.1f} ms, best_count {int(res.metric)}, refine inliers {res.n_inliers}, "
+          f"err {np.abs(res.matrix() - pr['T_gt']).max():.2e}", flush=True)
+if "features5m" in which:
+    pair = synthetic.make_pair(5_000_000, seed=566)
+    cloud = torch.from_numpy(pair["src"]).cuda()
+    r = 0.25
+    voxel = float(np.sqrt(np.pi * r * r / 352))
+    ms_d, surf = timed(lambda: ctx.downsample(cloud, voxel))
+    surf = surf.clone()
+    ms_n, _ = timed(lambda: ctx.normals_knn(surf, 30, None, pair["vp_src"]))
+    ms_f, f = timed(lambda: ctx.fpfh(cloud, surf, r))
+    print(f"config 4 features at 5M points/cloud: surface {surf.shape[0]}, downsample {ms_d:.1f} ms, normals {ms_n:.1f} ms, FPFH {ms_f:.1f} ms", flush=True)
+if "align5m" in which:
+    pair = synthetic.make_pair(5_000_000, seed=566)
+    s, t = torch.from_numpy(pair["src"]).cuda(), torch.from_numpy(pair["tgt"]).cuda()
+    p = capi.default_params(matching_id=0, metric_id=capi.METRIC_UNIFORMITY, feature_radius=0.25, bf_block_size=200000, max_iterations=1000000,
+                            distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
+    ms, res = timed(lambda: ctx.align(s, t, p), n=1)
+    print(f"5M-point pair end to end: {ms:.0f} ms, stage_ms {list(res.stage_ms)[:7]}, work fraction {ctx.match_work():.3f}, "
+          f"err {np.abs(res.matrix() - pair['T_gt']).max():.2e}", flush=True)
