@@ -8,6 +8,8 @@
 #include <chrono>
 #include <cmath>
 
+#include <climits>
+
 #include "lgr_internal.h"
 
 namespace {
@@ -129,6 +131,183 @@ extern "C" int lgr_filter_dev(lgr_ctx* ctx, int matching_id, const float* d_src,
 
 static void tick(lgr_ctx* ctx, int i) { (void) hipEventRecord(ctx->ev[i], ctx->stream); }
 
+// ---- multi-scale matching (feature_radius unset): include/matching.h:176-262 (initialize) and :264-352
+// (match_multiscale).  The heavy stages (5-NN, down-sampling chain, normals, FPFH, brute-force matching per level) run on
+// the device; the per-key-point level assignment (log2f/sqrtf of the reference's host arithmetic, level pruning) and
+// the proximity vote over the <= nr_scales matches of a key point run on the host between them.
+struct MsSide {
+    int n_kps = 0;
+    float iss_radius = 0.f;
+    int min_l2 = INT_MAX, max_l2 = INT_MIN;
+    std::vector<std::vector<int>> lists;   // per scale: key-point indices
+    std::vector<size_t> feat_off;          // per scale: row offset into the feature buffer
+    float* feat = nullptr;                 // device, sum(rows) x 33
+    int32_t* d_lists = nullptr;            // device copy of the lists, concatenated like feat_off
+    std::vector<float> xyz;                // host copy of the key points (3 floats each) for the vote
+};
+
+__global__ void gather_rows12_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int m, float* __restrict__ out) {
+    size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t) m * 12) return;
+    out[e] = pts[(size_t) idx[e / 12] * 12 + e % 12];
+}
+
+static int ms_initialize(lgr_ctx* ctx, MsSide& st, int side, const float* d_pcd, int n, const float* d_kps, int n_kps, float iss_radius,
+                         const lgr_params* p, const float* vp, float* ms) {
+    st.n_kps = n_kps; st.iss_radius = iss_radius;
+    const int k = 5;
+    LGR_CHECK(ctx, n >= k, LGR_ERR_INVALID_ARG);
+    // :180-188 density of every key point = distance to its 4th neighbour in the full cloud
+    int32_t* d_nn;
+    float* d_d2;
+    LGR_TRY(lgr_ws_t(ctx, WS_MS_KNN_I, (size_t) n_kps * k, &d_nn));
+    LGR_TRY(lgr_ws_t(ctx, WS_MS_KNN_D, (size_t) n_kps * k, &d_d2));
+    LGR_TRY(lgr_knn_dev(ctx, d_kps, n_kps, d_pcd, n, k, d_nn, d_d2));
+    std::vector<float> d2((size_t) n_kps * k);
+    std::vector<float> kp((size_t) n_kps * 12);
+    LGR_HIP(ctx, hipMemcpyAsync(d2.data(), d_d2, d2.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(kp.data(), d_kps, kp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    st.xyz.resize((size_t) n_kps * 3);
+    for (int i = 0; i < n_kps; ++i) for (int a = 0; a < 3; ++a) st.xyz[3 * (size_t) i + a] = kp[12 * (size_t) i + a];
+    std::vector<int> level(n_kps);
+    for (int i = 0; i < n_kps; ++i) {
+        float density = sqrtf(d2[(size_t) i * k + (k - 1)]);
+        float feature_radius = sqrtf((float) p->feature_nr_points * density * density / M_PI);
+        level[i] = (int) std::floor(std::log2(feature_radius) / std::log2(p->scale_factor));
+        st.min_l2 = std::min(level[i], st.min_l2);
+        st.max_l2 = std::max(level[i], st.max_l2);
+    }
+    // :189-208 levels with too few points are dropped, key points clamped into the remaining range
+    LGR_CHECK(ctx, (long long) st.max_l2 - st.min_l2 < 64, LGR_ERR_INVALID_ARG);   // non-finite densities (duplicate-only clouds)
+    std::vector<int> count(st.max_l2 - st.min_l2 + 1, 0);
+    for (int v : level) count[v - st.min_l2]++;
+    const int max_nr = *std::max_element(count.begin(), count.end());
+    size_t front = 0, back = count.size();
+    while (10 * count[front] < max_nr) { ++front; st.min_l2++; }
+    while (1000 * count[back - 1] < max_nr) { --back; st.max_l2--; }
+    for (int& v : level) v = std::min(std::max(v, st.min_l2), st.max_l2);
+    const int nr_scales = st.max_l2 - st.min_l2 + 1;
+    st.lists.assign(nr_scales, {});
+    for (int i = 0; i < n_kps; ++i)
+        for (int j = level[i]; j <= st.max_l2; ++j) st.lists[j - st.min_l2].push_back(i);
+    st.feat_off.assign(nr_scales + 1, 0);
+    for (int i = 0; i < nr_scales; ++i) st.feat_off[i + 1] = st.feat_off[i] + st.lists[i].size();
+    const size_t rows = st.feat_off[nr_scales];
+    LGR_TRY(lgr_ws_t(ctx, side == 0 ? WS_MS_FEAT_S : WS_MS_FEAT_T, rows * 33 + 1, &st.feat));
+    LGR_TRY(lgr_ws_t(ctx, side == 0 ? WS_MS_LIST_S : WS_MS_LIST_T, rows + 1, &st.d_lists));
+    for (int i = 0; i < nr_scales; ++i)
+        if (!st.lists[i].empty())
+            LGR_HIP(ctx, hipMemcpyAsync(st.d_lists + st.feat_off[i], st.lists[i].data(), st.lists[i].size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // :228-261 per scale: down-sample the previous level's cloud, normals, FPFH of the level's key points
+    float *bufA, *bufB, *sub;
+    LGR_TRY(lgr_ws_t(ctx, side == 0 ? WS_PIPE_SURF_S : WS_PIPE_SURF_T, (size_t) n * 12, &bufA));
+    LGR_TRY(lgr_ws_t(ctx, WS_MS_SURF2, (size_t) n * 12, &bufB));
+    LGR_TRY(lgr_ws_t(ctx, WS_MS_SUB, (size_t) std::max(n_kps, 1) * 12, &sub));
+    const float* in = d_pcd;
+    int n_in = n;
+    for (int i = 0; i < nr_scales; ++i) {
+        float search_radius = powf(p->scale_factor, (float) (st.min_l2 + i));
+        float voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
+        float* out = (i & 1) ? bufB : bufA;
+        int nd = 0;
+        tick(ctx, 0);
+        LGR_TRY(lgr_downsample_dev(ctx, in, n_in, voxel, out, &nd));
+        tick(ctx, 1);
+        LGR_TRY(lgr_normals_knn_dev(ctx, out, nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available));
+        tick(ctx, 2);
+        const int m = (int) st.lists[i].size();
+        if (m) {
+            gather_rows12_kernel<<<cdiv((long long) m * 12, 256), 256, 0, ctx->stream>>>(d_kps, st.d_lists + st.feat_off[i], m, sub);
+            LGR_TRY(lgr_fpfh_dev(ctx, sub, m, out, nd, search_radius, st.feat + st.feat_off[i] * 33));
+        }
+        tick(ctx, 3);
+        LGR_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+        float t;
+        for (int s = 0; s < 3; ++s) { (void) hipEventElapsedTime(&t, ctx->ev[s], ctx->ev[s + 1]); ms[s] += t; }
+        in = out; n_in = nd;
+    }
+    return LGR_OK;
+}
+
+// :316-349 one match per query: the candidate (one per level) with the largest proximity-weighted support among the
+// candidates, ties by the smaller descriptor distance
+static void ms_vote(const MsSide& tr, const std::vector<std::vector<int>>& mi, const std::vector<std::vector<float>>& md,
+                    std::vector<int32_t>& out_idx, std::vector<float>& out_dist) {
+    const int nq = (int) mi.size();
+    for (int i = 0; i < nq; ++i) {
+        const std::vector<int>& m = mi[i];
+        float best_c = 0.f, best_d = 0.f;
+        int best = -1;
+        for (size_t m1 = 0; m1 < m.size(); ++m1) {
+            float cnt = 0.f;
+            for (size_t m2 = m1; m2 < m.size(); ++m2) {
+                const float* a = tr.xyz.data() + 3 * (size_t) m[m1];
+                const float* b = tr.xyz.data() + 3 * (size_t) m[m2];
+                float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+                float dist_l2 = std::sqrt((dx * dx + dy * dy) + dz * dz);
+                if (dist_l2 < 32 * tr.iss_radius) cnt += tr.iss_radius / std::max(dist_l2, tr.iss_radius);
+            }
+            if (cnt > best_c || (cnt == best_c && md[i][m1] < best_d)) { best_c = cnt; best_d = md[i][m1]; best = (int) m1; }
+        }
+        out_idx[i] = best >= 0 ? m[best] : -1;
+        out_dist[i] = best >= 0 ? md[i][best] : 0.f;
+    }
+}
+
+static int ms_match_tables(lgr_ctx* ctx, const float* const* clouds, const int* sizes, const float* const* kclouds, const int* ksizes,
+                           const lgr_params* p, int32_t* d_ij, float* d_dij, int32_t* d_ji, float* d_dji, float* ms) {
+    MsSide st[2];
+    for (int c = 0; c < 2; ++c) {
+        const float* vp = c == 0 ? (p->has_vp_src ? p->vp_src : nullptr) : (p->has_vp_tgt ? p->vp_tgt : nullptr);
+        LGR_TRY(ms_initialize(ctx, st[c], c, clouds[c], sizes[c], kclouds[c], ksizes[c], c == 0 ? p->iss_radius_src : p->iss_radius_tgt, p, vp, ms));
+    }
+    tick(ctx, 4);
+    const bool need_ji = p->matching_id != LGR_MATCH_ONE_SIDED;
+    const int ns = ksizes[0], nt = ksizes[1];
+    std::vector<std::vector<int>> mi_ij(ns), mi_ji(need_ji ? nt : 0);
+    std::vector<std::vector<float>> md_ij(ns), md_ji(need_ji ? nt : 0);
+    const int lo = std::max(st[0].min_l2, st[1].min_l2), hi = std::min(st[0].max_l2, st[1].max_l2);
+    for (int level = lo; level <= hi; ++level) {
+        const int ia = level - st[0].min_l2, ib = level - st[1].min_l2;
+        const std::vector<int>& la = st[0].lists[ia];
+        const std::vector<int>& lb = st[1].lists[ib];
+        const int ma = (int) la.size(), mb = (int) lb.size();
+        if (ma == 0 || mb == 0) continue;
+        int32_t* r;
+        LGR_TRY(lgr_ws_t(ctx, WS_MS_RES, (size_t) 2 * (ma + mb) + 4, &r));
+        int32_t *ab_i = r, *ba_i = r + ma;
+        float *ab_d = (float*) (r + ma + mb), *ba_d = ab_d + ma;
+        const float* fa = st[0].feat + st[0].feat_off[ia] * 33;
+        const float* fb = st[1].feat + st[1].feat_off[ib] * 33;
+        if (need_ji) LGR_TRY(lgr_match_bf2_dev(ctx, fa, ma, fb, mb, p->bf_block_size, ab_i, ab_d, ba_i, ba_d));
+        else LGR_TRY(lgr_match_bf_dev(ctx, fa, ma, fb, mb, p->bf_block_size, ab_i, ab_d));
+        std::vector<int32_t> h((size_t) 2 * (ma + mb));
+        LGR_HIP(ctx, hipMemcpyAsync(h.data(), r, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int32_t *h_ab = h.data(), *h_ba = h.data() + ma;
+        const float *h_abd = (const float*) (h.data() + ma + mb), *h_bad = h_abd + ma;
+        for (int i = 0; i < ma; ++i)
+            if (h_ab[i] >= 0) { mi_ij[la[i]].push_back(lb[h_ab[i]]); md_ij[la[i]].push_back(h_abd[i]); }
+        if (need_ji)
+            for (int j = 0; j < mb; ++j)
+                if (h_ba[j] >= 0) { mi_ji[lb[j]].push_back(la[h_ba[j]]); md_ji[lb[j]].push_back(h_bad[j]); }
+    }
+    std::vector<int32_t> ij(ns), ji(need_ji ? nt : 0);
+    std::vector<float> dij(ns), dji(need_ji ? nt : 0);
+    ms_vote(st[1], mi_ij, md_ij, ij, dij);
+    if (need_ji) ms_vote(st[0], mi_ji, md_ji, ji, dji);
+    LGR_HIP(ctx, hipMemcpyAsync(d_ij, ij.data(), (size_t) ns * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(d_dij, dij.data(), (size_t) ns * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (need_ji) {
+        LGR_HIP(ctx, hipMemcpyAsync(d_ji, ji.data(), (size_t) nt * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(d_dji, dji.data(), (size_t) nt * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging vectors go out of scope
+    return LGR_OK;
+}
+
 // key-point cloud = pcd[kps_indices] (pcl::copyPointCloud, include/matching.h:167); 12 floats per point
 __global__ void gather_points_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int m, float* __restrict__ out) {
     size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,16 +326,20 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
                                        lgr_corr* d_out, int* n_out) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && p && d_out && n_out && ns > 1 && nt > 1, LGR_ERR_INVALID_ARG);
-    LGR_CHECK(ctx, p->feature_radius > 0.f, LGR_ERR_UNSUPPORTED);   // multi-scale matching: SURVEY 8f "next"
     LGR_CHECK(ctx, p->randomness == 1, LGR_ERR_UNSUPPORTED);        // data/test.yaml:14 "currently only 1 is supported"
     LGR_CHECK(ctx, p->feature_nr_points > 0 && p->normal_nr_points >= 1 && p->normal_nr_points <= 64 && p->bf_block_size > 0 && p->scale_factor > 1.f,
               LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     *n_out = 0;
     // include/matching.h:172,230-231: radius quantised to a power of scale_factor; voxel from feature_nr_points
-    int log2_radius = (int) std::floor(std::log2(p->feature_radius) / std::log2(p->scale_factor));
-    float search_radius = powf(p->scale_factor, (float) log2_radius);
-    float voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
+    // (feature_radius unset, i.e. <= 0 here: the multi-scale path below, include/matching.h:176-208)
+    const bool multiscale = !(p->feature_radius > 0.f);
+    float search_radius = 0.f, voxel = 0.f;
+    if (!multiscale) {
+        int log2_radius = (int) std::floor(std::log2(p->feature_radius) / std::log2(p->scale_factor));
+        search_radius = powf(p->scale_factor, (float) log2_radius);
+        voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
+    }
     const float* clouds[2] = {d_src, d_tgt};
     int sizes[2] = {ns, nt};
     // key points (src/correspondence_search.cpp:8-11): every point, or the ISS detections.  kps = pcd[kps_indices]
@@ -189,6 +372,15 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_SURF_S, (size_t) sizes[0] * 12, &surf[0]));
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_SURF_T, (size_t) sizes[1] * 12, &surf[1]));
     float ms[3] = {0, 0, 0};
+    int32_t *ij, *ji;
+    float *dij, *dji;
+    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_IJ, (size_t) ns, &ij));
+    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_JI, (size_t) nt, &ji));
+    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_DIJ, (size_t) ns, &dij));
+    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_DJI, (size_t) nt, &dji));
+    if (multiscale) {
+        LGR_TRY(ms_match_tables(ctx, clouds, sizes, kclouds, ksizes, p, ij, dij, ji, dji, ms));
+    } else {
     for (int c = 0; c < 2; ++c) {
         int nd = 0;
         tick(ctx, 0);
@@ -205,15 +397,10 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
         float t;
         for (int s = 0; s < 3; ++s) { (void) hipEventElapsedTime(&t, ctx->ev[s], ctx->ev[s + 1]); ms[s] += t; }
     }
-    int32_t *ij, *ji;
-    float *dij, *dji;
-    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_IJ, (size_t) ns, &ij));
-    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_JI, (size_t) nt, &ji));
-    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_DIJ, (size_t) ns, &dij));
-    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_DJI, (size_t) nt, &dji));
     tick(ctx, 4);
     if (p->matching_id == LGR_MATCH_ONE_SIDED) LGR_TRY(lgr_match_bf_dev(ctx, feat[0], ns, feat[1], nt, p->bf_block_size, ij, dij));
     else LGR_TRY(lgr_match_bf2_dev(ctx, feat[0], ns, feat[1], nt, p->bf_block_size, ij, dij, ji, dji));
+    }
     tick(ctx, 5);
     LGR_TRY(lgr_filter_dev(ctx, p->matching_id, kclouds[0], ns, kclouds[1], nt, ij, dij, ji, dji, p->distance_thr, p->cluster_k, d_out, n_out));
     if (iss && *n_out) finalize_kernel<<<cdiv(*n_out, 256), 256, 0, ctx->stream>>>(d_out, *n_out, kidx[0], kidx[1]);

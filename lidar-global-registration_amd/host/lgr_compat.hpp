@@ -148,7 +148,7 @@ inline lgr_params to_abi(const AlignmentParameters& p) {
     lgr_default_params(&a);
     a.feature_nr_points = p.feature_nr_points; a.normal_nr_points = p.normal_nr_points;
     a.edge_thr_coef = p.edge_thr_coef; a.distance_thr = p.distance_thr;
-    a.feature_radius = p.feature_radius.value_or(0.f);   // 0 -> LGR_ERR_UNSUPPORTED (multi-scale is not built yet)
+    a.feature_radius = p.feature_radius.value_or(0.f);   // unset -> 0 -> multi-scale matching (include/matching.h:176-208)
     a.scale_factor = p.scale_factor; a.confidence = p.confidence; a.bf_block_size = p.bf_block_size;
     a.cluster_k = p.cluster_k; a.randomness = p.randomness; a.n_samples = p.n_samples;
     a.alignment_id = p.alignment_id == "gror" ? LGR_ALIGN_GROR : LGR_ALIGN_RANSAC;

@@ -198,13 +198,125 @@ extern "C" int orc_filter(int matching_id, const float* src, int ns, const float
 //   downsample (:234) -> normals k (:235) -> [kps normals re-estimate :243-246: no observable effect for FPFH,
 //   skipped] -> FPFH (:248) -> 1-NN both ways (:306) -> filter.  The surface is kept in ORC_ORDER_CANONICAL.
 // stage_seconds: [0] downsample [1] normals [2] fpfh [3] match [4] filter
+// ---- multi-scale matching (feature_radius unset): include/matching.h:163-262 (initialize) and :264-352 (match_multiscale)
+namespace {
+struct MsStorage {
+    const float* kps = nullptr;       // key-point cloud, 12 floats per point
+    int n_kps = 0;
+    float iss_radius = 0.f;
+    int min_l2 = std::numeric_limits<int>::max(), max_l2 = std::numeric_limits<int>::lowest();
+    std::vector<std::vector<int>> kidx_ms;       // per scale: indices into kps
+    std::vector<std::vector<float>> feat_ms;     // per scale: rows x 33
+};
+
+// :176-208 per-key-point radius level from the 5-NN distance in the full cloud, level pruning; :209-262 per-scale clouds
+int ms_initialize(MsStorage& st, const float* pcd, int n, const float* kps, int n_kps, const int* kidx /* or null: identity */,
+                  float iss_radius, const lgr_orc_params* p, const float* vp, double* t) {
+    st.kps = kps; st.n_kps = n_kps; st.iss_radius = iss_radius;
+    const int k = 5;
+    if (n < k) return -6;
+    std::vector<int> log2_radii(n_kps);
+    {
+        std::vector<int> nn((size_t) n_kps * k);
+        std::vector<float> d2((size_t) n_kps * k);
+        orc_knn(kps, n_kps, pcd, n, k, nn.data(), d2.data());   // nearestKSearch(*pcd, kps_indices[i], k): the point itself comes first
+        (void) kidx;
+        for (int i = 0; i < n_kps; ++i) {
+            float density = sqrtf(d2[(size_t) i * k + (k - 1)]);
+            float feature_radius = sqrtf((float) p->feature_nr_points * density * density / M_PI);
+            log2_radii[i] = (int) std::floor(std::log2(feature_radius) / std::log2(p->scale_factor));
+            st.min_l2 = std::min(log2_radii[i], st.min_l2);
+            st.max_l2 = std::max(log2_radii[i], st.max_l2);
+        }
+    }
+    std::vector<int> count(st.max_l2 - (st.min_l2 - 1), 0);
+    for (int v : log2_radii) count[v - st.min_l2]++;
+    int max_nr = *std::max_element(count.begin(), count.end());
+    size_t front = 0, back = count.size();
+    while (10 * count[front] < max_nr) { ++front; st.min_l2++; }
+    while (1000 * count[back - 1] < max_nr) { --back; st.max_l2--; }
+    for (int& v : log2_radii) v = std::min(std::max(v, st.min_l2), st.max_l2);
+    int nr_scales = st.max_l2 - (st.min_l2 - 1);
+    st.kidx_ms.assign(nr_scales, {});
+    st.feat_ms.assign(nr_scales, {});
+    for (int i = 0; i < n_kps; ++i)
+        for (int j = log2_radii[i]; j <= st.max_l2; ++j) st.kidx_ms[j - st.min_l2].push_back(i);
+    std::vector<float> prev;
+    int n_prev = 0;
+    for (int i = 0; i < nr_scales; ++i) {
+        float search_radius = powf(p->scale_factor, (float) (st.min_l2 + i));
+        float voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
+        double ta = now_s();
+        const float* in = i == 0 ? pcd : prev.data();
+        int n_in = i == 0 ? n : n_prev;
+        std::vector<float> ds((size_t) n_in * 12);
+        int nd = 0;
+        if (orc_downsample(in, n_in, voxel, ORC_ORDER_CANONICAL, ds.data(), &nd)) return -4;
+        ds.resize((size_t) nd * 12);
+        double tb = now_s();
+        orc_normals_knn(ds.data(), nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available);
+        double tc = now_s();
+        const std::vector<int>& sel = st.kidx_ms[i];
+        std::vector<float> sub(sel.size() * 12);
+        for (size_t r = 0; r < sel.size(); ++r) memcpy(sub.data() + 12 * r, kps + 12 * (size_t) sel[r], 48);
+        st.feat_ms[i].resize(sel.size() * 33);
+        orc_fpfh(sub.data(), (int) sel.size(), ds.data(), nd, search_radius, st.feat_ms[i].data(), 0);
+        double td = now_s();
+        t[0] += tb - ta; t[1] += tc - tb; t[2] += td - tc;
+        prev.swap(ds); n_prev = nd;
+    }
+    return 0;
+}
+
+// :264-352: per common level brute-force matches, then one match per query by the proximity vote
+void ms_match(const MsStorage& q, const MsStorage& tr, const lgr_orc_params* p, std::vector<int>& out_idx, std::vector<float>& out_dist) {
+    std::vector<std::vector<int>> mi(q.n_kps);
+    std::vector<std::vector<float>> md(q.n_kps);
+    int lo = std::max(q.min_l2, tr.min_l2), hi = std::min(q.max_l2, tr.max_l2);
+    for (int level = lo; level <= hi; ++level) {
+        const std::vector<int>& qs = q.kidx_ms[level - q.min_l2];
+        const std::vector<int>& ts = tr.kidx_ms[level - tr.min_l2];
+        const std::vector<float>& qf = q.feat_ms[level - q.min_l2];
+        const std::vector<float>& tf = tr.feat_ms[level - tr.min_l2];
+        std::vector<int> idx(qs.size());
+        std::vector<float> dist(qs.size());
+        orc_match_bf(qf.data(), (int) qs.size(), tf.data(), (int) ts.size(), p->bf_block_size, idx.data(), dist.data());
+        for (size_t i = 0; i < qs.size(); ++i) {
+            if (!row_valid(qf.data() + 33 * i) || idx[i] < 0) continue;
+            mi[qs[i]].push_back(ts[idx[i]]);
+            md[qs[i]].push_back(dist[i]);
+        }
+    }
+    for (int i = 0; i < q.n_kps; ++i) {
+        const std::vector<int>& m = mi[i];
+        std::vector<float> cnt(m.size(), 0.f);
+        for (size_t m1 = 0; m1 < m.size(); ++m1)
+            for (size_t m2 = m1; m2 < m.size(); ++m2) {
+                const float* a = tr.kps + 12 * (size_t) m[m1];
+                const float* b = tr.kps + 12 * (size_t) m[m2];
+                float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+                float dist_l2 = std::sqrt((dx * dx + dy * dy) + dz * dz);
+                if (dist_l2 < 32 * tr.iss_radius) cnt[m1] += tr.iss_radius / std::max(dist_l2, tr.iss_radius);
+            }
+        float best_c = 0.f, best_d = 0.f;
+        int best = -1;
+        for (size_t k = 0; k < m.size(); ++k)
+            if (cnt[k] > best_c || (cnt[k] == best_c && md[i][k] < best_d)) { best_c = cnt[k]; best_d = md[i][k]; best = (int) k; }
+        out_idx[i] = best >= 0 ? m[best] : -1;
+        out_dist[i] = best >= 0 ? md[i][best] : 0.f;
+    }
+}
+}  // namespace
+
 extern "C" int orc_correspondences(const float* src_all, int ns_all, const float* tgt_all, int nt_all, const lgr_orc_params* p,
                                    lgr_orc_corr* out, int* n_out, double* st) {
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (!(p->feature_radius > 0.f)) return -3;
-    int log2_radius = (int) std::floor(std::log2(p->feature_radius) / std::log2(p->scale_factor));
-    float search_radius = powf(p->scale_factor, (float) log2_radius);
-    float voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
+    float search_radius = 0.f, voxel = 0.f;
+    if (p->feature_radius > 0.f) {
+        int log2_radius = (int) std::floor(std::log2(p->feature_radius) / std::log2(p->scale_factor));
+        search_radius = powf(p->scale_factor, (float) log2_radius);
+        voxel = sqrtf(M_PI * search_radius * search_radius / (float) p->feature_nr_points);
+    }
     std::vector<float> feat[2];
     const float* clouds[2] = {src_all, tgt_all};
     int sizes[2] = {ns_all, nt_all};
@@ -233,30 +345,46 @@ extern "C" int orc_correspondences(const float* src_all, int ns_all, const float
     const int ksizes[2] = {ns, nt};
     *n_out = 0;
     if (ns == 0 || nt == 0) { if (st) for (int i = 0; i < 8; ++i) st[i] = t[i]; return 0; }
-    for (int c = 0; c < 2; ++c) {
-        double t0 = now_s();
-        std::vector<float> ds((size_t) sizes[c] * 12);
-        int nd = 0;
-        if (orc_downsample(clouds[c], sizes[c], voxel, ORC_ORDER_CANONICAL, ds.data(), &nd)) return -4;
-        double t1 = now_s();
-        const float* vp = c == 0 ? (p->has_vp_src ? p->vp_src : nullptr) : (p->has_vp_tgt ? p->vp_tgt : nullptr);
-        orc_normals_knn(ds.data(), nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available);
-        double t2 = now_s();
-        feat[c].resize((size_t) ksizes[c] * 33);
-        orc_fpfh(kclouds[c], ksizes[c], ds.data(), nd, search_radius, feat[c].data(), 0);
-        double t3 = now_s();
-        t[0] += t1 - t0; t[1] += t2 - t1; t[2] += t3 - t2;
-    }
-    double t0 = now_s();
     std::vector<int> ij(ns), ji(nt);
     std::vector<float> dij(ns), dji(nt);
-    orc_match_bf(feat[0].data(), ns, feat[1].data(), nt, p->bf_block_size, ij.data(), dij.data());
-    bool need_ji = p->matching_id != ORC_MATCH_ONE_SIDED;
-    if (need_ji) orc_match_bf(feat[1].data(), nt, feat[0].data(), ns, p->bf_block_size, ji.data(), dji.data());
-    // NaN query rows have no match (include/matching.h:576,614)
-    for (int i = 0; i < ns; ++i) if (!row_valid(feat[0].data() + 33 * (size_t) i)) ij[i] = -1;
-    if (need_ji) for (int i = 0; i < nt; ++i) if (!row_valid(feat[1].data() + 33 * (size_t) i)) ji[i] = -1;
-    double t1 = now_s();
+    const bool need_ji = p->matching_id != ORC_MATCH_ONE_SIDED;
+    double t0, t1;
+    if (p->feature_radius > 0.f) {
+        for (int c = 0; c < 2; ++c) {
+            double ta = now_s();
+            std::vector<float> ds((size_t) sizes[c] * 12);
+            int nd = 0;
+            if (orc_downsample(clouds[c], sizes[c], voxel, ORC_ORDER_CANONICAL, ds.data(), &nd)) return -4;
+            double tb = now_s();
+            const float* vp = c == 0 ? (p->has_vp_src ? p->vp_src : nullptr) : (p->has_vp_tgt ? p->vp_tgt : nullptr);
+            orc_normals_knn(ds.data(), nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available);
+            double tc = now_s();
+            feat[c].resize((size_t) ksizes[c] * 33);
+            orc_fpfh(kclouds[c], ksizes[c], ds.data(), nd, search_radius, feat[c].data(), 0);
+            double td = now_s();
+            t[0] += tb - ta; t[1] += tc - tb; t[2] += td - tc;
+        }
+        t0 = now_s();
+        orc_match_bf(feat[0].data(), ns, feat[1].data(), nt, p->bf_block_size, ij.data(), dij.data());
+        if (need_ji) orc_match_bf(feat[1].data(), nt, feat[0].data(), ns, p->bf_block_size, ji.data(), dji.data());
+        // NaN query rows have no match (include/matching.h:576,614)
+        for (int i = 0; i < ns; ++i) if (!row_valid(feat[0].data() + 33 * (size_t) i)) ij[i] = -1;
+        if (need_ji) for (int i = 0; i < nt; ++i) if (!row_valid(feat[1].data() + 33 * (size_t) i)) ji[i] = -1;
+        t1 = now_s();
+    } else {
+        // multi-scale (feature_radius unset): include/matching.h:176-262 + match_multiscale :264-352
+        MsStorage st[2];
+        for (int c = 0; c < 2; ++c) {
+            const float* vp = c == 0 ? (p->has_vp_src ? p->vp_src : nullptr) : (p->has_vp_tgt ? p->vp_tgt : nullptr);
+            int rc = ms_initialize(st[c], clouds[c], sizes[c], kclouds[c], ksizes[c], iss ? kidx[c].data() : nullptr,
+                                   c == 0 ? p->iss_radius_src : p->iss_radius_tgt, p, vp, t);
+            if (rc) return rc;
+        }
+        t0 = now_s();
+        ms_match(st[0], st[1], p, ij, dij);
+        if (need_ji) ms_match(st[1], st[0], p, ji, dji);
+        t1 = now_s();
+    }
     int rc = orc_filter(p->matching_id, src, ns, tgt, nt, ij.data(), dij.data(), ji.data(), dji.data(),
                         p->distance_thr, p->cluster_k, out, n_out);
     double t2 = now_s();

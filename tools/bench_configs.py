@@ -53,3 +53,14 @@ if "align5m" in which:
     ms, res = timed(lambda: ctx.align(s, t, p), n=1)
     print(f"5M-point pair end to end: {ms:.0f} ms, stage_ms {list(res.stage_ms)[:7]}, work fraction {ctx.match_work():.3f}, "
           f"err {np.abs(res.matrix() - pair['T_gt']).max():.2e}", flush=True)
+if "iss1m" in which:
+    pair = synthetic.make_pair(1_000_000, seed=566)
+    s, t = torch.from_numpy(pair["src"]).cuda(), torch.from_numpy(pair["tgt"]).cuda()
+    for r in (0.05, 0.1):
+        ms, idx = timed(lambda: ctx.iss_keypoints(s, r))
+        print(f"ISS on 1M points, radius {r}: {idx.shape[0]} key points, {ms:.1f} ms", flush=True)
+    p = capi.default_params(matching_id=0, metric_id=capi.METRIC_UNIFORMITY, feature_radius=0.25, bf_block_size=200000, max_iterations=1000000,
+                            distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"], keypoint_id=1, iss_radius_src=0.05, iss_radius_tgt=0.05)
+    ms, res = timed(lambda: ctx.align(s, t, p), n=2)
+    print(f"1M-point pair with ISS key points (r = 0.05): {ms:.1f} ms, correspondences {res.n_correspondences}, inliers {res.n_inliers}, "
+          f"converged {res.converged}, err {np.abs(res.matrix() - pair['T_gt']).max():.2e}", flush=True)
