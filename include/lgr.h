@@ -109,6 +109,18 @@ int  lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12);
 /* ---- include/common.h:266-280 calculateBoundingBox ---- */
 int lgr_bbox_dev(lgr_ctx*, const float* d_pts, int n, float* d_min3_max3 /* 6 floats */);
 
+/* ---- loader preprocessing: the steps of loadPointClouds (src/common.cpp:429-470) after the PLY reader:
+ *      filterDuplicatePoints (:417-427), intensity = 1, voxel grid at 2 x calculatePointCloudDensity (:453-456,
+ *      include/common.h:288), estimateNormalsPoints(30).  out holds n points, out != pts.  vp3 NULL -> origin.
+ *      order (host entry): LGR_ORDER_REFERENCE reproduces the libstdc++ unordered_set / unordered_map output order. ---- */
+int lgr_preprocess(lgr_ctx*, const float* pts, int n, const float* vp3, int normals_available, int order, float* out, int* n_out, float* voxel_out);
+int lgr_preprocess_dev(lgr_ctx*, const float* d_pts, int n, const float* vp3 /* host */, int normals_available, float* d_out, int* n_out /* host */,
+                       float* voxel_out /* host, or NULL */);
+/* src/common.cpp:417-427 filterDuplicatePoints (first occurrence of every exact xyz, input order; intensity := 1 as :446-451) */
+int lgr_dedupe_dev(lgr_ctx*, const float* d_pts, int n, float* d_out, int* n_out /* host */);
+/* src/common.cpp:202-208 calculatePointCloudDensity(pcd, quantile) */
+int lgr_cloud_density_dev(lgr_ctx*, const float* d_pts, int n, float quantile, float* out /* host */);
+
 /* ---- include/common.h:304-310 detectKeyPoints(pcd, parameters, iss_radius) with keypoint_id = iss
  *      (src/common.cpp:657-691: pcl::ISSKeypoint3D, salient = non-max radius = iss_radius, thresholds 0.975,
  *      min_neighbors 4; the reference passes gamma/min_neighbors as constants, they are arguments here).

@@ -205,6 +205,34 @@ class Context:
         self.check(_lib.lgr_smoothed_densities_dev(self.h, _ptr(pts), pts.shape[0], int(k), _ptr(out)))
         return out
 
+    def preprocess(self, pts, vp=None, normals_available=False):
+        out = self.empty((pts.shape[0], 12), self.torch.float32)
+        n = C.c_int(0)
+        voxel = C.c_float(0)
+        v = (C.c_float * 3)(*[float(x) for x in vp]) if vp is not None else None
+        self.check(_lib.lgr_preprocess_dev(self.h, _ptr(pts), pts.shape[0], v, int(normals_available), _ptr(out), C.byref(n), C.byref(voxel)))
+        return out[: n.value], voxel.value
+
+    def preprocess_host(self, pts, vp=None, normals_available=False, order=ORDER_CANONICAL):
+        pts = np.ascontiguousarray(pts, np.float32)
+        out = np.zeros_like(pts)
+        n = C.c_int(0)
+        voxel = C.c_float(0)
+        v = (C.c_float * 3)(*[float(x) for x in vp]) if vp is not None else None
+        self.check(_lib.lgr_preprocess(self.h, _ptr(pts), pts.shape[0], v, int(normals_available), int(order), _ptr(out), C.byref(n), C.byref(voxel)))
+        return out[: n.value].copy(), voxel.value
+
+    def dedupe(self, pts):
+        out = self.empty((max(pts.shape[0], 1), 12), self.torch.float32)
+        n = C.c_int(0)
+        self.check(_lib.lgr_dedupe_dev(self.h, _ptr(pts), pts.shape[0], _ptr(out), C.byref(n)))
+        return out[: n.value]
+
+    def cloud_density(self, pts, quantile=0.8):
+        v = C.c_float(0)
+        self.check(_lib.lgr_cloud_density_dev(self.h, _ptr(pts), pts.shape[0], C.c_float(quantile), C.byref(v)))
+        return v.value
+
     def iss_keypoints(self, pts, radius, gamma21=0.975, gamma32=0.975, min_neighbors=4):
         idx = self.empty((max(pts.shape[0], 1),), self.torch.int32)
         n = C.c_int(0)

@@ -113,6 +113,11 @@ int orc_filter(int matching_id, const float* src, int ns, const float* tgt, int 
                const int* ij_idx, const float* ij_dist, const int* ji_idx, const float* ji_dist,
                float distance_thr, int cluster_k, lgr_orc_corr* out, int* n_out);
 
+/* loader preprocessing, src/common.cpp:417-427 (filterDuplicatePoints) and :446-459 (weights, 2 x density voxel grid,
+ * normals); out holds n points */
+int orc_dedupe(const float* pts, int n, int order, float* out, int* n_out);
+int orc_preprocess(const float* pts, int n, const float* vp3, int normals_available, int order, float* out, int* n_out, float* voxel_out);
+
 /* src/common.cpp:657-691 detectKeyPoints with keypoint_id = iss (pcl::ISSKeypoint3D, salient = non-max radius,
  * thresholds 0.975, min_neighbors 4): ascending indices.  out_idx holds n ints; third (optional) n doubles */
 int orc_iss_keypoints(const float* pts, int n, float radius, float gamma21, float gamma32, int min_neighbors,

@@ -419,3 +419,22 @@ def eigvals3d(S6):
     ev = np.zeros(3, np.float64)
     lib().orc_eigvals3d(_p(S6), _p(ev))
     return ev
+
+
+def dedupe(pts, order=ORDER_CANONICAL):
+    pts = _pts(pts)
+    out = np.zeros_like(pts)
+    n = C.c_int(0)
+    assert lib().orc_dedupe(_p(pts), pts.shape[0], order, _p(out), C.byref(n)) == 0
+    return out[: n.value].copy()
+
+
+def preprocess(pts, vp=None, normals_available=False, order=ORDER_CANONICAL):
+    pts = _pts(pts)
+    out = np.zeros_like(pts)
+    n = C.c_int(0)
+    voxel = C.c_float(0)
+    v = np.ascontiguousarray(vp, dtype=np.float32) if vp is not None else None
+    rc = lib().orc_preprocess(_p(pts), pts.shape[0], _p(v), int(normals_available), order, _p(out), C.byref(n), C.byref(voxel))
+    assert rc == 0, rc
+    return out[: n.value].copy(), voxel.value
