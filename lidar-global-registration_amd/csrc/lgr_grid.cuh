@@ -23,13 +23,15 @@ struct KnnList {
     float* d2;   // [kcap][BLOCK]
     int* id;     // [kcap][BLOCK]
     int k, count, t;
-    __device__ __forceinline__ void init(float* d2s, int* ids, int k_, int tid) { d2 = d2s; id = ids; k = k_; count = 0; t = tid; }
+    float wreg;   // register copy of the k-th distance once the list is full: most candidates are rejected without touching LDS
+    __device__ __forceinline__ void init(float* d2s, int* ids, int k_, int tid) { d2 = d2s; id = ids; k = k_; count = 0; t = tid; wreg = 0.f; }
     __device__ __forceinline__ float worst() const { return d2[(k - 1) * BLOCK + t]; }
     __device__ __forceinline__ void push(float d, int i) {
         int pos;
         if (count < k) pos = count++;
         else {
-            float wd = d2[(k - 1) * BLOCK + t];
+            if (d > wreg) return;
+            float wd = wreg;
             int wi = id[(k - 1) * BLOCK + t];
             if (!(d < wd || (d == wd && i < wi))) return;
             pos = k - 1;
@@ -42,6 +44,7 @@ struct KnnList {
             } else break;
         }
         d2[pos * BLOCK + t] = d; id[pos * BLOCK + t] = i;
+        if (count == k) wreg = d2[(k - 1) * BLOCK + t];
     }
     __device__ __forceinline__ float dist(int j) const { return d2[j * BLOCK + t]; }
     __device__ __forceinline__ int index(int j) const { return id[j * BLOCK + t]; }
@@ -59,15 +62,24 @@ __device__ __forceinline__ void lgr_knn_query(const GridDev& g, float qx, float 
             for (int y = c0y - s; y <= c0y + s; ++y) {
                 if (y < 0 || y >= g.dy) continue;
                 bool edge = (z == c0z - s) || (z == c0z + s) || (y == c0y - s) || (y == c0y + s);
-                int step = edge ? 1 : 2 * s;
-                if (step == 0) step = 1;
-                for (int x = c0x - s; x <= c0x + s; x += step) {
-                    if (x < 0 || x >= g.dx) continue;
-                    size_t c = ((size_t) z * g.dy + y) * g.dx + x;
-                    int b = g.cell_start[c], e = g.cell_start[c + 1];
+                const size_t row = ((size_t) z * g.dy + y) * g.dx;
+                if (edge || s == 0) {
+                    // the whole x run of this (z, y) row belongs to the shell: its cells are contiguous in memory
+                    int x0 = max(c0x - s, 0), x1 = min(c0x + s, g.dx - 1);
+                    if (x0 > x1) continue;
+                    int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
                     for (int t = b; t < e; ++t) {
                         float4 p = g.pxyz[t];
                         L.push(lgr_dist2(qx, qy, qz, p.x, p.y, p.z), __float_as_int(p.w));
+                    }
+                } else {
+                    for (int x = c0x - s; x <= c0x + s; x += 2 * s) {   // the two end cells of an interior row
+                        if (x < 0 || x >= g.dx) continue;
+                        int b = g.cell_start[row + x], e = g.cell_start[row + x + 1];
+                        for (int t = b; t < e; ++t) {
+                            float4 p = g.pxyz[t];
+                            L.push(lgr_dist2(qx, qy, qz, p.x, p.y, p.z), __float_as_int(p.w));
+                        }
                     }
                 }
             }
