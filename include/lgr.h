@@ -41,7 +41,7 @@ enum {
 };
 
 enum { LGR_MATCH_LR = 0, LGR_MATCH_ONE_SIDED = 1, LGR_MATCH_CLUSTER = 2 };      /* src/matching.cpp:21-75 */
-enum { LGR_METRIC_CORRESPONDENCES = 0, LGR_METRIC_UNIFORMITY = 1 };             /* src/metric.cpp:272-301 */
+enum { LGR_METRIC_CORRESPONDENCES = 0, LGR_METRIC_UNIFORMITY = 1, LGR_METRIC_CLOSEST_PLANE = 2, LGR_METRIC_COMBINATION = 3 };   /* src/metric.cpp:272-301 */
 enum { LGR_SCORE_CONSTANT = 0, LGR_SCORE_MAE = 1, LGR_SCORE_MSE = 2, LGR_SCORE_EXP = 3 };
 enum { LGR_ALIGN_RANSAC = 0, LGR_ALIGN_GROR = 1 };                              /* src/alignment.cpp:92-101 */
 enum { LGR_KEYPOINT_ANY = 0, LGR_KEYPOINT_ISS = 1 };                            /* src/common.cpp:657-691 */
@@ -198,6 +198,15 @@ int lgr_ransac_samples_dev(lgr_ctx*, uint64_t seed, int first, int n, int n_corr
 int lgr_evaluate_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                      const float T16[16] /* host */, int metric_id, int score_id,
                      uint8_t* d_mask, int* n_inliers, float* rmse, float* metric /* host outs */);
+
+/* ---- ClosestPlaneMetricEstimator::buildInliersAndEstimateMetric (src/metric.cpp:10-53,181-199) of one transform on the
+ *      sparse 1 % subset RANSAC uses (src/sac_prerejective_omp.cpp:109); the subset of hypothesis `counter` is defined by
+ *      Philox.  threshold = calculatePointCloudDensity(tgt).  pairs (optional, 2 ints per inlier, room for
+ *      0.01 * ns pairs): (source index, nearest target index), ascending source index.  In lgr_ransac / lgr_align:
+ *      params.metric_id = LGR_METRIC_CLOSEST_PLANE or LGR_METRIC_COMBINATION. ---- */
+int lgr_evaluate_plane_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const float T16[16] /* host */, int score_id,
+                           uint64_t seed, uint32_t counter, int* n_inliers, float* rmse, float* metric, float* threshold /* or NULL */,
+                           int32_t* pairs /* host, or NULL */, int* n_pairs);
 
 /* ---- include/transformation.h:6-7 estimateOptimalRigidTransformation(src, tgt, inliers, T) ---- */
 int lgr_refit_svd(lgr_ctx*, const float* src, const float* tgt, int ns, int nt, const lgr_corr* inliers, int n, float T16[16]);

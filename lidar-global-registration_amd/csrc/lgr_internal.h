@@ -66,7 +66,7 @@ enum {
     WS_RANSAC_T, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK,
     WS_PIPE_SURF_S, WS_PIPE_SURF_T, WS_PIPE_FEAT_S, WS_PIPE_FEAT_T, WS_PIPE_IJ, WS_PIPE_JI, WS_PIPE_DIJ, WS_PIPE_DJI,
     WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_FLAGS, WS_PIPE_MISC, WS_PIPE_KIDX_S, WS_PIPE_KIDX_T, WS_PIPE_KPS_S, WS_PIPE_KPS_T,
-    WS_MS_KNN_I, WS_MS_KNN_D, WS_MS_LIST_S, WS_MS_LIST_T, WS_MS_SUB, WS_MS_FEAT_S, WS_MS_FEAT_T, WS_MS_SURF2, WS_MS_RES,
+    WS_MS_KNN_I, WS_MS_KNN_D, WS_MS_LIST_S, WS_MS_LIST_T, WS_MS_SUB, WS_MS_FEAT_S, WS_MS_FEAT_T, WS_MS_SURF2, WS_MS_RES, WS_PLANE_VISITED, WS_PLANE_CLAIMED, WS_PLANE_OUT,
     WS_HOST_A, WS_HOST_B, WS_HOST_C, WS_HOST_D, WS_HOST_E, WS_HOST_F,
     WS_COUNT
 };
@@ -101,3 +101,21 @@ int lgr_grid_build(lgr_ctx* ctx, int slot_base, const float* d_pts, int n, float
 // both bounding boxes of a cloud: out12 (host) = true min3, true max3 (finite points only; +-inf when empty),
 // reference-quirk min3, max3 (include/common.h:266-280)
 int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
+
+// ---- closest-plane metric on the device (lgr_plane.hip) ----
+struct lgr_plane_dev {
+    GridDev g;                  // uniform grid over the target (cell = 1.001 * radius), with normals
+    float thr, r2;              // inlier threshold (target cloud density), squared search radius (2 * thr)
+    int n_sp, ns;               // sparse subset size = (int) (0.01 * |src|), |src|
+    const float* d_src;
+    uint64_t seed;
+    unsigned* visited;          // [n_wg][(ns + 31) / 32] claim bitmaps, all zero between hypotheses
+    int* claimed;               // [n_wg][n_sp]
+    int n_wg;
+};
+int lgr_plane_setup(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, uint64_t seed, lgr_plane_dev* out);
+// hypothesis h in [0, nh): transform d_Ts + 16 * off, Philox counter = counter_base + off, off = d_list ? d_list[h] : h.
+// d_rmse / d_pairs (+ d_n_pairs) optional; pairs = (source index, nearest target index) of the inliers, unordered.
+int lgr_plane_eval(lgr_ctx* ctx, const lgr_plane_dev& pd, const float* d_Ts, const int* d_list, int nh, unsigned counter_base, int score_id,
+                   int* d_cnt, float* d_metric, float* d_rmse, int2* d_pairs, int* d_n_pairs);
+

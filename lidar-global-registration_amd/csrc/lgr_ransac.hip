@@ -397,6 +397,30 @@ __global__ void flag_ge_kernel(const int2* __restrict__ counts, int nh, int* __r
     int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h < nh) flags[h] = counts[h].x >= MIN_NR_INLIERS ? 1 : 0;
 }
+// closest-plane metric plumbing: inlier counts of the plane test replace the correspondence counts (the estimator's
+// `inliers` are the plane pairs, src/metric.cpp:187-199); candidates pick up their plane metric; combination multiplies
+__global__ void plane_counts_kernel(const int* __restrict__ cnt, int nh, int2* __restrict__ counts) {
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < nh) counts[h].x = cnt[h];
+}
+__global__ void plane_pick_kernel(const int* __restrict__ flags, const int* __restrict__ pos, int nh, const int* __restrict__ cnt,
+                                  const float* __restrict__ cp, float* __restrict__ metric, int* __restrict__ ninl) {
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < nh && flags[h]) { metric[pos[h]] = cp[h]; ninl[pos[h]] = cnt[h]; }
+}
+__global__ void plane_mul_kernel(float* __restrict__ metric, const float* __restrict__ cp, int n) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) metric[j] = metric[j] * cp[j];   // metric_cs * metric_cp (src/metric.cpp:248)
+}
+__global__ void plane_pack_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const int2* __restrict__ pairs, int n,
+                                  float4* __restrict__ P0, float4* __restrict__ P1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* s = src + (size_t) pairs[i].x * 12;
+    const float* t = tgt + (size_t) pairs[i].y * 12;
+    P0[i] = make_float4(s[0], s[1], s[2], 0.f);
+    P1[i] = make_float4(t[0], t[1], t[2], 0.f);
+}
 __global__ void compact_kernel(const int* __restrict__ flags, const int* __restrict__ pos, int n, const int* __restrict__ map,
                                int* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -610,6 +634,68 @@ int evaluate_one(lgr_ctx* ctx, const float* d_T, const Packed& pk, int c, int me
 
 }  // namespace
 
+// single transform under a plane metric: counter = 0xFFFFFFFE / 0xFFFFFFFF for the two evaluations of the final block.
+// closest_plane: inliers / rmse / metric from the plane test, pairs (sorted by source index) returned for the refit.
+int evaluate_one_plane(lgr_ctx* ctx, const float* d_T, const Packed& pk, int c, int metric_id, int score_id, uint8_t* d_mask,
+                       const lgr_plane_dev& plane, unsigned counter, EvalOut* out, std::vector<int2>* pairs) {
+    int* pl;
+    LGR_TRY(lgr_ws_t(ctx, WS_PLANE_OUT, (size_t) 8 + 2 * (size_t) std::max(plane.n_sp, 1) + 8, &pl));
+    int* d_cnt = pl; float* d_cp = (float*) (pl + 1); float* d_rm = (float*) (pl + 2); int* d_np = pl + 3;
+    int2* d_pairs = (int2*) (pl + 8);
+    const bool want_pairs = pairs != nullptr;
+    LGR_TRY(lgr_plane_eval(ctx, plane, d_T, nullptr, 1, counter, score_id, d_cnt, d_cp, d_rm, want_pairs ? d_pairs : nullptr, d_np));
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 64 + (size_t) 8 * std::max(plane.n_sp, 1), (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, pl, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int cnt = h[0];
+    float cp, rm;
+    memcpy(&cp, &h[1], 4); memcpy(&rm, &h[2], 4);
+    if (want_pairs) {
+        pairs->resize(cnt);
+        if (cnt) {
+            LGR_HIP(ctx, hipMemcpyAsync(h + 16, d_pairs, (size_t) cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            memcpy(pairs->data(), h + 16, (size_t) cnt * 8);
+            std::sort(pairs->begin(), pairs->end(), [](const int2& a, const int2& b) { return a.x < b.x; });   // source indices are distinct
+        }
+    }
+    if (metric_id == LGR_METRIC_CLOSEST_PLANE) {
+        if (d_mask) LGR_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t) c, ctx->stream));
+        out->n_inl = cnt; out->rmse = rm; out->metric = cp;
+        return LGR_OK;
+    }
+    EvalOut e;
+    LGR_TRY(evaluate_one(ctx, d_T, pk, c, LGR_METRIC_CORRESPONDENCES, LGR_SCORE_CONSTANT, d_mask, &e));
+    out->n_inl = e.n_inl; out->rmse = e.rmse; out->metric = e.metric * cp;
+    return LGR_OK;
+}
+
+extern "C" int lgr_evaluate_plane_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const float T16[16], int score_id,
+                                      uint64_t seed, uint32_t counter, int* n_inliers, float* rmse, float* metric, float* threshold,
+                                      int32_t* pairs, int* n_pairs) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, d_src && d_tgt && T16 && n_inliers && rmse && metric && ns > 0 && nt > 1 && score_id >= 0 && score_id <= 3, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    lgr_plane_dev plane;
+    LGR_TRY(lgr_plane_setup(ctx, d_src, ns, d_tgt, nt, seed, &plane));
+    float* dT;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &dT));
+    LGR_HIP(ctx, hipMemcpyAsync(dT, T16, 64, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    Packed none{nullptr, nullptr, nullptr};
+    EvalOut e;
+    std::vector<int2> pr;
+    LGR_TRY(evaluate_one_plane(ctx, dT, none, 0, LGR_METRIC_CLOSEST_PLANE, score_id, nullptr, plane, counter, &e, pairs ? &pr : nullptr));
+    *n_inliers = e.n_inl; *rmse = e.rmse; *metric = e.metric;
+    if (threshold) *threshold = plane.thr;
+    if (pairs) {
+        for (size_t i = 0; i < pr.size(); ++i) { pairs[2 * i] = pr[i].x; pairs[2 * i + 1] = pr[i].y; }
+        if (n_pairs) *n_pairs = (int) pr.size();
+    }
+    return LGR_OK;
+}
+
 extern "C" int lgr_ransac_samples_dev(lgr_ctx* ctx, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, n >= 0 && n_corr >= 3 && (d_triples || n == 0) && first >= 0, LGR_ERR_INVALID_ARG);
@@ -658,7 +744,7 @@ static int batch_buffers(lgr_ctx* ctx, int nb, BatchBuffers* b) {
 // runs one batch.  h_counts: [0] n_ok, [1] n_cand (hypotheses with >= MIN_NR_INLIERS inliers)
 static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c, const Packed& pk,
                      const lgr_params* p, uint64_t seed, int first, int nb, const int32_t* d_triples, BatchBuffers& b,
-                     int* n_ok, int* n_cand) {
+                     int* n_ok, int* n_cand, const lgr_plane_dev* plane = nullptr) {
     hypotheses_kernel<<<cdiv(nb, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, first, nb, d_triples,
                                                               p->edge_thr_coef, b.Ts, b.ok);
     size_t tb = 0;
@@ -678,6 +764,17 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     LGR_HIP(ctx, hipMemsetAsync(b.counts, 0, (size_t) nh * 8, ctx->stream));
     dim3 g(cdiv(nh, CB), cdiv(c, CCH));
     count_kernel<<<g, CB, 0, ctx->stream>>>(b.Ts, b.list, nh, pk.P0, pk.P1, pk.sstar, c, b.counts);
+    int* pl_cnt = nullptr;
+    float* pl_cp = nullptr;
+    if (plane) {
+        LGR_TRY(lgr_ws_t(ctx, WS_PLANE_OUT, (size_t) 2 * nb + 16, &pl_cnt));
+        pl_cp = (float*) (pl_cnt + nb);
+    }
+    if (plane && p->metric_id == LGR_METRIC_CLOSEST_PLANE) {
+        // every hypothesis that passed the prerejection is evaluated on its sparse subset; its plane inliers are "the inliers"
+        LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list, nh, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr));
+        plane_counts_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(pl_cnt, nh, b.counts);
+    }
     flag_ge_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.counts, nh, b.flags2);
     LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, b.flags2, b.pos2, 0, (size_t) nh, rocprim::plus<int>(), ctx->stream));
     compact_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.flags2, b.pos2, nh, b.list, b.list2);
@@ -687,14 +784,25 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     int nh2 = h[0] + h[1];
     *n_cand = nh2;
     if (nh2 == 0) return LGR_OK;
-    LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr));
+    if (plane && p->metric_id == LGR_METRIC_CLOSEST_PLANE) {
+        plane_pick_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.flags2, b.pos2, nh, pl_cnt, pl_cp, b.metric, b.ninl);
+    } else if (plane) {   // combination: correspondences metric with the constant score (include/metric.h:191-192) x plane metric
+        LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, LGR_METRIC_CORRESPONDENCES, LGR_SCORE_CONSTANT, b.metric, b.ninl, nullptr, nullptr));
+        LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list2, nh2, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr));
+        plane_mul_kernel<<<cdiv(nh2, 256), 256, 0, ctx->stream>>>(b.metric, pl_cp, nh2);
+    } else {
+        LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr));
+    }
+    LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
 
 static int check_params(lgr_ctx* ctx, const lgr_params* p) {
     LGR_CHECK(ctx, p != nullptr, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, p->n_samples == 3, LGR_ERR_UNSUPPORTED);
-    LGR_CHECK(ctx, p->metric_id == LGR_METRIC_UNIFORMITY || p->metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);
+    LGR_CHECK(ctx, p->metric_id == LGR_METRIC_UNIFORMITY || p->metric_id == LGR_METRIC_CORRESPONDENCES ||
+                       p->metric_id == LGR_METRIC_CLOSEST_PLANE || p->metric_id == LGR_METRIC_COMBINATION,
+              LGR_ERR_UNSUPPORTED);   // weighted_closest_plane (src/weights.cpp) is not built
     LGR_CHECK(ctx, p->score_id >= 0 && p->score_id <= 3, LGR_ERR_INVALID_ARG);
     return LGR_OK;
 }
@@ -704,6 +812,7 @@ extern "C" int lgr_ransac_replay_dev(lgr_ctx* ctx, const float* d_src, int ns, c
                                      uint8_t* d_ok, float* d_T16, int32_t* d_n_inliers, float* d_metric) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_TRY(check_params(ctx, p));
+    LGR_CHECK(ctx, p->metric_id == LGR_METRIC_UNIFORMITY || p->metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);   // plane metrics: lgr_evaluate_plane_dev
     LGR_CHECK(ctx, d_src && d_tgt && d_corr && d_triples && d_ok && d_T16 && d_n_inliers && d_metric && c >= 3 && n >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
     if (n == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -781,10 +890,13 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     }
     BatchBuffers b;
     LGR_TRY(batch_buffers(ctx, std::min(batch, std::max(max_iterations, 1)), &b));
+    const bool plane_metric = p->metric_id == LGR_METRIC_CLOSEST_PLANE || p->metric_id == LGR_METRIC_COMBINATION;
+    lgr_plane_dev plane;
+    if (plane_metric) LGR_TRY(lgr_plane_setup(ctx, d_src, ns, d_tgt, nt, seed, &plane));
     while (done < bound) {
         int nb = std::min(batch, max_iterations - done);
         int n_ok = 0, n_cand = 0;
-        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand));
+        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand, plane_metric ? &plane : nullptr));
         num_rejections += nb - n_ok;
         if (n_cand > 0) {
             LGR_HIP(ctx, hipMemsetAsync(b.st, 0, sizeof(BatchStats), ctx->stream));
@@ -820,14 +932,35 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     uint8_t* d_mask = d_final_mask;
     if (!d_mask) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASK, (size_t) c + 16, &d_mask));
     EvalOut e;
-    LGR_TRY(evaluate_one(ctx, d_best, pk, c, p->metric_id, p->score_id, d_mask, &e));
+    std::vector<int2> plane_pairs;
+    if (plane_metric)
+        LGR_TRY(evaluate_one_plane(ctx, d_best, pk, c, p->metric_id, p->score_id, d_mask, plane, 0xFFFFFFFEu, &e,
+                                   p->metric_id == LGR_METRIC_CLOSEST_PLANE ? &plane_pairs : nullptr));
+    else LGR_TRY(evaluate_one(ctx, d_best, pk, c, p->metric_id, p->score_id, d_mask, &e));
     bool enough = e.n_inl > MIN_NR_FINAL_INLIERS || (float) e.n_inl > MIN_INLIER_RATE * (float) c;
-    float min_tol = p->metric_id == LGR_METRIC_UNIFORMITY ? 0.3f : 0.0f;   // include/metric.h:97-99 / 73-75
+    float min_tol = p->metric_id == LGR_METRIC_UNIFORMITY ? 0.3f : 0.0f;   // include/metric.h:97-99 / 73-75 / 124-126 / 198-200
     bool converged = enough && e.metric > min_tol;
     float* d_Tn = d_best + 16;
-    LGR_TRY(refit_launch(ctx, pk, c, d_mask, d_Tn));
+    if (p->metric_id == LGR_METRIC_CLOSEST_PLANE) {
+        // estimateOptimalRigidTransformation over the plane pairs (source point, nearest target point), ascending source index
+        const int np = (int) plane_pairs.size();
+        Packed pp;
+        float4* P;
+        LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_LIST, (size_t) 3 * std::max(np, 1) + 4, &P));
+        pp.P0 = P; pp.P1 = P + std::max(np, 1); pp.sstar = nullptr;
+        int2* d_pairs = (int2*) (P + 2 * (size_t) std::max(np, 1));
+        if (np) {
+            LGR_HIP(ctx, hipMemcpyAsync(d_pairs, plane_pairs.data(), (size_t) np * 8, hipMemcpyHostToDevice, ctx->stream));
+            plane_pack_kernel<<<cdiv(np, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_pairs, np, pp.P0, pp.P1);
+            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        LGR_TRY(refit_launch(ctx, pp, np, nullptr, d_Tn));
+    } else {
+        LGR_TRY(refit_launch(ctx, pk, c, d_mask, d_Tn));
+    }
     EvalOut e2;
-    LGR_TRY(evaluate_one(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, &e2));
+    if (plane_metric) LGR_TRY(evaluate_one_plane(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, plane, 0xFFFFFFFFu, &e2, nullptr));
+    else LGR_TRY(evaluate_one(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, &e2));
     float* hT;
     LGR_TRY(lgr_pinned(ctx, 64, (void**) &hT));
     LGR_HIP(ctx, hipMemcpyAsync(hT, d_Tn, 64, hipMemcpyDeviceToHost, ctx->stream));

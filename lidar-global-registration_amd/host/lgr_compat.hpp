@@ -156,7 +156,8 @@ inline lgr_params to_abi(const AlignmentParameters& p) {
     a.keypoint_id = p.keypoint_id == "iss" ? LGR_KEYPOINT_ISS : LGR_KEYPOINT_ANY;
     a.iss_radius_src = p.iss_radius_src; a.iss_radius_tgt = p.iss_radius_tgt;
     a.matching_id = p.matching_id == "cluster" ? LGR_MATCH_CLUSTER : (p.matching_id == "one_sided" ? LGR_MATCH_ONE_SIDED : LGR_MATCH_LR);
-    a.metric_id = p.metric_id == "uniformity" ? LGR_METRIC_UNIFORMITY : LGR_METRIC_CORRESPONDENCES;
+    a.metric_id = p.metric_id == "uniformity" ? LGR_METRIC_UNIFORMITY : p.metric_id == "closest_plane" ? LGR_METRIC_CLOSEST_PLANE
+                  : p.metric_id == "combination" ? LGR_METRIC_COMBINATION : LGR_METRIC_CORRESPONDENCES;   // weighted_closest_plane: not built
     a.score_id = p.score_id == "mae" ? LGR_SCORE_MAE : (p.score_id == "mse" ? LGR_SCORE_MSE : (p.score_id == "exp" ? LGR_SCORE_EXP : LGR_SCORE_CONSTANT));
     a.max_iterations = p.max_iterations; a.normals_available = p.normals_available; a.fix_seed = p.fix_seed;
     if (p.vp_src) { a.has_vp_src = 1; std::memcpy(a.vp_src, p.vp_src->data(), 12); }

@@ -17,7 +17,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_CSRC, "liblgr_hip.so")
 
 MATCH_LR, MATCH_ONE_SIDED, MATCH_CLUSTER = 0, 1, 2
-METRIC_CORRESPONDENCES, METRIC_UNIFORMITY = 0, 1
+METRIC_CORRESPONDENCES, METRIC_UNIFORMITY, METRIC_CLOSEST_PLANE, METRIC_COMBINATION = 0, 1, 2, 3
 KEYPOINT_ANY, KEYPOINT_ISS = 0, 1
 SCORE_CONSTANT, SCORE_MAE, SCORE_MSE, SCORE_EXP = 0, 1, 2, 3
 ALIGN_RANSAC, ALIGN_GROR = 0, 1
@@ -312,6 +312,17 @@ class Context:
         self.check(_lib.lgr_evaluate_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), c, T16,
                                          int(metric_id), int(score_id), _ptr(mask), C.byref(ni), C.byref(rm), C.byref(me)))
         return mask[:c].cpu().numpy(), ni.value, rm.value, me.value
+
+    def evaluate_plane(self, src, tgt, T, score_id=SCORE_CONSTANT, seed=566, counter=0, with_pairs=False):
+        T16 = (C.c_float * 16)(*np.asarray(T, np.float32).T.reshape(16).tolist())
+        n, rm, me, th, npairs = C.c_int(0), C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)
+        pairs = np.zeros((max(int(0.01 * src.shape[0]), 1), 2), np.int32) if with_pairs else None
+        self.check(_lib.lgr_evaluate_plane_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], T16, int(score_id), C.c_uint64(seed),
+                                               C.c_uint32(counter), C.byref(n), C.byref(rm), C.byref(me), C.byref(th), _ptr(pairs), C.byref(npairs)))
+        out = dict(n_inl=n.value, rmse=rm.value, metric=me.value, thr=th.value)
+        if with_pairs:
+            out["pairs"] = pairs[: npairs.value].copy()
+        return out
 
     def ransac_replay(self, src, tgt, corr, params, triples):
         torch = self.torch

@@ -29,7 +29,7 @@ extern "C" {
 typedef struct { int32_t query, match; float distance, threshold; } lgr_orc_corr;
 
 enum { ORC_ORDER_LIBSTDCXX = 0, ORC_ORDER_CANONICAL = 1 };
-enum { ORC_METRIC_CORRESPONDENCES = 0, ORC_METRIC_UNIFORMITY = 1 };
+enum { ORC_METRIC_CORRESPONDENCES = 0, ORC_METRIC_UNIFORMITY = 1, ORC_METRIC_CLOSEST_PLANE = 2, ORC_METRIC_COMBINATION = 3 };
 enum { ORC_SCORE_CONSTANT = 0, ORC_SCORE_MAE = 1, ORC_SCORE_MSE = 2, ORC_SCORE_EXP = 3 };
 enum { ORC_MATCH_LR = 0, ORC_MATCH_ONE_SIDED = 1, ORC_MATCH_CLUSTER = 2 };
 enum { ORC_RNG_MT19937_LEMIRE = 0, ORC_RNG_MT19937_REJECT = 1, ORC_RNG_PHILOX = 2 };
@@ -143,6 +143,10 @@ void orc_umeyama3(const float* src, const float* tgt, const int sidx[3], const i
 int orc_evaluate(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
                  const float T[16], int metric_id, int score_id,
                  uint8_t* mask, int* n_inl, float* rmse, float* metric);
+/* src/metric.cpp:10-53,181-199 closest-plane metric of one transform on the Philox-defined sparse subset (counter = the
+ * hypothesis / iteration index); pairs (optional, 2 ints per inlier): (source index, nearest target index), ascending */
+int orc_evaluate_plane(const float* src, int ns, const float* tgt, int nt, const float T[16], int score_id, uint64_t seed,
+                       uint32_t counter, int* n_inl, float* score, float* rmse, float* metric, float* thr, int* pairs);
 /* src/metric.cpp:103-123 */
 int orc_estimate_max_iterations(const float* src, const float* tgt, const lgr_orc_corr* corr, int c,
                                 const float T[16], float confidence, int nr_samples);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liblgr_oracle.so")
 
 ORDER_LIBSTDCXX, ORDER_CANONICAL = 0, 1
-METRIC_CORRESPONDENCES, METRIC_UNIFORMITY = 0, 1
+METRIC_CORRESPONDENCES, METRIC_UNIFORMITY, METRIC_CLOSEST_PLANE, METRIC_COMBINATION = 0, 1, 2, 3
 SCORE_CONSTANT, SCORE_MAE, SCORE_MSE, SCORE_EXP = 0, 1, 2, 3
 MATCH_LR, MATCH_ONE_SIDED, MATCH_CLUSTER = 0, 1, 2
 RNG_MT19937_LEMIRE, RNG_MT19937_REJECT, RNG_PHILOX = 0, 1, 2
@@ -438,3 +438,17 @@ def preprocess(pts, vp=None, normals_available=False, order=ORDER_CANONICAL):
     rc = lib().orc_preprocess(_p(pts), pts.shape[0], _p(v), int(normals_available), order, _p(out), C.byref(n), C.byref(voxel))
     assert rc == 0, rc
     return out[: n.value].copy(), voxel.value
+
+
+def evaluate_plane(src, tgt, T, score_id=SCORE_CONSTANT, seed=566, counter=0, with_pairs=False):
+    src, tgt = _pts(src), _pts(tgt)
+    T16 = np.ascontiguousarray(np.asarray(T, np.float32).T.reshape(16))
+    n, sc, rm, me, th = C.c_int(0), C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(0)
+    pairs = np.zeros((max(int(0.01 * src.shape[0]), 1), 2), np.int32) if with_pairs else None
+    rc = lib().orc_evaluate_plane(_p(src), src.shape[0], _p(tgt), tgt.shape[0], _p(T16), int(score_id), C.c_uint64(seed), C.c_uint32(counter),
+                                  C.byref(n), C.byref(sc), C.byref(rm), C.byref(me), C.byref(th), _p(pairs))
+    assert rc == 0, rc
+    out = dict(n_inl=n.value, score=sc.value, rmse=rm.value, metric=me.value, thr=th.value)
+    if with_pairs:
+        out["pairs"] = pairs[: n.value].copy()
+    return out

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../lgr_oracle.h"
+#include "orc_grid.h"
 #include "orc_math.h"
 
 using namespace orc;
@@ -40,8 +41,9 @@ extern "C" void orc_default_params(lgr_orc_params* p) {
 
 // ---------------------------------------------------------------- RNG
 // Philox4x32-10 (Salmon et al. 2011), counter = (iter, 0, 0, 0), key = (seed_lo, seed_hi).
-extern "C" void orc_philox(uint64_t seed, uint32_t iter, uint32_t out[4]) {
-    uint32_t c0 = iter, c1 = 0, c2 = 0, c3 = 0;
+static void philox4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+extern "C" void orc_philox(uint64_t seed, uint32_t iter, uint32_t out[4]) { philox4(seed, iter, 0, 0, 0, out); }
+static void philox4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
     uint32_t k0 = (uint32_t) seed, k1 = (uint32_t) (seed >> 32);
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t) 0xD2511F53u * c0;
@@ -184,13 +186,106 @@ inline float dist3(const float T[16], const float* s, const float* t) {
     return std::sqrt((dx * dx + dy * dy) + dz * dz);
 }
 
+// ---- closest-plane metric (src/metric.cpp:10-53 buildClosestPlaneInliers, :181-199 ClosestPlaneMetricEstimator) on the
+// sparse subset the RANSAC loop always uses (sparse = true, src/sac_prerejective_omp.cpp:109).
+// Canonical choices (the reference draws the subset from the thread's mt19937 stream, so neither the subset nor the
+// order of its float sums is reproducible): draw j of hypothesis `counter` = Philox4x32-10(counter, j / 4, 0x5A17, 0)[j % 4]
+// >> 1, idx = r % n with the reference's linear probing over `visited` (the resulting SET does not depend on the
+// insertion order); score and squared-error sums are accumulated in 2^-32 fixed point (order free, exact).
+struct PlaneCtx {
+    const float* src = nullptr; int ns = 0;
+    const float* tgt = nullptr; int nt = 0;
+    Grid g;
+    float thr = 0.f, r2 = 0.f;
+    int n_sp = 0;
+    uint64_t seed = 0;
+};
+struct PlaneEval { int n_inl; float score; float rmse; float metric; };
+
+void plane_setup(PlaneCtx& pc, const float* src, int ns, const float* tgt, int nt, uint64_t seed) {
+    pc.src = src; pc.ns = ns; pc.tgt = tgt; pc.nt = nt; pc.seed = seed;
+    float density = 0.f;
+    orc_cloud_density(tgt, nt, 0.8f, &density);            // setTargetCloud: inlier_threshold_ = calculatePointCloudDensity(tgt)
+    pc.thr = density;
+    float radius = 2 * pc.thr;                              // DIST_TO_PLANE_COEFFICIENT * inlier_threshold
+    pc.r2 = radius * radius;
+    pc.g.build(tgt, nt, radius * 1.001f);
+    pc.n_sp = (int) (0.01 * (float) ns);                    // SPARSE_POINTS_FRACTION * src.size()
+}
+
+PlaneEval plane_eval(const PlaneCtx& pc, const float T[16], uint32_t counter, int score_id, std::vector<uint32_t>& visited,
+                     std::vector<std::pair<int, int>>* list) {
+    const int n = pc.ns;
+    if ((int) visited.size() < (n + 31) / 32) visited.assign((n + 31) / 32, 0u);
+    std::vector<int> picked;
+    picked.reserve(pc.n_sp);
+    for (int j = 0; j < pc.n_sp; ++j) {
+        uint32_t w[4];
+        philox4(pc.seed, counter, (uint32_t) (j >> 2), 0x5A17u, 0u, w);
+        int idx = (int) ((w[j & 3] >> 1) % (uint32_t) n);
+        while ((visited[idx >> 5] >> (idx & 31)) & 1u) idx = (idx + 1) % n;
+        visited[idx >> 5] |= 1u << (idx & 31);
+        picked.push_back(idx);
+    }
+    long long sc = 0, sq = 0;
+    int cnt = 0;
+    if (list) list->clear();
+    for (int idx : picked) {
+        visited[idx >> 5] &= ~(1u << (idx & 31));
+        const float* s = pc.src + 12 * (size_t) idx;
+        float pt[3];
+        apply(T, s, pt);
+        if (!finite3(pt)) continue;
+        int nn = -1;
+        float best = 0.f;
+        pc.g.visit27(pt, [&](int q) {
+            float d2 = dist2(pt, pc.tgt + 12 * (size_t) q);
+            if (!(d2 < pc.r2)) return;
+            if (nn < 0 || d2 < best || (d2 == best && q < nn)) { nn = q; best = d2; }
+        });
+        if (nn < 0) continue;
+        const float* q = pc.tgt + 12 * (size_t) nn;
+        float dist = std::fabs((q[4] * (q[0] - pt[0]) + q[5] * (q[1] - pt[1])) + q[6] * (q[2] - pt[2]));
+        if (!(dist < pc.thr)) continue;
+        ++cnt;
+        float thr = pc.thr, value = 1.f;
+        switch (score_id) {
+            case ORC_SCORE_CONSTANT: value = 1.f; break;
+            case ORC_SCORE_MAE: value = std::fabs(dist - thr) / thr; break;
+            case ORC_SCORE_MSE: value = (dist - thr) * (dist - thr) / (thr * thr); break;
+            case ORC_SCORE_EXP: value = c_expf(-dist * dist / (2 * thr * thr)); break;
+        }
+        sc += (long long) ((double) value * 4294967296.0);
+        float rel = dist / thr;
+        sq += (long long) ((double) (rel * rel) * 4294967296.0);
+        if (list) list->push_back({idx, nn});
+    }
+    if (list) std::sort(list->begin(), list->end());
+    PlaneEval e;
+    e.n_inl = cnt;
+    e.score = (float) ((double) sc / 4294967296.0);
+    e.rmse = cnt ? pc.thr * (float) std::sqrt((double) sq / 4294967296.0 / (double) cnt) : std::numeric_limits<float>::max();
+    e.metric = (float) ((double) e.score / (0.01 * (double) (float) pc.ns));   // score / (SPARSE_POINTS_FRACTION * src.size())
+    return e;
+}
+
 struct Eval { int n_inl; float rmse; float metric; };
 
 // src/metric.cpp:125-165 (buildInliers + calculateScore :55-81) and :167-179 + src/analysis.cpp:95-130 (uniformity)
 Eval evaluate(const float* src, const float* tgt, const lgr_orc_corr* corr, int c, const float T[16],
               int metric_id, int score_id, const float* bbmin, const float* bbmax, uint8_t* mask,
-              std::vector<int>& hist /* 3*100*100 scratch */) {
+              std::vector<int>& hist /* 3*100*100 scratch */, const PlaneCtx* pc = nullptr, uint32_t counter = 0,
+              std::vector<uint32_t>* visited = nullptr, std::vector<std::pair<int, int>>* plane_list = nullptr) {
     Eval e{0, 0.f, 0.f};
+    if (metric_id == ORC_METRIC_CLOSEST_PLANE) {           // inliers, rmse and metric all come from the plane test
+        PlaneEval pe = plane_eval(*pc, T, counter, score_id, *visited, plane_list);
+        if (mask) std::memset(mask, 0, c);
+        e.n_inl = pe.n_inl; e.rmse = pe.rmse; e.metric = pe.metric;
+        return e;
+    }
+    const bool combination = metric_id == ORC_METRIC_COMBINATION;
+    const int plane_score_id = score_id;                   // the closest-plane member gets the configured score function,
+    if (combination) score_id = ORC_SCORE_CONSTANT;        // the member CorrespondencesMetricEstimator is default-constructed (include/metric.h:191-192)
     float rmse = 0.f, score = 0.f;
     bool uni = metric_id == ORC_METRIC_UNIFORMITY;
     if (uni) std::fill(hist.begin(), hist.end(), 0);
@@ -239,6 +334,10 @@ Eval evaluate(const float* src, const float* tgt, const lgr_orc_corr* corr, int 
         e.metric = c_cbrtf(entropy[0] * entropy[1] * entropy[2]);
     } else {
         e.metric = score / (float) c;
+    }
+    if (combination) {                                      // src/metric.cpp:239-249: metric_cs * metric_cp
+        PlaneEval pe = plane_eval(*pc, T, counter, plane_score_id, *visited, nullptr);
+        e.metric = e.metric * pe.metric;
     }
     return e;
 }
@@ -327,11 +426,26 @@ extern "C" int orc_evaluate(const float* src, int ns, const float* tgt, int nt, 
                             const float T[16], int metric_id, int score_id,
                             uint8_t* mask, int* n_inl, float* rmse, float* metric) {
     (void) nt;
+    if (metric_id == ORC_METRIC_CLOSEST_PLANE || metric_id == ORC_METRIC_COMBINATION) return -7;   // use orc_evaluate_plane
     float mn[3], mx[3];
     orc_bbox(src, ns, mn, mx);   // UniformityMetricEstimator::setSourceCloud src/metric.cpp:167-170
     std::vector<int> hist(30000);
     Eval e = evaluate(src, tgt, corr, c, T, metric_id, score_id, mn, mx, mask, hist);
     *n_inl = e.n_inl; *rmse = e.rmse; *metric = e.metric;
+    return 0;
+}
+
+// closest-plane metric of one transform (stage-level parity tests): count, score, rmse, metric_cp, threshold used
+extern "C" int orc_evaluate_plane(const float* src, int ns, const float* tgt, int nt, const float T[16], int score_id, uint64_t seed,
+                                  uint32_t counter, int* n_inl, float* score, float* rmse, float* metric, float* thr, int* pairs /* 2*n_sp or NULL */) {
+    if (ns < 1 || nt < 2) return -2;
+    PlaneCtx pc;
+    plane_setup(pc, src, ns, tgt, nt, seed);
+    std::vector<uint32_t> visited;
+    std::vector<std::pair<int, int>> list;
+    PlaneEval e = plane_eval(pc, T, counter, score_id, visited, pairs ? &list : nullptr);
+    *n_inl = e.n_inl; *score = e.score; *rmse = e.rmse; *metric = e.metric; *thr = pc.thr;
+    if (pairs) for (size_t i = 0; i < list.size(); ++i) { pairs[2 * i] = list[i].first; pairs[2 * i + 1] = list[i].second; }
     return 0;
 }
 
@@ -385,6 +499,12 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
     if (c < 3) { res->converged = 0; return 0; }
     float mn[3], mx[3];
     orc_bbox(src, ns, mn, mx);
+    const bool plane = p->metric_id == ORC_METRIC_CLOSEST_PLANE || p->metric_id == ORC_METRIC_COMBINATION;
+    PlaneCtx pc;
+    if (plane) {
+        if (nt < 2) return -2;
+        plane_setup(pc, src, ns, tgt, nt, p->seed);
+    }
     const int MIN_NR_INLIERS = 10, MIN_NR_FINAL_INLIERS = 20;
     const double MIN_INLIER_RATE = 0.15;
     int max_iterations = std::min(comb_or_max(c, p->n_samples), p->max_iterations);
@@ -404,6 +524,7 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
 #pragma omp parallel
             {
                 std::vector<int> hist(30000);
+                std::vector<uint32_t> visited;
 #pragma omp for schedule(dynamic, 8)
                 for (int b = 0; b < nb; ++b) {
                     uint32_t w[4];
@@ -414,7 +535,7 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
                     ok[b] = h.ok;
                     std::memcpy(&Ts[(size_t) b * 16], h.T, 64);
                     if (!h.ok) continue;
-                    Eval e = evaluate(src, tgt, corr, c, h.T, p->metric_id, p->score_id, mn, mx, nullptr, hist);
+                    Eval e = evaluate(src, tgt, corr, c, h.T, p->metric_id, p->score_id, mn, mx, nullptr, hist, &pc, (uint32_t) (done + b), &visited);
                     ninl[b] = e.n_inl; met[b] = e.metric;
                 }
             }
@@ -448,6 +569,7 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
             int lo = t * q + std::min(t, r), cnt = q + (t < r ? 1 : 0);
             RefRng rng(p->rng_mode, p->seed + (uint64_t) t);
             std::vector<int> hist(30000);
+            std::vector<uint32_t> visited;
             for (int i = lo; i < lo + cnt; ++i) {
                 if ((long long) L.its * T >= L.iters_local) continue;
                 ++L.its;
@@ -455,7 +577,7 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
                 orc_select3(rr, c, sample);
                 Hyp h = make_hyp(src, tgt, corr, sample, p->edge_thr_coef);
                 if (!h.ok) { ++L.rej; continue; }
-                Eval e = evaluate(src, tgt, corr, c, h.T, p->metric_id, p->score_id, mn, mx, nullptr, hist);
+                Eval e = evaluate(src, tgt, corr, c, h.T, p->metric_id, p->score_id, mn, mx, nullptr, hist, &pc, (uint32_t) i, &visited);
                 if (e.n_inl < MIN_NR_INLIERS) continue;
                 if (L.largest < e.n_inl) {
                     L.largest = e.n_inl;
@@ -472,16 +594,27 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
     }
 
     // :265-296 final re-estimation
+    // The two evaluations of the final block use a fresh generator in the reference (:270); here: counters 0xFFFFFFFE / 0xFFFFFFFF.
     std::vector<uint8_t> mask(c);
     std::vector<int> hist(30000);
-    Eval e = evaluate(src, tgt, corr, c, final_T, p->metric_id, p->score_id, mn, mx, mask.data(), hist);
+    std::vector<uint32_t> visited;
+    std::vector<std::pair<int, int>> plane_list;
+    Eval e = evaluate(src, tgt, corr, c, final_T, p->metric_id, p->score_id, mn, mx, mask.data(), hist, &pc, 0xFFFFFFFEu, &visited, &plane_list);
     bool enough = e.n_inl > MIN_NR_FINAL_INLIERS || (float) e.n_inl > MIN_INLIER_RATE * (float) c;
     float min_tol = p->metric_id == ORC_METRIC_UNIFORMITY ? 0.3f : 0.0f;   // include/metric.h:97-99 / 73-75
     bool converged = enough && e.metric > min_tol;
     float Tn[16];
-    if (e.n_inl > 0) refit(src, tgt, corr, c, mask.data(), Tn);
-    else { for (int i = 0; i < 16; ++i) Tn[i] = std::numeric_limits<float>::quiet_NaN(); }   // 0/0 centroids in the reference
-    Eval e2 = evaluate(src, tgt, corr, c, Tn, p->metric_id, p->score_id, mn, mx, mask.data(), hist);
+    if (e.n_inl > 0) {
+        if (p->metric_id == ORC_METRIC_CLOSEST_PLANE) {
+            // the inliers handed to estimateOptimalRigidTransformation are the (source point, nearest target point) pairs
+            // of the plane test (canonical order: ascending source index)
+            std::vector<lgr_orc_corr> pl(plane_list.size());
+            std::vector<uint8_t> all(plane_list.size(), 1);
+            for (size_t i = 0; i < pl.size(); ++i) pl[i] = lgr_orc_corr{plane_list[i].first, plane_list[i].second, 0.f, pc.thr};
+            refit(src, tgt, pl.data(), (int) pl.size(), all.data(), Tn);
+        } else refit(src, tgt, corr, c, mask.data(), Tn);
+    } else { for (int i = 0; i < 16; ++i) Tn[i] = std::numeric_limits<float>::quiet_NaN(); }   // 0/0 centroids in the reference
+    Eval e2 = evaluate(src, tgt, corr, c, Tn, p->metric_id, p->score_id, mn, mx, mask.data(), hist, &pc, 0xFFFFFFFFu, &visited, nullptr);
     if (final_mask) std::memcpy(final_mask, mask.data(), c);
     std::memcpy(res->T, Tn, 64);
     res->iterations = ransac_iterations;
