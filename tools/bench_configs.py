@@ -64,3 +64,13 @@ if "iss1m" in which:
     ms, res = timed(lambda: ctx.align(s, t, p), n=2)
     print(f"1M-point pair with ISS key points (r = 0.05): {ms:.1f} ms, correspondences {res.n_correspondences}, inliers {res.n_inliers}, "
           f"converged {res.converged}, err {np.abs(res.matrix() - pair['T_gt']).max():.2e}", flush=True)
+if "plane1m" in which:
+    pair = synthetic.make_pair(1_000_000, seed=566)
+    s, t = torch.from_numpy(pair["src"]).cuda(), torch.from_numpy(pair["tgt"]).cuda()
+    ctx.normals_knn(t, 30, None, pair["vp_tgt"])
+    for mid, name in ((3, "combination"), (2, "closest_plane")):
+        p = capi.default_params(matching_id=0, metric_id=mid, feature_radius=0.25, bf_block_size=200000, max_iterations=200000,
+                                distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"], keypoint_id=1, iss_radius_src=0.05, iss_radius_tgt=0.05)
+        ms, res = timed(lambda: ctx.align(s, t, p), n=1)
+        print(f"1M-point pair, ISS key points, metric {name}: {ms:.1f} ms (RANSAC {list(res.stage_ms)[5]:.1f} ms, {res.iterations} iterations), "
+              f"inliers {res.n_inliers}, metric {res.metric:.4f}, err {np.abs(res.matrix() - pair['T_gt']).max():.2e}", flush=True)
