@@ -233,6 +233,10 @@ int lgr_gror_node_degree_dev(lgr_ctx*, const float* d_src, const float* d_tgt, c
                              float resolution, int32_t* d_degree);
 
 /* ---- include/hypotheses.h:10-16 (host bookkeeping; compiled out in the reference, SAVE_MULTIPLE_HYPOTHESES false) ---- */
+/* include/hypotheses.h:14-16 chooseBestHypothesis(src, tgt, correspondences, params, tns) (src/hypotheses.cpp:50-129), the
+ * decision only: the hypothesis with the largest inlier uniformity (identity / index -1 when none is positive) */
+int lgr_choose_best_hypothesis_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                                   const float* tns16 /* host, n x 16 */, int n, float T_out16[16], int* best_index, float* uniformities /* host, n, or NULL */);
 int lgr_update_hypotheses(float* tns16, float* metrics, int n, int cap, const float* new_T16, float new_metric, float distance_thr);
 
 #ifdef __cplusplus

@@ -1036,6 +1036,35 @@ extern "C" int lgr_refit_svd(lgr_ctx* ctx, const float* src, const float* tgt, i
     return lgr_refit_svd_dev(ctx, ds, dt, dc, n, nullptr, T16);
 }
 
+// src/hypotheses.cpp:50-129 chooseBestHypothesis (compiled out in the reference like updateHypotheses): the decision --
+// the hypothesis whose correspondence inliers are spread most uniformly (strict >, identity when none is positive).  The
+// hypotheses.csv side output of the reference (inlier / overlap areas) is not produced.
+extern "C" int lgr_choose_best_hypothesis_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
+                                              const float* tns16, int n, float T_out16[16], int* best_index, float* uniformities) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && (tns16 || n == 0) && T_out16 && n >= 0 && c >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < 16; ++i) T_out16[i] = (i % 5 == 0) ? 1.f : 0.f;
+    int best_i = -1;
+    float best = 0.f;
+    if (n > 0) {
+        Packed pk;
+        LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+        float* dT;
+        LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_T, (size_t) n * 16, &dT));
+        LGR_HIP(ctx, hipMemcpyAsync(dT, tns16, (size_t) n * 64, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n; ++i) {
+            EvalOut e{0, 0.f, 0.f};
+            if (c > 0) LGR_TRY(evaluate_one(ctx, dT + (size_t) i * 16, pk, c, LGR_METRIC_UNIFORMITY, LGR_SCORE_MSE, nullptr, &e));
+            if (uniformities) uniformities[i] = e.metric;
+            if (e.metric > best) { best = e.metric; best_i = i; memcpy(T_out16, tns16 + (size_t) i * 16, 64); }
+        }
+    }
+    if (best_index) *best_index = best_i;
+    return LGR_OK;
+}
+
 // src/hypotheses.cpp:14-48 updateHypotheses: pure host bookkeeping (the call sites are compiled out in the reference,
 // SAVE_MULTIPLE_HYPOTHESES false, src/sac_prerejective_omp.cpp:11); tns16 = n column-major 4x4, capacity cap.
 extern "C" int lgr_update_hypotheses(float* tns16, float* metrics, int n, int cap, const float* new_T16, float new_metric, float distance_thr) {

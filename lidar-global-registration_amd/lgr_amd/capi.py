@@ -313,6 +313,17 @@ class Context:
                                          int(metric_id), int(score_id), _ptr(mask), C.byref(ni), C.byref(rm), C.byref(me)))
         return mask[:c].cpu().numpy(), ni.value, rm.value, me.value
 
+    def choose_best_hypothesis(self, src, tgt, corr, tns):
+        corr = self._corr_dev(corr)
+        n = len(tns)
+        buf = np.ascontiguousarray(np.stack([np.asarray(T, np.float32).T.reshape(16) for T in tns]), np.float32) if n else np.zeros((1, 16), np.float32)
+        out = (C.c_float * 16)()
+        bi = C.c_int(-1)
+        uni = np.zeros(max(n, 1), np.float32)
+        self.check(_lib.lgr_choose_best_hypothesis_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), corr.shape[0],
+                                                       _ptr(buf), n, out, C.byref(bi), _ptr(uni)))
+        return bi.value, np.array(out, np.float32).reshape(4, 4).T.copy(), uni[:n].copy()
+
     def evaluate_plane(self, src, tgt, T, score_id=SCORE_CONSTANT, seed=566, counter=0, with_pairs=False):
         T16 = (C.c_float * 16)(*np.asarray(T, np.float32).T.reshape(16).tolist())
         n, rm, me, th, npairs = C.c_int(0), C.c_float(0), C.c_float(0), C.c_float(0), C.c_int(0)

@@ -169,6 +169,9 @@ int orc_gror_node_degree(const float* src, const float* tgt, const lgr_orc_corr*
 int orc_gror(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
              float resolution, int K_optimal, float T16[16], int* diag8, float* best_angle);
 
+/* src/hypotheses.cpp:50-129 (decision only): index of the hypothesis with the largest inlier uniformity, or -1 */
+int orc_choose_best_hypothesis(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
+                               const float* tns, int n, float T_out[16], float* uniformities);
 /* src/hypotheses.cpp:14-48.  tns: n*16 (col-major) in/out, capacity cap. returns new n */
 int orc_update_hypotheses(float* tns, float* metrics, int n, int cap, const float* new_T, float new_metric, float distance_thr);
 /* src/analysis.cpp:19-24 */

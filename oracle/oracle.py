@@ -452,3 +452,13 @@ def evaluate_plane(src, tgt, T, score_id=SCORE_CONSTANT, seed=566, counter=0, wi
     if with_pairs:
         out["pairs"] = pairs[: n.value].copy()
     return out
+
+
+def choose_best_hypothesis(src, tgt, corr, tns):
+    src, tgt = _pts(src), _pts(tgt)
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    buf = np.ascontiguousarray(np.stack([_T16(T) for T in tns]), np.float32) if len(tns) else np.zeros((1, 16), np.float32)
+    out = np.zeros(16, np.float32)
+    uni = np.zeros(max(len(tns), 1), np.float32)
+    i = lib().orc_choose_best_hypothesis(_p(src), src.shape[0], _p(tgt), tgt.shape[0], _p(corr), corr.shape[0], _p(buf), len(tns), _p(out), _p(uni))
+    return i, out.reshape(4, 4).T.copy(), uni[: len(tns)].copy()

@@ -665,6 +665,26 @@ extern "C" void orc_rot_trans_diff(const float* T1, const float* T2, float* angl
     *tdist = (float) std::sqrt(dx * dx + dy * dy + dz * dz);
 }
 
+// src/hypotheses.cpp:50-129 chooseBestHypothesis, the decision only: the candidate with the largest uniformity of its
+// correspondence inliers (strict >, identity when none is positive); the hypotheses.csv side output (areas, overlaps) is
+// not reproduced.  tns: n column-major 4x4.  Returns the index chosen or -1.
+extern "C" int orc_choose_best_hypothesis(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
+                                          const float* tns, int n, float T_out[16], float* uniformities) {
+    (void) nt;
+    float mn[3], mx[3];
+    orc_bbox(src, ns, mn, mx);   // calculateCorrespondenceUniformity(src, inliers) computes the bounding box of src itself
+    std::vector<int> hist(30000);
+    float best = 0.f;
+    int best_i = -1;
+    for (int i = 0; i < 16; ++i) T_out[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int i = 0; i < n; ++i) {
+        Eval e = evaluate(src, tgt, corr, c, tns + 16 * (size_t) i, ORC_METRIC_UNIFORMITY, ORC_SCORE_MSE, mn, mx, nullptr, hist);
+        if (uniformities) uniformities[i] = e.metric;
+        if (e.metric > best) { best = e.metric; best_i = i; std::memcpy(T_out, tns + 16 * (size_t) i, 64); }
+    }
+    return best_i;
+}
+
 // src/hypotheses.cpp:14-48 updateHypotheses (MIN_ANGLE pi/9, MIN_DISTANCE_COEF 20, MIN_METRIC_COEF 0.1)
 extern "C" int orc_update_hypotheses(float* tns, float* metrics, int n, int cap, const float* new_T, float new_metric, float distance_thr) {
     std::vector<std::vector<float>> T(n, std::vector<float>(16));

@@ -184,3 +184,23 @@ def test_align_end_to_end(lgr, oracle, pair, matching):
     assert np.abs(res.matrix() - pair["T_gt"]).max() < 2e-2            # noise-limited accuracy vs ground truth
     res_h = lgr.align_host(pair["src"], pair["tgt"], p_g)
     np.testing.assert_array_equal(bits(res_h.matrix()), bits(res.matrix()))
+
+
+def test_choose_best_hypothesis(lgr, oracle, problem):
+    """chooseBestHypothesis (src/hypotheses.cpp:50-129, decision part): the hypothesis with the most uniformly spread
+    correspondence inliers wins; identity / -1 when no hypothesis has any inliers."""
+    from lgr_amd import synthetic
+    rng = np.random.default_rng(9)
+    T = problem["T_gt"]
+    tns = [synthetic.random_se3(rng), T, T @ np.array([[1, 0, 0, 0.02], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32), synthetic.random_se3(rng)]
+    src, tgt = cuda(problem["src"]), cuda(problem["tgt"])
+    oc = to_orc_corr(oracle, problem["corr"])
+    bi, Tb, uni = lgr.choose_best_hypothesis(src, tgt, problem["corr"], tns)
+    oi, oT, ouni = oracle.choose_best_hypothesis(problem["src"], problem["tgt"], oc, tns)
+    assert bi == oi and bi in (1, 2)
+    np.testing.assert_array_equal(bits(uni), bits(ouni))
+    np.testing.assert_array_equal(bits(Tb), bits(oT))
+    bi, Tb, _ = lgr.choose_best_hypothesis(src, tgt, problem["corr"], [tns[0], tns[3]])
+    assert bi == -1 and np.array_equal(Tb, np.eye(4, dtype=np.float32))
+    bi, Tb, _ = lgr.choose_best_hypothesis(src, tgt, problem["corr"], [])
+    assert bi == -1
