@@ -162,13 +162,15 @@ __device__ __forceinline__ int bin11(double t) {
 }
 
 constexpr int SB = 128;
-// SPFH rows for the surface points listed in the sorted order of the grid (thread t handles sorted position t).
+// SPFH rows for the surface points listed in the sorted order of the grid (thread t handles sorted position order[t]).
 // Counters live in LDS as [bin][thread] (bank = thread % 32: conflict-free).
 __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uint8_t* __restrict__ need /* by original index or NULL */,
+                                                   const int* __restrict__ order /* processing order of the sorted positions or NULL */,
                                                    float* __restrict__ spfh /* [n_surface][33] by original index */) {
     __shared__ int cnt[33 * SB];
     int t = blockIdx.x * SB + threadIdx.x;
     if (t >= g.n) return;
+    if (order) t = order[t];
     float4 P = g.pxyz[t];
     float4 N = g.pnrm[t];
     int p = __float_as_int(P.w);
@@ -253,14 +255,28 @@ __global__ __launch_bounds__(128) void fpfh_kernel(GridDev g, const float* __res
     for (int b = 0; b < 33; ++b) o[b] = (float) ((double) fp[b] * (b < 11 ? sum0 : (b < 22 ? sum1 : sum2)));
 }
 
-__global__ void kp_cell_keys(GridDev g, const float* __restrict__ kps, int m, unsigned* __restrict__ keys, int* __restrict__ vals) {
+// Processing order of key points / surface points: grid cell, then a Morton code of the position inside the cell
+// (2^sb steps per axis).  A wave then holds 64 spatially close points: its lanes walk the same 27 cells in lockstep
+// (wave-uniform loads) and mostly agree on which candidates lie within the radius, so fewer lanes idle through the
+// accept branch and candidates nobody accepts are skipped by the whole wave.  Scheduling only: every point still visits
+// its neighbours in the canonical order, and outputs go to the original index.
+__global__ void fine_keys(GridDev g, const float* __restrict__ pts, int stride, int m, int sb, unsigned* __restrict__ keys, int* __restrict__ vals) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    float x = kps[(size_t) i * 12], y = kps[(size_t) i * 12 + 1], z = kps[(size_t) i * 12 + 2];
+    float x = pts[(size_t) i * stride], y = pts[(size_t) i * stride + 1], z = pts[(size_t) i * stride + 2];
     unsigned k = 0xffffffffu;
     if (lgr_finite3(x, y, z)) {
         int cx = min(max(lgr_cellc(x, g.ox, g.h), 0), g.dx - 1), cy = min(max(lgr_cellc(y, g.oy, g.h), 0), g.dy - 1), cz = min(max(lgr_cellc(z, g.oz, g.h), 0), g.dz - 1);
         k = (unsigned) ((cz * g.dy + cy) * g.dx + cx);
+        if (sb > 0) {
+            const float q = (float) (1 << sb);
+            int sx = min(max((int) (((x - g.ox) / g.h - (float) cx) * q), 0), (1 << sb) - 1);
+            int sy = min(max((int) (((y - g.oy) / g.h - (float) cy) * q), 0), (1 << sb) - 1);
+            int sz = min(max((int) (((z - g.oz) / g.h - (float) cz) * q), 0), (1 << sb) - 1);
+            unsigned mort = 0;
+            for (int b = 0; b < sb; ++b) mort |= (((unsigned) sx >> b) & 1u) << (3 * b) | (((unsigned) sy >> b) & 1u) << (3 * b + 1) | (((unsigned) sz >> b) & 1u) << (3 * b + 2);
+            k = (k << (3 * sb)) | mort;
+        }
     }
     keys[i] = k; vals[i] = i;
 }
@@ -439,18 +455,28 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     LGR_TRY(lgr_ws_t(ctx, WS_SPFH, (size_t) n * 33 + 64 + (size_t) n, &spfh));
     // PCL computes SPFH only for surface points within r of some keypoint (spfh_indices); rows outside that set are
     // never read by the weighting step, so computing all rows gives the same FPFH output and saves the marking pass.
-    if (g.n > 0) spfh_kernel<<<cdiv(g.n, SB), SB, 0, ctx->stream>>>(g, r2, nullptr, spfh);
-    // keypoints in grid-cell order (locality of the SPFH row gathers)
+    // processing orders (fine_keys): cell bits + 3 * sb Morton bits must fit the 32-bit sort key
+    const long long n_cells = (long long) g.dx * g.dy * g.dz;
+    int cell_bits = 1;
+    while ((1ll << cell_bits) < n_cells) ++cell_bits;
+    const int sb = std::max(0, std::min(2, (32 - cell_bits) / 3));
+    const int key_bits = std::min(32, cell_bits + 3 * sb);
+    const int mx = std::max(m, g.n);
     unsigned *keys, *keys2;
     int *vals, *vals2;
-    LGR_TRY(lgr_ws_t(ctx, WS_KP_ORDER, (size_t) m * 4 + 16, &keys));
-    keys2 = keys + m; vals = (int*) (keys2 + m); vals2 = vals + m;
-    kp_cell_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, m, keys, vals);
+    LGR_TRY(lgr_ws_t(ctx, WS_KP_ORDER, (size_t) mx * 4 + 16, &keys));
+    keys2 = keys + mx; vals = (int*) (keys2 + mx); vals2 = vals + mx;
     size_t tb = 0;
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) mx, 0, key_bits, ctx->stream));
     void* tmp;
     LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
+    if (g.n > 0) {
+        fine_keys<<<cdiv(g.n, 256), 256, 0, ctx->stream>>>(g, reinterpret_cast<const float*>(g.pxyz), 4, g.n, sb, keys, vals);
+        LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) g.n, 0, key_bits, ctx->stream));
+        spfh_kernel<<<cdiv(g.n, SB), SB, 0, ctx->stream>>>(g, r2, nullptr, vals2, spfh);
+    }
+    fine_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, 12, m, sb, keys, vals);
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, key_bits, ctx->stream));
     fpfh_kernel<<<cdiv(m, 128), 128, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;

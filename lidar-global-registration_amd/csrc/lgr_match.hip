@@ -45,6 +45,9 @@ constexpr int MAXLEAF = KCL * SUBMAX;
 constexpr int KM_SAMPLE = 16384;    // sample rows per side
 constexpr int KM_ITERS = 6;
 constexpr int KM2_ITERS = 4;
+#ifndef LGR_MM_OCC
+#define LGR_MM_OCC 4          // waves per SIMD of match_mfma (2: 256 VGPRs, one workgroup per CU; 4: 128 VGPRs, two)
+#endif
 constexpr int NEAR_T = 64;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured optimum at 1M)
 #ifndef LGR_PRUNE_BETAS
 #define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
@@ -428,7 +431,7 @@ __device__ __forceinline__ f32x16 mfma_step(float a, float b, f32x16 c) { return
 __device__ __forceinline__ f32x16 mfma_step(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <bool COLDIR, bool F16>
-__global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>::frag* __restrict__ Ap, const typename OpFmt<F16>::frag* __restrict__ Bp,
+__global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename OpFmt<F16>::frag* __restrict__ Ap, const typename OpFmt<F16>::frag* __restrict__ Bp,
                                                      size_t bset_stride /* fragments */, float c_scale /* 2^2s, F16 only */, float out_scale /* 2^-2s */,
                                                      const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
                                                      int rg_rows, const int* __restrict__ tile_group, const unsigned* __restrict__ stage_mask,
@@ -550,6 +553,77 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
             //    the proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
             //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
             // The B fragment of the next tile is fetched from LDS before the epilogue runs.
+            // Epilogue of one finished 32x32 tile: tile ct of stage st; nxt = the stage computed after st.
+            auto epilogue = [&](const f32x16& acc, int st, int ct, int nxt) {
+                int v[16];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { v[g] = __float_as_int(acc[g]); rmin[g] = min(rmin[g], v[g]); }
+                if (COLDIR) {
+                    int cm = min(v[0], v[1]);
+#pragma unroll
+                    for (int g = 2; g < 16; g += 2) cm = min(min(cm, v[g]), v[g + 1]);
+                    // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
+                    auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
+                    int other = (int) (half ? sw[0] : sw[1]);
+                    cm = min(cm, other);
+                    // both halves hold the folded minimum: all 64 lanes issue the LDS atomic (no exec-mask branch in
+                    // the MFMA block; the two lanes of a column hit the same word with the same value)
+                    atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + (lane & 31)], cm);
+                }
+                // flush the row minima when the column group (train leaf) ends, or before skipped stages
+                const unsigned te = ct == 0 ? tend[0] : ct == 1 ? tend[1] : ct == 2 ? tend[2] : tend[3];
+                if (((te >> st) & 1u) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
+                    PROF_CNT(10);
+                    const int grp = tg_s[st * STAGE_TILES + ct];
+                    // Halving butterfly over the 32 lanes of each half wave: at every step a lane keeps half of
+                    // its registers and receives the partner's copy of them, so 16 registers x 32 lanes reduce to
+                    // one value per lane with 16 + 8 + 4 + 2 + 1 exchanges instead of 16 x 5; lane bits 4..1 then
+                    // select the register (= row) the lane ends up holding, and one atomic instruction with 16
+                    // active lanes per half wave writes all rows.
+                    int w8[8], w4[4], w2[2], w1;
+                    {
+                        const bool up = (lane & 16) != 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            int keep = up ? rmin[8 + j] : rmin[j], send = up ? rmin[j] : rmin[8 + j];
+                            w8[j] = min(keep, __shfl_xor(send, 16));
+                        }
+                    }
+                    {
+                        const bool up = (lane & 8) != 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int keep = up ? w8[4 + j] : w8[j], send = up ? w8[j] : w8[4 + j];
+                            w4[j] = min(keep, __shfl_xor(send, 8));
+                        }
+                    }
+                    {
+                        const bool up = (lane & 4) != 0;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            int keep = up ? w4[2 + j] : w4[j], send = up ? w4[j] : w4[2 + j];
+                            w2[j] = min(keep, __shfl_xor(send, 4));
+                        }
+                    }
+                    {
+                        const bool up = (lane & 2) != 0;
+                        int keep = up ? w2[1] : w2[0], send = up ? w2[0] : w2[1];
+                        w1 = min(keep, __shfl_xor(send, 2));
+                    }
+                    w1 = min(w1, __shfl_xor(w1, 1));
+                    // register index held by this lane: bit 3 <- lane bit 4, bit 2 <- bit 3, bit 1 <- bit 2, bit 0 <- bit 1
+                    const int g = (lane >> 1) & 15;
+                    if (F16) w1 = __float_as_int(__int_as_float(w1) * out_scale);   // back to d2~ (monotonic)
+                    if ((lane & 1) == 0 && w1 != IINF)
+                        atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], w1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rmin[r] = IINF;
+                }
+            };
+            // Schedules tried and measured on a dense 400k x 400k probe (35.9 ms as is; MFMA chains alone 24.9 ms: the
+            // chip holds ~1.4 GHz under this f16 MFMA load): deferring a tile's epilogue behind the next tile's MFMA
+            // chain (software pipeline, with and without register double buffering of the B fragments) -1..-2 % at
+            // 4 waves/SIMD with spills, +8 % at 2 waves/SIMD; no stage DMA -14 %; no barrier 0 %; no column minima -5 %.
             auto compute = [&](int st, int buf, int nxt) {
                 frag b[KS];
 #pragma unroll
@@ -563,68 +637,7 @@ __global__ __launch_bounds__(NTHR, 4) void match_mfma(const typename OpFmt<F16>:
 #pragma unroll
                         for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][((ct + 1) * KS + kk) * 64 + lane];
                     }
-                    int v[16];
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) { v[g] = __float_as_int(acc[g]); rmin[g] = min(rmin[g], v[g]); }
-                    if (COLDIR) {
-                        int cm = min(v[0], v[1]);
-#pragma unroll
-                        for (int g = 2; g < 16; g += 2) cm = min(min(cm, v[g]), v[g + 1]);
-                        // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
-                        auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
-                        int other = (int) (half ? sw[0] : sw[1]);
-                        cm = min(cm, other);
-                        if (lane < 32) atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + lane], cm);
-                    }
-                    // flush the row minima when the column group (train leaf) ends, or before skipped stages
-                    const unsigned te = ct == 0 ? tend[0] : ct == 1 ? tend[1] : ct == 2 ? tend[2] : tend[3];
-                    if (((te >> st) & 1u) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
-                        PROF_CNT(10);
-                        const int grp = tg_s[st * STAGE_TILES + ct];
-                        // Halving butterfly over the 32 lanes of each half wave: at every step a lane keeps half of
-                        // its registers and receives the partner's copy of them, so 16 registers x 32 lanes reduce to
-                        // one value per lane with 16 + 8 + 4 + 2 + 1 exchanges instead of 16 x 5; lane bits 4..1 then
-                        // select the register (= row) the lane ends up holding, and one atomic instruction with 16
-                        // active lanes per half wave writes all rows.
-                        int w8[8], w4[4], w2[2], w1;
-                        {
-                            const bool up = (lane & 16) != 0;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                int keep = up ? rmin[8 + j] : rmin[j], send = up ? rmin[j] : rmin[8 + j];
-                                w8[j] = min(keep, __shfl_xor(send, 16));
-                            }
-                        }
-                        {
-                            const bool up = (lane & 8) != 0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                int keep = up ? w8[4 + j] : w8[j], send = up ? w8[j] : w8[4 + j];
-                                w4[j] = min(keep, __shfl_xor(send, 8));
-                            }
-                        }
-                        {
-                            const bool up = (lane & 4) != 0;
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                int keep = up ? w4[2 + j] : w4[j], send = up ? w4[j] : w4[2 + j];
-                                w2[j] = min(keep, __shfl_xor(send, 4));
-                            }
-                        }
-                        {
-                            const bool up = (lane & 2) != 0;
-                            int keep = up ? w2[1] : w2[0], send = up ? w2[0] : w2[1];
-                            w1 = min(keep, __shfl_xor(send, 2));
-                        }
-                        w1 = min(w1, __shfl_xor(w1, 1));
-                        // register index held by this lane: bit 3 <- lane bit 4, bit 2 <- bit 3, bit 1 <- bit 2, bit 0 <- bit 1
-                        const int g = (lane >> 1) & 15;
-                        if (F16) w1 = __float_as_int(__int_as_float(w1) * out_scale);   // back to d2~ (monotonic)
-                        if ((lane & 1) == 0 && w1 != IINF)
-                            atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], w1);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) rmin[r] = IINF;
-                    }
+                    epilogue(acc, st, ct, nxt);
                 }
             };
             mask &= mask - 1u;   // st is taken
@@ -1576,7 +1589,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int2* ilist = (int2*) (ibuf + 2 * (size_t) n_flags);
     int* xcd_start = ibuf + 4 * (size_t) n_flags;   // [9]
     int* xcd_ctr = xcd_start + 16;                   // [8]
-    const int mfma_grid = 8 * 2 * std::max(1, ctx->n_cu / 8);   // two resident workgroups per CU
+    const int mfma_grid = 8 * (LGR_MM_OCC / 2) * std::max(1, ctx->n_cu / 8);   // resident workgroups: LGR_MM_OCC / 2 per CU
     auto launch_mfma = [&](const unsigned* mask) -> int {
         items_flag_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(mask, n_rb, n_cc, item_rb, n_ir, ccx, iflags);
         size_t sb = 0;
