@@ -10,9 +10,11 @@ are already resident in HBM.  Scan pairs shard across ranks (one independent pai
 collective is one all-gather of the 96-byte per-pair result record per step (RCCL when N > 1).
 
 Rank 0 prints ONE JSON line with the contract keys plus
-  "roofline"     : the dominant kernel (match_mfma, fp32 MFMA distance filter): algorithmic FLOP per launch
-                   (69 * Mq * Mt) / launch duration measured with hipEvents on the launch stream,
-                   against the dense fp32 MFMA peak of MI355X (157.3 TFLOP/s);
+  "roofline"     : the dominant kernel (match_mfma, the MFMA distance filter of the matcher; both masked launches of a
+                   step): MFMA FLOP issued (224 per computed pair on f16-split operands x M x M x executed tile
+                   fraction) / launch duration measured with hipEvents on the launch stream, against the dense f16
+                   MFMA peak of MI355X; the algorithmic 69 * Mq * Mt over the same time is given beside it
+                   ("effective_tflops_algorithmic"); "traffic" = HBM-side bytes from the committed PMC passes;
   "cpu_baseline" : the CPU oracle ("port": the reference itself needs PCL/OpenCV and cannot be built here) timed on
                    this host on a bounded sample of the same workload, extrapolated linearly where the stage is
                    linear in the sampled dimension (the sample is stated in the object).
@@ -41,6 +43,8 @@ def parse():
     ap.add_argument("--matching", default="lr", choices=["lr", "cluster", "one_sided"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -116,11 +120,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the product and has no CPU fallback")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()      # rehearsal: several ranks may share one card
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local)
     from lgr_amd import capi, synthetic, distributed
     ctx = capi.Context(local)
@@ -129,7 +138,8 @@ def main():
     params = make_params(capi, pair, args.matching)
     src = torch.from_numpy(pair["src"]).cuda(local)
     tgt = torch.from_numpy(pair["tgt"]).cuda(local)
-    record = torch.zeros((1, distributed.RECORD_FLOATS), dtype=torch.float32, device=f"cuda:{local}")   # 96-byte per-pair record
+    coll_dev = f"cuda:{local}" if args.backend == "nccl" else "cpu"
+    record = torch.zeros((1, distributed.RECORD_FLOATS), dtype=torch.float32, device=coll_dev)   # 96-byte per-pair record
 
     def step():
         res = ctx.align(src, tgt, params)
@@ -158,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -179,6 +189,16 @@ def main():
         peak = MFMA_F16_PEAK_TFLOPS if fmt == "f16" else MFMA_F32_PEAK_TFLOPS
         achieved = flop_per_pair * m * m * executed / (k_ms * 1e-3) / 1e12
         effective = alg_flop / (k_ms * 1e-3) / 1e12
+        # HBM-side bytes of the same kernel (both launches of one step) from the committed PMC passes (tools/pmc_bench.sh:
+        # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+        # only reported for the configuration it was collected on
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if m == 1_000_000 and args.matching == "lr" and fmt == "f16":
+                traffic = float(pt["traffic_bytes"])
+        except Exception:
+            traffic = None
         T = res.matrix()
         err = float(np.abs(T.astype(np.float64) - pair["T_gt"]).max())
         out = {
@@ -190,7 +210,7 @@ def main():
                        "points_per_cloud": m, "pairs_per_step": world, "matching": args.matching, "metric_id": "uniformity",
                        "bf_block_size": 200000, "max_iterations": 1000000, "parallelism": f"pairs sharded over {world} GPU(s)"},
             "roofline": {"kernel": "match_mfma<both directions> (all masked passes of one step)", "bound": "mfma", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "operand_format": "f16 two-term splits, f32 accumulate (224 MFMA FLOP/pair)" if fmt == "f16" else "f32 (68 MFMA FLOP/pair)",
                          "kernel_ms": k_ms, "executed_tile_fraction": executed, "effective_tflops_algorithmic": effective,
                          "rerank": mstats, "algorithmic_flop_per_launch": alg_flop, "directions_per_launch": n_dir},
