@@ -185,8 +185,8 @@ def main():
         # type.  The algorithmic 69 FLOP per pair over the same time is reported beside it.
         executed = float(np.mean(work))
         fmt = ctx.match_format()
-        flop_per_pair = 224.0 if fmt == "f16" else 68.0
-        peak = MFMA_F16_PEAK_TFLOPS if fmt == "f16" else MFMA_F32_PEAK_TFLOPS
+        flop_per_pair = {"f16": 224.0, "f16r": 192.0, "f32": 68.0}[fmt]
+        peak = MFMA_F32_PEAK_TFLOPS if fmt == "f32" else MFMA_F16_PEAK_TFLOPS
         achieved = flop_per_pair * m * m * executed / (k_ms * 1e-3) / 1e12
         effective = alg_flop / (k_ms * 1e-3) / 1e12
         # HBM-side bytes of the same kernel (both launches of one step) from the committed PMC passes (tools/pmc_bench.sh:
@@ -195,7 +195,7 @@ def main():
         traffic = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if m == 1_000_000 and args.matching == "lr" and fmt == "f16":
+            if m == 1_000_000 and args.matching == "lr" and fmt == pt.get("operand_format", "f16"):
                 traffic = float(pt["traffic_bytes"])
         except Exception:
             traffic = None
@@ -211,7 +211,9 @@ def main():
                        "bf_block_size": 200000, "max_iterations": 1000000, "parallelism": f"pairs sharded over {world} GPU(s)"},
             "roofline": {"kernel": "match_mfma<both directions> (all masked passes of one step)", "bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "operand_format": "f16 two-term splits, f32 accumulate (224 MFMA FLOP/pair)" if fmt == "f16" else "f32 (68 MFMA FLOP/pair)",
+                         "operand_format": {"f16": "f16 two-term splits, f32 accumulate, K = 112 (224 MFMA FLOP/pair)",
+                                            "f16r": "f16 two-term splits of 30 Helmert coordinates, f32 accumulate, K = 96 (192 MFMA FLOP/pair)",
+                                            "f32": "f32 (68 MFMA FLOP/pair)"}[fmt],
                          "kernel_ms": k_ms, "executed_tile_fraction": executed, "effective_tflops_algorithmic": effective,
                          "rerank": mstats, "algorithmic_flop_per_launch": alg_flop, "directions_per_launch": n_dir},
             "stage_ms": dict(zip(["downsample", "normals", "fpfh", "match", "filter", "ransac", "refit"],

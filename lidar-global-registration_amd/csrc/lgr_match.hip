@@ -63,10 +63,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // F16: v_mfma_f32_32x32x16_f16 (16x the f32 rate) on two-term f16 splits of the scaled f32 operands,
 //      x * 2^s = h1 + h2 (+ residual <= 2^-22 |x|):  a.b ~ a1.b1 + a1.b2 + a2.b1  -> concatenated K = 3 * 33 + 6 norm slots
 //      = 105, padded to 112 = 7 steps, fragment = 8 halves (lane l: row l & 31, k = 16 * step + 8 * (l >> 5) + j).
-template <bool F16> struct OpFmt;
-template <> struct OpFmt<false> { typedef float frag; static constexpr int KS = 17; };
-template <> struct OpFmt<true> { typedef f16x8 frag; static constexpr int KS = 7; };
-constexpr int KCAT16 = 112;
+// F16R: the same on 30 coordinates.  Every 11-bin block of an FPFH row sums to 100, so differences of rows have no component
+//      along the block's all-ones direction; in a Helmert basis of the block that direction is one coordinate, the other
+//      10 carry the whole distance.  K = 3 * 30 + 6 = 96 = 6 steps (-1/7 of the MFMA work, LDS reads and operand bytes).
+//      Used only when the dropped coordinates are (numerically) constant over both sets; their largest measured energy
+//      enters the error bound, so any input stays exact (match_impl, "rot").
+enum { FMT_F32 = 0, FMT_F16 = 1, FMT_F16R = 2 };
+template <int FMT> struct OpFmt;
+template <> struct OpFmt<FMT_F32> { typedef float frag; static constexpr int KS = 17; };
+template <> struct OpFmt<FMT_F16> { typedef f16x8 frag; static constexpr int KS = 7; };
+template <> struct OpFmt<FMT_F16R> { typedef f16x8 frag; static constexpr int KS = 6; };
 struct F16Scale { float s_mul; float inv_s2; float a_norm[3]; };   // 2^s, 2^-2s, the three a-side norm-slot constants
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -309,11 +315,27 @@ __global__ void pack_kernel(const float* __restrict__ X, const int* __restrict__
 // rows: h = split(-2 x' 2^s);  cols: h = split(x' 2^s);  a norm enters as the three-term f16 expansion of
 // N = |x'|^2 2^2s against the constants A1..A3 on the other side (N = A1 B1 + A2 B2 + A3 B3 up to 2^-33 N or the f16
 // flush limit).
+// Helmert coordinates of one 11-bin block: y_k = (x_0 + .. + x_{k-1} - k x_k) / sqrt(k (k + 1)), k = 1..10 (orthonormal, all
+// orthogonal to (1,..,1)); *u = (x_0 + .. + x_10) / sqrt(11) is the dropped coordinate.
+__device__ __forceinline__ void helmert11(const float* __restrict__ x, float* __restrict__ y, float* u) {
+    const float rs[10] = {0.70710678118654752f, 0.40824829046386302f, 0.28867513459481288f, 0.22360679774997897f, 0.18257418583505537f,
+                          0.15430334996209191f, 0.13363062095621219f, 0.11785113019775793f, 0.10540925533894598f, 0.09534625892455924f};
+    float pre = x[0];
+#pragma unroll
+    for (int k = 1; k <= 10; ++k) {
+        y[k - 1] = (pre - (float) k * x[k]) * rs[k - 1];
+        pre = pre + x[k];
+    }
+    *u = pre * 0.30151134457776363f;
+}
+
+template <bool ROT, bool NORMS_ONLY>
 __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
                               const float* __restrict__ cen, const int* __restrict__ blkcl, F16Scale sc,
-                              _Float16* __restrict__ P, float* __restrict__ nrm) {
+                              _Float16* __restrict__ P, float* __restrict__ nrm, unsigned* __restrict__ drop_max) {
     int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= n_pad) return;
+    const bool in_range = pos < n_pad;
+    if (!in_range) pos = n_pad - 1;           // keep whole waves alive for the reduction below; nothing is stored
     int set = role == 1 ? blockIdx.y : 0;
     int o = perm[pos];
     int c = role == 1 ? set : blkcl[pos / BLOCK_ROWS];
@@ -327,29 +349,51 @@ __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict
         for (int k = 0; k < 33; ++k) v[k] = 0.f;
         n2 = __uint_as_float(0x7f800000u);
     }
-    nrm[(size_t) set * n_pad + pos] = n2;
-    if (!P) return;   // norms only (first pass: the scale is chosen from the largest norm)
+    if (in_range) nrm[(size_t) set * n_pad + pos] = n2;   // |x'|^2 in all 33 coordinates: the magnitude the error bounds are stated in
+    if (NORMS_ONLY) {
+        // first pass: norms (the scale is chosen from the largest one) and the largest energy of the three coordinates
+        // the rotated format drops, u_k = (sum of block k of x') / sqrt(11): summed in double (exact for any realistic
+        // exponent spread), rounded up; one atomic per wave
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { s0 += (double) v[k]; s1 += (double) v[11 + k]; s2 += (double) v[22 + k]; }
+        float d2 = (o >= 0 && in_range) ? (float) (((s0 * s0 + s1 * s1) + s2 * s2) * (1.0001 / 11.0)) * 1.000001f + 1e-20f * n2 : 0.f;
+        for (int sh = 32; sh > 0; sh >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, sh));
+        // (a plain look first: same-address atomics from every wave would serialise in L2; a stale value only costs an atomic)
+        if ((threadIdx.x & 63) == 0 && d2 > 0.f && __float_as_uint(d2) > *(volatile unsigned*) drop_max) atomicMax(drop_max, __float_as_uint(d2));
+        return;
+    }
+    float y[30], u0, u1, u2;
+    if (ROT) { helmert11(v, y, &u0); helmert11(v + 11, y + 10, &u1); helmert11(v + 22, y + 20, &u2); }
+    if (!in_range) return;
+    constexpr int nd = ROT ? 30 : 33, ks = ROT ? OpFmt<FMT_F16R>::KS : OpFmt<FMT_F16>::KS;
     int tile = pos >> 5, r = pos & 31;
-    _Float16* base = P + ((size_t) set * (n_pad / TILE) + tile) * OpFmt<true>::KS * 64 * 8;
+    _Float16* base = P + ((size_t) set * (n_pad / TILE) + tile) * ks * 64 * 8;
     auto put = [&](int cidx, _Float16 h) {
         int step = cidx >> 4, khalf = (cidx >> 3) & 1, j = cidx & 7;
         base[((size_t) step * 64 + (khalf << 5) + r) * 8 + j] = h;
     };
     const float mul = role == 0 ? -2.0f * sc.s_mul : sc.s_mul;
+    float n2m = n2;                           // the norm the MFMA chain must see: of the operand coordinates
+    if (ROT && o >= 0) {
+        n2m = 0.f;
 #pragma unroll
-    for (int k = 0; k < 33; ++k) {
-        float x = v[k] * mul;                 // exact (power of two)
+        for (int k = 0; k < 30; ++k) n2m = n2m + y[k] * y[k];
+    }
+#pragma unroll
+    for (int k = 0; k < nd; ++k) {
+        float x = (ROT ? y[k] : v[k]) * mul;  // exact (power of two)
         _Float16 h1 = (_Float16) x;           // round to nearest
         _Float16 h2 = (_Float16) (x - (float) h1);
-        if (role == 0) { put(k, h1); put(33 + k, h1); put(66 + k, h2); }
-        else { put(k, h1); put(33 + k, h2); put(66 + k, h1); }
+        if (role == 0) { put(k, h1); put(nd + k, h1); put(2 * nd + k, h2); }
+        else { put(k, h1); put(nd + k, h2); put(2 * nd + k, h1); }
     }
-    // norm slots: 99..101 carry |b'|^2 (expansion on the column side, constants on the row side), 102..104 carry
+    // norm slots: 3 nd .. 3 nd + 2 carry |b'|^2 (expansion on the column side, constants on the row side), the next three
     // |a'|^2 the other way round, so d2~ 2^2s = |b'|^2 - 2 a'.b' + |a'|^2 comes out of the MFMA chain with C = 0
-    const int mine = role == 0 ? 102 : 99, other = role == 0 ? 99 : 102;
+    const int mine = 3 * nd + (role == 0 ? 3 : 0), other = 3 * nd + (role == 0 ? 0 : 3);
     put(other, (_Float16) sc.a_norm[0]); put(other + 1, (_Float16) sc.a_norm[1]); put(other + 2, (_Float16) sc.a_norm[2]);
     if (o >= 0) {
-        float N = n2 * (sc.s_mul * sc.s_mul);
+        float N = n2m * (sc.s_mul * sc.s_mul);
         _Float16 b1 = (_Float16) (N / sc.a_norm[0]);
         float r1 = __builtin_fmaf(-sc.a_norm[0], (float) b1, N);
         _Float16 b2 = (_Float16) (r1 / sc.a_norm[1]);
@@ -360,7 +404,7 @@ __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict
         put(mine, (_Float16) __uint_as_float(0x7f800000u)); put(mine + 1, (_Float16) 0.f); put(mine + 2, (_Float16) 0.f);   // padding: +inf
     }
 #pragma unroll
-    for (int cidx = 105; cidx < KCAT16; ++cidx) put(cidx, (_Float16) 0.f);
+    for (int cidx = 3 * nd + 6; cidx < ks * 16; ++cidx) put(cidx, (_Float16) 0.f);
 }
 
 // largest finite |x - c|^2 over all rows and sets (float bits through atomicMax; values are >= 0): one atomic per block
@@ -430,8 +474,8 @@ __device__ unsigned long long g_prof[16];
 __device__ __forceinline__ f32x16 mfma_step(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma_step(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-template <bool COLDIR, bool F16>
-__global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename OpFmt<F16>::frag* __restrict__ Ap, const typename OpFmt<F16>::frag* __restrict__ Bp,
+template <bool COLDIR, int FMT>
+__global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename OpFmt<FMT>::frag* __restrict__ Ap, const typename OpFmt<FMT>::frag* __restrict__ Bp,
                                                      size_t bset_stride /* fragments */, float c_scale /* 2^2s, F16 only */, float out_scale /* 2^-2s */,
                                                      const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
                                                      int rg_rows, const int* __restrict__ tile_group, const unsigned* __restrict__ stage_mask,
@@ -441,8 +485,9 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                                                      int* __restrict__ xcd_ctr) {
     // column stage double buffered in LDS: the next stage is prefetched into registers while the current one is
     // consumed and written to the other buffer afterwards -> one barrier per stage, global latency hidden
-    typedef typename OpFmt<F16>::frag frag;
-    constexpr int KS = OpFmt<F16>::KS;
+    constexpr bool F16 = FMT != FMT_F32;
+    typedef typename OpFmt<FMT>::frag frag;
+    constexpr int KS = OpFmt<FMT>::KS;
     constexpr int STAGE_FRAGS = STAGE_TILES * KS * 64;
     constexpr int STAGE_VEC4 = STAGE_FRAGS * (int) sizeof(frag) / 16;   // 16-byte pieces per stage
     __shared__ __attribute__((aligned(16))) frag Bs[2][STAGE_FRAGS];
@@ -1475,37 +1520,34 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // ---- 3. pack operands, group maxima, stage -> leaf map
     const bool f16 = env_int("LGR_MATCH_F16", 1) != 0;
     g_last_stats.f16 = f16 ? 1 : 0;
-    const int KS = f16 ? OpFmt<true>::KS : OpFmt<false>::KS;
-    const size_t frag_bytes = f16 ? sizeof(f16x8) : sizeof(float);
-    const size_t a_op_bytes = (size_t) ta * KS * 64 * frag_bytes;
-    const size_t bset_stride = (size_t) tb * KS * 64;   // fragments per column set
-    char *Aop, *Bop;
-    float *nAp, *nBp;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ROWMIN, a_op_bytes + (size_t) ma_pad * 4 + 256, &Aop));
-    nAp = (float*) (Aop + ((a_op_bytes + 255) & ~(size_t) 255));
-    const size_t b_op_bytes = KCL * bset_stride * frag_bytes;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_COLMIN, b_op_bytes + (size_t) KCL * mb_pad * 4 + 256, &Bop));
-    nBp = (float*) (Bop + ((b_op_bytes + 255) & ~(size_t) 255));
     EpsExtra ex{0.f, 0.f, 1.f};
     float c_scale = 1.f, out_scale = 1.f;
-    if (!f16) {
-        pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, (float*) Aop, nAp);
-        pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, (float*) Bop, nBp);
-    } else {
-        // norms first: the power-of-two scale 2^s puts the largest operand (2 |a'| 2^s, |b'| 2^s) just under 2^15
-        F16Scale sc{1.f, 1.f, {1.f, 1.f, 1.f}};
-        pack16_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, nullptr, nAp);
-        pack16_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp);
+    F16Scale sc{1.f, 1.f, {1.f, 1.f, 1.f}};
+    bool rot = false;
+    float *nAp, *nBp;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_NORMS, (size_t) ma_pad + (size_t) KCL * mb_pad + 64, &nAp));
+    nBp = nAp + ma_pad;
+    if (f16) {
+        // norms first: the power-of-two scale 2^s puts the largest operand (2 |a'| 2^s, |b'| 2^s) just under 2^15; the same
+        // pass measures the largest energy of the three coordinates the rotated 30-D format would drop
         unsigned* d_max = (unsigned*) (misc + 128);
-        LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
+        LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 8, ctx->stream));
+        pack16_kernel<false, true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, nullptr, nAp, d_max + 1);
+        pack16_kernel<false, true><<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp, d_max + 1);
         norm_max_kernel<<<std::min(cdiv(ma_pad, 256), 2048), 256, 0, ctx->stream>>>(nAp, (size_t) ma_pad, d_max);
         norm_max_kernel<<<std::min(cdiv((long long) KCL * mb_pad, 256), 2048), 256, 0, ctx->stream>>>(nBp, (size_t) KCL * mb_pad, d_max);
         unsigned* h_max;
         LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_max));
-        LGR_HIP(ctx, hipMemcpyAsync(h_max, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(h_max, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        float r2;
+        float r2, drop2;
         memcpy(&r2, h_max, 4);
+        memcpy(&drop2, h_max + 1, 4);
+        // Rotated format (FMT_F16R) when what it drops is negligible: with u the dropped coordinates of a row relative to a
+        // centre, d2 = d2_30 + |u_a - u_b|^2 and 0 <= |u_a - u_b|^2 <= 4 max |u|^2 -- that bound joins the absolute error
+        // term, so the choice below only trades speed.  FPFH rows: every block sums to 100 -> max |u|^2 ~ 1e-7.
+        const int rot_env = env_int("LGR_MATCH_ROT", -1);
+        rot = rot_env >= 0 ? rot_env != 0 : (4.0 * (double) drop2 <= 1e-8 * (double) r2);
         double R = std::sqrt((double) r2);
         int sexp = R > 0 ? (int) std::floor(std::log2(16384.0 / R)) : 14;
         sexp = std::max(-40, std::min(14, sexp));
@@ -1526,8 +1568,33 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         ex.lin = (float) (12.0 * tau);
         ex.abs = (float) (2.0 * std::ldexp(1.0, -14) * (sc.a_norm[2] + sc.a_norm[1] / 2048.0 + sc.a_norm[0] / 4194304.0) * (double) sc.inv_s2 * 1.01);   // both norms
         ex.quad = 2.f;
-        pack16_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
-        pack16_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
+        if (rot) {
+            // Helmert coordinates are computed in f32: |dy| <= 10.4 u |x'| per vector (prefix sums of <= 11 terms, one
+            // rounded constant) -> 20.8 u (x + y)^2 on d2, 0.13 of the unit 4 g40 (x + y)^2; the dropped energy is absolute
+            ex.quad = 2.2f;
+            ex.abs = (float) ((double) ex.abs + 4.0 * (double) drop2 * 1.0001);
+        }
+    }
+    g_last_stats.f16 = f16 ? (rot ? 2 : 1) : 0;
+    const int KS = !f16 ? OpFmt<FMT_F32>::KS : rot ? OpFmt<FMT_F16R>::KS : OpFmt<FMT_F16>::KS;
+    const size_t frag_bytes = f16 ? sizeof(f16x8) : sizeof(float);
+    const size_t a_op_bytes = (size_t) ta * KS * 64 * frag_bytes;
+    const size_t bset_stride = (size_t) tb * KS * 64;   // fragments per column set
+    char *Aop, *Bop;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ROWMIN, a_op_bytes + 256, &Aop));
+    const size_t b_op_bytes = KCL * bset_stride * frag_bytes;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_COLMIN, b_op_bytes + 256, &Bop));
+    if (!f16) {
+        pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, (float*) Aop, nAp);
+        pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, (float*) Bop, nBp);
+    } else {
+        if (rot) {
+            pack16_kernel<true, false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, nullptr);
+            pack16_kernel<true, false><<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
+        } else {
+            pack16_kernel<false, false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, nullptr);
+            pack16_kernel<false, false><<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
+        }
     }
     const int n_rg = cdiv(ma_pad, rg_rows);
     // column groups of the row-minimum table: a leaf, cut into pieces of at most GROUP_COLS columns (k-means leaves of
@@ -1602,12 +1669,15 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_CHECK(ctx, ctx->mfma_timed < 8, LGR_ERR_INVALID_ARG);
         (void) hipEventRecord(ctx->ev[9 + 2 * ctx->mfma_timed], ctx->stream);
 #define LGR_MFMA_ARGS bset_stride, c_scale, out_scale, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin, n_cc, item_rb, ilist, xcd_start, xcd_ctr
-        if (f16) {
-            if (both) match_mfma<true, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
-            else match_mfma<false, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+        if (f16 && rot) {
+            if (both) match_mfma<true, FMT_F16R><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, FMT_F16R><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+        } else if (f16) {
+            if (both) match_mfma<true, FMT_F16><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, FMT_F16><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
         } else {
-            if (both) match_mfma<true, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
-            else match_mfma<false, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
+            if (both) match_mfma<true, FMT_F32><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, FMT_F32><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
         }
 #undef LGR_MFMA_ARGS
         (void) hipEventRecord(ctx->ev[10 + 2 * ctx->mfma_timed], ctx->stream);

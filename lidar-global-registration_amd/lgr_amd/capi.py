@@ -172,10 +172,11 @@ class Context:
         return f.value
 
     def match_format(self):
-        """'f16' (split operands on the f16 MFMA) or 'f32' for the last match call"""
+        """'f16' (split operands on the f16 MFMA, K = 112), 'f16r' (the same on 30 rotated coordinates, K = 96) or 'f32'
+        for the last match call"""
         v = C.c_int(0)
         self.check(_lib.lgr_match_last_format(C.byref(v)))
-        return "f16" if v.value else "f32"
+        return {0: "f32", 1: "f16", 2: "f16r"}[v.value]
 
     def match_check(self):
         """(rows, cols) worst |filtered - exact| / eps of the last match call run with LGR_MATCH_CHECK=1, or -1"""

@@ -140,17 +140,20 @@ def test_match_clustered_parity_and_skipping(lgr, oracle, matcher_mode, ma, mb):
         assert w == 1.0
 
 
-@pytest.mark.parametrize("fmt", ["f16", "f32"])
+@pytest.mark.parametrize("fmt", ["f16", "f16r", "f32"])
 @pytest.mark.parametrize("kind", ["fpfh", "clustered", "tiny", "wide", "duplicates"])
 def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, kind):
     """The MFMA filter value of every computed (query, group) entry must lie within the proven eps of the exact group
-    minimum (computed in double on the device, LGR_MATCH_CHECK=1) -- on the f16-split operand format and on f32, for
+    minimum (computed in double on the device, LGR_MATCH_CHECK=1) -- on both f16-split operand formats and on f32, for
     FPFH-like rows, tight clusters, tiny and wide dynamic ranges and exact duplicates; results stay oracle-exact."""
     import torch
     if matcher_mode == "prune_sub1":
         pytest.skip("same code path as prune_sub4")
     monkeypatch.setenv("LGR_MATCH_CHECK", "1")
-    monkeypatch.setenv("LGR_MATCH_F16", "1" if fmt == "f16" else "0")
+    monkeypatch.setenv("LGR_MATCH_F16", "0" if fmt == "f32" else "1")
+    # f16r: the rotated 30-coordinate format forced on ANY data (rows whose blocks do not sum to a constant make its
+    # dropped-coordinate term large: the bound must still hold and the result stay exact); f16: forced off
+    monkeypatch.setenv("LGR_MATCH_ROT", "1" if fmt == "f16r" else "0")
     rng = np.random.default_rng(77)
     ma, mb = 6000, 9000
     if kind == "fpfh":
@@ -171,6 +174,23 @@ def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, ki
     run_both(lgr, oracle, a, b, 2500)
     lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 2500)
     lgr.sync()
+    assert lgr.match_format() == fmt
     r_rows, r_cols = lgr.match_check()
     assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
     print(f"filter bound ratio [{fmt} {kind} {matcher_mode}]: rows {r_rows:.3g} cols {r_cols:.3g}")
+
+
+def test_rotated_format_selection(lgr, oracle, monkeypatch, matcher_mode):
+    """FPFH-like rows (every 11-bin block sums to 100) take the 30-coordinate operand format on their own; one row with a
+    different block sum switches the call back to 33 coordinates; both give the oracle's result."""
+    import torch
+    if matcher_mode != "auto":
+        pytest.skip("format selection does not depend on the skipping mode")
+    monkeypatch.delenv("LGR_MATCH_ROT", raising=False)
+    rng = np.random.default_rng(123)
+    a, b = fpfh_like(rng, 3000), fpfh_like(rng, 4000)
+    run_both(lgr, oracle, a, b, 1000)
+    assert lgr.match_format() == "f16r"
+    b[77, 3] += 0.25
+    run_both(lgr, oracle, a, b, 1000)
+    assert lgr.match_format() == "f16"
