@@ -387,15 +387,16 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
 }
 
 // ---------------------------------------------------------------------------------------------------- batch reduce
+constexpr int MAX_ROUND_BATCHES = 16;   // batches of the schedule evaluated per round of launches
 struct BatchStats {
     unsigned long long best_key;   // (metric bits << 32) | (0xffffffff - batch offset); 0 = none
     unsigned long long rec_key;    // (n_inl << 32) | (0xffffffff - batch offset); 0 = none
     int n_ok, n_cand, rec_support, pad;
 };
 
-__global__ void flag_ge_kernel(const int2* __restrict__ counts, int nh, int* __restrict__ flags) {
+__global__ void flag_ge_kernel(const int2* __restrict__ counts, int nh, int min_inliers, int* __restrict__ flags) {
     int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h < nh) flags[h] = counts[h].x >= MIN_NR_INLIERS ? 1 : 0;
+    if (h < nh) flags[h] = counts[h].x >= min_inliers ? 1 : 0;
 }
 // closest-plane metric plumbing: inlier counts of the plane test replace the correspondence counts (the estimator's
 // `inliers` are the plane pairs, src/metric.cpp:187-199); candidates pick up their plane metric; combination multiplies
@@ -426,30 +427,27 @@ __global__ void compact_kernel(const int* __restrict__ flags, const int* __restr
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && flags[i]) out[pos[i]] = map ? map[i] : i;
 }
+// Batch statistics, one BatchStats per sub-batch of `sub` iterations (several batches of the reference schedule are
+// evaluated by one round of launches; the host replays them in order, see lgr_ransac_dev).
 __global__ void reduce_kernel(const int* __restrict__ list2, int nh2, const float* __restrict__ metric, const int* __restrict__ ninl,
-                              const int* __restrict__ list, const int2* __restrict__ counts, int nh, BatchStats* __restrict__ st) {
-    // list2[j] = batch offset of candidate j; metric[j], ninl[j] its phase-2 results.  counts[] is indexed by the
-    // position in the ok-list `list` (needed for the support of the record holder).
-    unsigned long long bk = 0, rk = 0;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nh2; j += gridDim.x * blockDim.x) {
-        unsigned off = (unsigned) list2[j];
-        unsigned long long k1 = ((unsigned long long) __float_as_uint(metric[j]) << 32) | (0xffffffffu - off);
-        unsigned long long k2 = ((unsigned long long) (unsigned) ninl[j] << 32) | (0xffffffffu - off);
-        bk = k1 > bk ? k1 : bk; rk = k2 > rk ? k2 : rk;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long a = __shfl_xor(bk, o), b = __shfl_xor(rk, o);
-        bk = a > bk ? a : bk; rk = b > rk ? b : rk;
-    }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&st->best_key, bk); atomicMax(&st->rec_key, rk); }
+                              int sub, BatchStats* __restrict__ st) {
+    // list2[j] = offset of candidate j in the round; metric[j], ninl[j] its phase-2 results
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nh2) return;
+    unsigned off = (unsigned) list2[j];
+    BatchStats* t = st + off / (unsigned) sub;
+    atomicMax(&t->best_key, ((unsigned long long) __float_as_uint(metric[j]) << 32) | (0xffffffffu - off));
+    atomicMax(&t->rec_key, ((unsigned long long) (unsigned) ninl[j] << 32) | (0xffffffffu - off));
 }
-__global__ void support_kernel(const int* __restrict__ list, const int2* __restrict__ counts, int nh, BatchStats* __restrict__ st) {
-    // find the support count of the record holder (its position in the ok-list)
-    unsigned long long rk = st->rec_key;
-    if (rk == 0) return;
-    int off = (int) (0xffffffffu - (unsigned) (rk & 0xffffffffu));
-    for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
-        if (list[h] == off) st->rec_support = counts[h].y;
+__global__ void support_kernel(const int* __restrict__ list, const int2* __restrict__ counts, int nh, int sub, BatchStats* __restrict__ st) {
+    // per sub-batch: number of prerejection survivors, and the support count of the record holder
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nh) return;
+    int off = list[h];
+    BatchStats* t = st + off / sub;
+    atomicAdd(&t->n_ok, 1);
+    unsigned long long rk = t->rec_key;
+    if (rk != 0 && (int) (0xffffffffu - (unsigned) (rk & 0xffffffffu)) == off) t->rec_support = counts[h].y;
 }
 
 // ordered compaction of the inlier pairs (mask -> flags -> exclusive scan -> scatter) ahead of the sequential refit
@@ -733,7 +731,7 @@ struct BatchBuffers {
 static int batch_buffers(lgr_ctx* ctx, int nb, BatchBuffers* b) {
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_T, (size_t) nb * 16, &b->Ts));
     int* s;
-    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_STATS, (size_t) nb * 12 + 64, &s));
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_STATS, (size_t) nb * 12 + 64 + MAX_ROUND_BATCHES * (sizeof(BatchStats) / 4), &s));
     b->ok = s; b->pos = s + nb; b->list = s + 2 * (size_t) nb; b->counts = (int2*) (s + 3 * (size_t) nb);
     b->flags2 = s + 5 * (size_t) nb; b->pos2 = s + 6 * (size_t) nb; b->list2 = s + 7 * (size_t) nb;
     b->metric = (float*) (s + 8 * (size_t) nb); b->ninl = s + 9 * (size_t) nb;
@@ -744,7 +742,7 @@ static int batch_buffers(lgr_ctx* ctx, int nb, BatchBuffers* b) {
 // runs one batch.  h_counts: [0] n_ok, [1] n_cand (hypotheses with >= MIN_NR_INLIERS inliers)
 static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c, const Packed& pk,
                      const lgr_params* p, uint64_t seed, int first, int nb, const int32_t* d_triples, BatchBuffers& b,
-                     int* n_ok, int* n_cand, const lgr_plane_dev* plane = nullptr) {
+                     int* n_ok, int* n_cand, const lgr_plane_dev* plane = nullptr, int min_inliers = MIN_NR_INLIERS) {
     hypotheses_kernel<<<cdiv(nb, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, first, nb, d_triples,
                                                               p->edge_thr_coef, b.Ts, b.ok);
     size_t tb = 0;
@@ -775,7 +773,7 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
         LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list, nh, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr));
         plane_counts_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(pl_cnt, nh, b.counts);
     }
-    flag_ge_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.counts, nh, b.flags2);
+    flag_ge_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.counts, nh, min_inliers, b.flags2);
     LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, b.flags2, b.pos2, 0, (size_t) nh, rocprim::plus<int>(), ctx->stream));
     compact_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.flags2, b.pos2, nh, b.list, b.list2);
     LGR_HIP(ctx, hipMemcpyAsync(h, b.pos2 + (nh - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -888,32 +886,65 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
         LGR_HIP(ctx, hipMemcpyAsync(d_best, I, 64, hipMemcpyHostToDevice, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    BatchBuffers b;
-    LGR_TRY(batch_buffers(ctx, std::min(batch, std::max(max_iterations, 1)), &b));
     const bool plane_metric = p->metric_id == LGR_METRIC_CLOSEST_PLANE || p->metric_id == LGR_METRIC_COMBINATION;
+    // Rounds.  The schedule is defined per batch (bound and best hypothesis are updated after every `batch` iterations).
+    // Only ~0.2 % of the samples survive the prerejection, so one batch is a few hundred hypotheses -- far too few to
+    // fill the chip, and every batch costs three host round trips.  Several batches are therefore evaluated by one round
+    // of launches with per-batch statistics, and the host replays the batches in order; batches beyond the point where
+    // the bound stops the loop are discarded, so results are those of the batch-by-batch schedule.  The first round is
+    // one batch (it usually brings the first bound and the candidate gate).
+    const int round_cap = plane_metric ? 1 : MAX_ROUND_BATCHES;   // the plane metrics key their subsets by batch: one at a time
+    BatchBuffers b;
+    LGR_TRY(batch_buffers(ctx, (int) std::min<long long>((long long) batch * round_cap, std::max(max_iterations, 1)), &b));
     lgr_plane_dev plane;
     if (plane_metric) LGR_TRY(lgr_plane_setup(ctx, d_src, ns, d_tgt, nt, seed, &plane));
+    const bool ransac_debug = getenv("LGR_RANSAC_DEBUG") != nullptr;
+    bool first_round = true;
     while (done < bound) {
-        int nb = std::min(batch, max_iterations - done);
+        long long want = (long long) std::min(bound, max_iterations) - done;
+        int n_batches = first_round ? 1 : (int) std::min<long long>(round_cap, (want + batch - 1) / batch);
+        first_round = false;
+        int nb = (int) std::min<long long>((long long) n_batches * batch, max_iterations - done);
+        n_batches = (nb + batch - 1) / batch;
         int n_ok = 0, n_cand = 0;
-        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand, plane_metric ? &plane : nullptr));
-        num_rejections += nb - n_ok;
-        if (n_cand > 0) {
-            LGR_HIP(ctx, hipMemsetAsync(b.st, 0, sizeof(BatchStats), ctx->stream));
-            reduce_kernel<<<std::min(cdiv(n_cand, 256), 64), 256, 0, ctx->stream>>>(b.list2, n_cand, b.metric, b.ninl, b.list, b.counts, n_ok, b.st);
-            support_kernel<<<std::min(cdiv(n_ok, 256), 64), 256, 0, ctx->stream>>>(b.list, b.counts, n_ok, b.st);
-            BatchStats* hs;
-            LGR_TRY(lgr_pinned(ctx, sizeof(BatchStats), (void**) &hs));
-            LGR_HIP(ctx, hipMemcpyAsync(hs, b.st, sizeof(BatchStats), hipMemcpyDeviceToHost, ctx->stream));
+        // Candidate gate.  The reference scores every hypothesis with >= MIN_NR_INLIERS inliers and keeps the best metric
+        // (strict >).  A hypothesis with n inliers cannot reach the best metric m found so far when its metric's upper
+        // bound is below m: uniformity <= ln(n) / ln(10^4) (entropy of n points over 10^4 cells, src/analysis.cpp:95-130),
+        // correspondences <= n / C (scores <= 1, src/metric.cpp:55-81) -- such hypotheses are not scored (0.1 % slack for
+        // the float evaluation).  The record inlier set is unaffected: a new record has more inliers than the best
+        // hypothesis, which itself passes the gate.
+        int min_inliers = MIN_NR_INLIERS;
+        if (final_metric > 0.f && p->metric_id == LGR_METRIC_UNIFORMITY)
+            min_inliers = std::max(min_inliers, (int) std::floor(std::pow(10000.0, (double) final_metric / 1.001)) - 1);
+        else if (final_metric > 0.f && p->metric_id == LGR_METRIC_CORRESPONDENCES)
+            min_inliers = std::max(min_inliers, (int) std::floor((double) final_metric * (double) c / 1.001) - 1);
+        LGR_HIP(ctx, hipMemsetAsync(b.st, 0, sizeof(BatchStats) * n_batches, ctx->stream));
+        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand, plane_metric ? &plane : nullptr, min_inliers));
+        if (ransac_debug) fprintf(stderr, "[lgr] ransac round at %d: %d iterations (%d batches), %d pass the prerejection, %d scored (gate %d inliers), best metric %.4f, largest %d, bound %d\n",
+                                  done, nb, n_batches, n_ok, n_cand, min_inliers, final_metric, largest, bound);
+        BatchStats* hs;
+        LGR_TRY(lgr_pinned(ctx, sizeof(BatchStats) * MAX_ROUND_BATCHES, (void**) &hs));
+        if (n_ok > 0) {
+            if (n_cand > 0) reduce_kernel<<<cdiv(n_cand, 256), 256, 0, ctx->stream>>>(b.list2, n_cand, b.metric, b.ninl, batch, b.st);
+            support_kernel<<<cdiv(n_ok, 256), 256, 0, ctx->stream>>>(b.list, b.counts, n_ok, batch, b.st);
+            LGR_HIP(ctx, hipMemcpyAsync(hs, b.st, sizeof(BatchStats) * n_batches, hipMemcpyDeviceToHost, ctx->stream));
             LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            BatchStats s = *hs;
+        } else {
+            memset(hs, 0, sizeof(BatchStats) * n_batches);
+        }
+        // replay the batches of this round in schedule order
+        const int round_first = done;
+        for (int j = 0; j < n_batches && done < bound; ++j) {
+            const BatchStats s = hs[j];
+            const int nbj = std::min(batch, max_iterations - done);
+            num_rejections += nbj - s.n_ok;
             if (s.best_key) {
                 unsigned mb = (unsigned) (s.best_key >> 32);
                 float m;
                 memcpy(&m, &mb, 4);
                 int off = (int) (0xffffffffu - (unsigned) (s.best_key & 0xffffffffu));
                 if (final_metric < m) {   // src/sac_prerejective_omp.cpp:232-235 / :251-254
-                    final_metric = m; best_iter = done + off;
+                    final_metric = m; best_iter = round_first + off;
                     LGR_HIP(ctx, hipMemcpyAsync(d_best, b.Ts + (size_t) off * 16, 64, hipMemcpyDeviceToDevice, ctx->stream));
                 }
             }
@@ -924,8 +955,9 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
                     bound = std::min(bound, est_from_support(s.rec_support, c, p->confidence, p->n_samples));
                 }
             }
+            done += nbj;
+            if (done >= max_iterations) break;
         }
-        done += nb;
         if (done >= max_iterations) break;
     }
     // :265-296 final re-estimation
