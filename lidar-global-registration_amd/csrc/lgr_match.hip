@@ -805,30 +805,77 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
     }
 }
 
-// the near_t smallest finite entries of a strided vector -> sched = 1   (one wave per vector; dynamic LDS: len bits)
-__global__ void near_kernel(int near_t, const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
-                            uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride) {
-    extern __shared__ unsigned taken[];
-    const int vec = blockIdx.x, lane = threadIdx.x;
+// the near_t smallest finite entries of a strided vector -> need1 = 1; ties go to the lowest index.  One 256-thread block
+// per vector: the vector is read once into LDS (dynamic: len words), a bitwise radix select finds the near_t-th smallest
+// key (entries are >= 0, so the float bits order like the values), then everything below it and the first ties are marked.
+constexpr int NEAR_THREADS = 256;
+constexpr int NEAR_LDS_MAX = 36 * 1024;   // entries that fit the dynamic LDS slab (144 KB); longer vectors are re-read from global
+template <bool IN_LDS>
+__global__ __launch_bounds__(NEAR_THREADS) void near_kernel(int near_t, const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
+                                                            uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride) {
+    extern __shared__ unsigned keys[];
+    __shared__ int cnt_s, base_s;
+    __shared__ int wave_cnt[NEAR_THREADS / 64];
+    const int vec = blockIdx.x, tid = threadIdx.x;
     if (vec >= n_vec) return;
-    for (int w = lane; w < (len + 31) / 32; w += 64) taken[w] = 0u;
+    constexpr unsigned INF = 0x7f800000u;
+    auto load = [&](int e) {
+        unsigned k = __float_as_uint(LBsq[vec * vec_stride + e * elem_stride]);
+        return k > INF ? INF : k;                   // negative values / NaN cannot occur; anything odd counts as "not finite"
+    };
+    auto key_of = [&](int e) { return IN_LDS ? keys[e] : load(e); };
+    int n_fin = 0;
+    for (int e = tid; e < len; e += NEAR_THREADS) {
+        unsigned k = load(e);
+        if (IN_LDS) keys[e] = k;
+        n_fin += k < INF ? 1 : 0;
+    }
+    if (tid == 0) cnt_s = 0;
     __syncthreads();
-    for (int t = 0; t < near_t; ++t) {
-        float bv = __uint_as_float(0x7f800000u);
-        int bi = -1;
-        for (int e = lane; e < len; e += 64) {
-            if ((taken[e >> 5] >> (e & 31)) & 1u) continue;
-            float v = LBsq[vec * vec_stride + e * elem_stride];
-            if (v < bv) { bv = v; bi = e; }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            float ov = __shfl_xor(bv, o);
-            int oi = __shfl_xor(bi, o);
-            if (ov < bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
-        }
-        if (bi < 0) break;
-        if (lane == 0) { taken[bi >> 5] |= 1u << (bi & 31); need1[vec * need_vec_stride + bi * need_elem_stride] = 1; }
+    for (int o = 32; o > 0; o >>= 1) n_fin += __shfl_xor(n_fin, o);
+    if ((tid & 63) == 0) atomicAdd(&cnt_s, n_fin);
+    __syncthreads();
+    int k = min(near_t, cnt_s);                     // how many to mark
+    __syncthreads();
+    if (k == 0) return;
+    // k-th smallest key (1-based) by radix select from the top bit; `k` becomes its rank among the equal keys
+    unsigned prefix = 0u;
+    for (int bit = 30; bit >= 0; --bit) {           // bit 31 is 0 everywhere
+        if (tid == 0) cnt_s = 0;
         __syncthreads();
+        const unsigned hi_mask = ~((2u << bit) - 1u);   // bits above `bit`
+        int c0 = 0;
+        for (int e = tid; e < len; e += NEAR_THREADS) {
+            unsigned key = key_of(e);
+            c0 += ((key & hi_mask) == prefix && !((key >> bit) & 1u)) ? 1 : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o);
+        if ((tid & 63) == 0 && c0) atomicAdd(&cnt_s, c0);
+        __syncthreads();
+        const int zeros = cnt_s;
+        __syncthreads();
+        if (k > zeros) { k -= zeros; prefix |= 1u << bit; }
+    }
+    // mark the keys below the k-th ...
+    for (int e = tid; e < len; e += NEAR_THREADS)
+        if (key_of(e) < prefix) need1[vec * need_vec_stride + e * need_elem_stride] = 1;
+    // ... and the first k entries equal to it, in index order (rows of NEAR_THREADS consecutive entries)
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < len; e0 += NEAR_THREADS) {
+        const int e = e0 + tid;
+        const bool tie = e < len && key_of(e) == prefix;
+        const unsigned long long bal = __ballot(tie);
+        if ((tid & 63) == 0) wave_cnt[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < (tid >> 6); ++w) before += wave_cnt[w];
+        before += __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if (tie && before < k) need1[vec * need_vec_stride + e * need_elem_stride] = 1;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < NEAR_THREADS / 64; ++w) t += wave_cnt[w]; base_s += t; }
+        __syncthreads();
+        if (base_s >= k) break;   // uniform
     }
 }
 
@@ -1741,8 +1788,18 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
         lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
-        near_kernel<<<n_rb, 64, (size_t) (n_leaves + 31) / 32 * 4, ctx->stream>>>(near_t, LBsq, n_rb, n_leaves, (size_t) n_leaves, 1, sched, (size_t) n_leaves, 1);
-        near_kernel<<<n_leaves, 64, (size_t) (n_rb + 31) / 32 * 4, ctx->stream>>>(near_t, LBsq, n_leaves, n_rb, 1, (size_t) n_leaves, sched, 1, (size_t) n_leaves);
+        auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {
+            if (len <= NEAR_LDS_MAX) {
+                if ((size_t) len * 4 > 64 * 1024)
+                    LGR_HIP(ctx, hipFuncSetAttribute((const void*) near_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, len * 4));
+                near_kernel<true><<<n_vec, NEAR_THREADS, (size_t) len * 4, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es);
+            } else {
+                near_kernel<false><<<n_vec, NEAR_THREADS, 0, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es);
+            }
+            return LGR_OK;
+        };
+        LGR_TRY(launch_near(n_rb, n_leaves, (size_t) n_leaves, 1));
+        LGR_TRY(launch_near(n_leaves, n_rb, 1, (size_t) n_leaves));
         // passes 1..: tiles within beta * U of the bounds known so far; the last pass (beta = 1) takes everything the
         // bounds cannot exclude
         static const float betas[] = {LGR_PRUNE_BETAS};

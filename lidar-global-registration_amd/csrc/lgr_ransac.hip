@@ -464,38 +464,59 @@ __global__ void compact_pairs_kernel(const float4* __restrict__ P0, const float4
 // ---------------------------------------------------------------------------------------------------- refit
 // src/transformation.cpp:4-38: sequential float sums over the inliers in correspondence order.  Lanes 0..5 own the
 // six centroid accumulators, then lanes 0..8 the nine entries of H; the SVD and R, t follow on lane 0.
-__global__ void refit_kernel(const float4* __restrict__ P0, const float4* __restrict__ P1, const uint8_t* __restrict__ mask, int c,
-                             float* __restrict__ Tout) {
+constexpr int RCH = 2048;   // pairs staged per chunk
+__global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ P0, const float4* __restrict__ P1, const uint8_t* __restrict__ mask, int c,
+                                                    float* __restrict__ Tout) {
+    // the sums are sequential by definition; the pairs are staged through LDS by the whole block (coalesced loads), so the
+    // summing lanes walk LDS instead of waiting on one global load per term
+    __shared__ float sp[RCH * 8];     // [pair][sx sy sz tx ty tz - -]: the summing lanes read consecutive words
+    __shared__ uint8_t sm[RCH];
     __shared__ float cen[6];
     __shared__ float Hs[9];
     __shared__ int sn;
-    int l = threadIdx.x;
-    if (l < 6) {
+    const int l = threadIdx.x;
+    auto stage = [&](int i0) {
+        __syncthreads();
+        for (int i = l; i < RCH && i0 + i < c; i += blockDim.x) {
+            float4 p = P0[i0 + i], q = P1[i0 + i];
+            *reinterpret_cast<float4*>(&sp[i * 8]) = make_float4(p.x, p.y, p.z, q.x);
+            *reinterpret_cast<float2*>(&sp[i * 8 + 4]) = make_float2(q.y, q.z);
+            sm[i] = mask ? mask[i0 + i] : (uint8_t) 1;
+        }
+        __syncthreads();
+    };
+    {
         float acc = 0.f;
         int n = 0;
-        for (int i = 0; i < c; ++i) {
-            if (mask && !mask[i]) continue;
-            float4 v = l < 3 ? P0[i] : P1[i];
-            int a = l % 3;
-            acc += a == 0 ? v.x : (a == 1 ? v.y : v.z);
-            ++n;
+        for (int i0 = 0; i0 < c; i0 += RCH) {
+            stage(i0);
+            if (l < 6) {
+                const int m = min(RCH, c - i0);
+                for (int i = 0; i < m; ++i) {
+                    if (!sm[i]) continue;
+                    acc += sp[i * 8 + l];
+                    ++n;
+                }
+            }
         }
-        cen[l] = acc / (float) n;
+        if (l < 6) cen[l] = acc / (float) n;
         if (l == 0) sn = n;
     }
-    __syncthreads();
-    if (l < 9) {
-        int a = l / 3, b = l % 3;
-        float ca = cen[a], cb = cen[3 + b];
-        float acc = 0.f;
-        for (int i = 0; i < c; ++i) {
-            if (mask && !mask[i]) continue;
-            float4 p = P0[i], q = P1[i];
-            float pa = a == 0 ? p.x : (a == 1 ? p.y : p.z);
-            float qb = b == 0 ? q.x : (b == 1 ? q.y : q.z);
-            acc += (pa - ca) * (qb - cb);
+    {
+        const int a = l / 3, b = l % 3;
+        float acc = 0.f, ca = 0.f, cb = 0.f;
+        for (int i0 = 0; i0 < c; i0 += RCH) {
+            stage(i0);   // (its first barrier also publishes cen[])
+            if (l < 9) {
+                if (i0 == 0) { ca = cen[a]; cb = cen[3 + b]; }
+                const int m = min(RCH, c - i0);
+                for (int i = 0; i < m; ++i) {
+                    if (!sm[i]) continue;
+                    acc += (sp[i * 8 + a] - ca) * (sp[i * 8 + 3 + b] - cb);
+                }
+            }
         }
-        Hs[l] = acc;
+        if (l < 9) Hs[l] = acc;
     }
     __syncthreads();
     if (l == 0) {
@@ -563,7 +584,7 @@ int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const lgr
 // refit over the inliers flagged in d_mask (NULL: all pairs): compaction in correspondence order, then refit_kernel
 int refit_launch(lgr_ctx* ctx, const Packed& pk, int c, const uint8_t* d_mask, float* d_Tout) {
     if (!d_mask || c == 0) {
-        refit_kernel<<<1, 64, 0, ctx->stream>>>(pk.P0, pk.P1, nullptr, c, d_Tout);
+        refit_kernel<<<1, 256, 0, ctx->stream>>>(pk.P0, pk.P1, nullptr, c, d_Tout);
         LGR_HIP(ctx, hipGetLastError());
         return LGR_OK;
     }
@@ -586,7 +607,7 @@ int refit_launch(lgr_ctx* ctx, const Packed& pk, int c, const uint8_t* d_mask, f
     LGR_HIP(ctx, hipMemcpyAsync(h + 1, flags + (c - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int n = h[0] + h[1];
-    refit_kernel<<<1, 64, 0, ctx->stream>>>(Q0, Q1, nullptr, n, d_Tout);
+    refit_kernel<<<1, 256, 0, ctx->stream>>>(Q0, Q1, nullptr, n, d_Tout);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
