@@ -933,18 +933,39 @@ __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* 
                                            int n_groups, int p_of_query, const int* __restrict__ cl_of_group, int t_pad, EpsExtra ex) {
     // ROWDIR: query = row i of cluster p (xq = |a'|), train group g of columns: y = gmaxB[p][g]
     // COLDIR: query = column i, train group g = row group of cluster p(g): x = gmaxA[g], y = |b - c_p(g)| (per set)
-    double x, y;
-    if (ROWDIR) { x = (double) xq; y = (double) gmax[(size_t) p_of_query * n_groups + g]; }
+    // evaluated in float, inflated by 1e-5 (the five roundings below are worth 3e-7): an upper bound of the proven eps
+    float x, y;
+    if (ROWDIR) { x = xq; y = gmax[(size_t) p_of_query * n_groups + g]; }
     else {
         int p = cl_of_group[g];
-        x = (double) gmax[g];
-        float nb = nT_sets[(size_t) p * t_pad + i];
-        y = sqrt((double) nb) * 1.0000002;
+        x = gmax[g];
+        y = sqrtf(nT_sets[(size_t) p * t_pad + i]) * 1.0000002f;
     }
-    const double u = 5.9604644775390625e-8;
-    const double g40 = 40 * u / (1 - 40 * u);
-    double s = x + y;
-    return (float) ((4.0 * (double) ex.quad * g40 * s * s + (double) ex.lin * s + (double) ex.abs) * 1.000001 + 1e-30);
+    const float c_quad = 9.5367477e-6f * ex.quad;   // 4 g40 = 4 * 40 u / (1 - 40 u) = 9.53677e-6, rounded up
+    const float s = x + y;
+    return ((c_quad * s) * s + ex.lin * s + ex.abs) * 1.00001f + 1e-30f;
+}
+
+// Table scan of one query: calls f(group, value) for every computed, finite entry table[g][i].  Four loads are in flight
+// before the first value is used (the loop body is short; one dependent global load per iteration was the whole cost).
+template <class F>
+__device__ __forceinline__ void scan_groups(const float* __restrict__ table, size_t q_pad, int i, int n_list, int n_groups,
+                                            const int* __restrict__ list_s, F&& f) {
+    const int n_it = n_list < 0 ? n_groups : n_list;
+    int k = 0;
+    for (; k + 4 <= n_it; k += 4) {
+        int g[4];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] = n_list < 0 ? k + j : list_s[k + j]; v[j] = table[(size_t) g[j] * q_pad + i]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (v[j] < FLT_BIG) f(g[j], v[j]);
+    }
+    for (; k < n_it; ++k) {
+        const int g = n_list < 0 ? k : list_s[k];
+        const float v = table[(size_t) g * q_pad + i];
+        if (v < FLT_BIG) f(g, v);
+    }
 }
 
 // Which table entries were computed at all (skipping leaves most of them at +inf): byte matrices derived from the
@@ -1005,13 +1026,10 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
         int p = blkclQ[blockIdx.x];
         float xq = sqrtf(nQ[i]) * 1.0000002f;
         ub = __uint_as_float(0x7f800000u);
-        for (int k = 0; k < (n_list < 0 ? n_groups : n_list); ++k) {
-            const int g = n_list < 0 ? k : list_s[k];
-            float v = table[(size_t) g * q_pad + i];
-            if (!(v < FLT_BIG)) continue;
+        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
             float e = group_eps<true>(i, g, xq, nullptr, gmax, n_groups, p, nullptr, q_pad, ex);
             ub = fminf(ub, v + e);
-        }
+        });
     }
     for (int o = 32; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
     __shared__ float sh[BLOCK_ROWS / 64];
@@ -1030,13 +1048,10 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
     const int n_list = comp_list(comp, blockIdx.x * blockDim.x, t_pad, n_rg, list_s);
     if (j >= t_pad || permT[j] < 0) return;
     float ub = __uint_as_float(0x7f800000u);
-    for (int k = 0; k < (n_list < 0 ? n_rg : n_list); ++k) {
-        const int g = n_list < 0 ? k : list_s[k];
-        float v = table[(size_t) g * t_pad + j];
-        if (!(v < FLT_BIG)) continue;
+    scan_groups(table, (size_t) t_pad, j, n_list, n_rg, list_s, [&](int g, float v) {
         float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad, ex);
         ub = fminf(ub, v + e);
-    }
+    });
     ub = ub > 0.f ? ub : 0.f;
     atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
 }
@@ -1138,17 +1153,17 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
     }
 }
 
+constexpr int CAND_KEEP = 4;   // smallest lower bounds kept per query by rerank_count (up to CAND_KEEP - 1 candidates without a rescan)
 template <bool ROWDIR>
 __global__ void rerank_count(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                              const float* __restrict__ nQ /* ROWDIR: |a'|^2 per padded row */, const int* __restrict__ blkclQ,
                              const float* __restrict__ nQ_sets /* COLDIR: |b - c_p|^2 [KCL][q_pad] */, const float* __restrict__ gmax,
                              const int* __restrict__ cl_of_group, int dense_limit, EpsExtra ex, CompView comp,
-                             float* __restrict__ thr_out, int* __restrict__ counts, unsigned* __restrict__ dense,
-                             RerankCounters* __restrict__ cnt) {
+                             float* __restrict__ thr_out, int* __restrict__ counts, int* __restrict__ cand /* [q_pad][CAND_KEEP] */,
+                             unsigned* __restrict__ dense, RerankCounters* __restrict__ cnt) {
     extern __shared__ int list_s[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s);
-    const int n_it = n_list < 0 ? n_groups : n_list;
     if (i >= q_pad) return;
     counts[i] = 0;
     int o = permQ[i];
@@ -1156,25 +1171,41 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
     float nq = ROWDIR ? nQ[i] : 0.f;
     float xq = ROWDIR ? sqrtf(nq) * 1.0000002f : 0.f;
+    // one scan: the smallest upper bound, and the CAND_KEEP smallest lower bounds with their groups.  Candidates are the
+    // groups whose lower bound does not exceed thr (derived from the smallest upper bound); there is about one per query,
+    // so they are almost always among the kept ones and neither a second scan here nor one in rerank_emit is needed.
     float ub = __uint_as_float(0x7f800000u);
-    for (int k = 0; k < n_it; ++k) {
-        const int g = n_list < 0 ? k : list_s[k];
-        float v = table[(size_t) g * q_pad + i];
-        if (!(v < FLT_BIG)) continue;
+    float lo[CAND_KEEP];
+    int lg[CAND_KEEP];
+#pragma unroll
+    for (int j = 0; j < CAND_KEEP; ++j) { lo[j] = __uint_as_float(0x7f800000u); lg[j] = -1; }
+    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
         ub = fminf(ub, v + e);
-    }
+        float l = v - e;
+        int gi = g;
+        if (l < lo[CAND_KEEP - 1]) {
+#pragma unroll
+            for (int j = 0; j < CAND_KEEP; ++j)
+                if (l < lo[j]) { float tl = lo[j]; int tg = lg[j]; lo[j] = l; lg[j] = gi; l = tl; gi = tg; }
+        }
+    });
     if (!(ub < FLT_BIG)) return;     // no valid train row at all
     double d2 = fmax((double) ub, 0.0);   // both tables hold d2~ = S + |a'|^2
     float thr = (float) ((double) ub + 1e-5 * d2 + 8.0 * 5.9604644775390625e-8 * fabs((double) ub) + 1e-30);
     if (thr < ub) thr = ub;
     int nc = 0;
-    for (int k = 0; k < n_it; ++k) {
-        const int g = n_list < 0 ? k : list_s[k];
-        float v = table[(size_t) g * q_pad + i];
-        if (!(v < FLT_BIG)) continue;
-        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
-        nc += (v - e <= thr) ? 1 : 0;
+    if (lo[CAND_KEEP - 1] <= thr) {
+        // the kept list may be incomplete: count by a second scan, rerank_emit rescans too (cand[0] = -1)
+        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
+            float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
+            nc += (v - e <= thr) ? 1 : 0;
+        });
+        cand[(size_t) i * CAND_KEEP] = -1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < CAND_KEEP - 1; ++j)
+            if (lo[j] <= thr) { cand[(size_t) i * CAND_KEEP + nc] = lg[j]; ++nc; }
     }
     if (nc > dense_limit) {
         unsigned pos = atomicAdd(&cnt->n_dense, 1u);
@@ -1189,8 +1220,8 @@ template <bool ROWDIR>
 __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q_pad, const float* __restrict__ nQ,
                             const int* __restrict__ blkclQ, const float* __restrict__ nQ_sets, const float* __restrict__ gmax,
                             const int* __restrict__ cl_of_group, EpsExtra ex, CompView comp, const float* __restrict__ thr_in,
-                            const int* __restrict__ counts, const int* __restrict__ offs, unsigned* __restrict__ item_q,
-                            unsigned* __restrict__ item_g) {
+                            const int* __restrict__ counts, const int* __restrict__ cand, const int* __restrict__ offs,
+                            unsigned* __restrict__ item_q, unsigned* __restrict__ item_g) {
     extern __shared__ int list_s[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s);
@@ -1199,13 +1230,14 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
     float xq = ROWDIR ? sqrtf(nQ[i]) * 1.0000002f : 0.f;
     float thr = thr_in[i];
     int pos = offs[i];
-    for (int k = 0; k < (n_list < 0 ? n_groups : n_list); ++k) {
-        const int g = n_list < 0 ? k : list_s[k];
-        float v = table[(size_t) g * q_pad + i];
-        if (!(v < FLT_BIG)) continue;
+    if (cand[(size_t) i * CAND_KEEP] >= 0) {   // the candidates rerank_count kept
+        for (int j = 0; j < counts[i]; ++j) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) cand[(size_t) i * CAND_KEEP + j]; ++pos; }
+        return;
+    }
+    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
         if (v - e <= thr) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) g; ++pos; }
-    }
+    });
 }
 
 // 4b. exact distances of the (query position, train group) items, sorted by group: a workgroup takes 256 consecutive
@@ -1398,10 +1430,11 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
                unsigned* stat_items, unsigned* stat_dense) {
     const int q_pad = qs.n_pad;
     unsigned* dense;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_DENSE, (size_t) q_pad * 4 + 64, &dense));
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_DENSE, (size_t) q_pad * (4 + CAND_KEEP) + 64, &dense));
     float* thr = (float*) (dense + q_pad);
     int* counts = (int*) (dense + 2 * (size_t) q_pad);
     int* offs = (int*) (dense + 3 * (size_t) q_pad);
+    int* cand = (int*) (dense + 4 * (size_t) q_pad);
     char* misc;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, 4096, &misc));
     RerankCounters* cnt = (RerankCounters*) (misc + 64);
@@ -1409,7 +1442,7 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
     int nblocks = (ts.m + block - 1) / block;
     int dense_limit = std::max(64, n_groups / 2);
     rerank_count<ROWDIR><<<cdiv(q_pad, 256), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(table, n_groups, q_pad, qs.perm, nQ, qs.blkcl, nQ_sets, gmax,
-                                                                   cl_of_group, dense_limit, ex, comp, thr, counts, dense, cnt);
+                                                                   cl_of_group, dense_limit, ex, comp, thr, counts, cand, dense, cnt);
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, counts, offs, 0, (size_t) q_pad, rocprim::plus<int>(), ctx->stream));
     void* tmp;
@@ -1429,7 +1462,7 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS, (size_t) 4 * n_items + 64, &ib));
         unsigned *item_q = ib, *item_g = ib + n_items, *item_q2 = ib + 2 * (size_t) n_items, *item_g2 = ib + 3 * (size_t) n_items;
         rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
-                                                                      ex, comp, thr, counts, offs, item_q, item_g);
+                                                                      ex, comp, thr, counts, cand, offs, item_q, item_g);
         int bits = 1;
         while ((1 << bits) < n_groups) ++bits;
         size_t sb = 0;
