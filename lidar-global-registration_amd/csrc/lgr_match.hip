@@ -232,11 +232,18 @@ __global__ void km2_update(float* __restrict__ cen2, float* __restrict__ sums2, 
 // key = (leaf << 22) | (bits(r2) >> 9), leaf = cluster * sub + sub-centre: sort by cluster, leaf, then distance to the
 // cluster centre.  Invalid rows: 0xffffffff.  counts[leaf] / counts[MAXLEAF] (invalid) and the squared leaf radii
 // rmax[leaf] = max |x - c_leaf|^2 (float bits) are accumulated through LDS.
-__global__ void assign_kernel(const float* __restrict__ X, int m, const float* __restrict__ cen, const float* __restrict__ cen2, int sub,
-                              unsigned* __restrict__ keys, int* __restrict__ vals, uint8_t* __restrict__ valid,
-                              int* __restrict__ counts /* [MAXLEAF+1] */, unsigned* __restrict__ rmax /* [MAXLEAF] */) {
-    __shared__ int lc[MAXLEAF + 1];
-    __shared__ unsigned lr[MAXLEAF];
+constexpr int ASSIGN_THREADS = 512;
+__global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __restrict__ X, int m, const float* __restrict__ cen, const float* __restrict__ cen2, int sub,
+                                                                unsigned* __restrict__ keys, int* __restrict__ vals, uint8_t* __restrict__ valid,
+                                                                int* __restrict__ counts /* [MAXLEAF+1] */, unsigned* __restrict__ rmax /* [MAXLEAF] */) {
+    // All sub-centres live in LDS (dynamic; up to 16 x 64 x 33 floats = 135 KB): every lane walks the sub-centres of ITS
+    // cluster, which from global memory is a per-lane gather of 33 x sub words.  The odd pitch per cluster keeps lanes of
+    // different clusters on different banks; lanes of one cluster read the same word (broadcast).
+    extern __shared__ float c2s[];
+    const int pitch = sub * 33 + 1;
+    int* lc = (int*) (c2s + KCL * pitch);
+    unsigned* lr = (unsigned*) (lc + MAXLEAF + 1);
+    for (int e = threadIdx.x; e < KCL * sub * 33; e += blockDim.x) c2s[(e / (sub * 33)) * pitch + e % (sub * 33)] = cen2[e];
     for (int i = threadIdx.x; i <= MAXLEAF; i += blockDim.x) { lc[i] = 0; if (i < MAXLEAF) lr[i] = 0u; }
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,7 +255,7 @@ __global__ void assign_kernel(const float* __restrict__ X, int m, const float* _
             int c = nearest_centre(v, cen, r2);
             if (r2 < FLT_BIG) {
                 float rl2;
-                int j = nearest_sub(v, cen2 + (size_t) c * sub * 33, sub, rl2);
+                int j = nearest_sub(v, c2s + c * pitch, sub, rl2);
                 int leaf = c * sub + j;
                 key = ((unsigned) leaf << 22) | (__float_as_uint(r2) >> 9);
                 atomicAdd(&lc[leaf], 1);
@@ -775,25 +782,39 @@ constexpr float LB_SHRINK = 0.99999f, LB_GROW = 1.00001f;
 __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asorted, const int* __restrict__ permA, const float* __restrict__ cen2,
                                                  const unsigned* __restrict__ r2max, const int* __restrict__ leaf_count, int n_leaves,
                                                  float* __restrict__ LBsq) {
-    __shared__ float rows[BLOCK_ROWS * 33];
+    constexpr int ROW_LD = 34;   // even row pitch: the packed loads below stay 8-byte aligned
+    __shared__ __attribute__((aligned(16))) float rows[BLOCK_ROWS * ROW_LD];
     __shared__ int okr[BLOCK_ROWS];
     const int rb = blockIdx.x;
-    for (int e = threadIdx.x; e < BLOCK_ROWS * 33; e += 256) rows[e] = Asorted[(size_t) rb * BLOCK_ROWS * 33 + e];
+    for (int e = threadIdx.x; e < BLOCK_ROWS * 33; e += 256) rows[(e / 33) * ROW_LD + e % 33] = Asorted[(size_t) rb * BLOCK_ROWS * 33 + e];
     okr[threadIdx.x] = permA[rb * BLOCK_ROWS + threadIdx.x] >= 0;
     __syncthreads();
+    typedef float v2f __attribute__((ext_vector_type(2)));
     for (int g = threadIdx.x; g < n_leaves; g += 256) {
         float out = __uint_as_float(0x7f800000u);
         if (leaf_count[g] > 0) {
-            float c[33];
+            // |a - c|^2 on packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: two coordinates per instruction, even and odd
+            // coordinates in separate accumulators); any summation order is fine here, the bound carries 1e-5 of slack
+            v2f c2[16];
+            float c32;
 #pragma unroll
-            for (int k = 0; k < 33; ++k) c[k] = cen2[(size_t) g * 33 + k];
+            for (int k = 0; k < 16; ++k) { c2[k].x = cen2[(size_t) g * 33 + 2 * k]; c2[k].y = cen2[(size_t) g * 33 + 2 * k + 1]; }
+            c32 = cen2[(size_t) g * 33 + 32];
             float dmin = __uint_as_float(0x7f800000u);
             for (int i = 0; i < BLOCK_ROWS; ++i) {
                 if (!okr[i]) continue;
-                float d = 0.f;
+                const float* __restrict__ r = rows + i * ROW_LD;
+                v2f d = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 33; ++k) { float t = rows[i * 33 + k] - c[k]; d = d + t * t; }
-                dmin = fminf(dmin, d);
+                for (int k = 0; k < 16; ++k) {
+#pragma clang fp contract(fast)
+                    v2f a = *reinterpret_cast<const v2f*>(r + 2 * k);
+                    v2f t = a - c2[k];
+                    d = t * t + d;
+                }
+                float t32 = r[32] - c32;
+                float dd = __builtin_fmaf(t32, t32, d.x + d.y);
+                dmin = fminf(dmin, dd);
             }
             if (dmin < FLT_BIG) {
                 float lb = sqrtf(dmin) * LB_SHRINK - sqrtf(__uint_as_float(r2max[g])) * LB_GROW;
@@ -1046,14 +1067,18 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
     extern __shared__ int list_s[];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_list = comp_list(comp, blockIdx.x * blockDim.x, t_pad, n_rg, list_s);
-    if (j >= t_pad || permT[j] < 0) return;
-    float ub = __uint_as_float(0x7f800000u);
-    scan_groups(table, (size_t) t_pad, j, n_list, n_rg, list_s, [&](int g, float v) {
-        float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad, ex);
-        ub = fminf(ub, v + e);
-    });
-    ub = ub > 0.f ? ub : 0.f;
-    atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
+    float ub = 0.f;   // padding columns need nothing
+    if (j < t_pad && permT[j] >= 0) {
+        ub = __uint_as_float(0x7f800000u);
+        scan_groups(table, (size_t) t_pad, j, n_list, n_rg, list_s, [&](int g, float v) {
+            float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad, ex);
+            ub = fminf(ub, v + e);
+        });
+        ub = ub > 0.f ? ub : 0.f;
+    }
+    // the 32 columns of a tile share a leaf: one atomic per tile (t_pad is a multiple of the block size, so whole waves get here)
+    for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
+    if ((threadIdx.x & 31) == 0 && j < t_pad && ub > 0.f) atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
 }
 // tile scheduling of one pass (section 3b).  sched_kernel: tiles of the previous pass become done; a tile not yet
 // done is scheduled when  LBsq <= beta_sq * U  of its row block or (both directions) of its leaf.  mask_kernel turns the
@@ -1380,7 +1405,9 @@ int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const fl
     unsigned* rmax = (unsigned*) (kbuf + body + 8192);   // [MAXLEAF]
     s->leaf_count = counts; s->r2max = rmax;
     LGR_HIP(ctx, hipMemsetAsync(counts, 0, 16384, ctx->stream));
-    assign_kernel<<<cdiv(m, 256), 256, 0, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax);
+    const size_t assign_lds = ((size_t) KCL * (sub * 33 + 1) + 2 * MAXLEAF + 1) * 4;
+    if (assign_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) assign_lds));
+    assign_kernel<<<cdiv(m, ASSIGN_THREADS), ASSIGN_THREADS, assign_lds, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax);
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
     void* tmp;
