@@ -606,14 +606,15 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
             //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
             // The B fragment of the next tile is fetched from LDS before the epilogue runs.
             // Epilogue of one finished 32x32 tile: tile ct of stage st; nxt = the stage computed after st.
-            auto epilogue = [&](const f32x16& acc, int st, int ct, int nxt) {
-                int v[16];
+            auto row_min1 = [&](const f32x16& acc) {
 #pragma unroll
-                for (int g = 0; g < 16; ++g) { v[g] = __float_as_int(acc[g]); rmin[g] = min(rmin[g], v[g]); }
+                for (int g = 0; g < 16; ++g) rmin[g] = min(rmin[g], __float_as_int(acc[g]));
+            };
+            auto col_min = [&](const f32x16& acc, int st, int ct) {
                 if (COLDIR) {
-                    int cm = min(v[0], v[1]);
+                    int cm = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
-                    for (int g = 2; g < 16; g += 2) cm = min(min(cm, v[g]), v[g + 1]);
+                    for (int g = 2; g < 16; g += 2) cm = min(min(cm, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
                     // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
                     auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
                     int other = (int) (half ? sw[0] : sw[1]);
@@ -622,9 +623,14 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                     // the MFMA block; the two lanes of a column hit the same word with the same value)
                     atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + (lane & 31)], cm);
                 }
-                // flush the row minima when the column group (train leaf) ends, or before skipped stages
+            };
+            auto tile_ends_group = [&](int st, int ct) {
                 const unsigned te = ct == 0 ? tend[0] : ct == 1 ? tend[1] : ct == 2 ? tend[2] : tend[3];
-                if (((te >> st) & 1u) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
+                return ((te >> st) & 1u) != 0u;
+            };
+            auto maybe_flush = [&](int st, int ct, int nxt) {
+                // flush the row minima when the column group (train leaf) ends, or before skipped stages
+                if (tile_ends_group(st, ct) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
                     PROF_CNT(10);
                     const int grp = tg_s[st * STAGE_TILES + ct];
                     // Halving butterfly over the 32 lanes of each half wave: at every step a lane keeps half of
@@ -672,10 +678,18 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                     for (int r = 0; r < 16; ++r) rmin[r] = IINF;
                 }
             };
+            // Epilogue of one finished 32x32 tile: tile ct of stage st; nxt = the stage computed after st.
+            auto epilogue = [&](const f32x16& acc, int st, int ct, int nxt) {
+                row_min1(acc);
+                col_min(acc, st, ct);
+                maybe_flush(st, ct, nxt);
+            };
             // Schedules tried and measured on a dense 400k x 400k probe (35.9 ms as is; MFMA chains alone 24.9 ms: the
             // chip holds ~1.4 GHz under this f16 MFMA load): deferring a tile's epilogue behind the next tile's MFMA
             // chain (software pipeline, with and without register double buffering of the B fragments) -1..-2 % at
-            // 4 waves/SIMD with spills, +8 % at 2 waves/SIMD; no stage DMA -14 %; no barrier 0 %; no column minima -5 %.
+            // 4 waves/SIMD with spills, +8 % at 2 waves/SIMD; no stage DMA -14 %; no barrier 0 %; no column minima -5 %;
+            // two column tiles per epilogue (one v_min3 per accumulator pair for the row minima, 8 fewer vector
+            // instructions per tile): +13 % at 4 waves/SIMD (spills), -1.4 % at 2 waves/SIMD.
             auto compute = [&](int st, int buf, int nxt) {
                 frag b[KS];
 #pragma unroll

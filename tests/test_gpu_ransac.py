@@ -92,7 +92,9 @@ def test_evaluate_mask_and_refit(lgr, oracle, problem):
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-5) and np.linalg.det(R) > 0.999
 
 
-@pytest.mark.parametrize("metric,batch,iters", [(1, 4096, 20000), (0, 16384, 50000), (1, 1000, 3000)])
+# small batches: the device evaluates up to 16 schedule batches per round of launches and replays them on the host; the
+# result must be the batch-by-batch schedule's (the oracle's), also when the adaptive bound ends the loop inside a round
+@pytest.mark.parametrize("metric,batch,iters", [(1, 4096, 20000), (0, 16384, 50000), (1, 1000, 3000), (1, 256, 20000), (0, 300, 30000), (0, 64, 12000)])
 def test_ransac_whole_loop(lgr, oracle, problem, metric, batch, iters):
     from lgr_amd import capi
     p_o, p_g = params_pair(oracle, capi, metric_id=metric, score_id=2, max_iterations=iters, ransac_batch=batch)
