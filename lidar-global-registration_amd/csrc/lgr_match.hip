@@ -337,20 +337,27 @@ __device__ __forceinline__ void helmert11(const float* __restrict__ x, float* __
 }
 
 template <bool ROT, bool NORMS_ONLY>
-__global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
+__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
                               const float* __restrict__ cen, const int* __restrict__ blkcl, F16Scale sc,
                               _Float16* __restrict__ P, float* __restrict__ nrm, unsigned* __restrict__ drop_max) {
     int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = pos < n_pad;
     if (!in_range) pos = n_pad - 1;           // keep whole waves alive for the reduction below; nothing is stored
-    int set = role == 1 ? blockIdx.y : 0;
-    int o = perm[pos];
-    int c = role == 1 ? set : blkcl[pos / BLOCK_ROWS];
+    // the row is read once (a 132-byte gather) and packed for every set: 16 column sets, one per centre, or the row set
+    const int n_sets = role == 1 ? KCL : 1;
+    const int o = perm[pos];
+    float x0[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) x0[k] = o >= 0 ? X[(size_t) o * 33 + k] : 0.f;
+    float drop = 0.f;
+#pragma unroll 1
+    for (int set = 0; set < n_sets; ++set) {
+    const int c = role == 1 ? set : blkcl[pos / BLOCK_ROWS];
     float v[33];
     float n2 = 0.f;
     if (o >= 0) {
 #pragma unroll
-        for (int k = 0; k < 33; ++k) { v[k] = X[(size_t) o * 33 + k] - cen[c * 33 + k]; n2 = n2 + v[k] * v[k]; }
+        for (int k = 0; k < 33; ++k) { v[k] = x0[k] - cen[c * 33 + k]; n2 = n2 + v[k] * v[k]; }
     } else {
 #pragma unroll
         for (int k = 0; k < 33; ++k) v[k] = 0.f;
@@ -365,21 +372,18 @@ __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict
 #pragma unroll
         for (int k = 0; k < 11; ++k) { s0 += (double) v[k]; s1 += (double) v[11 + k]; s2 += (double) v[22 + k]; }
         float d2 = (o >= 0 && in_range) ? (float) (((s0 * s0 + s1 * s1) + s2 * s2) * (1.0001 / 11.0)) * 1.000001f + 1e-20f * n2 : 0.f;
-        for (int sh = 32; sh > 0; sh >>= 1) d2 = fmaxf(d2, __shfl_xor(d2, sh));
-        // (a plain look first: same-address atomics from every wave would serialise in L2; a stale value only costs an atomic)
-        if ((threadIdx.x & 63) == 0 && d2 > 0.f && __float_as_uint(d2) > *(volatile unsigned*) drop_max) atomicMax(drop_max, __float_as_uint(d2));
-        return;
+        drop = fmaxf(drop, d2);
+        continue;
     }
     float y[30], u0, u1, u2;
     if (ROT) { helmert11(v, y, &u0); helmert11(v + 11, y + 10, &u1); helmert11(v + 22, y + 20, &u2); }
-    if (!in_range) return;
+    if (!in_range) continue;
     constexpr int nd = ROT ? 30 : 33, ks = ROT ? OpFmt<FMT_F16R>::KS : OpFmt<FMT_F16>::KS;
     int tile = pos >> 5, r = pos & 31;
-    _Float16* base = P + ((size_t) set * (n_pad / TILE) + tile) * ks * 64 * 8;
-    auto put = [&](int cidx, _Float16 h) {
-        int step = cidx >> 4, khalf = (cidx >> 3) & 1, j = cidx & 7;
-        base[((size_t) step * 64 + (khalf << 5) + r) * 8 + j] = h;
-    };
+    // the row's K = 16 ks halves are assembled in registers (all indices are compile-time constants) and leave as
+    // 2 ks 16-byte pieces: piece (step, khalf) of row r sits at fragment (step * 64 + khalf * 32 + r)
+    _Float16 hv[ks * 16];
+    auto put = [&](int cidx, _Float16 h) { hv[cidx] = h; };
     const float mul = role == 0 ? -2.0f * sc.s_mul : sc.s_mul;
     float n2m = n2;                           // the norm the MFMA chain must see: of the operand coordinates
     if (ROT && o >= 0) {
@@ -397,21 +401,38 @@ __global__ void pack16_kernel(const float* __restrict__ X, const int* __restrict
     }
     // norm slots: 3 nd .. 3 nd + 2 carry |b'|^2 (expansion on the column side, constants on the row side), the next three
     // |a'|^2 the other way round, so d2~ 2^2s = |b'|^2 - 2 a'.b' + |a'|^2 comes out of the MFMA chain with C = 0
-    const int mine = 3 * nd + (role == 0 ? 3 : 0), other = 3 * nd + (role == 0 ? 0 : 3);
-    put(other, (_Float16) sc.a_norm[0]); put(other + 1, (_Float16) sc.a_norm[1]); put(other + 2, (_Float16) sc.a_norm[2]);
+    const bool rows = role == 0;
+    const _Float16 c0 = (_Float16) sc.a_norm[0], c1 = (_Float16) sc.a_norm[1], c2 = (_Float16) sc.a_norm[2];
+    _Float16 b1, b2, b3;
     if (o >= 0) {
         float N = n2m * (sc.s_mul * sc.s_mul);
-        _Float16 b1 = (_Float16) (N / sc.a_norm[0]);
+        b1 = (_Float16) (N / sc.a_norm[0]);
         float r1 = __builtin_fmaf(-sc.a_norm[0], (float) b1, N);
-        _Float16 b2 = (_Float16) (r1 / sc.a_norm[1]);
+        b2 = (_Float16) (r1 / sc.a_norm[1]);
         float r2 = __builtin_fmaf(-sc.a_norm[1], (float) b2, r1);
-        _Float16 b3 = (_Float16) (r2 / sc.a_norm[2]);
-        put(mine, b1); put(mine + 1, b2); put(mine + 2, b3);
+        b3 = (_Float16) (r2 / sc.a_norm[2]);
     } else {
-        put(mine, (_Float16) __uint_as_float(0x7f800000u)); put(mine + 1, (_Float16) 0.f); put(mine + 2, (_Float16) 0.f);   // padding: +inf
+        b1 = (_Float16) __uint_as_float(0x7f800000u); b2 = (_Float16) 0.f; b3 = (_Float16) 0.f;   // padding: +inf
     }
+    // columns: [expansion | constants], rows: [constants | expansion]
+    put(3 * nd + 0, rows ? c0 : b1); put(3 * nd + 1, rows ? c1 : b2); put(3 * nd + 2, rows ? c2 : b3);
+    put(3 * nd + 3, rows ? b1 : c0); put(3 * nd + 4, rows ? b2 : c1); put(3 * nd + 5, rows ? b3 : c2);
 #pragma unroll
     for (int cidx = 3 * nd + 6; cidx < ks * 16; ++cidx) put(cidx, (_Float16) 0.f);
+    f16x8* base = reinterpret_cast<f16x8*>(P) + ((size_t) set * (n_pad / TILE) + tile) * ks * 64;
+#pragma unroll
+    for (int piece = 0; piece < 2 * ks; ++piece) {
+        f16x8 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = hv[piece * 8 + j];
+        base[(piece >> 1) * 64 + ((piece & 1) << 5) + r] = w;
+    }
+    }   // sets
+    if (NORMS_ONLY) {
+        for (int sh = 32; sh > 0; sh >>= 1) drop = fmaxf(drop, __shfl_xor(drop, sh));
+        // (a plain look first: same-address atomics from every wave would serialise in L2; a stale value only costs an atomic)
+        if ((threadIdx.x & 63) == 0 && drop > 0.f && __float_as_uint(drop) > *(volatile unsigned*) drop_max) atomicMax(drop_max, __float_as_uint(drop));
+    }
 }
 
 // largest finite |x - c|^2 over all rows and sets (float bits through atomicMax; values are >= 0): one atomic per block
@@ -1654,7 +1675,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned* d_max = (unsigned*) (misc + 128);
         LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 8, ctx->stream));
         pack16_kernel<false, true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, nullptr, nAp, d_max + 1);
-        pack16_kernel<false, true><<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp, d_max + 1);
+        pack16_kernel<false, true><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp, d_max + 1);
         norm_max_kernel<<<std::min(cdiv(ma_pad, 256), 2048), 256, 0, ctx->stream>>>(nAp, (size_t) ma_pad, d_max);
         norm_max_kernel<<<std::min(cdiv((long long) KCL * mb_pad, 256), 2048), 256, 0, ctx->stream>>>(nBp, (size_t) KCL * mb_pad, d_max);
         unsigned* h_max;
@@ -1711,10 +1732,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     } else {
         if (rot) {
             pack16_kernel<true, false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, nullptr);
-            pack16_kernel<true, false><<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
+            pack16_kernel<true, false><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
         } else {
             pack16_kernel<false, false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, nullptr);
-            pack16_kernel<false, false><<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
+            pack16_kernel<false, false><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
         }
     }
     const int n_rg = cdiv(ma_pad, rg_rows);

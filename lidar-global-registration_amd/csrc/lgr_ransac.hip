@@ -638,11 +638,13 @@ int metric_launch(lgr_ctx* ctx, const float* Ts, const int* list2, int nh2, cons
 
 struct EvalOut { int n_inl; float rmse; float metric; };
 // single transform (device pointer d_T to 16 floats): mask + stats
-int evaluate_one(lgr_ctx* ctx, const float* d_T, const Packed& pk, int c, int metric_id, int score_id, uint8_t* d_mask, EvalOut* out) {
+int evaluate_one(lgr_ctx* ctx, const float* d_T, const Packed& pk, int c, int metric_id, int score_id, uint8_t* d_mask, EvalOut* out,
+                 bool want_rmse = true /* false: no ordered inlier list when the metric itself does not need one (rmse = 0) */) {
     float* res;
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &res));
     float* d_metric = res + 32; int* d_ninl = (int*) (res + 33); float* d_rmse = res + 34;
-    LGR_TRY(metric_launch(ctx, d_T, nullptr, 1, pk, c, metric_id, score_id, d_metric, d_ninl, d_rmse, d_mask));
+    if (!want_rmse) LGR_HIP(ctx, hipMemsetAsync(d_rmse, 0, 4, ctx->stream));
+    LGR_TRY(metric_launch(ctx, d_T, nullptr, 1, pk, c, metric_id, score_id, d_metric, d_ninl, want_rmse ? d_rmse : nullptr, d_mask));
     float* h;
     LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
     LGR_HIP(ctx, hipMemcpyAsync(h, d_metric, 12, hipMemcpyDeviceToHost, ctx->stream));
@@ -989,7 +991,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     if (plane_metric)
         LGR_TRY(evaluate_one_plane(ctx, d_best, pk, c, p->metric_id, p->score_id, d_mask, plane, 0xFFFFFFFEu, &e,
                                    p->metric_id == LGR_METRIC_CLOSEST_PLANE ? &plane_pairs : nullptr));
-    else LGR_TRY(evaluate_one(ctx, d_best, pk, c, p->metric_id, p->score_id, d_mask, &e));
+    else LGR_TRY(evaluate_one(ctx, d_best, pk, c, p->metric_id, p->score_id, d_mask, &e, false));   // the final block uses inliers and metric only
     bool enough = e.n_inl > MIN_NR_FINAL_INLIERS || (float) e.n_inl > MIN_INLIER_RATE * (float) c;
     float min_tol = p->metric_id == LGR_METRIC_UNIFORMITY ? 0.3f : 0.0f;   // include/metric.h:97-99 / 73-75 / 124-126 / 198-200
     bool converged = enough && e.metric > min_tol;
@@ -1013,7 +1015,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     }
     EvalOut e2;
     if (plane_metric) LGR_TRY(evaluate_one_plane(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, plane, 0xFFFFFFFFu, &e2, nullptr));
-    else LGR_TRY(evaluate_one(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, &e2));
+    else LGR_TRY(evaluate_one(ctx, d_Tn, pk, c, p->metric_id, p->score_id, d_mask, &e2, false));
     float* hT;
     LGR_TRY(lgr_pinned(ctx, 64, (void**) &hT));
     LGR_HIP(ctx, hipMemcpyAsync(hT, d_Tn, 64, hipMemcpyDeviceToHost, ctx->stream));
