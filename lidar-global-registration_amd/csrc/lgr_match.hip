@@ -1004,22 +1004,29 @@ __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* 
 
 // Table scan of one query: calls f(group, value) for every computed, finite entry table[g][i].  Four loads are in flight
 // before the first value is used (the loop body is short; one dependent global load per iteration was the whole cost).
+// `own` (columns): the computed-flags of the query's own leaf.  A block of 256 columns can span two leaves, so the
+// block's list is a superset; entries that were never computed are never initialised (init_tables_kernel) and must not
+// be read.  nullptr: the list is exact (rows: one row block per workgroup) or everything was computed.
 template <class F>
 __device__ __forceinline__ void scan_groups(const float* __restrict__ table, size_t q_pad, int i, int n_list, int n_groups,
-                                            const int* __restrict__ list_s, F&& f) {
+                                            const int* __restrict__ list_s, const uint8_t* __restrict__ own, F&& f) {
     const int n_it = n_list < 0 ? n_groups : n_list;
+    const float inf = __uint_as_float(0x7f800000u);
     int k = 0;
     for (; k + 4 <= n_it; k += 4) {
         int g[4];
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { g[j] = n_list < 0 ? k + j : list_s[k + j]; v[j] = table[(size_t) g[j] * q_pad + i]; }
+        for (int j = 0; j < 4; ++j) {
+            g[j] = n_list < 0 ? k + j : list_s[k + j];
+            v[j] = (!own || own[g[j]]) ? table[(size_t) g[j] * q_pad + i] : inf;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (v[j] < FLT_BIG) f(g[j], v[j]);
     }
     for (; k < n_it; ++k) {
         const int g = n_list < 0 ? k : list_s[k];
-        const float v = table[(size_t) g * q_pad + i];
+        const float v = (!own || own[g]) ? table[(size_t) g * q_pad + i] : inf;
         if (v < FLT_BIG) f(g, v);
     }
 }
@@ -1035,12 +1042,14 @@ __device__ __forceinline__ const uint8_t* comp_row(const CompView& c, int i, int
 }
 // compact list (dynamic LDS) of the groups computed for any query of this block; returns its length, or -1 when
 // nothing was skipped (iterate all groups).  Every thread of the block must call it.
-__device__ __forceinline__ int comp_list(const CompView& c, int i0, int n_i, int n_groups, int* list_s, int span = 0) {
+__device__ __forceinline__ int comp_list(const CompView& c, int i0, int n_i, int n_groups, int* list_s, int span = 0, bool* several = nullptr) {
     __shared__ int cnt_s;
+    if (several) *several = false;
     if (!c.m) return -1;
     if (threadIdx.x == 0) cnt_s = 0;
     __syncthreads();
     const int t0 = i0 / TILE, t1 = (min(i0 + (span ? span : (int) blockDim.x), n_i) - 1) / TILE;
+    if (several && c.row_of_tile) *several = c.row_of_tile[t0] != c.row_of_tile[t1];   // tiles are sorted by leaf
     for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
         uint8_t f = 0;
         if (c.row_of_tile) {
@@ -1082,7 +1091,7 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
         int p = blkclQ[blockIdx.x];
         float xq = sqrtf(nQ[i]) * 1.0000002f;
         ub = __uint_as_float(0x7f800000u);
-        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
+        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, nullptr, [&](int g, float v) {
             float e = group_eps<true>(i, g, xq, nullptr, gmax, n_groups, p, nullptr, q_pad, ex);
             ub = fminf(ub, v + e);
         });
@@ -1101,11 +1110,12 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
                              const int* __restrict__ tile_group, EpsExtra ex, CompView comp, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
     extern __shared__ int list_s[];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, t_pad, n_rg, list_s);
+    bool several;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, t_pad, n_rg, list_s, 0, &several);
     float ub = 0.f;   // padding columns need nothing
     if (j < t_pad && permT[j] >= 0) {
         ub = __uint_as_float(0x7f800000u);
-        scan_groups(table, (size_t) t_pad, j, n_list, n_rg, list_s, [&](int g, float v) {
+        scan_groups(table, (size_t) t_pad, j, n_list, n_rg, list_s, several ? comp_row(comp, j, 0) : nullptr, [&](int g, float v) {
             float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad, ex);
             ub = fminf(ub, v + e);
         });
@@ -1115,6 +1125,42 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
     for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
     if ((threadIdx.x & 31) == 0 && j < t_pad && ub > 0.f) atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
 }
+// +inf for the table entries a masked pass is about to compute for the first time (the tables hold 10 GB at 1M x 1M and
+// only a fifth of them is ever computed or read: no blanket fill).  Row table: (group of a newly scheduled leaf, the 256
+// rows of the block).  Column table: the columns of the leaf in the block's row group, written by the lowest newly
+// scheduled block of the group unless an earlier pass already computed that (row group, leaf).  Entries that only a
+// boundary stage touches (a stage is computed when any leaf it overlaps is scheduled) may hold anything: nothing reads
+// them until their own (block, leaf) is scheduled, and that initialises them here.
+__global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* __restrict__ sched, const uint8_t* __restrict__ done, int n_rb, int n_leaves,
+                                                                  const int* __restrict__ leaf_g0 /* [n_leaves + 1] */, const int* __restrict__ group_start,
+                                                                  int rg_blocks, int* __restrict__ rowmin, size_t ma_pad, int* __restrict__ colmin, size_t mb_pad) {
+    __shared__ uint8_t s_s[MAXLEAF];   // 0: nothing, 1: rows only, 3: rows and columns
+    const int rb = blockIdx.x, tid = threadIdx.x;
+    const int rg = rb / rg_blocks, rb_lo = rg * rg_blocks, rb_hi = min(n_rb, rb_lo + rg_blocks);
+    for (int l = tid; l < n_leaves; l += BLOCK_ROWS) {
+        uint8_t f = sched[(size_t) rb * n_leaves + l] ? 1 : 0;
+        if (f && colmin) {
+            bool first = true;
+            for (int r = rb_lo; r < rb_hi; ++r) {
+                if (done[(size_t) r * n_leaves + l]) first = false;
+                if (r < rb && sched[(size_t) r * n_leaves + l]) first = false;
+            }
+            if (first) f = 3;
+        }
+        s_s[l] = f;
+    }
+    __syncthreads();
+    constexpr int IINF = 0x7f800000;
+    for (int l = 0; l < n_leaves; ++l) {
+        const uint8_t f = s_s[l];
+        if (!f) continue;
+        const int g0 = leaf_g0[l], g1 = leaf_g0[l + 1];
+        for (int g = g0; g < g1; ++g) rowmin[(size_t) g * ma_pad + (size_t) rb * BLOCK_ROWS + tid] = IINF;
+        if ((f & 2) && g0 < g1)
+            for (int col = group_start[g0] + tid; col < group_start[g1]; col += BLOCK_ROWS) colmin[(size_t) rg * mb_pad + col] = IINF;
+    }
+}
+
 // tile scheduling of one pass (section 3b).  sched_kernel: tiles of the previous pass become done; a tile not yet
 // done is scheduled when  LBsq <= beta_sq * U  of its row block or (both directions) of its leaf.  mask_kernel turns the
 // scheduled (row block, leaf) tiles into stage masks: a stage is computed when any leaf it overlaps is scheduled.
@@ -1223,7 +1269,8 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
                              unsigned* __restrict__ dense, RerankCounters* __restrict__ cnt) {
     extern __shared__ int list_s[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s);
+    bool several;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s, 0, &several);
     if (i >= q_pad) return;
     counts[i] = 0;
     int o = permQ[i];
@@ -1239,7 +1286,8 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     int lg[CAND_KEEP];
 #pragma unroll
     for (int j = 0; j < CAND_KEEP; ++j) { lo[j] = __uint_as_float(0x7f800000u); lg[j] = -1; }
-    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
+    const uint8_t* own = (ROWDIR || !several) ? nullptr : comp_row(comp, i, 0);   // the list is exact unless the block spans two leaves
+    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, own, [&](int g, float v) {
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
         ub = fminf(ub, v + e);
         float l = v - e;
@@ -1257,7 +1305,7 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     int nc = 0;
     if (lo[CAND_KEEP - 1] <= thr) {
         // the kept list may be incomplete: count by a second scan, rerank_emit rescans too (cand[0] = -1)
-        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
+        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, own, [&](int g, float v) {
             float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
             nc += (v - e <= thr) ? 1 : 0;
         });
@@ -1284,7 +1332,8 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
                             unsigned* __restrict__ item_q, unsigned* __restrict__ item_g) {
     extern __shared__ int list_s[];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s);
+    bool several;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s, 0, &several);
     if (i >= q_pad || counts[i] == 0) return;
     int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
     float xq = ROWDIR ? sqrtf(nQ[i]) * 1.0000002f : 0.f;
@@ -1294,7 +1343,7 @@ __global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q
         for (int j = 0; j < counts[i]; ++j) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) cand[(size_t) i * CAND_KEEP + j]; ++pos; }
         return;
     }
-    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, [&](int g, float v) {
+    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, (ROWDIR || !several) ? nullptr : comp_row(comp, i, 0), [&](int g, float v) {
         float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
         if (v - e <= thr) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) g; ++pos; }
     });
@@ -1787,7 +1836,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     unsigned long long* bestA = (unsigned long long*) (rowmin + tab_floats + (tab_floats & 1));
     unsigned long long* bestB = bestA + ma;
     fill_u64<<<cdiv(ma + mb, 256), 256, 0, ctx->stream>>>(bestA, ma + mb, ~0ull);
-    LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
+    // dense mode: +inf everywhere; skipping mode: init_tables_kernel covers what each pass computes (LGR_MATCH_POISON=1, tests: the
+    // rest is filled with 0 -- the most harmful value a stale entry could have -- to show that nothing reads it)
+    if (!prune) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
+    else if (env_int("LGR_MATCH_POISON", 0)) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0, tab_floats, ctx->stream));
     const int n_cc = cdiv(mb_pad, CHUNK_COLS);
     // work items of the persistent MFMA kernel: one row group (the owner of its column minima) x one column chunk
     const int item_rb = both ? std::min(rg_rows / BLOCK_ROWS, 16) : 4;
@@ -1856,6 +1908,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
+        const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
@@ -1867,11 +1920,15 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
         int* group_leaf = (int*) (pb + o_gl);
+        int* leaf_g0 = (int*) (pb + o_lg);
         LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, o_cr - o_done, ctx->stream));   // done, sched, masks, bounds, stats
         {
-            std::vector<int> h(n_groups);
+            std::vector<int> h(n_groups), hl(n_leaves + 1, n_groups);
             for (int g = 0; g < n_groups; ++g) h[g] = h_tiles[tb + h_group_start[g] / TILE];
+            for (int g = n_groups - 1; g >= 0; --g) hl[h[g]] = g;                     // first group of every leaf that has one
+            for (int l = n_leaves - 1; l >= 0; --l) hl[l] = std::min(hl[l], hl[l + 1]);   // empty leaves: g0 == g1
             LGR_HIP(ctx, hipMemcpyAsync(group_leaf, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            LGR_HIP(ctx, hipMemcpyAsync(leaf_g0, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         auto build_comp = [&]() {
@@ -1911,6 +1968,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves, done, sched);
             }
             mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, mask, mstats);
+            init_tables_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
+                                                                     colmin, (size_t) mb_pad);
             LGR_TRY(launch_mfma(mask));
         }
         build_comp();   // final state for the rerank scans

@@ -19,6 +19,9 @@ def matcher_mode(request, monkeypatch):
         monkeypatch.setenv("LGR_MATCH_PRUNE", "1")
         monkeypatch.setenv("LGR_MATCH_NEAR", "2")       # narrow first pass, so that tiles really are skipped at test sizes
         monkeypatch.setenv("LGR_MATCH_SUB", request.param.replace("prune_sub", ""))
+        # the minimum tables are initialised only where a pass computes; everything else is pre-filled with 0 (the most
+        # harmful stale value) to show that no uninitialised entry is ever read
+        monkeypatch.setenv("LGR_MATCH_POISON", "1")
     return request.param
 
 
