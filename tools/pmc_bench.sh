@@ -29,8 +29,13 @@ if 'FETCH_SIZE' in tot and 'WRITE_SIZE' in tot:
     # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB-like units of 1024 B here; on gfx950 FETCH_SIZE
     # tallies wide streaming reads at half their size -> doubled
     fetch = 2.0 * 1024.0 * sum(tot['FETCH_SIZE']); write = 1024.0 * sum(tot['WRITE_SIZE'])
+    fmt = "f16"
+    for line in open('gpurun_out/pmcb_3.log'):
+        if line.startswith('{"metric"'):
+            of = json.loads(line)["roofline"]["operand_format"]
+            fmt = "f16r" if "K = 96" in of else ("f32" if of.startswith("f32") else "f16")
     json.dump({"kernel": "match_mfma (both masked launches of one 1M-pt bench step)", "fetch_bytes_corrected": fetch, "write_bytes": write,
-               "traffic_bytes": fetch + write, "launches": len(tot['FETCH_SIZE']),
+               "traffic_bytes": fetch + write, "launches": len(tot['FETCH_SIZE']), "operand_format": fmt,
                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/pmc_bench.sh; FETCH_SIZE x2 (gfx950)"},
               open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
 PY
