@@ -325,7 +325,9 @@ __global__ void finalize_kernel(lgr_corr* __restrict__ corr, int n, const int32_
 extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params* p,
                                        lgr_corr* d_out, int* n_out) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    LGR_CHECK(ctx, d_src && d_tgt && p && d_out && n_out && ns > 1 && nt > 1, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, (d_src || ns == 0) && (d_tgt || nt == 0) && p && n_out && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
+    if (ns < 2 || nt < 2) { *n_out = 0; return LGR_OK; }   // nothing to match (the reference ends with an empty correspondence list)
+    LGR_CHECK(ctx, d_out != nullptr, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, p->randomness == 1, LGR_ERR_UNSUPPORTED);        // data/test.yaml:14 "currently only 1 is supported"
     LGR_CHECK(ctx, p->feature_nr_points > 0 && p->normal_nr_points >= 1 && p->normal_nr_points <= 64 && p->bf_block_size > 0 && p->scale_factor > 1.f,
               LGR_ERR_INVALID_ARG);
@@ -415,7 +417,9 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
 
 extern "C" int lgr_correspondences(lgr_ctx* ctx, const float* src, int ns, const float* tgt, int nt, const lgr_params* p, lgr_corr* out, int* n_out) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    LGR_CHECK(ctx, src && tgt && p && out && n_out && ns > 1 && nt > 1, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, (src || ns == 0) && (tgt || nt == 0) && p && n_out && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
+    if (ns < 2 || nt < 2) { *n_out = 0; return LGR_OK; }
+    LGR_CHECK(ctx, out != nullptr, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     float *ds, *dt;
     lgr_corr* dc;
@@ -432,9 +436,17 @@ extern "C" int lgr_correspondences(lgr_ctx* ctx, const float* src, int ns, const
 
 extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params* p, lgr_result* res) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    LGR_CHECK(ctx, d_src && d_tgt && p && res && ns > 1 && nt > 1, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, (d_src || ns == 0) && (d_tgt || nt == 0) && p && res && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
     // alignTeaser throws in the reference (src/alignment.cpp:40)
     LGR_CHECK(ctx, p->alignment_id == LGR_ALIGN_RANSAC || p->alignment_id == LGR_ALIGN_GROR, LGR_ERR_UNSUPPORTED);
+    LGR_CHECK(ctx, p->n_samples == 3, LGR_ERR_UNSUPPORTED);
+    if (ns < 2 || nt < 2) {
+        // a cloud without two points gives no correspondences; the reference then leaves the identity, not converged
+        // (selectCorrespondences refuses fewer than n_samples, src/sac_prerejective_omp.cpp:36-42)
+        memset(res, 0, sizeof(*res));
+        for (int i = 0; i < 16; ++i) res->transformation[i] = (i % 5 == 0) ? 1.f : 0.f;
+        return LGR_OK;
+    }
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     auto t0 = std::chrono::steady_clock::now();
     lgr_corr* dc;
@@ -462,7 +474,8 @@ extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const flo
 
 extern "C" int lgr_align(lgr_ctx* ctx, const float* src, int ns, const float* tgt, int nt, const lgr_params* p, lgr_result* res) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    LGR_CHECK(ctx, src && tgt && p && res && ns > 1 && nt > 1, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, (src || ns == 0) && (tgt || nt == 0) && p && res && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
+    if (ns < 2 || nt < 2) return lgr_align_dev(ctx, nullptr, 0, nullptr, 0, p, res);   // identity, not converged
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     float *ds, *dt;
     LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) ns * 12, &ds));
