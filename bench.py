@@ -221,7 +221,7 @@ def main():
             "result": {"converged": int(res.converged), "iterations": int(res.iterations), "n_correspondences": int(res.n_correspondences),
                        "n_inliers": int(res.n_inliers), "max_abs_err_vs_gt": err},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             corr = ctx.correspondences(src, tgt, params).cpu().numpy().view(capi.CORR_DTYPE).reshape(-1)
             t, total, cores, S2 = cpu_baseline(pair, corr, int(res.iterations), args, args.matching)
             out["cpu_baseline"] = {
