@@ -1598,8 +1598,9 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
 // statistics of the last match call (bench/diagnostics): candidate (query, group) items and dense-fallback queries
 // per direction, group counts, and the column stages the MFMA passes executed out of all (row block, stage) pairs
 struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; };
-static lgr_match_stats g_last_stats;
-static double g_last_check[2] = {-1, -1};
+// diagnostics of the calling thread's last match call (one context per host thread)
+static thread_local lgr_match_stats g_last_stats;
+static thread_local double g_last_check[2] = {-1, -1};
 extern "C" int lgr_match_last_stats(unsigned* out6) {
     out6[0] = g_last_stats.items_ab; out6[1] = g_last_stats.dense_ab; out6[2] = g_last_stats.items_ba;
     out6[3] = g_last_stats.dense_ba; out6[4] = (unsigned) g_last_stats.sub_cols; out6[5] = (unsigned) g_last_stats.rg_rows;

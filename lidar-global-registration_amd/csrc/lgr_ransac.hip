@@ -616,11 +616,8 @@ size_t metric_smem() { return (size_t) (30000 + 64) * 4; }
 
 int metric_launch(lgr_ctx* ctx, const float* Ts, const int* list2, int nh2, const Packed& pk, int c, int metric_id, int score_id,
                   float* metric_out, int* ninl_out, float* rmse_out, uint8_t* mask) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        LGR_HIP(ctx, hipFuncSetAttribute((const void*) metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
-        attr_set = true;
-    }
+    // per device, so not cached in a process-wide flag (a process may hold contexts on several GPUs); the call is a host-side table update
+    LGR_HIP(ctx, hipFuncSetAttribute((const void*) metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
     bool need_list = metric_id != LGR_METRIC_UNIFORMITY || rmse_out;
     // hypotheses are processed in waves of at most `wave` workgroups so that the ordered inlier lists stay bounded
     int wave = std::max(1, std::min(nh2, 512));
