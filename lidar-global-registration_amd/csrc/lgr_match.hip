@@ -861,6 +861,96 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
     }
 }
 
+// ---- bounding-box bounds (section 3b).  A leaf's ball is a poor container in 33 dimensions; its axis-aligned box in a
+// fixed orthonormal basis (the principal axes of a sample of both sets) excludes a fifth more tiles at 1M x 1M.  For a row
+// block with box [amin, amax] and a leaf with box [blo, bhi] every pair is at least sqrt(sum_k gap_k^2) apart,
+// gap_k = max(0, amin_k - bhi_k, blo_k - amax_k).  Any orthonormal V gives a valid bound; float rounding of the rotation
+// is taken off every gap (4.1e-6 * largest |x - mu|), the rest is covered like the ball bound's roundings (LB_SHRINK).
+__global__ __launch_bounds__(256) void cov_kernel(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, float* __restrict__ out /* [34][33]: sums, then products */) {
+    __shared__ float acc[34 * 33];
+    for (int i = threadIdx.x; i < 34 * 33; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < ns && smp_ok[r]) {
+        float x[33];
+#pragma unroll
+        for (int k = 0; k < 33; ++k) { x[k] = smp[(size_t) r * 33 + k]; atomicAdd(&acc[k], x[k]); }
+        for (int a = 0; a < 33; ++a)
+            for (int b = a; b < 33; ++b) atomicAdd(&acc[33 + a * 33 + b], x[a] * x[b]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 34 * 33; i += 256) if (acc[i] != 0.f) atomicAdd(&out[i], acc[i]);
+}
+// boxes of row segments in the basis (rows of V, y = V (x - mu)); segments: fixed 256-row blocks (starts == nullptr) or
+// [starts[s], starts[s + 1]).  box[s][0..32] = min, [33..65] = max (transposed: box[c][s]); rmax2: largest |x - mu|^2 seen.
+__global__ __launch_bounds__(256) void box_kernel(const float* __restrict__ Xs, const int* __restrict__ perm, const int* __restrict__ starts, int n_seg,
+                                                  const float* __restrict__ V /* [33][33] */, const float* __restrict__ mu, int transposed,
+                                                  float* __restrict__ box, unsigned* __restrict__ rmax2) {
+    __shared__ float Vs[33 * 33 + 33];
+    __shared__ float red[4][66];
+    for (int i = threadIdx.x; i < 33 * 33; i += 256) Vs[i] = V[i];
+    if (threadIdx.x < 33) Vs[33 * 33 + threadIdx.x] = mu[threadIdx.x];
+    __syncthreads();
+    const int seg = blockIdx.x;
+    const int b = starts ? starts[seg] : seg * BLOCK_ROWS, e = starts ? starts[seg + 1] : (seg + 1) * BLOCK_ROWS;
+    const float inf = __uint_as_float(0x7f800000u);
+    float mn[33], mx[33], r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) { mn[k] = inf; mx[k] = -inf; }
+    for (int r = b + threadIdx.x; r < e; r += 256) {
+        if (perm[r] < 0) continue;
+        float x[33];
+        float n2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 33; ++k) { x[k] = Xs[(size_t) r * 33 + k] - Vs[33 * 33 + k]; n2 = __builtin_fmaf(x[k], x[k], n2); }
+        r2 = fmaxf(r2, n2);
+#pragma unroll 3
+        for (int k = 0; k < 33; ++k) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 33; ++j) y = __builtin_fmaf(Vs[k * 33 + j], x[j], y);
+            mn[k] = fminf(mn[k], y); mx[k] = fmaxf(mx[k], y);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) {
+        float a = mn[k], c = mx[k];
+        for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); c = fmaxf(c, __shfl_xor(c, o)); }
+        if (lane == 0) { red[wave][k] = a; red[wave][33 + k] = c; }
+    }
+    for (int o = 32; o > 0; o >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o));
+    if (lane == 0 && r2 > 0.f && __float_as_uint(r2) > *(volatile unsigned*) rmax2) atomicMax(rmax2, __float_as_uint(r2));
+    __syncthreads();
+    if (threadIdx.x < 66) {
+        const int c = threadIdx.x;
+        float v = red[0][c];
+        for (int w = 1; w < 4; ++w) v = c < 33 ? fminf(v, red[w][c]) : fmaxf(v, red[w][c]);
+        box[transposed ? (size_t) c * n_seg + seg : (size_t) seg * 66 + c] = v;
+    }
+}
+// LBsq[rb][leaf] = max(ball bound, box bound)
+__global__ __launch_bounds__(256) void box_lb_kernel(const float* __restrict__ boxA /* [n_rb][66] */, const float* __restrict__ boxBt /* [66][n_leaves] */,
+                                                     int n_leaves, const unsigned* __restrict__ rmax2, float* __restrict__ LBsq) {
+    __shared__ float a[66];
+    const int rb = blockIdx.x;
+    if (threadIdx.x < 66) a[threadIdx.x] = boxA[(size_t) rb * 66 + threadIdx.x];
+    __syncthreads();
+    const float delta = 4.1e-6f * sqrtf(__uint_as_float(*rmax2)) * 1.01f;
+    for (int g = threadIdx.x; g < n_leaves; g += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 33; ++k) {
+            float gap = fmaxf(a[k] - boxBt[(size_t) (33 + k) * n_leaves + g], boxBt[(size_t) k * n_leaves + g] - a[33 + k]) - delta;
+            if (gap > 0.f) s = __builtin_fmaf(gap, gap, s);
+        }
+        const size_t idx = (size_t) rb * n_leaves + g;
+        const float old = LBsq[idx];
+        const float lb = s * (LB_SHRINK * LB_SHRINK * LB_SHRINK);
+        if (old < FLT_BIG && lb > old && lb < FLT_BIG) LBsq[idx] = lb;
+    }
+}
+
 // the near_t smallest finite entries of a strided vector -> need1 = 1; ties go to the lowest index.  One 256-thread block
 // per vector: the vector is read once into LDS (dynamic: len words), a bitwise radix select finds the near_t-th smallest
 // key (entries are >= 0, so the float bits order like the values), then everything below it and the first ties are marked.
@@ -1634,6 +1724,65 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// Orthonormal basis for the box bounds: principal axes of the k-means sample (both sets).  Covariance on the device,
+// cyclic Jacobi on the host (33 x 33), rows of V = eigenvectors, mu = sample mean.  LGR_MATCH_BOX=2: raw coordinates.
+static int box_basis(lgr_ctx* ctx, const float* smp, const int* smp_ok, int ns, float* d_basis /* [34][33]: V rows, then mu */) {
+    std::vector<float> h(34 * 33, 0.f);
+    if (env_int("LGR_MATCH_BOX", 1) != 2) {
+        LGR_HIP(ctx, hipMemsetAsync(d_basis, 0, 34 * 33 * 4, ctx->stream));
+        cov_kernel<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, d_basis);
+        LGR_HIP(ctx, hipMemcpyAsync(h.data(), d_basis, 34 * 33 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    double n = 0;   // number of sample rows is not returned: recover it from the data only through ratios -> count valid rows on the host side instead
+    std::vector<double> C(33 * 33, 0.0), mu(33, 0.0);
+    std::vector<double> Vd(33 * 33, 0.0);
+    for (int i = 0; i < 33; ++i) Vd[i * 33 + i] = 1.0;
+    // the kernel stores plain sums; the row count is the sum of ok flags, which equals sum(x0 * 1) only if we had a ones column --
+    // use the trace-free route: count rows separately
+    {
+        // count of valid sample rows: h holds sums only, so fetch the flags (ns <= 32768 ints)
+        std::vector<int> ok((size_t) ns);
+        LGR_HIP(ctx, hipMemcpyAsync(ok.data(), smp_ok, (size_t) ns * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int v : ok) n += v ? 1 : 0;
+    }
+    if (n >= 2 && env_int("LGR_MATCH_BOX", 1) != 2) {
+        for (int k = 0; k < 33; ++k) mu[k] = h[k] / n;
+        for (int a = 0; a < 33; ++a)
+            for (int b = a; b < 33; ++b) {
+                double c = h[33 + a * 33 + b] / n - mu[a] * mu[b];
+                C[a * 33 + b] = c; C[b * 33 + a] = c;
+            }
+        for (int sweep = 0; sweep < 12; ++sweep)
+            for (int p = 0; p < 32; ++p)
+                for (int q = p + 1; q < 33; ++q) {
+                    double apq = C[p * 33 + q];
+                    if (std::fabs(apq) < 1e-300) continue;
+                    double theta = (C[q * 33 + q] - C[p * 33 + p]) / (2.0 * apq);
+                    double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                    double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                    for (int k = 0; k < 33; ++k) {
+                        double ckp = C[k * 33 + p], ckq = C[k * 33 + q];
+                        C[k * 33 + p] = c * ckp - sn * ckq; C[k * 33 + q] = sn * ckp + c * ckq;
+                    }
+                    for (int k = 0; k < 33; ++k) {
+                        double cpk = C[p * 33 + k], cqk = C[q * 33 + k];
+                        C[p * 33 + k] = c * cpk - sn * cqk; C[q * 33 + k] = sn * cpk + c * cqk;
+                    }
+                    for (int k = 0; k < 33; ++k) {   // rows of Vd are the eigenvectors
+                        double vpk = Vd[p * 33 + k], vqk = Vd[q * 33 + k];
+                        Vd[p * 33 + k] = c * vpk - sn * vqk; Vd[q * 33 + k] = sn * vpk + c * vqk;
+                    }
+                }
+    }
+    for (int i = 0; i < 33 * 33; ++i) h[i] = (float) Vd[i];
+    for (int k = 0; k < 33; ++k) h[33 * 33 + k] = (float) mu[k];
+    LGR_HIP(ctx, hipMemcpyAsync(d_basis, h.data(), 34 * 33 * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h goes out of scope
+    return LGR_OK;
+}
+
 static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, int mb, int block,
                       int32_t* d_ab_idx, float* d_ab_dist, int32_t* d_ba_idx, float* d_ba_dist) {
     LGR_CHECK(ctx, ctx && (d_a || ma == 0) && (d_b || mb == 0) && (d_ab_idx || ma == 0) && (d_ab_dist || ma == 0), LGR_ERR_INVALID_ARG);
@@ -1910,6 +2059,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_stats = pcarve(sizeof(MaskStats));
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
+        const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4), o_basis = pcarve((size_t) (34 * 33 + 64) * 4);
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
@@ -1940,6 +2090,17 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
         lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
+        if (env_int("LGR_MATCH_BOX", 1)) {
+            float* boxA = (float*) (pb + o_boxa);
+            float* boxBt = (float*) (pb + o_boxb);
+            float* basis = (float*) (pb + o_basis);              // V [33][33], mu [33]
+            unsigned* rmax2 = (unsigned*) (basis + 34 * 33);
+            LGR_TRY(box_basis(ctx, smp, smp_ok, ns, basis));
+            LGR_HIP(ctx, hipMemsetAsync(rmax2, 0, 4, ctx->stream));
+            box_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
+            box_kernel<<<n_leaves, 256, 0, ctx->stream>>>(sortedB, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
+            box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
+        }
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
         auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {
             if (len <= NEAR_LDS_MAX) {
