@@ -48,7 +48,7 @@ constexpr int KM2_ITERS = 4;
 #ifndef LGR_MM_OCC
 #define LGR_MM_OCC 4          // waves per SIMD of match_mfma (2: 256 VGPRs, one workgroup per CU; 4: 128 VGPRs, two)
 #endif
-constexpr int NEAR_T = 64;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured optimum at 1M)
+constexpr int NEAR_T = 48;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured optimum at 1M with the box bounds: 32 / 48 / 64 / 96 -> 84.2 / 83.3 / 84.4 / 87.0 ms per pair)
 #ifndef LGR_PRUNE_BETAS
 #define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
 #endif
@@ -866,20 +866,31 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
 // block with box [amin, amax] and a leaf with box [blo, bhi] every pair is at least sqrt(sum_k gap_k^2) apart,
 // gap_k = max(0, amin_k - bhi_k, blo_k - amax_k).  Any orthonormal V gives a valid bound; float rounding of the rotation
 // is taken off every gap (4.1e-6 * largest |x - mu|), the rest is covered like the ball bound's roundings (LB_SHRINK).
-__global__ __launch_bounds__(256) void cov_kernel(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, float* __restrict__ out /* [34][33]: sums, then products */) {
-    __shared__ float acc[34 * 33];
-    for (int i = threadIdx.x; i < 34 * 33; i += 256) acc[i] = 0.f;
+constexpr int COV_ROWS = 384, COV_THREADS = 640;   // rows per block; 33 sums + 561 products (a <= b) + the row count = 595 workers
+__global__ __launch_bounds__(COV_THREADS) void cov_kernel(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns,
+                                                          float* __restrict__ out /* [34][33]: sums, products (a <= b), then out[34 * 33] = row count */) {
+    __shared__ float rows[COV_ROWS * 33];
+    __shared__ int okr[COV_ROWS];
+    const int r0 = blockIdx.x * COV_ROWS, nr = min(COV_ROWS, ns - r0);
+    for (int i = threadIdx.x; i < nr * 33; i += COV_THREADS) rows[i] = smp[(size_t) r0 * 33 + i];
+    for (int i = threadIdx.x; i < nr; i += COV_THREADS) okr[i] = smp_ok[r0 + i];
     __syncthreads();
-    int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < ns && smp_ok[r]) {
-        float x[33];
-#pragma unroll
-        for (int k = 0; k < 33; ++k) { x[k] = smp[(size_t) r * 33 + k]; atomicAdd(&acc[k], x[k]); }
-        for (int a = 0; a < 33; ++a)
-            for (int b = a; b < 33; ++b) atomicAdd(&acc[33 + a * 33 + b], x[a] * x[b]);
+    const int w = threadIdx.x;
+    if (w > 594) return;
+    float acc = 0.f;
+    if (w < 33) {
+        for (int r = 0; r < nr; ++r) if (okr[r]) acc += rows[r * 33 + w];
+        atomicAdd(&out[w], acc);
+    } else if (w < 594) {
+        int p = w - 33, a = 0;
+        while (p >= 33 - a) { p -= 33 - a; ++a; }   // pair (a, b = a + p)
+        const int b2 = a + p;
+        for (int r = 0; r < nr; ++r) if (okr[r]) acc = __builtin_fmaf(rows[r * 33 + a], rows[r * 33 + b2], acc);
+        atomicAdd(&out[33 + a * 33 + b2], acc);
+    } else {
+        for (int r = 0; r < nr; ++r) acc += okr[r] ? 1.f : 0.f;
+        atomicAdd(&out[34 * 33], acc);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 34 * 33; i += 256) if (acc[i] != 0.f) atomicAdd(&out[i], acc[i]);
 }
 // boxes of row segments in the basis (rows of V, y = V (x - mu)); segments: fixed 256-row blocks (starts == nullptr) or
 // [starts[s], starts[s + 1]).  box[s][0..32] = min, [33..65] = max (transposed: box[c][s]); rmax2: largest |x - mu|^2 seen.
@@ -1726,34 +1737,27 @@ static int env_int(const char* name, int dflt) {
 
 // Orthonormal basis for the box bounds: principal axes of the k-means sample (both sets).  Covariance on the device,
 // cyclic Jacobi on the host (33 x 33), rows of V = eigenvectors, mu = sample mean.  LGR_MATCH_BOX=2: raw coordinates.
-static int box_basis(lgr_ctx* ctx, const float* smp, const int* smp_ok, int ns, float* d_basis /* [34][33]: V rows, then mu */) {
-    std::vector<float> h(34 * 33, 0.f);
-    if (env_int("LGR_MATCH_BOX", 1) != 2) {
-        LGR_HIP(ctx, hipMemsetAsync(d_basis, 0, 34 * 33 * 4, ctx->stream));
-        cov_kernel<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, d_basis);
-        LGR_HIP(ctx, hipMemcpyAsync(h.data(), d_basis, 34 * 33 * 4, hipMemcpyDeviceToHost, ctx->stream));
+static int box_basis(lgr_ctx* ctx, const float* smp, const int* smp_ok, int ns, float* d_basis /* [34][33] + 1: V rows, then mu */) {
+    std::vector<float> h(34 * 33 + 1, 0.f);
+    const bool raw = env_int("LGR_MATCH_BOX", 1) == 2;
+    if (!raw) {
+        LGR_HIP(ctx, hipMemsetAsync(d_basis, 0, (34 * 33 + 1) * 4, ctx->stream));
+        cov_kernel<<<cdiv(ns, COV_ROWS), COV_THREADS, 0, ctx->stream>>>(smp, smp_ok, ns, d_basis);
+        LGR_HIP(ctx, hipMemcpyAsync(h.data(), d_basis, (34 * 33 + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    double n = 0;   // number of sample rows is not returned: recover it from the data only through ratios -> count valid rows on the host side instead
-    std::vector<double> C(33 * 33, 0.0), mu(33, 0.0);
-    std::vector<double> Vd(33 * 33, 0.0);
+    const double n = h[34 * 33];
+    std::vector<double> C(33 * 33, 0.0), mu(33, 0.0), Vd(33 * 33, 0.0);
     for (int i = 0; i < 33; ++i) Vd[i * 33 + i] = 1.0;
-    // the kernel stores plain sums; the row count is the sum of ok flags, which equals sum(x0 * 1) only if we had a ones column --
-    // use the trace-free route: count rows separately
-    {
-        // count of valid sample rows: h holds sums only, so fetch the flags (ns <= 32768 ints)
-        std::vector<int> ok((size_t) ns);
-        LGR_HIP(ctx, hipMemcpyAsync(ok.data(), smp_ok, (size_t) ns * 4, hipMemcpyDeviceToHost, ctx->stream));
-        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int v : ok) n += v ? 1 : 0;
-    }
-    if (n >= 2 && env_int("LGR_MATCH_BOX", 1) != 2) {
+    if (!raw && n >= 2) {
         for (int k = 0; k < 33; ++k) mu[k] = h[k] / n;
         for (int a = 0; a < 33; ++a)
             for (int b = a; b < 33; ++b) {
                 double c = h[33 + a * 33 + b] / n - mu[a] * mu[b];
                 C[a * 33 + b] = c; C[b * 33 + a] = c;
             }
+        // cyclic Jacobi; rows of Vd become the eigenvectors.  Whatever it converges to, Vd stays a product of plane
+        // rotations, i.e. orthonormal -- which is all the bound needs.
         for (int sweep = 0; sweep < 12; ++sweep)
             for (int p = 0; p < 32; ++p)
                 for (int q = p + 1; q < 33; ++q) {
@@ -1770,7 +1774,7 @@ static int box_basis(lgr_ctx* ctx, const float* smp, const int* smp_ok, int ns, 
                         double cpk = C[p * 33 + k], cqk = C[q * 33 + k];
                         C[p * 33 + k] = c * cpk - sn * cqk; C[q * 33 + k] = sn * cpk + c * cqk;
                     }
-                    for (int k = 0; k < 33; ++k) {   // rows of Vd are the eigenvectors
+                    for (int k = 0; k < 33; ++k) {
                         double vpk = Vd[p * 33 + k], vqk = Vd[q * 33 + k];
                         Vd[p * 33 + k] = c * vpk - sn * vqk; Vd[q * 33 + k] = sn * vpk + c * vqk;
                     }
@@ -2059,7 +2063,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_stats = pcarve(sizeof(MaskStats));
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
-        const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4), o_basis = pcarve((size_t) (34 * 33 + 64) * 4);
+        const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4), o_basis = pcarve((size_t) (34 * 33 + 64) * 4);   // V, mu, count / rmax2
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
@@ -2094,7 +2098,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             float* boxA = (float*) (pb + o_boxa);
             float* boxBt = (float*) (pb + o_boxb);
             float* basis = (float*) (pb + o_basis);              // V [33][33], mu [33]
-            unsigned* rmax2 = (unsigned*) (basis + 34 * 33);
+            unsigned* rmax2 = (unsigned*) (basis + 34 * 33 + 8);
             LGR_TRY(box_basis(ctx, smp, smp_ok, ns, basis));
             LGR_HIP(ctx, hipMemsetAsync(rmax2, 0, 4, ctx->stream));
             box_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
