@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void box_lb_kernel(const float* __restrict__ b
         const size_t idx = (size_t) rb * n_leaves + g;
         const float old = LBsq[idx];
         const float lb = s * (LB_SHRINK * LB_SHRINK * LB_SHRINK);
-        if (old < FLT_BIG && lb > old && lb < FLT_BIG) LBsq[idx] = lb;
+        if (old < FLT_BIG && lb > old && lb < FLT_BIG) LBsq[idx] = lb;   // (the box alone: 19.4 % of the tiles, the ball alone 22.2 %, both 17.4 %)
     }
 }
 
@@ -2149,6 +2149,16 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             fprintf(stderr, "[lgr] stages per pass:");
             for (int k = 0; k <= n_beta; ++k) fprintf(stderr, " %llu", hs->stages[k]);
             fprintf(stderr, " of %.0f (n_rb %d n_cc %d item_rb %d leaves %d)\n", g_last_stats.stages_all, n_rb, n_cc, item_rb, n_leaves);
+            // what the schedule asks for at leaf granularity (the stages computed above also cover the neighbours' boundary tiles)
+            std::vector<uint8_t> hd((size_t) n_rb * n_leaves), hsch((size_t) n_rb * n_leaves);
+            LGR_HIP(ctx, hipMemcpy(hd.data(), done, hd.size(), hipMemcpyDeviceToHost));
+            LGR_HIP(ctx, hipMemcpy(hsch.data(), sched, hsch.size(), hipMemcpyDeviceToHost));
+            double need_cols = 0;
+            for (int rb = 0; rb < n_rb; ++rb)
+                for (int l = 0; l < n_leaves; ++l)
+                    if (hd[(size_t) rb * n_leaves + l] | hsch[(size_t) rb * n_leaves + l]) need_cols += B.h_leaf_start[l + 1] - B.h_leaf_start[l];
+            fprintf(stderr, "[lgr] scheduled (row block, leaf) pairs cover %.4f of the tiles; computed stages %.4f\n",
+                    need_cols / ((double) n_rb * mb_pad), g_last_stats.stages_done / g_last_stats.stages_all);
         }
     }
     LGR_HIP(ctx, hipGetLastError());

@@ -22,7 +22,18 @@ def main():
     la = two_level(fa, 16, 64, 1); lb = two_level(fb, 16, 64, 2)
     oka, okb = torch.isfinite(fa).all(1), torch.isfinite(fb).all(1)
     fa, la, fb, lb = fa[oka], la[oka], fb[okb], lb[okb]
-    oa, ob = torch.argsort(la, stable=True), torch.argsort(lb, stable=True)
+    mode = sys.argv[3] if len(sys.argv) > 3 else "leaf"
+    if mode == "pc1":        # rows inside a leaf ordered along the first global principal axis: row blocks become slabs
+        mu0 = fb.mean(0, keepdim=True)
+        _, _, V0 = torch.pca_lowrank(fb - mu0, q=2, center=False)
+        key = ((fa - mu0) @ V0[:, 0])
+        oa = torch.argsort(key); oa = oa[torch.argsort(la[oa], stable=True)]
+    elif mode == "radial":   # rows inside a leaf ordered by the distance to the global mean (like the cluster-centre order in use)
+        key = (fa - fa.mean(0, keepdim=True)).norm(dim=1)
+        oa = torch.argsort(key); oa = oa[torch.argsort(la[oa], stable=True)]
+    else:
+        oa = torch.argsort(la, stable=True)
+    ob = torch.argsort(lb, stable=True)
     fas, fbs, lbs = fa[oa], fb[ob], lb[ob]
     nblk = fas.shape[0] // RB
     fas = fas[: nblk * RB]
