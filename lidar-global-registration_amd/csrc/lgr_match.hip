@@ -252,15 +252,18 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
         bool ok = row_finite(X + (size_t) i * 33, v);
         unsigned key = 0xffffffffu;
         if (ok) {
+            // a finite row whose squared distance to every centre overflows float stays a valid row (its exact distance to
+            // a duplicate of itself is 0 in the reference); it lands in leaf 0 of cluster 0 with an infinite radius, and
+            // the overflow sends the whole call down the exact dense path (match_impl, force_dense)
             int c = nearest_centre(v, cen, r2);
-            if (r2 < FLT_BIG) {
-                float rl2;
-                int j = nearest_sub(v, c2s + c * pitch, sub, rl2);
-                int leaf = c * sub + j;
-                key = ((unsigned) leaf << 22) | (__float_as_uint(r2) >> 9);
-                atomicAdd(&lc[leaf], 1);
-                atomicMax(&lr[leaf], __float_as_uint(rl2));
-            } else ok = false;
+            float rl2;
+            int j = nearest_sub(v, c2s + c * pitch, sub, rl2);
+            if (!(r2 < FLT_BIG)) r2 = __uint_as_float(0x7f800000u);
+            if (!(rl2 < FLT_BIG)) rl2 = __uint_as_float(0x7f800000u);
+            int leaf = c * sub + j;
+            key = ((unsigned) leaf << 22) | (__float_as_uint(r2) >> 9);
+            atomicAdd(&lc[leaf], 1);
+            atomicMax(&lr[leaf], __float_as_uint(rl2));
         }
         if (!ok) atomicAdd(&lc[MAXLEAF], 1);
         keys[i] = key; vals[i] = i; valid[i] = ok ? 1 : 0;
@@ -288,7 +291,7 @@ __global__ void place_kernel(const unsigned* __restrict__ keys_sorted, const int
 // padding positions (perm < 0): rows [0.., 1] / cols [0.., +inf], nrm = +inf
 __global__ void pack_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
                             const float* __restrict__ cen, const int* __restrict__ blkcl,
-                            float* __restrict__ P, float* __restrict__ nrm) {
+                            float* __restrict__ P, float* __restrict__ nrm, unsigned* __restrict__ ovf) {
     int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= n_pad) return;
     int set = role == 1 ? blockIdx.y : 0;
@@ -305,6 +308,7 @@ __global__ void pack_kernel(const float* __restrict__ X, const int* __restrict__
         n2 = __uint_as_float(0x7f800000u);
     }
     nrm[(size_t) set * n_pad + pos] = n2;
+    if (o >= 0 && !(n2 < FLT_BIG)) *ovf = 1u;   // |x'|^2 overflows float: the filter cannot represent this row
     int tile = pos >> 5, r = pos & 31;
     float* base = P + ((size_t) set * (n_pad / TILE) + tile) * KK * 64 + r;
 #pragma unroll
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X
         for (int k = 0; k < 11; ++k) { s0 += (double) v[k]; s1 += (double) v[11 + k]; s2 += (double) v[22 + k]; }
         float d2 = (o >= 0 && in_range) ? (float) (((s0 * s0 + s1 * s1) + s2 * s2) * (1.0001 / 11.0)) * 1.000001f + 1e-20f * n2 : 0.f;
         drop = fmaxf(drop, d2);
+        if (o >= 0 && in_range && !(n2 < FLT_BIG)) drop_max[1] = 1u;   // |x'|^2 overflows float: the filter cannot represent this row
         continue;
     }
     float y[30], u0, u1, u2;
@@ -1365,7 +1370,7 @@ template <bool ROWDIR>
 __global__ void rerank_count(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                              const float* __restrict__ nQ /* ROWDIR: |a'|^2 per padded row */, const int* __restrict__ blkclQ,
                              const float* __restrict__ nQ_sets /* COLDIR: |b - c_p|^2 [KCL][q_pad] */, const float* __restrict__ gmax,
-                             const int* __restrict__ cl_of_group, int dense_limit, EpsExtra ex, CompView comp,
+                             const int* __restrict__ cl_of_group, int dense_limit /* < 0: every query takes the dense path */, EpsExtra ex, CompView comp,
                              float* __restrict__ thr_out, int* __restrict__ counts, int* __restrict__ cand /* [q_pad][CAND_KEEP] */,
                              unsigned* __restrict__ dense, RerankCounters* __restrict__ cnt) {
     extern __shared__ int list_s[];
@@ -1376,6 +1381,11 @@ __global__ void rerank_count(const float* __restrict__ table, int n_groups, int 
     counts[i] = 0;
     int o = permQ[i];
     if (o < 0) return;
+    if (dense_limit < 0) {   // the filter is not usable for this call (a centred norm overflows float): exact brute force
+        unsigned pos = atomicAdd(&cnt->n_dense, 1u);
+        dense[pos] = (unsigned) o;
+        return;
+    }
     int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
     float nq = ROWDIR ? nQ[i] : 0.f;
     float xq = ROWDIR ? sqrtf(nq) * 1.0000002f : 0.f;
@@ -1639,7 +1649,7 @@ template <bool ROWDIR>
 int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
                const float* nQ, const float* nQ_sets, const float* gmax, const int* cl_of_group,
                const float* T, const float* Tsorted, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
-               unsigned* stat_items, unsigned* stat_dense) {
+               unsigned* stat_items, unsigned* stat_dense, bool force_dense) {
     const int q_pad = qs.n_pad;
     unsigned* dense;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_DENSE, (size_t) q_pad * (4 + CAND_KEEP) + 64, &dense));
@@ -1652,7 +1662,7 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
     RerankCounters* cnt = (RerankCounters*) (misc + 64);
     LGR_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(RerankCounters), ctx->stream));
     int nblocks = (ts.m + block - 1) / block;
-    int dense_limit = std::max(64, n_groups / 2);
+    int dense_limit = force_dense ? -1 : std::max(64, n_groups / 2);
     rerank_count<ROWDIR><<<cdiv(q_pad, 256), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(table, n_groups, q_pad, qs.perm, nQ, qs.blkcl, nQ_sets, gmax,
                                                                    cl_of_group, dense_limit, ex, comp, thr, counts, cand, dense, cnt);
     size_t tb = 0;
@@ -1872,22 +1882,24 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     float *nAp, *nBp;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_NORMS, (size_t) ma_pad + (size_t) KCL * mb_pad + 64, &nAp));
     nBp = nAp + ma_pad;
+    unsigned* d_max = (unsigned*) (misc + 128);   // [0] largest finite norm, [1] dropped energy, [2] norm overflow flag
+    LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 12, ctx->stream));
+    bool force_dense = false;
     if (f16) {
         // norms first: the power-of-two scale 2^s puts the largest operand (2 |a'| 2^s, |b'| 2^s) just under 2^15; the same
         // pass measures the largest energy of the three coordinates the rotated 30-D format would drop
-        unsigned* d_max = (unsigned*) (misc + 128);
-        LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 8, ctx->stream));
         pack16_kernel<false, true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, nullptr, nAp, d_max + 1);
         pack16_kernel<false, true><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp, d_max + 1);
         norm_max_kernel<<<std::min(cdiv(ma_pad, 256), 2048), 256, 0, ctx->stream>>>(nAp, (size_t) ma_pad, d_max);
         norm_max_kernel<<<std::min(cdiv((long long) KCL * mb_pad, 256), 2048), 256, 0, ctx->stream>>>(nBp, (size_t) KCL * mb_pad, d_max);
         unsigned* h_max;
         LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_max));
-        LGR_HIP(ctx, hipMemcpyAsync(h_max, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(h_max, d_max, 12, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         float r2, drop2;
         memcpy(&r2, h_max, 4);
         memcpy(&drop2, h_max + 1, 4);
+        force_dense = h_max[2] != 0u;
         // Rotated format (FMT_F16R) when what it drops is negligible: with u the dropped coordinates of a row relative to a
         // centre, d2 = d2_30 + |u_a - u_b|^2 and 0 <= |u_a - u_b|^2 <= 4 max |u|^2 -- that bound joins the absolute error
         // term, so the choice below only trades speed.  FPFH rows: every block sums to 100 -> max |u|^2 ~ 1e-7.
@@ -1930,8 +1942,13 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const size_t b_op_bytes = KCL * bset_stride * frag_bytes;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_COLMIN, b_op_bytes + 256, &Bop));
     if (!f16) {
-        pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, (float*) Aop, nAp);
-        pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, (float*) Bop, nBp);
+        pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, (float*) Aop, nAp, d_max + 2);
+        pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, (float*) Bop, nBp, d_max + 2);
+        unsigned* h_ovf;
+        LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_ovf));
+        LGR_HIP(ctx, hipMemcpyAsync(h_ovf, d_max + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        force_dense = h_ovf[0] != 0u;
     } else {
         if (rot) {
             pack16_kernel<true, false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, nullptr);
@@ -2185,10 +2202,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
 
     // ---- 5. exact rerank
     LGR_TRY((run_rerank<true>(ctx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
-                              d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab)));
+                              d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab, force_dense)));
     if (both)
         LGR_TRY((run_rerank<false>(ctx, ex, comp_cols, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
-                                   d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba)));
+                                   d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba, force_dense)));
     return LGR_OK;
 }
 

@@ -197,3 +197,12 @@ def test_rotated_format_selection(lgr, oracle, monkeypatch, matcher_mode):
     b[77, 3] += 0.25
     run_both(lgr, oracle, a, b, 1000)
     assert lgr.match_format() == "f16"
+
+
+def test_extreme_magnitudes_do_not_break_the_bounds(lgr, oracle, matcher_mode):
+    """Rows of magnitude 1e18 beside ordinary ones: squared norms and the sample covariance of the box-bound basis overflow
+    float.  Bounds that cannot be evaluated must switch themselves off, never skip a tile: results stay the oracle's."""
+    rng = np.random.default_rng(31)
+    a, b = fpfh_like(rng, 3000), fpfh_like(rng, 4000)
+    a[::97] *= 1e18; b[::89] *= 1e18; b[5] = a[97]; a[11] = b[89 * 3]
+    run_both(lgr, oracle, a, b, 1500)

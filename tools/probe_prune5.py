@@ -19,7 +19,8 @@ def main():
     ctx.sync()
     RB, T = 256, 64
     NPC = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    la = two_level(fa, 16, 64, 1); lb = two_level(fb, 16, 64, 2)
+    K2 = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+    la = two_level(fa, 16, K2, 1); lb = two_level(fb, 16, K2, 2)
     oka, okb = torch.isfinite(fa).all(1), torch.isfinite(fb).all(1)
     fa, la, fb, lb = fa[oka], la[oka], fb[okb], lb[okb]
     mode = sys.argv[3] if len(sys.argv) > 3 else "leaf"
