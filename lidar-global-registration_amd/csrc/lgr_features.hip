@@ -74,15 +74,22 @@ __global__ void voxel_accumulate(const float* __restrict__ pts, const unsigned l
 constexpr int NB = 128;
 
 // pcl::NormalEstimationOMP (k-NN) + flipNormalTowardsViewpoint + postprocessNormals; see oracle orc_normals_knn.
+// by_grid: the queries are the surface points themselves; thread t takes the point at sorted position t of the grid, so a
+// wave's 64 queries sit in one or two cells and walk the same rings (coherent loops and loads); points that are not in the
+// grid (non-finite) are written by the `else` branch of a second launch over the original order (by_grid = 2).
 __global__ __launch_bounds__(NB) void normals_kernel(GridDev g, const float* __restrict__ surf, float* __restrict__ pts, int n,
-                                                      int k, float vpx, float vpy, float vpz) {
+                                                      int k, float vpx, float vpy, float vpz, int by_grid) {
     extern __shared__ float smem[];
     float* sd = smem;
     int* si = (int*) (smem + (size_t) k * NB);
     int i = blockIdx.x * NB + threadIdx.x;
-    if (i >= n) return;
+    if (by_grid == 1) {
+        if (i >= g.n) return;
+        i = __float_as_int(g.pxyz[i].w);
+    } else if (i >= n) return;
     float* p = pts + (size_t) i * 12;
     float px = p[0], py = p[1], pz = p[2];
+    if (by_grid == 2 && lgr_finite3(px, py, pz)) return;   // done by the grid-ordered launch
     KnnList<NB> L;
     L.init(sd, si, k, threadIdx.x);
     if (lgr_finite3(px, py, pz) && g.n > 0) lgr_knn_query(g, px, py, pz, L);
@@ -420,7 +427,13 @@ extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const floa
     GridDev g;
     LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, S, ns, 0.f, 4.f, &g));
     size_t sm = (size_t) k * NB * 8;
-    normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vp3 ? vp3[0] : 0.f, vp3 ? vp3[1] : 0.f, vp3 ? vp3[2] : 0.f);
+    const float vx = vp3 ? vp3[0] : 0.f, vy = vp3 ? vp3[1] : 0.f, vz = vp3 ? vp3[2] : 0.f;
+    if (!d_surf) {
+        if (g.n > 0) normals_kernel<<<cdiv(g.n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 1);
+        if (g.n < n) normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 2);   // non-finite points: NaN normals
+    } else {
+        normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 0);
+    }
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
