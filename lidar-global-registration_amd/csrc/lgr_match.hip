@@ -207,8 +207,14 @@ __device__ __forceinline__ int nearest_sub(const float* v, const float* __restri
     }
     return bj;
 }
-__global__ void km2_accum(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen2, int sub,
-                          float* __restrict__ sums2 /* [KCL*sub][34] */) {
+constexpr int KM2_THREADS = 512;
+__global__ __launch_bounds__(KM2_THREADS) void km2_accum(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen2, int sub,
+                                                         float* __restrict__ sums2 /* [KCL*sub][34] */) {
+    // sub-centres of all clusters in LDS (odd pitch per cluster, as in assign_kernel): no per-lane gathers from global memory
+    extern __shared__ float c2s[];
+    const int pitch = sub * 33 + 1;
+    for (int e = threadIdx.x; e < KCL * sub * 33; e += blockDim.x) c2s[(e / (sub * 33)) * pitch + e % (sub * 33)] = cen2[e];
+    __syncthreads();
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ns) return;
     int p = label[s];
@@ -216,7 +222,7 @@ __global__ void km2_accum(const float* __restrict__ smp, const int* __restrict__
     float v[33], d;
 #pragma unroll
     for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
-    int j = nearest_sub(v, cen2 + (size_t) p * sub * 33, sub, d);
+    int j = nearest_sub(v, c2s + p * pitch, sub, d);
     float* dst = sums2 + ((size_t) p * sub + j) * 34;
     for (int k = 0; k < 33; ++k) atomicAdd(&dst[k], v[k]);
     atomicAdd(&dst[33], 1.0f);
@@ -830,39 +836,50 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
     okr[threadIdx.x] = permA[rb * BLOCK_ROWS + threadIdx.x] >= 0;
     __syncthreads();
     typedef float v2f __attribute__((ext_vector_type(2)));
-    for (int g = threadIdx.x; g < n_leaves; g += 256) {
-        float out = __uint_as_float(0x7f800000u);
-        if (leaf_count[g] > 0) {
-            // |a - c|^2 on packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: two coordinates per instruction, even and odd
-            // coordinates in separate accumulators); any summation order is fine here, the bound carries 1e-5 of slack
-            v2f c2[16];
-            float c32;
+    // |a - c|^2 on packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: two coordinates per instruction, even and odd coordinates
+    // in separate accumulators); any summation order is fine here, the bound carries 1e-5 of slack.  Two leaves per thread
+    // and row pass: every row read from LDS feeds two centres.
+    for (int g0 = threadIdx.x; g0 < n_leaves; g0 += 2 * 256) {
+        const int g1 = g0 + 256;
+        const bool h1 = g1 < n_leaves;
+        v2f c0[16], c1[16];
+        float c032, c132;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { c2[k].x = cen2[(size_t) g * 33 + 2 * k]; c2[k].y = cen2[(size_t) g * 33 + 2 * k + 1]; }
-            c32 = cen2[(size_t) g * 33 + 32];
-            float dmin = __uint_as_float(0x7f800000u);
-            for (int i = 0; i < BLOCK_ROWS; ++i) {
-                if (!okr[i]) continue;
-                const float* __restrict__ r = rows + i * ROW_LD;
-                v2f d = {0.f, 0.f};
+        for (int k = 0; k < 16; ++k) {
+            c0[k].x = cen2[(size_t) g0 * 33 + 2 * k]; c0[k].y = cen2[(size_t) g0 * 33 + 2 * k + 1];
+            c1[k].x = h1 ? cen2[(size_t) g1 * 33 + 2 * k] : 0.f; c1[k].y = h1 ? cen2[(size_t) g1 * 33 + 2 * k + 1] : 0.f;
+        }
+        c032 = cen2[(size_t) g0 * 33 + 32]; c132 = h1 ? cen2[(size_t) g1 * 33 + 32] : 0.f;
+        float dmin0 = __uint_as_float(0x7f800000u), dmin1 = dmin0;
+        for (int i = 0; i < BLOCK_ROWS; ++i) {
+            if (!okr[i]) continue;
+            const float* __restrict__ r = rows + i * ROW_LD;
+            v2f d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < 16; ++k) {
 #pragma clang fp contract(fast)
-                    v2f a = *reinterpret_cast<const v2f*>(r + 2 * k);
-                    v2f t = a - c2[k];
-                    d = t * t + d;
-                }
-                float t32 = r[32] - c32;
-                float dd = __builtin_fmaf(t32, t32, d.x + d.y);
-                dmin = fminf(dmin, dd);
+                v2f a = *reinterpret_cast<const v2f*>(r + 2 * k);
+                v2f t0 = a - c0[k], t1 = a - c1[k];
+                d0 = t0 * t0 + d0; d1 = t1 * t1 + d1;
             }
-            if (dmin < FLT_BIG) {
+            const float r32 = r[32];
+            float t0 = r32 - c032, t1 = r32 - c132;
+            dmin0 = fminf(dmin0, __builtin_fmaf(t0, t0, d0.x + d0.y));
+            dmin1 = fminf(dmin1, __builtin_fmaf(t1, t1, d1.x + d1.y));
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int g = w ? g1 : g0;
+            if (g >= n_leaves) break;
+            const float dmin = w ? dmin1 : dmin0;
+            float out = __uint_as_float(0x7f800000u);
+            if (leaf_count[g] > 0 && dmin < FLT_BIG) {
                 float lb = sqrtf(dmin) * LB_SHRINK - sqrtf(__uint_as_float(r2max[g])) * LB_GROW;
                 lb = lb > 0.f ? lb : 0.f;
                 out = lb * lb * LB_SHRINK;
             }
+            LBsq[(size_t) rb * n_leaves + g] = out;
         }
-        LBsq[(size_t) rb * n_leaves + g] = out;
     }
 }
 
@@ -1850,7 +1867,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     if (sub > 1) {
         LGR_HIP(ctx, hipMemsetAsync(sums2, 0, (size_t) n_leaves * 34 * 4, ctx->stream));
         for (int it = 0; it < KM2_ITERS; ++it) {
-            km2_accum<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, label, ns, cen2, sub, sums2);
+            const size_t km2_lds = (size_t) KCL * (sub * 33 + 1) * 4;
+            if (km2_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) km2_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
+            km2_accum<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, ctx->stream>>>(smp, label, ns, cen2, sub, sums2);
             km2_update<<<cdiv(n_leaves, 64), 64, 0, ctx->stream>>>(cen2, sums2, n_leaves);
         }
     }
