@@ -42,7 +42,10 @@ constexpr int PAD = 256;
 constexpr int KCL = 16;             // k-means centres (operand centring)
 constexpr int SUBMAX = 64;          // second-level centres per cluster ("leaves": sort order + skip bounds)
 constexpr int MAXLEAF = KCL * SUBMAX;
-constexpr int KM_SAMPLE = 16384;    // sample rows per side
+#ifndef LGR_KM_SAMPLE
+#define LGR_KM_SAMPLE 16384
+#endif
+constexpr int KM_SAMPLE = LGR_KM_SAMPLE;    // sample rows per side
 #ifndef LGR_KM_ITERS
 #define LGR_KM_ITERS 16   // Lloyd iterations, first / second level (6 / 4 -> 10 / 8 -> 16 / 8: 81.7 -> 80.2 -> 79.5 ms per 1M pair; tighter leaves)
 #endif
