@@ -61,7 +61,10 @@ constexpr int NEAR_T = 48;          // pass 0 visits the NEAR_T nearest leaves o
 #ifndef LGR_PRUNE_BETAS
 #define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
 #endif
-constexpr int GROUP_COLS = 1024;     // largest column group of the row-minimum table (leaves are cut into such pieces)
+#ifndef LGR_GROUP_COLS
+#define LGR_GROUP_COLS 1024
+#endif
+constexpr int GROUP_COLS = LGR_GROUP_COLS;     // largest column group of the row-minimum table (leaves are cut into such pieces)
 constexpr int STAGES_PER_CHUNK = CHUNK_COLS / STAGE_COLS;   // 32 -> one 32-bit stage mask per (row block, chunk)
 constexpr float FLT_BIG = 3.4028234663852886e38f;
 
