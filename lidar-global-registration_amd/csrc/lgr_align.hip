@@ -20,10 +20,16 @@ __device__ __forceinline__ float corr_threshold(float a, float b, float dthr) {
     return (dthr < m) ? dthr : m;       // std::min(m, dthr)
 }
 
-// calculateCorrespondenceDistance (include/matching.h:524-550) with randomness = 1
+// calculateCorrespondenceDistance (include/matching.h:524-550) with randomness = 1: of the k spatial neighbours of i that
+// have a match, the share whose match is NOT among the k spatial neighbours of j.  The neighbour list of j is read once
+// into registers (KMAX ints), so the k x k membership test touches no memory (it was 1600 dependent global loads per
+// correspondence and direction: 44 ms at 1M in the cluster mode).
+template <int KMAX>
 __device__ __forceinline__ float cluster_distance(int i, int j, int k, const int32_t* __restrict__ knn_a, const int32_t* __restrict__ knn_b,
                                                    const int32_t* __restrict__ ab_idx) {
-    const int32_t* nb = knn_b + (size_t) j * k;
+    int nb[KMAX];
+#pragma unroll
+    for (int b = 0; b < KMAX; ++b) nb[b] = b < k ? knn_b[(size_t) j * k + b] : -2;   // -2 never equals a match index
     int consistent = 0, pairs = 0;
     for (int a = 0; a < k; ++a) {
         int in = knn_a[(size_t) i * k + a];
@@ -31,7 +37,8 @@ __device__ __forceinline__ float cluster_distance(int i, int j, int k, const int
         int mt = ab_idx[in];
         if (mt < 0) continue;
         bool hit = false;
-        for (int b = 0; b < k; ++b) hit = hit || (nb[b] == mt);
+#pragma unroll
+        for (int b = 0; b < KMAX; ++b) hit = hit || (nb[b] == mt);
         consistent += hit ? 1 : 0;
         pairs++;
     }
@@ -39,6 +46,7 @@ __device__ __forceinline__ float cluster_distance(int i, int j, int k, const int
     return 1.f - (float) consistent / (float) pairs;
 }
 
+template <int KMAX>
 __global__ void filter_flags(int matching_id, int ns, const int32_t* __restrict__ ij, const float* __restrict__ dij,
                              const int32_t* __restrict__ ji, const float* __restrict__ dji,
                              const int32_t* __restrict__ knn_s, const int32_t* __restrict__ knn_t, int k,
@@ -52,8 +60,8 @@ __global__ void filter_flags(int matching_id, int ns, const int32_t* __restrict_
         if (matching_id == LGR_MATCH_ONE_SIDED) { keep = 1; d = dij[i]; }
         else if (matching_id == LGR_MATCH_LR) { keep = ji[j] == i ? 1 : 0; d = dji[j]; }   // reverse-direction distance (:444)
         else {
-            float di = cluster_distance(i, j, k, knn_s, knn_t, ij);
-            float dj = cluster_distance(j, i, k, knn_t, knn_s, ji);
+            float di = cluster_distance<KMAX>(i, j, k, knn_s, knn_t, ij);
+            float dj = cluster_distance<KMAX>(j, i, k, knn_t, knn_s, ji);
             keep = (di < 0.95f && dj < 0.95f) ? 1 : 0;      // MATCHING_CLUSTER_THRESHOLD include/common.h:52
             d = (di < dj) ? dj : di;                         // std::max(distance_i, distance_j)
         }
@@ -112,7 +120,9 @@ extern "C" int lgr_filter_dev(lgr_ctx* ctx, int matching_id, const float* d_src,
     float* dist;
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_FLAGS, (size_t) ns * 3 + 16, &flags));
     pos = flags + ns; dist = (float*) (pos + ns);
-    filter_flags<<<cdiv(ns, 128), 128, 0, ctx->stream>>>(matching_id, ns, d_ij_idx, d_ij_dist, d_ji_idx, d_ji_dist, knn_s, knn_t, cluster_k, flags, dist);
+    if (matching_id != LGR_MATCH_CLUSTER) filter_flags<1><<<cdiv(ns, 128), 128, 0, ctx->stream>>>(matching_id, ns, d_ij_idx, d_ij_dist, d_ji_idx, d_ji_dist, knn_s, knn_t, cluster_k, flags, dist);
+    else if (cluster_k <= 40) filter_flags<40><<<cdiv(ns, 128), 128, 0, ctx->stream>>>(matching_id, ns, d_ij_idx, d_ij_dist, d_ji_idx, d_ji_dist, knn_s, knn_t, cluster_k, flags, dist);
+    else filter_flags<64><<<cdiv(ns, 128), 128, 0, ctx->stream>>>(matching_id, ns, d_ij_idx, d_ij_dist, d_ji_idx, d_ji_dist, knn_s, knn_t, cluster_k, flags, dist);
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, flags, pos, 0, (size_t) ns, rocprim::plus<int>(), ctx->stream));
     void* tmp;

@@ -102,15 +102,22 @@ __global__ void gather_points(const float* __restrict__ pts, const int* __restri
 constexpr int KNN_BLOCK = 128;
 
 // mode 0: full table idx/d2 [nq][k];  mode 1: dk[i] = sqrt(d2[k-1]) (NaN if fewer), nn1[i] = idx[1] (i if fewer)
+// by_grid (the queries are the grid's own points): 1 = thread t takes the point at sorted position t, so a wave's queries
+// sit in one or two cells and walk the same rings; 2 = second launch in the original order for the points that are not in
+// the grid (non-finite); 0 = queries in the order given.
 template <int MODE>
 __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(GridDev g, const float* __restrict__ q, int nq, int k,
-                                                        int32_t* __restrict__ idx, float* __restrict__ d2) {
+                                                        int32_t* __restrict__ idx, float* __restrict__ d2, int by_grid) {
     extern __shared__ float smem[];
     float* sd = smem;
     int* si = (int*) (smem + (size_t) k * KNN_BLOCK);
     int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
-    if (i >= nq) return;
+    if (by_grid == 1) {
+        if (i >= g.n) return;
+        i = __float_as_int(g.pxyz[i].w);
+    } else if (i >= nq) return;
     float x = q[(size_t) i * 12], y = q[(size_t) i * 12 + 1], z = q[(size_t) i * 12 + 2];
+    if (by_grid == 2 && lgr_finite3(x, y, z)) return;   // done by the grid-ordered launch
     KnnList<KNN_BLOCK> L;
     L.init(sd, si, k, threadIdx.x);
     if (lgr_finite3(x, y, z) && g.n > 0) lgr_knn_query(g, x, y, z, L);
@@ -241,7 +248,12 @@ extern "C" int lgr_knn_dev(lgr_ctx* ctx, const float* d_q, int nq, const float* 
     GridDev g;
     LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, 4.f, &g));
     size_t sm = (size_t) k * KNN_BLOCK * 8;
-    knn_kernel<0><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2);
+    if (d_q == d_pts && nq == n) {
+        if (g.n > 0) knn_kernel<0><<<cdiv(g.n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 1);
+        if (g.n < nq) knn_kernel<0><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 2);
+    } else {
+        knn_kernel<0><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 0);
+    }
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
@@ -257,7 +269,8 @@ extern "C" int lgr_smoothed_densities_dev(lgr_ctx* ctx, const float* d_pts, int 
     LGR_TRY(lgr_ws_t(ctx, WS_DENS_A, (size_t) n, &dk));
     LGR_TRY(lgr_ws_t(ctx, WS_DENS_B, (size_t) n, &nn1));
     size_t sm = (size_t) k * KNN_BLOCK * 8;
-    knn_kernel<1><<<cdiv(n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_pts, n, k, nn1, dk);
+    if (g.n > 0) knn_kernel<1><<<cdiv(g.n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_pts, n, k, nn1, dk, 1);
+    if (g.n < n) knn_kernel<1><<<cdiv(n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_pts, n, k, nn1, dk, 2);
     density_min<<<cdiv(n, 256), 256, 0, ctx->stream>>>(dk, nn1, n, d_out);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
