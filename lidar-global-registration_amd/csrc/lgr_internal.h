@@ -63,7 +63,7 @@ enum {
     WS_GRID_A, WS_GRID_B = WS_GRID_A + 7, WS_GRID_C = WS_GRID_B + 7, WS_GRID_TMP = WS_GRID_C + 7, WS_GRID_MISC,
     WS_DS_KEYS, WS_DS_VALS, WS_DS_KEYS2, WS_DS_VALS2, WS_DS_FLAGS, WS_DS_MISC,
     WS_SPFH, WS_KP_ORDER, WS_DENS_A, WS_DENS_B, WS_DENS_C,
-    WS_RANSAC_T, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK,
+    WS_RANSAC_T, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK, WS_RANSAC_MASKT,
     WS_PIPE_SURF_S, WS_PIPE_SURF_T, WS_PIPE_FEAT_S, WS_PIPE_FEAT_T, WS_PIPE_IJ, WS_PIPE_JI, WS_PIPE_DIJ, WS_PIPE_DJI,
     WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_FLAGS, WS_PIPE_MISC, WS_PIPE_KIDX_S, WS_PIPE_KIDX_T, WS_PIPE_KPS_S, WS_PIPE_KPS_T,
     WS_MS_KNN_I, WS_MS_KNN_D, WS_MS_LIST_S, WS_MS_LIST_T, WS_MS_SUB, WS_MS_FEAT_S, WS_MS_FEAT_T, WS_MS_SURF2, WS_MS_RES, WS_PLANE_VISITED, WS_PLANE_CLAIMED, WS_PLANE_OUT,

@@ -209,7 +209,8 @@ constexpr int CB = 64;        // hypotheses per workgroup
 constexpr int CCH = 2048;     // correspondences per workgroup
 __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts, const int* __restrict__ list, int nh,
                                                     const float4* __restrict__ P0, const float4* __restrict__ P1,
-                                                    const float* __restrict__ sstar, int c, int2* __restrict__ counts) {
+                                                    const float* __restrict__ sstar, int c, int2* __restrict__ counts,
+                                                    unsigned* __restrict__ maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */) {
     __shared__ float4 s0[CB], s1[CB];
     __shared__ float st[CB];
     int h = blockIdx.x * CB + threadIdx.x;
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts,
         if (i < c1) { s0[threadIdx.x] = P0[i]; s1[threadIdx.x] = P1[i]; st[threadIdx.x] = sstar[i]; }
         __syncthreads();
         int nj = min(CB, c1 - base);
+        unsigned long long bits = 0ull;
         for (int j = 0; j < nj; ++j) {
             float4 a = s0[j], b = s1[j];
             float ss = st[j];
@@ -236,8 +238,16 @@ __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts,
             float dx = ox - b.x, dy = oy - b.y, dz = oz - b.z;
             float d4 = (dx * dx + dz * dz) + (dy * dy + 0.f);   // Eigen 4-vector squaredNorm reduction
             float d3 = (dx * dx + dy * dy) + dz * dz;           // 3-vector block norm
-            ninl += d4 < ss ? 1 : 0;
+            const bool in = d4 < ss;
+            ninl += in ? 1 : 0;
             nsup += d3 < ss ? 1 : 0;
+            bits |= (unsigned long long) (in ? 1 : 0) << j;
+        }
+        // inlier bits of this hypothesis for the correspondences [base, base + 64): word-major, so the lanes (consecutive
+        // hypotheses) store consecutive words; phase 2 walks the set bits instead of testing every correspondence again
+        if (maskT && act) {
+            maskT[(size_t) (base >> 5) * nh + h] = (unsigned) bits;
+            if (base + 32 < c) maskT[(size_t) ((base >> 5) + 1) * nh + h] = (unsigned) (bits >> 32);
         }
     }
     if (act) { atomicAdd(&counts[h].x, ninl); atomicAdd(&counts[h].y, nsup); }
@@ -271,7 +281,9 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
                                                      const float* __restrict__ sstar, int c, int metric_id, int score_id,
                                                      float* __restrict__ metric_out, int* __restrict__ ninl_out,
                                                      float* __restrict__ rmse_out, uint8_t* __restrict__ mask,
-                                                     float2* __restrict__ scratch /* [gridDim.x][c] inlier (dist, thr) lists */) {
+                                                     float2* __restrict__ scratch /* [gridDim.x][c] inlier (dist, thr) lists */,
+                                                     const unsigned* __restrict__ maskT /* count_kernel's inlier bits [words][mask_nh], or nullptr */,
+                                                     const int* __restrict__ hpos /* candidate -> column of maskT */, int mask_nh) {
     extern __shared__ int hist[];   // 30000 ints (uniformity) + 64 ints scan scratch
     __shared__ float T[16];
     __shared__ int s_count;
@@ -287,7 +299,30 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
     int* scan = hist + 30000;
     float2* lst = scratch ? scratch + (size_t) hb * c : nullptr;
     __syncthreads();
-    for (int base = 0; base < c; base += MB) {
+    const bool from_bits = maskT && uni && !lst && !mask;
+    if (from_bits) {
+        // uniformity needs the inlier SET only: walk the set bits of the masks the counting phase left (a candidate has a
+        // few thousand inliers among hundreds of thousands of correspondences)
+        const int col = hpos[hb];
+        const int n_words = (c + 31) >> 5;
+        int cnt = 0;
+        for (int w = tid; w < n_words; w += MB) {
+            unsigned m = maskT[(size_t) w * mask_nh + col];
+            cnt += __popc(m);
+            while (m) {
+                const int i = (w << 5) + __ffs((int) m) - 1;
+                m &= m - 1u;
+                const int bins = __float_as_int(P1[i].w);
+                const int b0 = bins & 0xff, b1 = (bins >> 8) & 0xff, b2 = (bins >> 16) & 0xff;
+                atomicAdd(&hist[(0 * 100 + b1) * 100 + b2], 1);
+                atomicAdd(&hist[(1 * 100 + b2) * 100 + b0], 1);
+                atomicAdd(&hist[(2 * 100 + b0) * 100 + b1], 1);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if ((tid & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
+    }
+    for (int base = 0; base < c && !from_bits; base += MB) {
         int i = base + tid;
         bool in = false;
         float dist = 0.f, thr = 0.f;
@@ -615,7 +650,8 @@ int refit_launch(lgr_ctx* ctx, const Packed& pk, int c, const uint8_t* d_mask, f
 size_t metric_smem() { return (size_t) (30000 + 64) * 4; }
 
 int metric_launch(lgr_ctx* ctx, const float* Ts, const int* list2, int nh2, const Packed& pk, int c, int metric_id, int score_id,
-                  float* metric_out, int* ninl_out, float* rmse_out, uint8_t* mask) {
+                  float* metric_out, int* ninl_out, float* rmse_out, uint8_t* mask,
+                  const unsigned* maskT = nullptr, const int* hpos = nullptr, int mask_nh = 0) {
     // per device, so not cached in a process-wide flag (a process may hold contexts on several GPUs); the call is a host-side table update
     LGR_HIP(ctx, hipFuncSetAttribute((const void*) metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
     bool need_list = metric_id != LGR_METRIC_UNIFORMITY || rmse_out;
@@ -627,7 +663,7 @@ int metric_launch(lgr_ctx* ctx, const float* Ts, const int* list2, int nh2, cons
         int nh = std::min(wave, nh2 - h0);
         metric_kernel<<<nh, MB, metric_smem(), ctx->stream>>>(Ts, list2 ? list2 + h0 : nullptr, nh, pk.P0, pk.P1, pk.sstar, c, metric_id,
                                                               score_id, metric_out + h0, ninl_out + h0,
-                                                              rmse_out ? rmse_out + h0 : nullptr, mask, scratch);
+                                                              rmse_out ? rmse_out + h0 : nullptr, mask, scratch, maskT, hpos ? hpos + h0 : nullptr, mask_nh);
     }
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
@@ -746,16 +782,16 @@ extern "C" int lgr_evaluate_dev(lgr_ctx* ctx, const float* d_src, int ns, const 
 
 // one batch: hypotheses -> ok-list -> counts -> candidate list -> metrics.  Returns device arrays + host counts.
 struct BatchBuffers {
-    float* Ts; int* ok; int* pos; int* list; int2* counts; int* flags2; int* pos2; int* list2; float* metric; int* ninl; BatchStats* st;
+    float* Ts; int* ok; int* pos; int* list; int2* counts; int* flags2; int* pos2; int* list2; float* metric; int* ninl; int* hpos; BatchStats* st;
 };
 static int batch_buffers(lgr_ctx* ctx, int nb, BatchBuffers* b) {
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_T, (size_t) nb * 16, &b->Ts));
     int* s;
-    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_STATS, (size_t) nb * 12 + 64 + MAX_ROUND_BATCHES * (sizeof(BatchStats) / 4), &s));
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_STATS, (size_t) nb * 13 + 64 + MAX_ROUND_BATCHES * (sizeof(BatchStats) / 4), &s));
     b->ok = s; b->pos = s + nb; b->list = s + 2 * (size_t) nb; b->counts = (int2*) (s + 3 * (size_t) nb);
     b->flags2 = s + 5 * (size_t) nb; b->pos2 = s + 6 * (size_t) nb; b->list2 = s + 7 * (size_t) nb;
-    b->metric = (float*) (s + 8 * (size_t) nb); b->ninl = s + 9 * (size_t) nb;
-    b->st = (BatchStats*) (s + 10 * (size_t) nb + ((10 * (size_t) nb) & 1));
+    b->metric = (float*) (s + 8 * (size_t) nb); b->ninl = s + 9 * (size_t) nb; b->hpos = s + 10 * (size_t) nb;
+    b->st = (BatchStats*) (s + 11 * (size_t) nb + ((11 * (size_t) nb) & 1));
     return LGR_OK;
 }
 
@@ -781,7 +817,12 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     if (nh == 0) return LGR_OK;
     LGR_HIP(ctx, hipMemsetAsync(b.counts, 0, (size_t) nh * 8, ctx->stream));
     dim3 g(cdiv(nh, CB), cdiv(c, CCH));
-    count_kernel<<<g, CB, 0, ctx->stream>>>(b.Ts, b.list, nh, pk.P0, pk.P1, pk.sstar, c, b.counts);
+    // inlier bit masks for phase 2 (uniformity / correspondence-count metrics need the inlier set only); skipped when they
+    // would not fit 2 GB (then phase 2 tests every correspondence again)
+    unsigned* maskT = nullptr;
+    const size_t mask_words = (size_t) ((c + 31) >> 5) * nh;
+    if (!plane && p->metric_id == LGR_METRIC_UNIFORMITY && mask_words * 4 <= ((size_t) 2 << 30)) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASKT, mask_words, &maskT));
+    count_kernel<<<g, CB, 0, ctx->stream>>>(b.Ts, b.list, nh, pk.P0, pk.P1, pk.sstar, c, b.counts, maskT);
     int* pl_cnt = nullptr;
     float* pl_cp = nullptr;
     if (plane) {
@@ -796,6 +837,7 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     flag_ge_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.counts, nh, min_inliers, b.flags2);
     LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, b.flags2, b.pos2, 0, (size_t) nh, rocprim::plus<int>(), ctx->stream));
     compact_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.flags2, b.pos2, nh, b.list, b.list2);
+    if (maskT) compact_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.flags2, b.pos2, nh, nullptr, b.hpos);   // candidate -> ok-list position
     LGR_HIP(ctx, hipMemcpyAsync(h, b.pos2 + (nh - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
     LGR_HIP(ctx, hipMemcpyAsync(h + 1, b.flags2 + (nh - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -809,7 +851,7 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
         LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list2, nh2, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr));
         plane_mul_kernel<<<cdiv(nh2, 256), 256, 0, ctx->stream>>>(b.metric, pl_cp, nh2);
     } else {
-        LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr));
+        LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr, maskT, b.hpos, nh));
     }
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
