@@ -656,7 +656,7 @@ int metric_launch(lgr_ctx* ctx, const float* Ts, const int* list2, int nh2, cons
     LGR_HIP(ctx, hipFuncSetAttribute((const void*) metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
     bool need_list = metric_id != LGR_METRIC_UNIFORMITY || rmse_out;
     // hypotheses are processed in waves of at most `wave` workgroups so that the ordered inlier lists stay bounded
-    int wave = std::max(1, std::min(nh2, 512));
+    int wave = need_list ? std::max(1, std::min(nh2, 512)) : std::max(1, nh2);   // without lists: all candidates in one launch
     float2* scratch = nullptr;
     if (need_list) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_LIST, (size_t) wave * std::max(c, 1), &scratch));
     for (int h0 = 0; h0 < nh2; h0 += wave) {
