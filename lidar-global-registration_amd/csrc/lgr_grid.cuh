@@ -17,34 +17,65 @@ __device__ __forceinline__ bool lgr_finite3(float x, float y, float z) {
     return fabsf(x) <= 3.4028234663852886e38f && fabsf(y) <= 3.4028234663852886e38f && fabsf(z) <= 3.4028234663852886e38f;
 }
 
-// Per-thread sorted k-best list kept in LDS: slot-major [k][BLOCK] so lane i always hits bank (i % 32).
+// Per-thread k-best list kept in LDS, slot-major [k][BLOCK] so lane i always hits bank (i % 32).  While the search runs
+// it is a binary MAX-heap under the total order (d2, index): a candidate that beats the root replaces it and sifts down in at
+// most log2(k) steps.  (A sorted list with insertion costs up to k shifts per accepted candidate, and a wave pays the longest
+// shift of any of its lanes for nearly every candidate: 46 k vector + 57 k scalar instructions per wave in the normals
+// kernel.)  finalize() heap-sorts in place, after which dist(j) / index(j) are in ascending (d2, index) order -- the same
+// k entries in the same order as a sorted insertion would have produced, because the order is total.
 template <int BLOCK>
 struct KnnList {
     float* d2;   // [kcap][BLOCK]
     int* id;     // [kcap][BLOCK]
     int k, count, t;
-    float wreg;   // register copy of the k-th distance once the list is full: most candidates are rejected without touching LDS
+    float wreg;   // register copy of the root's distance once the heap is full: most candidates are rejected without touching LDS
     __device__ __forceinline__ void init(float* d2s, int* ids, int k_, int tid) { d2 = d2s; id = ids; k = k_; count = 0; t = tid; wreg = 0.f; }
-    __device__ __forceinline__ float worst() const { return d2[(k - 1) * BLOCK + t]; }
-    __device__ __forceinline__ void push(float d, int i) {
-        int pos;
-        if (count < k) pos = count++;
-        else {
-            if (d > wreg) return;
-            float wd = wreg;
-            int wi = id[(k - 1) * BLOCK + t];
-            if (!(d < wd || (d == wd && i < wi))) return;
-            pos = k - 1;
-        }
-        while (pos > 0) {
-            float pd = d2[(pos - 1) * BLOCK + t];
-            int pi = id[(pos - 1) * BLOCK + t];
-            if (d < pd || (d == pd && i < pi)) {
-                d2[pos * BLOCK + t] = pd; id[pos * BLOCK + t] = pi; --pos;
-            } else break;
+    __device__ __forceinline__ static bool less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+    __device__ __forceinline__ float worst() const { return d2[t]; }   // root (valid when count == k)
+    __device__ __forceinline__ void sift_down(int pos, int n, float d, int i) {   // place (d, i) at pos of the heap [0, n)
+        for (;;) {
+            int c = 2 * pos + 1;
+            if (c >= n) break;
+            float cd = d2[c * BLOCK + t];
+            int ci = id[c * BLOCK + t];
+            if (c + 1 < n) {
+                float rd = d2[(c + 1) * BLOCK + t];
+                int ri = id[(c + 1) * BLOCK + t];
+                if (less(cd, ci, rd, ri)) { cd = rd; ci = ri; ++c; }
+            }
+            if (!less(d, i, cd, ci)) break;
+            d2[pos * BLOCK + t] = cd; id[pos * BLOCK + t] = ci;
+            pos = c;
         }
         d2[pos * BLOCK + t] = d; id[pos * BLOCK + t] = i;
-        if (count == k) wreg = d2[(k - 1) * BLOCK + t];
+    }
+    __device__ __forceinline__ void push(float d, int i) {
+        if (count < k) {
+            int pos = count++;   // sift up
+            while (pos > 0) {
+                int par = (pos - 1) >> 1;
+                float pd = d2[par * BLOCK + t];
+                int pi = id[par * BLOCK + t];
+                if (!less(pd, pi, d, i)) break;
+                d2[pos * BLOCK + t] = pd; id[pos * BLOCK + t] = pi;
+                pos = par;
+            }
+            d2[pos * BLOCK + t] = d; id[pos * BLOCK + t] = i;
+            if (count == k) wreg = d2[t];
+            return;
+        }
+        if (d > wreg) return;
+        if (!less(d, i, wreg, id[t])) return;
+        sift_down(0, k, d, i);
+        wreg = d2[t];
+    }
+    __device__ __forceinline__ void finalize() {   // heap sort: ascending (d2, index)
+        for (int n = count - 1; n > 0; --n) {
+            float ld = d2[n * BLOCK + t];
+            int li = id[n * BLOCK + t];
+            d2[n * BLOCK + t] = d2[t]; id[n * BLOCK + t] = id[t];
+            sift_down(0, n, ld, li);
+        }
     }
     __device__ __forceinline__ float dist(int j) const { return d2[j * BLOCK + t]; }
     __device__ __forceinline__ int index(int j) const { return id[j * BLOCK + t]; }
@@ -90,6 +121,7 @@ __device__ __forceinline__ void lgr_knn_query(const GridDev& g, float qx, float 
             if (L.worst() <= lim * lim) break;
         }
     }
+    L.finalize();
 }
 
 // visit every point of the 27 cells around q in canonical order: cells (z, y, x) ascending, inside a cell
