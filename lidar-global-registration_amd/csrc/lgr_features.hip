@@ -197,7 +197,8 @@ __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uin
         int b1 = bin11(((double) f1 + MPI) * (double) d_pi);
         int b2 = 11 + bin11(((double) f2 + 1.0) * 0.5);
         int b3 = 22 + bin11(((double) f3 + 1.0) * 0.5);
-        cnt[b1 * SB + threadIdx.x]++; cnt[b2 * SB + threadIdx.x]++; cnt[b3 * SB + threadIdx.x]++;
+        // no-return LDS adds (ds_add_u32): nothing waits on the counters until the end of the kernel
+        atomicAdd(&cnt[b1 * SB + threadIdx.x], 1); atomicAdd(&cnt[b2 * SB + threadIdx.x], 1); atomicAdd(&cnt[b3 * SB + threadIdx.x], 1);
     });
     float* row = spfh + (size_t) p * 33;
     float incr = 100.0f / (float) (k - 1);
