@@ -140,31 +140,6 @@ __device__ __forceinline__ int nearest_centre(const float* v, const float* __res
     }
     return bi;
 }
-__global__ void km_accum(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, const float* __restrict__ cen,
-                         float* __restrict__ sums /* [KCL][34] */) {
-    __shared__ float ls[KCL * 34];
-    for (int i = threadIdx.x; i < KCL * 34; i += blockDim.x) ls[i] = 0.f;
-    __syncthreads();
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < ns && smp_ok[s]) {
-        float v[33], d;
-#pragma unroll
-        for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
-        int c = nearest_centre(v, cen, d);
-        for (int k = 0; k < 33; ++k) atomicAdd(&ls[c * 34 + k], v[k]);
-        atomicAdd(&ls[c * 34 + 33], 1.0f);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < KCL * 34; i += blockDim.x)
-        if (ls[i] != 0.f) atomicAdd(&sums[i], ls[i]);
-}
-__global__ void km_update(float* __restrict__ cen, float* __restrict__ sums) {
-    int c = threadIdx.x;
-    if (c >= KCL) return;
-    float n = sums[c * 34 + 33];
-    for (int k = 0; k < 33; ++k) { if (n > 0.f) cen[c * 33 + k] = sums[c * 34 + k] / n; sums[c * 34 + k] = 0.f; }
-    sums[c * 34 + 33] = 0.f;
-}
 // second level: `sub` centres inside every cluster, seeded with evenly spaced sample members of the cluster
 __global__ void km_label(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, const float* __restrict__ cen,
                          int* __restrict__ label) {
@@ -220,9 +195,11 @@ __device__ __forceinline__ int nearest_sub(const float* v, const float* __restri
     return bj;
 }
 constexpr int KM2_THREADS = 512;
-__global__ __launch_bounds__(KM2_THREADS) void km2_accum(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen2, int sub,
-                                                         float* __restrict__ sums2 /* [KCL*sub][34] */) {
-    // sub-centres of all clusters in LDS (odd pitch per cluster, as in assign_kernel): no per-lane gathers from global memory
+// Lloyd step of the second level in two deterministic kernels (no float atomics: the same centres, hence the same tile
+// schedule and timing, on every run).  km2_label: leaf of every sample (sub-centres of all clusters in LDS, odd pitch per
+// cluster as in assign_kernel).  km2_centres: one wave per leaf sums its samples in sample order and writes the new centre.
+__global__ __launch_bounds__(KM2_THREADS) void km2_label(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen2, int sub,
+                                                         int* __restrict__ leaf_of /* [ns], -1: no cluster */) {
     extern __shared__ float c2s[];
     const int pitch = sub * 33 + 1;
     for (int e = threadIdx.x; e < KCL * sub * 33; e += blockDim.x) c2s[(e / (sub * 33)) * pitch + e % (sub * 33)] = cen2[e];
@@ -230,21 +207,79 @@ __global__ __launch_bounds__(KM2_THREADS) void km2_accum(const float* __restrict
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ns) return;
     int p = label[s];
-    if (p < 0) return;
-    float v[33], d;
+    int leaf = -1;
+    if (p >= 0) {
+        float v[33], d;
 #pragma unroll
-    for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
-    int j = nearest_sub(v, c2s + p * pitch, sub, d);
-    float* dst = sums2 + ((size_t) p * sub + j) * 34;
-    for (int k = 0; k < 33; ++k) atomicAdd(&dst[k], v[k]);
-    atomicAdd(&dst[33], 1.0f);
+        for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
+        leaf = p * sub + nearest_sub(v, c2s + p * pitch, sub, d);
+    }
+    leaf_of[s] = leaf;
 }
-__global__ void km2_update(float* __restrict__ cen2, float* __restrict__ sums2, int n_leaves) {
-    int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n_leaves) return;
-    float n = sums2[(size_t) l * 34 + 33];
-    for (int k = 0; k < 33; ++k) { if (n > 0.f) cen2[(size_t) l * 33 + k] = sums2[(size_t) l * 34 + k] / n; sums2[(size_t) l * 34 + k] = 0.f; }
-    sums2[(size_t) l * 34 + 33] = 0.f;
+// level 1: 16 centres over the whole sample -> 1024 threads per centre, the 16 wave sums combined in a fixed order
+constexpr int KMC_THREADS = 1024;
+__global__ __launch_bounds__(KMC_THREADS) void km_centres(const float* __restrict__ smp, const int* __restrict__ label, int ns, float* __restrict__ cen) {
+    __shared__ float part[KMC_THREADS / 64][34];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) acc[k] = 0.f;
+    int n = 0;
+    for (int s0 = threadIdx.x; s0 < ns; s0 += KMC_THREADS * 8) {
+        int lb[8];   // eight label loads in flight (a label per iteration is one exposed load latency per iteration)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lb[u] = s0 + KMC_THREADS * u < ns ? label[s0 + KMC_THREADS * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (lb[u] != c) continue;
+            const int s = s0 + KMC_THREADS * u;
+            ++n;
+#pragma unroll
+            for (int k = 0; k < 33; ++k) acc[k] += smp[(size_t) s * 33 + k];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+#pragma unroll
+    for (int k = 0; k < 33; ++k) {
+        float a = acc[k];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) part[wave][k] = a;
+    }
+    if (lane == 0) part[wave][33] = (float) n;
+    __syncthreads();
+    if (threadIdx.x < 33) {
+        float cnt = 0.f, sum = 0.f;
+        for (int w = 0; w < KMC_THREADS / 64; ++w) { cnt += part[w][33]; sum += part[w][threadIdx.x]; }
+        if (cnt > 0.f) cen[c * 33 + threadIdx.x] = sum / cnt;
+    }
+}
+__global__ __launch_bounds__(64) void km2_centres(const float* __restrict__ smp, const int* __restrict__ leaf_of, int ns, float* __restrict__ cen2) {
+    const int leaf = blockIdx.x, lane = threadIdx.x;
+    float acc[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) acc[k] = 0.f;
+    int n = 0;
+    for (int s0 = lane; s0 < ns; s0 += 64 * 16) {
+        int lb[16];   // sixteen label loads in flight
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lb[u] = s0 + 64 * u < ns ? leaf_of[s0 + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (lb[u] != leaf) continue;
+            const int s = s0 + 64 * u;
+            ++n;
+#pragma unroll
+            for (int k = 0; k < 33; ++k) acc[k] += smp[(size_t) s * 33 + k];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if (n == 0) return;   // empty leaf: the centre stays
+#pragma unroll
+    for (int k = 0; k < 33; ++k) {
+        float a = acc[k];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) cen2[(size_t) leaf * 33 + k] = a / (float) n;
+    }
 }
 
 // key = (leaf << 22) | (bits(r2) >> 9), leaf = cluster * sub + sub-centre: sort by cluster, leaf, then distance to the
@@ -902,7 +937,7 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
 // is taken off every gap (4.1e-6 * largest |x - mu|), the rest is covered like the ball bound's roundings (LB_SHRINK).
 constexpr int COV_ROWS = 384, COV_THREADS = 640;   // rows per block; 33 sums + 561 products (a <= b) + the row count = 595 workers
 __global__ __launch_bounds__(COV_THREADS) void cov_kernel(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns,
-                                                          float* __restrict__ out /* [34][33]: sums, products (a <= b), then out[34 * 33] = row count */) {
+                                                          float* __restrict__ part /* [blocks][34 * 33 + 1]: sums, products (a <= b), row count */) {
     __shared__ float rows[COV_ROWS * 33];
     __shared__ int okr[COV_ROWS];
     const int r0 = blockIdx.x * COV_ROWS, nr = min(COV_ROWS, ns - r0);
@@ -911,20 +946,29 @@ __global__ __launch_bounds__(COV_THREADS) void cov_kernel(const float* __restric
     __syncthreads();
     const int w = threadIdx.x;
     if (w > 594) return;
+    float* out = part + (size_t) blockIdx.x * (34 * 33 + 1);
     float acc = 0.f;
     if (w < 33) {
         for (int r = 0; r < nr; ++r) if (okr[r]) acc += rows[r * 33 + w];
-        atomicAdd(&out[w], acc);
+        out[w] = acc;
     } else if (w < 594) {
         int p = w - 33, a = 0;
         while (p >= 33 - a) { p -= 33 - a; ++a; }   // pair (a, b = a + p)
         const int b2 = a + p;
         for (int r = 0; r < nr; ++r) if (okr[r]) acc = __builtin_fmaf(rows[r * 33 + a], rows[r * 33 + b2], acc);
-        atomicAdd(&out[33 + a * 33 + b2], acc);
+        out[33 + a * 33 + b2] = acc;
     } else {
         for (int r = 0; r < nr; ++r) acc += okr[r] ? 1.f : 0.f;
-        atomicAdd(&out[34 * 33], acc);
+        out[34 * 33] = acc;
     }
+}
+// block partials -> totals, summed in block order (deterministic basis, hence a deterministic tile schedule)
+__global__ void cov_reduce(const float* __restrict__ part, int n_blocks, float* __restrict__ out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > 34 * 33) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_blocks; ++b) acc += part[(size_t) b * (34 * 33 + 1) + e];
+    out[e] = acc;
 }
 // boxes of row segments in the basis (rows of V, y = V (x - mu)); segments: fixed 256-row blocks (starts == nullptr) or
 // [starts[s], starts[s + 1]).  box[s][0..32] = min, [33..65] = max (transposed: box[c][s]); rmax2: largest |x - mu|^2 seen.
@@ -1780,8 +1824,12 @@ static int box_basis(lgr_ctx* ctx, const float* smp, const int* smp_ok, int ns, 
     std::vector<float> h(34 * 33 + 1, 0.f);
     const bool raw = env_int("LGR_MATCH_BOX", 1) == 2;
     if (!raw) {
-        LGR_HIP(ctx, hipMemsetAsync(d_basis, 0, (34 * 33 + 1) * 4, ctx->stream));
-        cov_kernel<<<cdiv(ns, COV_ROWS), COV_THREADS, 0, ctx->stream>>>(smp, smp_ok, ns, d_basis);
+        const int nb = cdiv(ns, COV_ROWS);
+        float* part;
+        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_DENSE, (size_t) nb * (34 * 33 + 1) + 64, &part));   // scratch: the rerank buffers are not live yet
+        LGR_HIP(ctx, hipMemsetAsync(part, 0, (size_t) nb * (34 * 33 + 1) * 4, ctx->stream));   // the a > b product slots are never written
+        cov_kernel<<<nb, COV_THREADS, 0, ctx->stream>>>(smp, smp_ok, ns, part);
+        cov_reduce<<<cdiv(34 * 33 + 1, 256), 256, 0, ctx->stream>>>(part, nb, d_basis);
         LGR_HIP(ctx, hipMemcpyAsync(h.data(), d_basis, (34 * 33 + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -1861,7 +1909,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const size_t o_smp = carve((size_t) ns * 33 * 4), o_ok = carve((size_t) ns * 4), o_label = carve((size_t) ns * 4);
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, off, &misc));
     float* cen = (float*) (misc + 256);                 // [KCL][33]
-    float* sums = (float*) (misc + 4096);               // [KCL][34]
     float* cen2 = (float*) (misc + o_cen2);             // [n_leaves][33]
     float* sums2 = (float*) (misc + o_sums2);
     float* smp = (float*) (misc + o_smp);
@@ -1869,20 +1916,20 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int* label = (int*) (misc + o_label);
     km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok);
     km_init<<<1, 64, 0, ctx->stream>>>(smp, smp_ok, ns, cen);
-    LGR_HIP(ctx, hipMemsetAsync(sums, 0, KCL * 34 * 4, ctx->stream));
-    for (int it = 0; it < KM_ITERS; ++it) {
-        km_accum<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, cen, sums);
-        km_update<<<1, 64, 0, ctx->stream>>>(cen, sums);
+    for (int it = 0; it < KM_ITERS; ++it) {   // Lloyd, deterministic (no float atomics)
+        km_label<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, cen, label);
+        km_centres<<<KCL, KMC_THREADS, 0, ctx->stream>>>(smp, label, ns, cen);
     }
     km_label<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, cen, label);
     km2_init<<<KCL, 64, 0, ctx->stream>>>(smp, label, ns, cen, sub, cen2);
     if (sub > 1) {
-        LGR_HIP(ctx, hipMemsetAsync(sums2, 0, (size_t) n_leaves * 34 * 4, ctx->stream));
+        int* leaf_of = (int*) sums2;   // [ns] (the slab of the former atomic sums: MAXLEAF * 34 floats >= 2 * KM_SAMPLE)
+        static_assert((size_t) MAXLEAF * 34 >= 2 * (size_t) KM_SAMPLE, "leaf_of fits the sums2 slab");
+        const size_t km2_lds = (size_t) KCL * (sub * 33 + 1) * 4;
+        if (km2_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) km2_label, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
         for (int it = 0; it < KM2_ITERS; ++it) {
-            const size_t km2_lds = (size_t) KCL * (sub * 33 + 1) * 4;
-            if (km2_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) km2_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
-            km2_accum<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, ctx->stream>>>(smp, label, ns, cen2, sub, sums2);
-            km2_update<<<cdiv(n_leaves, 64), 64, 0, ctx->stream>>>(cen2, sums2, n_leaves);
+            km2_label<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, ctx->stream>>>(smp, label, ns, cen2, sub, leaf_of);
+            km2_centres<<<n_leaves, 64, 0, ctx->stream>>>(smp, leaf_of, ns, cen2);
         }
     }
 
