@@ -1,0 +1,88 @@
+// lgr_match_common.cuh -- constants, operand formats and small helpers of the matcher (included by lgr_match.hip).
+#pragma once
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "lgr_internal.h"
+
+namespace {
+
+
+constexpr int KK = 17;              // K = 34 -> 17 MFMA steps of k = 2
+constexpr int TILE = 32;
+constexpr int RW = 1;               // row tiles per wave
+constexpr int WAVES = 8;
+constexpr int NTHR = WAVES * 64;    // threads per workgroup of the MFMA kernel
+constexpr int BLOCK_ROWS = TILE * RW * WAVES;   // 256
+constexpr int STAGE_TILES = 4;
+constexpr int STAGE_COLS = STAGE_TILES * TILE;  // 128
+constexpr int CHUNK_COLS = 4096;
+constexpr int PAD = 256;
+constexpr int KCL = 16;             // k-means centres (operand centring)
+constexpr int SUBMAX = 64;          // second-level centres per cluster ("leaves": sort order + skip bounds)
+constexpr int MAXLEAF = KCL * SUBMAX;
+#ifndef LGR_KM_SAMPLE
+#define LGR_KM_SAMPLE 16384
+#endif
+constexpr int KM_SAMPLE = LGR_KM_SAMPLE;    // sample rows per side
+#ifndef LGR_KM_ITERS
+#define LGR_KM_ITERS 16   // Lloyd iterations, first / second level (6 / 4 -> 10 / 8 -> 16 / 8: 81.7 -> 80.2 -> 79.5 ms per 1M pair; tighter leaves)
+#endif
+constexpr int KM_ITERS = LGR_KM_ITERS;
+#ifndef LGR_KM2_ITERS
+#define LGR_KM2_ITERS 8
+#endif
+constexpr int KM2_ITERS = LGR_KM2_ITERS;
+#ifndef LGR_MM_OCC
+#define LGR_MM_OCC 4          // waves per SIMD of match_mfma (2: 256 VGPRs, one workgroup per CU; 4: 128 VGPRs, two)
+#endif
+constexpr int NEAR_T = 48;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured optimum at 1M with the box bounds: 32 / 48 / 64 / 96 -> 84.2 / 83.3 / 84.4 / 87.0 ms per pair)
+#ifndef LGR_PRUNE_BETAS
+#define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
+#endif
+#ifndef LGR_GROUP_COLS
+#define LGR_GROUP_COLS 1024
+#endif
+constexpr int GROUP_COLS = LGR_GROUP_COLS;     // largest column group of the row-minimum table (leaves are cut into such pieces)
+constexpr int STAGES_PER_CHUNK = CHUNK_COLS / STAGE_COLS;   // 32 -> one 32-bit stage mask per (row block, chunk)
+constexpr float FLT_BIG = 3.4028234663852886e38f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// MFMA operand formats.  F32: v_mfma_f32_32x32x2_f32, K = 34 (33 dims + norm slot) -> 17 steps, fragment = 1 float.
+// F16: v_mfma_f32_32x32x16_f16 (16x the f32 rate) on two-term f16 splits of the scaled f32 operands,
+//      x * 2^s = h1 + h2 (+ residual <= 2^-22 |x|):  a.b ~ a1.b1 + a1.b2 + a2.b1  -> concatenated K = 3 * 33 + 6 norm slots
+//      = 105, padded to 112 = 7 steps, fragment = 8 halves (lane l: row l & 31, k = 16 * step + 8 * (l >> 5) + j).
+// F16R: the same on 30 coordinates.  Every 11-bin block of an FPFH row sums to 100, so differences of rows have no component
+//      along the block's all-ones direction; in a Helmert basis of the block that direction is one coordinate, the other
+//      10 carry the whole distance.  K = 3 * 30 + 6 = 96 = 6 steps (-1/7 of the MFMA work, LDS reads and operand bytes).
+//      Used only when the dropped coordinates are (numerically) constant over both sets; their largest measured energy
+//      enters the error bound, so any input stays exact (match_impl, "rot").
+enum { FMT_F32 = 0, FMT_F16 = 1, FMT_F16R = 2 };
+template <int FMT> struct OpFmt;
+template <> struct OpFmt<FMT_F32> { typedef float frag; static constexpr int KS = 17; };
+template <> struct OpFmt<FMT_F16> { typedef f16x8 frag; static constexpr int KS = 7; };
+template <> struct OpFmt<FMT_F16R> { typedef f16x8 frag; static constexpr int KS = 6; };
+struct F16Scale { float s_mul; float inv_s2; float a_norm[3]; };   // 2^s, 2^-2s, the three a-side norm-slot constants
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ bool row_finite(const float* __restrict__ r, float* v) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) { v[k] = r[k]; ok = ok && (fabsf(v[k]) <= FLT_BIG); }
+    return ok;
+}
+
+
+}  // namespace

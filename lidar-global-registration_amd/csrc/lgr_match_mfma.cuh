@@ -1,0 +1,331 @@
+// lgr_match_mfma.cuh -- 3. the MFMA filter kernel and its work list.
+// Part of the brute-force FPFH matcher; see the header of lgr_match.hip and DESIGN.md section 3.
+#pragma once
+#include "lgr_match_common.cuh"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3. MFMA filter kernel.  One work item = one row group (item_rb row blocks of 256) x one 4096-column chunk (32 stages of 128).
+//    Wave w of row block rb owns row tile rb*8 + w; all waves share the column stage staged in LDS.
+//    The column operand set is chosen per row block: Bp + blkcl[rb] * bset_stride.
+//    stage_mask[rb][chunk] (optional) selects the stages to compute: bound-based skipping, section 3b.
+//    Row minima are flushed per column group (tile_group[tile], a leaf of the train side) with an integer atomicMin
+//    on the float bits; column minima per row group with a read-modify-write (one owner per entry).  Both tables must
+//    be initialised to +inf bits, so several masked passes accumulate into the same tables.
+#ifdef EXP_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_T(var) unsigned long long var = wall_clock64()
+#define PROF_ADD(slot, a, b) do { if (tid == 0) atomicAdd(&g_prof[slot], (b) - (a)); } while (0)
+#define PROF_CNT(slot) do { if (tid == 0) atomicAdd(&g_prof[slot], 1ull); } while (0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, a, b)
+#define PROF_CNT(slot)
+#endif
+__device__ __forceinline__ f32x16 mfma_step(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma_step(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <bool COLDIR, int FMT>
+__global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename OpFmt<FMT>::frag* __restrict__ Ap, const typename OpFmt<FMT>::frag* __restrict__ Bp,
+                                                     size_t bset_stride /* fragments */, float c_scale /* 2^2s, F16 only */, float out_scale /* 2^-2s */,
+                                                     const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
+                                                     int rg_rows, const int* __restrict__ tile_group, const unsigned* __restrict__ stage_mask,
+                                                     int* __restrict__ rowmin /* [n_groups][ma_pad] */,
+                                                     int* __restrict__ colmin /* [ma_pad/rg_rows][mb_pad] */,
+                                                     int n_cc, int item_rb, const int2* __restrict__ items, const int* __restrict__ xcd_start,
+                                                     int* __restrict__ xcd_ctr) {
+    // column stage double buffered in LDS: the next stage is prefetched into registers while the current one is
+    // consumed and written to the other buffer afterwards -> one barrier per stage, global latency hidden
+    constexpr bool F16 = FMT != FMT_F32;
+    typedef typename OpFmt<FMT>::frag frag;
+    constexpr int KS = OpFmt<FMT>::KS;
+    constexpr int STAGE_FRAGS = STAGE_TILES * KS * 64;
+    constexpr int STAGE_VEC4 = STAGE_FRAGS * (int) sizeof(frag) / 16;   // 16-byte pieces per stage
+    __shared__ __attribute__((aligned(16))) frag Bs[2][STAGE_FRAGS];
+    __shared__ int cmin_s[CHUNK_COLS];
+    __shared__ int tg_s[CHUNK_COLS / TILE];
+    __shared__ int item_s;
+
+    // Persistent workgroups over a compacted work list.  An item is (column chunk, item_rb row blocks) with at least
+    // one stage to compute.  Hardware places workgroup i on XCD i % 8; the list is partitioned per XCD (XCD x owns the
+    // chunks x, x + 8, ...; items ordered by chunk, then rows), and the workgroups of an XCD pull items in order from
+    // a shared counter: a chunk's B operand stays in one L2 while its items run, chunks of different cost interleave
+    // across the XCDs, and nobody idles behind a static partition.  (Speed only: any item order gives the same tables.)
+    const int xcd = blockIdx.x % 8;
+    const int item0 = xcd_start[xcd], n_items = xcd_start[xcd + 1] - item0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int rg_blocks = rg_rows / BLOCK_ROWS;
+    const int n_rb_total = ma_pad / BLOCK_ROWS;
+    constexpr int IINF = 0x7f800000;   // +inf as bits
+    static_assert(STAGE_VEC4 % 64 == 0, "a stage is a whole number of 1 KB DMA pieces");
+    if (COLDIR) {
+        for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = IINF;   // every flush leaves the array at +inf again
+    }
+    int cur_cc = -1, col_tile0 = 0, n_coltiles = 0;
+    unsigned full = 0u;
+    unsigned tend[STAGE_TILES] = {0u, 0u, 0u, 0u};
+    PROF_T(t_wg0);
+    PROF_CNT(8);
+
+  for (;;) {
+    __syncthreads();   // all waves are done with the previous item (tg_s, item_s, cmin_s)
+    if (tid == 0) item_s = atomicAdd(&xcd_ctr[xcd], 1);
+    __syncthreads();
+    const int it = item_s;
+    if (it >= n_items) break;
+    const int2 item = items[item0 + it];
+    const int cc = item.x, rb0 = item.y;
+    const int n_rb = min(item_rb, n_rb_total - rb0);
+    if (cc != cur_cc) {
+        cur_cc = cc;
+        col_tile0 = cc * (CHUNK_COLS / TILE);
+        n_coltiles = min(CHUNK_COLS / TILE, mb_pad / TILE - col_tile0);
+        const int n_stages = n_coltiles / STAGE_TILES;
+        full = n_stages >= 32 ? 0xffffffffu : ((1u << n_stages) - 1u);
+        // column group (train leaf) of every 32-column tile of this chunk; tend[ct] bit st = tile ct of stage st is
+        // the last tile of its group (uniform registers: nothing is loaded between the MFMA chains)
+        if (tid < CHUNK_COLS / TILE) tg_s[tid] = tid < n_coltiles ? tile_group[col_tile0 + tid] : -1;
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < STAGE_TILES; ++ct) {
+            int t = (lane & 31) * STAGE_TILES + ct;
+            bool e = t < n_coltiles && (t == n_coltiles - 1 || tg_s[t + 1] != tg_s[t]);
+            tend[ct] = __builtin_amdgcn_readfirstlane((unsigned) (__ballot(e) & 0xffffffffull));
+        }
+    }
+    // the stage masks of the item's row blocks, fetched once (lane rbi holds the mask of row block rb0 + rbi)
+    unsigned my_mask = full;
+    if (stage_mask) my_mask = lane < n_rb ? (stage_mask[(size_t) (rb0 + lane) * n_cc + cc] & full) : 0u;
+    bool col_dirty = false;
+
+    for (int rbi = 0; rbi < n_rb; ++rbi) {
+        const int rb = rb0 + rbi;
+        unsigned mask = stage_mask ? __builtin_amdgcn_readlane(my_mask, rbi) : full;   // uniform over the workgroup
+        if (mask) {
+            PROF_T(t_v0);
+            PROF_CNT(9);
+            col_dirty = true;
+            const int row_tile = rb * (BLOCK_ROWS / TILE) + wave * RW;
+            const frag* Bset = Bp + (size_t) blkcl[rb] * bset_stride + (size_t) col_tile0 * KS * 64;
+            // A fragments (coalesced 256-B loads) and the |a'|^2 of the 16 rows each lane's accumulators cover
+            frag a[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a[kk] = Ap[((size_t) row_tile * KS + kk) * 64 + lane];
+            f32x16 nav = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (!F16) {   // f32 operands: |a'|^2 through the accumulator input (the f16 format carries it in K slots)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) nav[g] = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
+            }
+            int rmin[16];   // float bit patterns, see the epilogue note
+#pragma unroll
+            for (int g = 0; g < 16; ++g) rmin[g] = IINF;
+
+            // Column stages go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers; each wave
+            // instruction copies one contiguous 1 KB piece, the stage image has the same order in memory and in LDS).
+            auto stage_dma = [&](int stage, int to_buf) {
+                const char* src = reinterpret_cast<const char*>(Bset + (size_t) stage * STAGE_FRAGS);
+                char* dst = reinterpret_cast<char*>(Bs[to_buf]);
+#pragma unroll
+                for (int piece = wave; piece < STAGE_VEC4 / 64; piece += WAVES)
+                    __builtin_amdgcn_global_load_lds((const void*) (src + piece * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*) (dst + piece * 1024), 16, 0, 0);
+            };
+            // first active stage of this row block (barrier first: every wave is past the previous row block's LDS reads)
+            int st = __builtin_ctz(mask);
+            __syncthreads();
+            stage_dma(st, 0);
+            __syncthreads();   // waits for the DMA (vmcnt(0)) and makes the stage visible
+            PROF_T(t_v1);
+            PROF_ADD(0, t_v0, t_v1);
+            // Stage loop: the DMA of the next active stage into the other buffer is issued before the current stage is
+            // consumed; the barrier at the end of the stage waits for it.
+            // On gfx950 the f32 MFMA runs on the FP32 lanes the VALU uses (equal peak rate; no co-execution was
+            // measured: removing the epilogue saved exactly its VALU time), so the epilogue is kept minimal:
+            //  * |a'|^2 enters through the accumulator input of the first MFMA step (f32) or through spare K slots
+            //    (f16): d2~ = S + |a'|^2 costs nothing;
+            //  * minima are taken on the bit patterns with v_min_i32 / v_min3_i32 (one instruction per slot, no
+            //    canonicalising v_max pair as a float min of raw MFMA output needs).  Signed-int order equals float
+            //    order except among negative values, where it keeps the one closest to zero; d2~ < 0 only within
+            //    the proven error eps of a true distance >= 0, so the filtered minimum stays within eps;
+            //  * a VALU lane swap instead of an LDS shuffle folds the two lane halves of the column chain.
+            // The B fragment of the next tile is fetched from LDS before the epilogue runs.
+            // Epilogue of one finished 32x32 tile: tile ct of stage st; nxt = the stage computed after st.
+            auto row_min1 = [&](const f32x16& acc) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) rmin[g] = min(rmin[g], __float_as_int(acc[g]));
+            };
+            auto col_min = [&](const f32x16& acc, int st, int ct) {
+                if (COLDIR) {
+                    int cm = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
+#pragma unroll
+                    for (int g = 2; g < 16; g += 2) cm = min(min(cm, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
+                    // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
+                    auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
+                    int other = (int) (half ? sw[0] : sw[1]);
+                    cm = min(cm, other);
+                    // both halves hold the folded minimum: all 64 lanes issue the LDS atomic (no exec-mask branch in
+                    // the MFMA block; the two lanes of a column hit the same word with the same value)
+                    atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + (lane & 31)], cm);
+                }
+            };
+            auto tile_ends_group = [&](int st, int ct) {
+                const unsigned te = ct == 0 ? tend[0] : ct == 1 ? tend[1] : ct == 2 ? tend[2] : tend[3];
+                return ((te >> st) & 1u) != 0u;
+            };
+            auto maybe_flush = [&](int st, int ct, int nxt) {
+                // flush the row minima when the column group (train leaf) ends, or before skipped stages
+                if (tile_ends_group(st, ct) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
+                    PROF_CNT(10);
+                    const int grp = tg_s[st * STAGE_TILES + ct];
+                    // Halving butterfly over the 32 lanes of each half wave: at every step a lane keeps half of
+                    // its registers and receives the partner's copy of them, so 16 registers x 32 lanes reduce to
+                    // one value per lane with 16 + 8 + 4 + 2 + 1 exchanges instead of 16 x 5; lane bits 4..1 then
+                    // select the register (= row) the lane ends up holding, and one atomic instruction with 16
+                    // active lanes per half wave writes all rows.
+                    int w8[8], w4[4], w2[2], w1;
+                    {
+                        const bool up = (lane & 16) != 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            int keep = up ? rmin[8 + j] : rmin[j], send = up ? rmin[j] : rmin[8 + j];
+                            w8[j] = min(keep, __shfl_xor(send, 16));
+                        }
+                    }
+                    {
+                        const bool up = (lane & 8) != 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int keep = up ? w8[4 + j] : w8[j], send = up ? w8[j] : w8[4 + j];
+                            w4[j] = min(keep, __shfl_xor(send, 8));
+                        }
+                    }
+                    {
+                        const bool up = (lane & 4) != 0;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            int keep = up ? w4[2 + j] : w4[j], send = up ? w4[j] : w4[2 + j];
+                            w2[j] = min(keep, __shfl_xor(send, 4));
+                        }
+                    }
+                    {
+                        const bool up = (lane & 2) != 0;
+                        int keep = up ? w2[1] : w2[0], send = up ? w2[0] : w2[1];
+                        w1 = min(keep, __shfl_xor(send, 2));
+                    }
+                    w1 = min(w1, __shfl_xor(w1, 1));
+                    // register index held by this lane: bit 3 <- lane bit 4, bit 2 <- bit 3, bit 1 <- bit 2, bit 0 <- bit 1
+                    const int g = (lane >> 1) & 15;
+                    if (F16) w1 = __float_as_int(__int_as_float(w1) * out_scale);   // back to d2~ (monotonic)
+                    if ((lane & 1) == 0 && w1 != IINF)
+                        atomicMin(&rowmin[(size_t) grp * ma_pad + row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half], w1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rmin[r] = IINF;
+                }
+            };
+            // Epilogue of one finished 32x32 tile: tile ct of stage st; nxt = the stage computed after st.
+            auto epilogue = [&](const f32x16& acc, int st, int ct, int nxt) {
+                row_min1(acc);
+                col_min(acc, st, ct);
+                maybe_flush(st, ct, nxt);
+            };
+            // Schedules tried and measured on a dense 400k x 400k probe (35.9 ms as is; MFMA chains alone 24.9 ms: the
+            // chip holds ~1.4 GHz under this f16 MFMA load): deferring a tile's epilogue behind the next tile's MFMA
+            // chain (software pipeline, with and without register double buffering of the B fragments) -1..-2 % at
+            // 4 waves/SIMD with spills, +8 % at 2 waves/SIMD; no stage DMA -14 %; no barrier 0 %; no column minima -5 %;
+            // two column tiles per epilogue (one v_min3 per accumulator pair for the row minima, 8 fewer vector
+            // instructions per tile): +13 % at 4 waves/SIMD (spills), -1.4 % at 2 waves/SIMD.
+            auto compute = [&](int st, int buf, int nxt) {
+                frag b[KS];
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
+#pragma unroll
+                for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                    f32x16 acc = mfma_step(a[0], b[0], nav);
+#pragma unroll
+                    for (int kk = 1; kk < KS; ++kk) acc = mfma_step(a[kk], b[kk], acc);
+                    if (ct + 1 < STAGE_TILES) {
+#pragma unroll
+                        for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][((ct + 1) * KS + kk) * 64 + lane];
+                    }
+                    epilogue(acc, st, ct, nxt);
+                }
+            };
+            mask &= mask - 1u;   // st is taken
+            int buf = 0;
+            while (true) {
+                int nxt = -1;
+                if (mask) { nxt = __builtin_ctz(mask); mask &= mask - 1u; }
+                if (nxt >= 0) stage_dma(nxt, buf ^ 1);
+                compute(st, buf, nxt);
+                if (nxt < 0) break;
+                PROF_T(t_s0);
+                __syncthreads();   // DMA landed (vmcnt(0)) and visible; all waves done with the buffer refilled next
+                PROF_T(t_s1);
+                PROF_ADD(2, t_s0, t_s1);
+                buf ^= 1;
+                st = nxt;
+            }
+            PROF_T(t_v2);
+            PROF_ADD(1, t_v1, t_v2);
+        }
+    }
+    // column minima of this item -> table (the item covers exactly one row group: single owner, plain read-modify-write)
+    if (COLDIR && col_dirty) {
+        PROF_T(t_c0);
+        __syncthreads();
+        int rg = rb0 / rg_blocks;
+        int ncols = n_coltiles * TILE;
+        int* dst = colmin + (size_t) rg * mb_pad + col_tile0 * TILE;
+        constexpr int NCM = CHUNK_COLS / NTHR;   // 8 columns per thread: all loads in flight before the merge
+        int cur[NCM], old[NCM];
+#pragma unroll
+        for (int j = 0; j < NCM; ++j) {
+            int i = tid + NTHR * j;
+            cur[j] = i < ncols ? cmin_s[i] : IINF;
+            old[j] = cur[j] != IINF ? dst[i] : IINF;
+        }
+#pragma unroll
+        for (int j = 0; j < NCM; ++j) {
+            int i = tid + NTHR * j;
+            if (cur[j] != IINF) {
+                int v = F16 ? __float_as_int(__int_as_float(cur[j]) * out_scale) : cur[j];
+                if (v < old[j]) dst[i] = v;
+                cmin_s[i] = IINF;
+            }
+        }
+        PROF_T(t_c1);
+        PROF_ADD(3, t_c0, t_c1);
+    }
+  }
+    PROF_T(t_wg1);
+    PROF_ADD(4, t_wg0, t_wg1);
+}
+
+// work list of match_mfma: flag every (XCD-major chunk, item row) that has something to compute, scan, emit
+__global__ void items_flag_kernel(const unsigned* __restrict__ mask, int n_rb, int n_cc, int item_rb, int n_ir, int ccx, int* __restrict__ flags) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 8 * ccx * n_ir) return;
+    int xcd = j / (ccx * n_ir), rem = j % (ccx * n_ir);
+    int cc = (rem / n_ir) * 8 + xcd, ir = rem % n_ir;
+    int f = 0;
+    if (cc < n_cc) {
+        if (!mask) f = 1;
+        else
+            for (int r = ir * item_rb; r < min(n_rb, (ir + 1) * item_rb); ++r) f |= mask[(size_t) r * n_cc + cc] != 0u ? 1 : 0;
+    }
+    flags[j] = f;
+}
+__global__ void items_emit_kernel(const int* __restrict__ flags, const int* __restrict__ pos, int item_rb, int n_ir, int ccx,
+                                  int2* __restrict__ items, int* __restrict__ xcd_start /* [9] */) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_xcd = ccx * n_ir;
+    if (j >= 8 * per_xcd) return;
+    int xcd = j / per_xcd, rem = j % per_xcd;
+    if (flags[j]) items[pos[j]] = make_int2((rem / n_ir) * 8 + xcd, (rem % n_ir) * item_rb);
+    if (rem == 0) xcd_start[xcd] = pos[j];
+    if (j == 8 * per_xcd - 1) xcd_start[8] = pos[j] + flags[j];
+}
+
+
+}  // namespace

@@ -1,0 +1,672 @@
+// lgr_match_rerank.cuh -- 4. exact canonical distance, error bounds, table scans, schedule, table init, self-check, exact re-rank.
+// Part of the brute-force FPFH matcher; see the header of lgr_match.hip and DESIGN.md section 3.
+#pragma once
+#include "lgr_match_common.cuh"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// exact canonical distance: cv::hal::normL2Sqr_ (OpenCV 4.5.1, SSE baseline: 4 lanes x 4 accumulators over blocks
+// of 16 floats, mul then add, reduce ((acc0+acc1)+acc2)+acc3 then (s0+s2)+(s1+s3), scalar tail) followed by sqrt.
+// Must stay op-for-op identical to oracle/src/orc_matching.cpp:l2sqr33 (compiled with -ffp-contract=off).
+__device__ __forceinline__ float exact_l2(const float* __restrict__ a, const float* __restrict__ b) {
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[i][l] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                int j = 16 * blk + 4 * i + l;
+                float t = a[j] - b[j];
+                acc[i][l] = t * t + acc[i][l];
+            }
+    float s[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) s[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+    float d = (s[0] + s[2]) + (s[1] + s[3]);
+    float t = a[32] - b[32];
+    d = d + t * t;
+    return __builtin_sqrtf(d);   // IEEE-correct sequence (NOT __fsqrt_rn, which is the 1-ulp v_sqrt_f32 on gfx950)
+}
+
+// tie rank of train index j: highest bf block first, lowest index inside a block first (smaller rank wins)
+__device__ __forceinline__ unsigned tie_rank(int j, int block, int nblocks) {
+    int blk = j / block;
+    return (unsigned) ((nblocks - 1 - blk) * (long long) block + (j - blk * block));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 4a. candidate groups per query.  table[g][q_pad] holds, for padded query position i and train group g, the
+// filtered minimum v of d2~ = S + |a'|^2.  Proven bound of |filtered - true| for
+// every pair of (query i, group g)  (DESIGN.md "matcher margin"): centring (2 roundings) + fma chain of 34 products
+// + norm rounding + the column-direction add:  eps = 4 g40 (x + y)^2, g40 = 40u/(1-40u), u = 2^-24, where x, y are
+// |q - c| and the group's max |t - c| for the centre c the pair was computed with.
+//   upper = v + eps, lower = v - eps;  UB = min_g upper;  group g is a candidate iff lower_g <= UB + slack, with
+//   slack = 1e-5 * d2(UB) (two rows whose true d2 differ by less may tie or swap in the canonical float distance)
+//         + float rounding of the comparison.
+struct RerankCounters { unsigned n_items; unsigned n_dense; unsigned pad0; unsigned pad1; };
+
+// extra terms of the f16-split operand path (0 on the f32 path): eps += lin * (x + y) + abs
+struct EpsExtra { float lin, abs, quad; };   // quad: multiplier of the 4 g40 (x + y)^2 term (1 on the f32 path)
+
+template <bool ROWDIR>
+__device__ __forceinline__ float group_eps(int i, int g, float xq, const float* __restrict__ nT_sets, const float* __restrict__ gmax,
+                                           int n_groups, int p_of_query, const int* __restrict__ cl_of_group, int t_pad, EpsExtra ex) {
+    // ROWDIR: query = row i of cluster p (xq = |a'|), train group g of columns: y = gmaxB[p][g]
+    // COLDIR: query = column i, train group g = row group of cluster p(g): x = gmaxA[g], y = |b - c_p(g)| (per set)
+    // evaluated in float, inflated by 1e-5 (the five roundings below are worth 3e-7): an upper bound of the proven eps
+    float x, y;
+    if (ROWDIR) { x = xq; y = gmax[(size_t) p_of_query * n_groups + g]; }
+    else {
+        int p = cl_of_group[g];
+        x = gmax[g];
+        y = sqrtf(nT_sets[(size_t) p * t_pad + i]) * 1.0000002f;
+    }
+    const float c_quad = 9.5367477e-6f * ex.quad;   // 4 g40 = 4 * 40 u / (1 - 40 u) = 9.53677e-6, rounded up
+    const float s = x + y;
+    return ((c_quad * s) * s + ex.lin * s + ex.abs) * 1.00001f + 1e-30f;
+}
+
+// Table scan of one query: calls f(group, value) for every computed, finite entry table[g][i].  Four loads are in flight
+// before the first value is used (the loop body is short; one dependent global load per iteration was the whole cost).
+// `own` (columns): the computed-flags of the query's own leaf.  A block of 256 columns can span two leaves, so the
+// block's list is a superset; entries that were never computed are never initialised (init_tables_kernel) and must not
+// be read.  nullptr: the list is exact (rows: one row block per workgroup) or everything was computed.
+template <class F>
+__device__ __forceinline__ void scan_groups(const float* __restrict__ table, size_t q_pad, int i, int n_list, int n_groups,
+                                            const int* __restrict__ list_s, const uint8_t* __restrict__ own, F&& f) {
+    const int n_it = n_list < 0 ? n_groups : n_list;
+    const float inf = __uint_as_float(0x7f800000u);
+    int k = 0;
+    for (; k + 4 <= n_it; k += 4) {
+        int g[4];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g[j] = n_list < 0 ? k + j : list_s[k + j];
+            v[j] = (!own || own[g[j]]) ? table[(size_t) g[j] * q_pad + i] : inf;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (v[j] < FLT_BIG) f(g[j], v[j]);
+    }
+    for (; k < n_it; ++k) {
+        const int g = n_list < 0 ? k : list_s[k];
+        const float v = (!own || own[g]) ? table[(size_t) g * q_pad + i] : inf;
+        if (v < FLT_BIG) f(g, v);
+    }
+}
+
+// Which table entries were computed at all (skipping leaves most of them at +inf): byte matrices derived from the
+// done | scheduled tiles, so the table scans below read only the entries that can be finite.
+//   rows:  comp_r[row block][column group]      cols:  comp_c[leaf][row group]
+struct CompView { const uint8_t* m; int stride; const int* row_of_tile; };   // m == nullptr: everything was computed
+__device__ __forceinline__ const uint8_t* comp_row(const CompView& c, int i, int block_row) {
+    if (!c.m) return nullptr;
+    int r = c.row_of_tile ? c.row_of_tile[i / TILE] : block_row;
+    return c.m + (size_t) r * c.stride;
+}
+// compact list (dynamic LDS) of the groups computed for any query of this block; returns its length, or -1 when
+// nothing was skipped (iterate all groups).  Every thread of the block must call it.
+__device__ __forceinline__ int comp_list(const CompView& c, int i0, int n_i, int n_groups, int* list_s, int span = 0, bool* several = nullptr) {
+    __shared__ int cnt_s;
+    if (several) *several = false;
+    if (!c.m) return -1;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    const int t0 = i0 / TILE, t1 = (min(i0 + (span ? span : (int) blockDim.x), n_i) - 1) / TILE;
+    if (several && c.row_of_tile) *several = c.row_of_tile[t0] != c.row_of_tile[t1];   // tiles are sorted by leaf
+    for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+        uint8_t f = 0;
+        if (c.row_of_tile) {
+            int prev = -1;
+            for (int t = t0; t <= t1; ++t) { int r = c.row_of_tile[t]; if (r != prev) { f |= c.m[(size_t) r * c.stride + g]; prev = r; } }
+        } else f = c.m[(size_t) (i0 / BLOCK_ROWS) * c.stride + g];
+        if (f) list_s[atomicAdd(&cnt_s, 1)] = g;
+    }
+    __syncthreads();
+    return cnt_s;
+}
+__global__ void comp_rows_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched, const int* __restrict__ group_leaf,
+                                 int n_rb, int n_leaves, int n_groups, uint8_t* __restrict__ comp_r) {
+    size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t) n_rb * n_groups) return;
+    int rb = (int) (idx / n_groups), g = (int) (idx % n_groups);
+    size_t t = (size_t) rb * n_leaves + group_leaf[g];
+    comp_r[idx] = done[t] | sched[t];
+}
+__global__ void comp_cols_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched, int n_rb, int n_leaves, int n_rg,
+                                 int rg_blocks, uint8_t* __restrict__ comp_c) {
+    size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t) n_leaves * n_rg) return;
+    int l = (int) (idx / n_rg), rg = (int) (idx % n_rg);
+    uint8_t v = 0;
+    for (int rb = rg * rg_blocks; rb < min(n_rb, (rg + 1) * rg_blocks); ++rb) v |= done[(size_t) rb * n_leaves + l] | sched[(size_t) rb * n_leaves + l];
+    comp_c[idx] = v;
+}
+
+// upper bounds after a masked pass (section 3b): largest over the row block / the leaf of  min_g (filtered + eps)
+__global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
+                                                            const float* __restrict__ nQ, const int* __restrict__ blkclQ,
+                                                            const float* __restrict__ gmax, EpsExtra ex, CompView comp, float* __restrict__ u_rb) {
+    extern __shared__ int list_s[];
+    const int i = blockIdx.x * BLOCK_ROWS + threadIdx.x;
+    const int n_list = comp_list(comp, blockIdx.x * BLOCK_ROWS, q_pad, n_groups, list_s);
+    float ub = -1.f;   // padding rows need nothing
+    if (i < q_pad && permQ[i] >= 0) {
+        int p = blkclQ[blockIdx.x];
+        float xq = sqrtf(nQ[i]) * 1.0000002f;
+        ub = __uint_as_float(0x7f800000u);
+        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, nullptr, [&](int g, float v) {
+            float e = group_eps<true>(i, g, xq, nullptr, gmax, n_groups, p, nullptr, q_pad, ex);
+            ub = fminf(ub, v + e);
+        });
+    }
+    for (int o = 32; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
+    __shared__ float sh[BLOCK_ROWS / 64];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ub;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLOCK_ROWS / 64; ++w) ub = fmaxf(ub, sh[w]);
+        u_rb[blockIdx.x] = ub;
+    }
+}
+__global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pad, const int* __restrict__ permT,
+                             const float* __restrict__ nT_sets, const float* __restrict__ gmaxA, const int* __restrict__ cl_of_rg,
+                             const int* __restrict__ tile_group, EpsExtra ex, CompView comp, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
+    extern __shared__ int list_s[];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    bool several;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, t_pad, n_rg, list_s, 0, &several);
+    float ub = 0.f;   // padding columns need nothing
+    if (j < t_pad && permT[j] >= 0) {
+        ub = __uint_as_float(0x7f800000u);
+        scan_groups(table, (size_t) t_pad, j, n_list, n_rg, list_s, several ? comp_row(comp, j, 0) : nullptr, [&](int g, float v) {
+            float e = group_eps<false>(j, g, 0.f, nT_sets, gmaxA, n_rg, 0, cl_of_rg, t_pad, ex);
+            ub = fminf(ub, v + e);
+        });
+        ub = ub > 0.f ? ub : 0.f;
+    }
+    // the 32 columns of a tile share a leaf: one atomic per tile (t_pad is a multiple of the block size, so whole waves get here)
+    for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
+    if ((threadIdx.x & 31) == 0 && j < t_pad && ub > 0.f) atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
+}
+// +inf for the table entries a masked pass is about to compute for the first time (the tables hold 10 GB at 1M x 1M and
+// only a fifth of them is ever computed or read: no blanket fill).  Row table: (group of a newly scheduled leaf, the 256
+// rows of the block).  Column table: the columns of the leaf in the block's row group, written by the lowest newly
+// scheduled block of the group unless an earlier pass already computed that (row group, leaf).  Entries that only a
+// boundary stage touches (a stage is computed when any leaf it overlaps is scheduled) may hold anything: nothing reads
+// them until their own (block, leaf) is scheduled, and that initialises them here.
+__global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* __restrict__ sched, const uint8_t* __restrict__ done, int n_rb, int n_leaves,
+                                                                  const int* __restrict__ leaf_g0 /* [n_leaves + 1] */, const int* __restrict__ group_start,
+                                                                  int rg_blocks, int* __restrict__ rowmin, size_t ma_pad, int* __restrict__ colmin, size_t mb_pad) {
+    __shared__ uint8_t s_s[MAXLEAF];   // 0: nothing, 1: rows only, 3: rows and columns
+    const int rb = blockIdx.x, tid = threadIdx.x;
+    const int rg = rb / rg_blocks, rb_lo = rg * rg_blocks, rb_hi = min(n_rb, rb_lo + rg_blocks);
+    for (int l = tid; l < n_leaves; l += BLOCK_ROWS) {
+        uint8_t f = sched[(size_t) rb * n_leaves + l] ? 1 : 0;
+        if (f && colmin) {
+            bool first = true;
+            for (int r = rb_lo; r < rb_hi; ++r) {
+                if (done[(size_t) r * n_leaves + l]) first = false;
+                if (r < rb && sched[(size_t) r * n_leaves + l]) first = false;
+            }
+            if (first) f = 3;
+        }
+        s_s[l] = f;
+    }
+    __syncthreads();
+    constexpr int IINF = 0x7f800000;
+    for (int l = 0; l < n_leaves; ++l) {
+        const uint8_t f = s_s[l];
+        if (!f) continue;
+        const int g0 = leaf_g0[l], g1 = leaf_g0[l + 1];
+        for (int g = g0; g < g1; ++g) rowmin[(size_t) g * ma_pad + (size_t) rb * BLOCK_ROWS + tid] = IINF;
+        if ((f & 2) && g0 < g1)
+            for (int col = group_start[g0] + tid; col < group_start[g1]; col += BLOCK_ROWS) colmin[(size_t) rg * mb_pad + col] = IINF;
+    }
+}
+
+// tile scheduling of one pass (section 3b).  sched_kernel: tiles of the previous pass become done; a tile not yet
+// done is scheduled when  LBsq <= beta_sq * U  of its row block or (both directions) of its leaf.  mask_kernel turns the
+// scheduled (row block, leaf) tiles into stage masks: a stage is computed when any leaf it overlaps is scheduled.
+struct MaskStats { unsigned long long stages[8]; };
+__global__ void sched_kernel(int both, float beta_sq, const float* __restrict__ LBsq, const float* __restrict__ u_rb,
+                             const unsigned* __restrict__ u_leaf, int n_rb, int n_leaves, uint8_t* __restrict__ done, uint8_t* __restrict__ sched) {
+    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t) n_rb * n_leaves) return;
+    const int rb = (int) (idx / n_leaves), g = (int) (idx % n_leaves);
+    uint8_t d = done[idx] | sched[idx];
+    done[idx] = d;
+    uint8_t s = 0;
+    if (!d) {
+        float lb = LBsq[idx], urb = u_rb[rb];
+        bool need = urb >= 0.f && lb <= beta_sq * (urb * LB_GROW + 1e-12f);
+        if (both) { float ug = __uint_as_float(u_leaf[g]); need = need || lb <= beta_sq * (ug * LB_GROW + 1e-12f); }
+        s = need ? 1 : 0;
+    }
+    sched[idx] = s;
+}
+__global__ void mask_kernel(int pass, const uint8_t* __restrict__ sched, const int* __restrict__ tile_group,
+                            int n_rb, int n_cc, int n_leaves, int n_stage_total, unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned m = 0u;
+    if (idx < n_rb * n_cc) {
+        const int rb = idx / n_cc, cc = idx % n_cc;
+        for (int s = 0; s < STAGES_PER_CHUNK; ++s) {
+            int gst = cc * STAGES_PER_CHUNK + s;
+            if (gst >= n_stage_total) break;
+            bool on = false;
+            int gprev = -1;
+            for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                int g = tile_group[gst * STAGE_TILES + ct];
+                if (g == gprev) continue;
+                gprev = g;
+                on = on || sched[(size_t) rb * n_leaves + g] != 0;
+            }
+            if (on) m |= 1u << s;
+        }
+        mask[idx] = m;
+    }
+    unsigned c = __popc(m);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats->stages[pass], (unsigned long long) c);
+}
+
+// Self-check of the filter bound (LGR_MATCH_CHECK=1, test sizes only): for sampled queries and every computed group,
+// |filtered minimum - exact minimum of the squared distance (double)| / eps, maximised through atomicMax on the float
+// bits.  eps is a proven bound, so the ratio must stay <= 1; tests assert it on both operand formats.
+template <bool ROWDIR>
+__global__ void check_kernel(const float* __restrict__ table, int n_groups, int q_pad, int group_size, const int* __restrict__ starts,
+                             const float* __restrict__ Qsorted, const int* __restrict__ permQ, const float* __restrict__ Tsorted,
+                             const int* __restrict__ permT, int t_pad, const float* __restrict__ nQ, const int* __restrict__ blkclQ,
+                             const float* __restrict__ nQ_sets, const float* __restrict__ gmax, const int* __restrict__ cl_of_group,
+                             EpsExtra ex, CompView comp, int stride, const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched,
+                             int n_leaves, unsigned* __restrict__ worst) {
+    extern __shared__ int list_s[];
+    const int i = blockIdx.x * stride;   // sampled padded query position
+    // the computed groups of the row block (rows) / of the leaf (columns) this query lives in
+    const int n_list = comp_list(comp, ROWDIR ? (i / BLOCK_ROWS) * BLOCK_ROWS : (i / TILE) * TILE, q_pad, n_groups, list_s, ROWDIR ? BLOCK_ROWS : TILE);
+    // columns: a row group is computed row block by row block; the table holds the minimum over the computed ones only
+    const int my_leaf = (!ROWDIR && done && i < q_pad) ? comp.row_of_tile[i / TILE] : -1;
+    if (i >= q_pad || permQ[i] < 0) return;
+    const int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
+    const float xq = ROWDIR ? sqrtf(nQ[i]) * 1.0000002f : 0.f;
+    float q[33];
+    for (int k = 0; k < 33; ++k) q[k] = Qsorted[(size_t) i * 33 + k];
+    for (int kk = 0; kk < (n_list < 0 ? n_groups : n_list); ++kk) {
+        const int g = n_list < 0 ? kk : list_s[kk];
+        const float v = table[(size_t) g * q_pad + i];
+        const int j0 = starts ? starts[g] : g * group_size, j1 = starts ? starts[g + 1] : min(t_pad, j0 + group_size);
+        double best = 1e300;
+        for (int j = j0 + (int) threadIdx.x; j < j1; j += blockDim.x) {
+            if (permT[j] < 0) continue;
+            if (my_leaf >= 0) {
+                size_t t = (size_t) (j / BLOCK_ROWS) * n_leaves + my_leaf;
+                if (!(done[t] | sched[t])) continue;
+            }
+            double d = 0;
+            for (int k = 0; k < 33; ++k) { double t = (double) q[k] - (double) Tsorted[(size_t) j * 33 + k]; d += t * t; }
+            best = d < best ? d : best;
+        }
+        for (int o = 32; o > 0; o >>= 1) { double other = __shfl_xor(best, o); best = other < best ? other : best; }
+        __shared__ double sh[4];
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int) (blockDim.x >> 6); ++w) best = sh[w] < best ? sh[w] : best;
+            if (best < 1e299) {   // the group has valid rows: the table entry must be finite and within eps
+                float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
+                float ratio = (v < FLT_BIG) ? (float) (fabs((double) v - best) / (double) e) : 1e30f;
+                atomicMax(worst, __float_as_uint(ratio));
+            }
+        }
+    }
+}
+
+constexpr int CAND_KEEP = 4;   // smallest lower bounds kept per query by rerank_count (up to CAND_KEEP - 1 candidates without a rescan)
+template <bool ROWDIR>
+__global__ void rerank_count(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
+                             const float* __restrict__ nQ /* ROWDIR: |a'|^2 per padded row */, const int* __restrict__ blkclQ,
+                             const float* __restrict__ nQ_sets /* COLDIR: |b - c_p|^2 [KCL][q_pad] */, const float* __restrict__ gmax,
+                             const int* __restrict__ cl_of_group, int dense_limit /* < 0: every query takes the dense path */, EpsExtra ex, CompView comp,
+                             float* __restrict__ thr_out, int* __restrict__ counts, int* __restrict__ cand /* [q_pad][CAND_KEEP] */,
+                             unsigned* __restrict__ dense, RerankCounters* __restrict__ cnt) {
+    extern __shared__ int list_s[];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool several;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s, 0, &several);
+    if (i >= q_pad) return;
+    counts[i] = 0;
+    int o = permQ[i];
+    if (o < 0) return;
+    if (dense_limit < 0) {   // the filter is not usable for this call (a centred norm overflows float): exact brute force
+        unsigned pos = atomicAdd(&cnt->n_dense, 1u);
+        dense[pos] = (unsigned) o;
+        return;
+    }
+    int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
+    float nq = ROWDIR ? nQ[i] : 0.f;
+    float xq = ROWDIR ? sqrtf(nq) * 1.0000002f : 0.f;
+    // one scan: the smallest upper bound, and the CAND_KEEP smallest lower bounds with their groups.  Candidates are the
+    // groups whose lower bound does not exceed thr (derived from the smallest upper bound); there is about one per query,
+    // so they are almost always among the kept ones and neither a second scan here nor one in rerank_emit is needed.
+    float ub = __uint_as_float(0x7f800000u);
+    float lo[CAND_KEEP];
+    int lg[CAND_KEEP];
+#pragma unroll
+    for (int j = 0; j < CAND_KEEP; ++j) { lo[j] = __uint_as_float(0x7f800000u); lg[j] = -1; }
+    const uint8_t* own = (ROWDIR || !several) ? nullptr : comp_row(comp, i, 0);   // the list is exact unless the block spans two leaves
+    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, own, [&](int g, float v) {
+        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
+        ub = fminf(ub, v + e);
+        float l = v - e;
+        int gi = g;
+        if (l < lo[CAND_KEEP - 1]) {
+#pragma unroll
+            for (int j = 0; j < CAND_KEEP; ++j)
+                if (l < lo[j]) { float tl = lo[j]; int tg = lg[j]; lo[j] = l; lg[j] = gi; l = tl; gi = tg; }
+        }
+    });
+    if (!(ub < FLT_BIG)) return;     // no valid train row at all
+    double d2 = fmax((double) ub, 0.0);   // both tables hold d2~ = S + |a'|^2
+    float thr = (float) ((double) ub + 1e-5 * d2 + 8.0 * 5.9604644775390625e-8 * fabs((double) ub) + 1e-30);
+    if (thr < ub) thr = ub;
+    int nc = 0;
+    if (lo[CAND_KEEP - 1] <= thr) {
+        // the kept list may be incomplete: count by a second scan, rerank_emit rescans too (cand[0] = -1)
+        scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, own, [&](int g, float v) {
+            float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
+            nc += (v - e <= thr) ? 1 : 0;
+        });
+        cand[(size_t) i * CAND_KEEP] = -1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < CAND_KEEP - 1; ++j)
+            if (lo[j] <= thr) { cand[(size_t) i * CAND_KEEP + nc] = lg[j]; ++nc; }
+    }
+    if (nc > dense_limit) {
+        unsigned pos = atomicAdd(&cnt->n_dense, 1u);
+        dense[pos] = (unsigned) o;
+        return;
+    }
+    thr_out[i] = thr;
+    counts[i] = nc;
+}
+
+template <bool ROWDIR>
+__global__ void rerank_emit(const float* __restrict__ table, int n_groups, int q_pad, const float* __restrict__ nQ,
+                            const int* __restrict__ blkclQ, const float* __restrict__ nQ_sets, const float* __restrict__ gmax,
+                            const int* __restrict__ cl_of_group, EpsExtra ex, CompView comp, const float* __restrict__ thr_in,
+                            const int* __restrict__ counts, const int* __restrict__ cand, const int* __restrict__ offs,
+                            unsigned* __restrict__ item_q, unsigned* __restrict__ item_g) {
+    extern __shared__ int list_s[];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool several;
+    const int n_list = comp_list(comp, blockIdx.x * blockDim.x, q_pad, n_groups, list_s, 0, &several);
+    if (i >= q_pad || counts[i] == 0) return;
+    int p = ROWDIR ? blkclQ[i / BLOCK_ROWS] : 0;
+    float xq = ROWDIR ? sqrtf(nQ[i]) * 1.0000002f : 0.f;
+    float thr = thr_in[i];
+    int pos = offs[i];
+    if (cand[(size_t) i * CAND_KEEP] >= 0) {   // the candidates rerank_count kept
+        for (int j = 0; j < counts[i]; ++j) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) cand[(size_t) i * CAND_KEEP + j]; ++pos; }
+        return;
+    }
+    scan_groups(table, (size_t) q_pad, i, n_list, n_groups, list_s, (ROWDIR || !several) ? nullptr : comp_row(comp, i, 0), [&](int g, float v) {
+        float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
+        if (v - e <= thr) { item_q[pos] = (unsigned) i; item_g[pos] = (unsigned) g; ++pos; }
+    });
+}
+
+// 4b. exact distances of the (query position, train group) items, sorted by group: a workgroup takes 256 consecutive
+// items (almost always one group) and every thread scans the group's train rows for its own query with the canonical
+// distance.  The train row address is wave uniform (made explicit with readfirstlane), so the rows arrive through the
+// scalar cache as SGPR operands of the VALU ops: no vector loads, no LDS in the inner loop.
+constexpr int RQ_THREADS = 256;
+__global__ __launch_bounds__(RQ_THREADS) void rerank_grouped(const float* __restrict__ Q, const int* __restrict__ permQ,
+                                                             const float* __restrict__ Tsorted, const int* __restrict__ permT, int t_pad,
+                                                             int group_size, const int* __restrict__ starts /* variable groups, or nullptr */,
+                                                             int block, int nblocks, const unsigned* __restrict__ item_g,
+                                                             const unsigned* __restrict__ item_q, unsigned n_items,
+                                                             unsigned long long* __restrict__ best) {
+    __shared__ unsigned next_g;
+    const int tid = threadIdx.x;
+    const unsigned idx = blockIdx.x * RQ_THREADS + tid;
+    const bool act = idx < n_items;
+    const unsigned g = act ? item_g[idx] : 0xffffffffu;
+    const int qo = act ? permQ[item_q[idx]] : -1;
+    float q[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) q[k] = act ? Q[(size_t) qo * 33 + k] : 0.f;
+    unsigned long long bk = ~0ull;
+    unsigned cur = item_g[blockIdx.x * RQ_THREADS];   // items are sorted: the first one has the smallest group
+    while (cur != 0xffffffffu) {
+        const int j0 = __builtin_amdgcn_readfirstlane(starts ? starts[cur] : (int) cur * group_size);
+        const int j1 = __builtin_amdgcn_readfirstlane(starts ? starts[cur + 1] : min(t_pad, j0 + group_size));
+        // waves without an item of this group skip it (wave-uniform branch)
+        if (__ballot(act && g == cur) != 0ull) {
+            for (int j = j0; j < j1; ++j) {
+                const int to = __builtin_amdgcn_readfirstlane(permT[j]);
+                if (to < 0) continue;                // padding
+                const float* __restrict__ tp = Tsorted + (size_t) j * 33;   // wave-uniform address -> scalar loads
+                float t[33];
+#pragma unroll
+                for (int k = 0; k < 33; ++k) t[k] = tp[k];
+                float d = exact_l2(q, t);
+                if (act && g == cur && d < FLT_BIG) {   // batchDistance keeps only d < FLT_MAX
+                    unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | tie_rank(to, block, nblocks);
+                    bk = key < bk ? key : bk;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) next_g = 0xffffffffu;
+        __syncthreads();
+        if (act && g > cur) atomicMin(&next_g, g);
+        __syncthreads();
+        cur = next_g;
+    }
+    if (act && bk != ~0ull) atomicMin(&best[qo], bk);
+}
+
+// 4c. dense fallback (degenerate data: more than half of all groups qualify, e.g. huge sets of identical rows):
+// plain exact brute force over the original train rows, parallel over (256 dense queries) x (column chunk).
+constexpr int DENSE_CHUNK = 8192;
+__global__ __launch_bounds__(256) void rerank_dense(const float* __restrict__ Q, const float* __restrict__ T,
+                                                    const uint8_t* __restrict__ validT, int nt, int block, int nblocks,
+                                                    const unsigned* __restrict__ dense, unsigned n_dense,
+                                                    unsigned long long* __restrict__ best) {
+    __shared__ float Ts[64 * 33];
+    __shared__ uint8_t vTs[64];
+    int c0 = blockIdx.y * DENSE_CHUNK, c1 = min(nt, c0 + DENSE_CHUNK);
+    for (unsigned base = blockIdx.x * 256; base < n_dense; base += gridDim.x * 256) {
+        unsigned di = base + threadIdx.x;
+        bool act = di < n_dense;
+        unsigned qi = act ? dense[di] : 0;
+        float q[33];
+#pragma unroll
+        for (int k = 0; k < 33; ++k) q[k] = act ? Q[(size_t) qi * 33 + k] : 0.f;
+        unsigned long long bk = ~0ull;
+        for (int j0 = c0; j0 < c1; j0 += 64) {
+            __syncthreads();
+            int nj = min(64, c1 - j0);
+            for (int i = threadIdx.x; i < nj * 33; i += 256) Ts[i] = T[(size_t) j0 * 33 + i];
+            if (threadIdx.x < nj) vTs[threadIdx.x] = validT[j0 + threadIdx.x];
+            __syncthreads();
+            if (act) {
+                for (int jj = 0; jj < nj; ++jj) {
+                    if (!vTs[jj]) continue;
+                    float d = exact_l2(q, Ts + jj * 33);
+                    if (!(d < FLT_BIG)) continue;
+                    unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | tie_rank(j0 + jj, block, nblocks);
+                    bk = key < bk ? key : bk;
+                }
+            }
+        }
+        if (act && bk != ~0ull) atomicMin(&best[qi], bk);
+        __syncthreads();
+    }
+}
+
+__global__ void fill_u64(unsigned long long* __restrict__ p, int n, unsigned long long v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void rerank_finalize(const unsigned long long* __restrict__ best, int nq, int block, int nblocks,
+                                int32_t* __restrict__ idx, float* __restrict__ dist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    unsigned long long k = best[i];
+    if (k == ~0ull) { idx[i] = -1; dist[i] = 0.f; return; }
+    unsigned rank = (unsigned) (k & 0xffffffffu);
+    int qb = rank / block, r = rank % block;
+    int blk = nblocks - 1 - qb;
+    idx[i] = blk * block + r;
+    dist[i] = __uint_as_float((unsigned) (k >> 32));
+}
+
+int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// one side (A or B) after clustering
+struct Side {
+    int m = 0, n_valid = 0, n_pad = 0;
+    int* perm = nullptr;          // [n_pad] padded position -> original row or -1
+    uint8_t* valid = nullptr;     // [m]
+    int* blkcl = nullptr;         // [n_pad / 256] cluster of each 256-row block (device)
+    int* leaf_start = nullptr;    // [n_leaves + 1] padded start of every leaf (device); leaf l covers [start[l], start[l+1])
+    int* leaf_count = nullptr;    // [MAXLEAF + 1] valid rows per leaf (device; [MAXLEAF] = invalid rows)
+    unsigned* r2max = nullptr;    // [MAXLEAF] squared leaf radius bits (device)
+    std::vector<int> h_blkcl;     // host copies
+    std::vector<int> h_leaf_start;
+};
+
+// assign + sort + place one side.  Leaves start at multiples of leaf_unit, clusters at multiples of cluster_unit
+// (a multiple of 256 and of leaf_unit); padding positions carry perm = -1.
+int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const float* cen2, int sub, int leaf_unit, int cluster_unit,
+               int ws_keys, int ws_perm, Side* s) {
+    s->m = m;
+    const int n_leaves = KCL * sub;
+    unsigned *keys, *keys2;
+    int *vals, *vals2;
+    char* kbuf;
+    size_t body = (((size_t) m * 17 + 255) & ~(size_t) 255);
+    LGR_TRY(lgr_ws_t(ctx, ws_keys, body + 16384, &kbuf));
+    keys = (unsigned*) kbuf; keys2 = keys + m; vals = (int*) (keys2 + m); vals2 = vals + m;
+    s->valid = (uint8_t*) (vals2 + m);
+    int* counts = (int*) (kbuf + body);               // [MAXLEAF + 1]
+    unsigned* rmax = (unsigned*) (kbuf + body + 8192);   // [MAXLEAF]
+    s->leaf_count = counts; s->r2max = rmax;
+    LGR_HIP(ctx, hipMemsetAsync(counts, 0, 16384, ctx->stream));
+    const size_t assign_lds = ((size_t) KCL * (sub * 33 + 1) + 2 * MAXLEAF + 1) * 4;
+    if (assign_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) assign_lds));
+    assign_kernel<<<cdiv(m, ASSIGN_THREADS), ASSIGN_THREADS, assign_lds, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
+    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 8192, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, counts, (MAXLEAF + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> starts(2 * (size_t) MAXLEAF + 2, 0);   // [0..MAXLEAF): sorted start, [MAXLEAF..2*MAXLEAF]: padded start
+    int acc = 0, pacc = 0;
+    s->h_blkcl.clear();
+    s->h_leaf_start.assign(n_leaves + 1, 0);
+    for (int c = 0; c < KCL; ++c) {
+        int cluster_begin = pacc;
+        for (int j = 0; j < sub; ++j) {
+            int l = c * sub + j;
+            starts[l] = acc; starts[MAXLEAF + l] = pacc;
+            s->h_leaf_start[l] = pacc;
+            acc += h[l];
+            pacc += pad_to(h[l], leaf_unit);
+        }
+        pacc = pad_to(pacc, cluster_unit);
+        for (int b = 0; b < (pacc - cluster_begin) / BLOCK_ROWS; ++b) s->h_blkcl.push_back(c);
+    }
+    s->h_leaf_start[n_leaves] = pacc;
+    starts[MAXLEAF + n_leaves] = pacc;
+    s->n_valid = acc; s->n_pad = pacc;
+    if (s->n_pad == 0) return LGR_OK;
+    int* pbuf;
+    LGR_TRY(lgr_ws_t(ctx, ws_perm, (size_t) s->n_pad + s->h_blkcl.size() + starts.size() + 64, &pbuf));
+    s->perm = pbuf; s->blkcl = pbuf + s->n_pad;
+    int* d_starts = s->blkcl + s->h_blkcl.size();
+    s->leaf_start = d_starts + MAXLEAF;
+    LGR_HIP(ctx, hipMemsetAsync(s->perm, 0xff, (size_t) s->n_pad * 4, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(s->blkcl, s->h_blkcl.data(), s->h_blkcl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(d_starts, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host staging buffers go out of scope
+    if (s->n_valid) place_kernel<<<cdiv(s->n_valid, 256), 256, 0, ctx->stream>>>(keys2, vals2, s->n_valid, d_starts, d_starts + MAXLEAF, s->perm);
+    return LGR_OK;
+}
+
+template <bool ROWDIR>
+int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
+               const float* nQ, const float* nQ_sets, const float* gmax, const int* cl_of_group,
+               const float* T, const float* Tsorted, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
+               unsigned* stat_items, unsigned* stat_dense, bool force_dense) {
+    const int q_pad = qs.n_pad;
+    unsigned* dense;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_DENSE, (size_t) q_pad * (4 + CAND_KEEP) + 64, &dense));
+    float* thr = (float*) (dense + q_pad);
+    int* counts = (int*) (dense + 2 * (size_t) q_pad);
+    int* offs = (int*) (dense + 3 * (size_t) q_pad);
+    int* cand = (int*) (dense + 4 * (size_t) q_pad);
+    char* misc;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, 4096, &misc));
+    RerankCounters* cnt = (RerankCounters*) (misc + 64);
+    LGR_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(RerankCounters), ctx->stream));
+    int nblocks = (ts.m + block - 1) / block;
+    int dense_limit = force_dense ? -1 : std::max(64, n_groups / 2);
+    rerank_count<ROWDIR><<<cdiv(q_pad, 256), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(table, n_groups, q_pad, qs.perm, nQ, qs.blkcl, nQ_sets, gmax,
+                                                                   cl_of_group, dense_limit, ex, comp, thr, counts, cand, dense, cnt);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, counts, offs, 0, (size_t) q_pad, rocprim::plus<int>(), ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
+    LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, counts, offs, 0, (size_t) q_pad, rocprim::plus<int>(), ctx->stream));
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, offs + (q_pad - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 1, counts + (q_pad - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + 2, cnt, sizeof(RerankCounters), hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned n_items = (unsigned) (h[0] + h[1]);
+    unsigned n_dense = ((RerankCounters*) (h + 2))->n_dense;
+    *stat_items = n_items; *stat_dense = n_dense;
+    if (n_items) {
+        unsigned* ib;
+        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS, (size_t) 4 * n_items + 64, &ib));
+        unsigned *item_q = ib, *item_g = ib + n_items, *item_q2 = ib + 2 * (size_t) n_items, *item_g2 = ib + 3 * (size_t) n_items;
+        rerank_emit<ROWDIR><<<cdiv(q_pad, 256), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(table, n_groups, q_pad, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group,
+                                                                      ex, comp, thr, counts, cand, offs, item_q, item_g);
+        int bits = 1;
+        while ((1 << bits) < n_groups) ++bits;
+        size_t sb = 0;
+        LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sb, item_g, item_g2, item_q, item_q2, (size_t) n_items, 0, bits, ctx->stream));
+        void* stmp;
+        LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, sb, &stmp));
+        LGR_HIP(ctx, rocprim::radix_sort_pairs(stmp, sb, item_g, item_g2, item_q, item_q2, (size_t) n_items, 0, bits, ctx->stream));
+        rerank_grouped<<<cdiv(n_items, RQ_THREADS), RQ_THREADS, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, starts, block, nblocks,
+                                                                                 item_g2, item_q2, n_items, best);
+    }
+    if (n_dense) {
+        dim3 g(std::min(cdiv(n_dense, 256), 64), cdiv(ts.m, DENSE_CHUNK));
+        rerank_dense<<<g, 256, 0, ctx->stream>>>(Q, T, ts.valid, ts.m, block, nblocks, dense, n_dense, best);
+    }
+    rerank_finalize<<<cdiv(qs.m, 256), 256, 0, ctx->stream>>>(best, qs.m, block, nblocks, d_idx, d_dist);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+
+}  // namespace
