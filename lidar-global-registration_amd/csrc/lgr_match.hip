@@ -400,6 +400,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     g_last_stats.stages_all = (double) n_rb * n_stage_total;
     CompView comp_rows{nullptr, 0, nullptr}, comp_cols{nullptr, 0, nullptr};
     const uint8_t *chk_done = nullptr, *chk_sched = nullptr;
+    const float* chk_lb = nullptr;
+    const unsigned* chk_ustage = nullptr;
     if (!prune) {
         LGR_TRY(launch_mfma(nullptr));
         g_last_stats.stages_done = g_last_stats.stages_all;
@@ -411,6 +413,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
+        const size_t o_ust = pcarve((size_t) n_stage_total * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
         const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4), o_basis = pcarve((size_t) (34 * 33 + 64) * 4);   // V, mu, count / rmax2
@@ -422,6 +425,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         float* u_rb = (float*) (pb + o_urb);
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
+        unsigned* u_stage = (unsigned*) (pb + o_ust);
+        const bool colstage = both && env_int("LGR_MATCH_COLSTAGE", 1) != 0;
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
         int* group_leaf = (int*) (pb + o_gl);
@@ -440,7 +445,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             comp_rows_kernel<<<cdiv((long long) n_rb * n_groups, 256), 256, 0, ctx->stream>>>(done, sched, group_leaf, n_rb, n_leaves, n_groups, comp_r);
             if (both) comp_cols_kernel<<<cdiv((long long) n_leaves * n_rg, 256), 256, 0, ctx->stream>>>(done, sched, n_rb, n_leaves, n_rg, rg_rows / BLOCK_ROWS, comp_c);
         };
-        chk_done = done; chk_sched = sched;
+        chk_done = done; chk_sched = sched; chk_lb = LBsq; chk_ustage = colstage ? u_stage : nullptr;
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
         lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
@@ -478,12 +483,15 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 row_u_kernel<<<n_rb, BLOCK_ROWS, (size_t) (n_groups + 8) * 4, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, comp_rows, u_rb);
                 if (both) {
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
-                    col_u_kernel<<<cdiv(mb_pad, 256), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, comp_cols, u_leaf);
+                    LGR_HIP(ctx, hipMemsetAsync(u_stage, 0, (size_t) n_stage_total * 4, ctx->stream));
+                    col_u_kernel<<<cdiv(mb_pad, 256), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, comp_cols, u_leaf,
+                                                                                                   colstage ? u_stage : nullptr);
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
-                sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves, done, sched);
+                sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves,
+                                                                                            colstage && pass == n_beta ? 1 : 0, done, sched);
             }
-            mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, mask, mstats);
+            mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage, mask, mstats);
             init_tables_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             LGR_TRY(launch_mfma(mask));
@@ -509,6 +517,24 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                     if (hd[(size_t) rb * n_leaves + l] | hsch[(size_t) rb * n_leaves + l]) need_cols += B.h_leaf_start[l + 1] - B.h_leaf_start[l];
             fprintf(stderr, "[lgr] scheduled (row block, leaf) pairs cover %.4f of the tiles; computed stages %.4f\n",
                     need_cols / ((double) n_rb * mb_pad), g_last_stats.stages_done / g_last_stats.stages_all);
+            // which criterion asked for the final-pass tiles (hsch = the last pass): the block's rows, the leaf's columns, or both
+            std::vector<float> hlb((size_t) n_rb * n_leaves), hurb(n_rb);
+            std::vector<unsigned> hul(MAXLEAF);
+            LGR_HIP(ctx, hipMemcpy(hlb.data(), LBsq, hlb.size() * 4, hipMemcpyDeviceToHost));
+            LGR_HIP(ctx, hipMemcpy(hurb.data(), u_rb, hurb.size() * 4, hipMemcpyDeviceToHost));
+            LGR_HIP(ctx, hipMemcpy(hul.data(), u_leaf, hul.size() * 4, hipMemcpyDeviceToHost));
+            double by_rows = 0, by_cols = 0, by_both = 0;
+            for (int rb = 0; rb < n_rb; ++rb)
+                for (int l = 0; l < n_leaves; ++l) {
+                    if (!hsch[(size_t) rb * n_leaves + l]) continue;
+                    float lb = hlb[(size_t) rb * n_leaves + l], ug;
+                    memcpy(&ug, &hul[l], 4);
+                    bool r = hurb[rb] >= 0.f && lb <= hurb[rb] * 1.00001f + 1e-12f, c = lb <= ug * 1.00001f + 1e-12f;
+                    double w = B.h_leaf_start[l + 1] - B.h_leaf_start[l];
+                    (r && c ? by_both : r ? by_rows : by_cols) += w;
+                }
+            const double tot = (double) n_rb * mb_pad;
+            fprintf(stderr, "[lgr] final pass by criterion: rows only %.4f, columns only %.4f, both %.4f of the tiles\n", by_rows / tot, by_cols / tot, by_both / tot);
         }
     }
     LGR_HIP(ctx, hipGetLastError());
@@ -519,11 +545,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const int stride = 37;
         check_kernel<true><<<cdiv(ma_pad, stride), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(
             (const float*) rowmin, n_groups, ma_pad, 0, group_start, sortedA, A.perm, sortedB, B.perm, mb_pad, nAp, A.blkcl, nullptr, gmaxB, nullptr,
-            ex, comp_rows, stride, nullptr, nullptr, 0, d_worst);
+            ex, comp_rows, stride, nullptr, nullptr, 0, nullptr, nullptr, d_worst);
         if (both)
             check_kernel<false><<<cdiv(mb_pad, stride), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>(
                 (const float*) colmin, n_rg, mb_pad, rg_rows, nullptr, sortedB, B.perm, sortedA, A.perm, ma_pad, nullptr, nullptr, nBp, gmaxA, cl_of_rg,
-                ex, comp_cols, stride, chk_done, chk_sched, n_leaves, d_worst + 1);
+                ex, comp_cols, stride, chk_done, chk_sched, n_leaves, chk_lb, chk_ustage, d_worst + 1);
         unsigned* hw;
         LGR_TRY(lgr_pinned(ctx, 64, (void**) &hw));
         LGR_HIP(ctx, hipMemcpyAsync(hw, d_worst, 8, hipMemcpyDeviceToHost, ctx->stream));

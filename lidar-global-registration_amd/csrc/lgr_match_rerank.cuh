@@ -137,7 +137,7 @@ __global__ void comp_rows_kernel(const uint8_t* __restrict__ done, const uint8_t
     if (idx >= (size_t) n_rb * n_groups) return;
     int rb = (int) (idx / n_groups), g = (int) (idx % n_groups);
     size_t t = (size_t) rb * n_leaves + group_leaf[g];
-    comp_r[idx] = done[t] | sched[t];
+    comp_r[idx] = (done[t] | sched[t]) & 1;   // bit 1 (column-partial, see sched_kernel) leaves the row entries incomplete: not for the row scans
 }
 __global__ void comp_cols_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched, int n_rb, int n_leaves, int n_rg,
                                  int rg_blocks, uint8_t* __restrict__ comp_c) {
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
 }
 __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pad, const int* __restrict__ permT,
                              const float* __restrict__ nT_sets, const float* __restrict__ gmaxA, const int* __restrict__ cl_of_rg,
-                             const int* __restrict__ tile_group, EpsExtra ex, CompView comp, unsigned* __restrict__ u_leaf /* float bits, >= 0 */) {
+                             const int* __restrict__ tile_group, EpsExtra ex, CompView comp, unsigned* __restrict__ u_leaf /* float bits, >= 0 */,
+                             unsigned* __restrict__ u_stage /* [stages] or nullptr: the same maximum per 128-column stage */) {
     extern __shared__ int list_s[];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     bool several;
@@ -193,7 +194,10 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
     }
     // the 32 columns of a tile share a leaf: one atomic per tile (t_pad is a multiple of the block size, so whole waves get here)
     for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
-    if ((threadIdx.x & 31) == 0 && j < t_pad && ub > 0.f) atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
+    if ((threadIdx.x & 31) == 0 && j < t_pad && ub > 0.f) {
+        atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
+        if (u_stage) atomicMax(&u_stage[j / STAGE_COLS], __float_as_uint(ub));
+    }
 }
 // +inf for the table entries a masked pass is about to compute for the first time (the tables hold 10 GB at 1M x 1M and
 // only a fifth of them is ever computed or read: no blanket fill).  Row table: (group of a newly scheduled leaf, the 256
@@ -208,14 +212,15 @@ __global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* 
     const int rb = blockIdx.x, tid = threadIdx.x;
     const int rg = rb / rg_blocks, rb_lo = rg * rg_blocks, rb_hi = min(n_rb, rb_lo + rg_blocks);
     for (int l = tid; l < n_leaves; l += BLOCK_ROWS) {
-        uint8_t f = sched[(size_t) rb * n_leaves + l] ? 1 : 0;
-        if (f && colmin) {
+        const uint8_t sv = sched[(size_t) rb * n_leaves + l];
+        uint8_t f = (sv & 1) ? 1 : 0;   // rows of the block: whole-leaf tiles only
+        if (sv && colmin) {
             bool first = true;
             for (int r = rb_lo; r < rb_hi; ++r) {
                 if (done[(size_t) r * n_leaves + l]) first = false;
                 if (r < rb && sched[(size_t) r * n_leaves + l]) first = false;
             }
-            if (first) f = 3;
+            if (first) f |= 2;
         }
         s_s[l] = f;
     }
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* 
         const uint8_t f = s_s[l];
         if (!f) continue;
         const int g0 = leaf_g0[l], g1 = leaf_g0[l + 1];
-        for (int g = g0; g < g1; ++g) rowmin[(size_t) g * ma_pad + (size_t) rb * BLOCK_ROWS + tid] = IINF;
+        if (f & 1) for (int g = g0; g < g1; ++g) rowmin[(size_t) g * ma_pad + (size_t) rb * BLOCK_ROWS + tid] = IINF;
         if ((f & 2) && g0 < g1)
             for (int col = group_start[g0] + tid; col < group_start[g1]; col += BLOCK_ROWS) colmin[(size_t) rg * mb_pad + col] = IINF;
     }
@@ -235,8 +240,12 @@ __global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* 
 // done is scheduled when  LBsq <= beta_sq * U  of its row block or (both directions) of its leaf.  mask_kernel turns the
 // scheduled (row block, leaf) tiles into stage masks: a stage is computed when any leaf it overlaps is scheduled.
 struct MaskStats { unsigned long long stages[8]; };
+// Tile states: bit 0 = the whole (row block, leaf) tile is scheduled; bit 1 (col_partial, final pass only) = only the
+// block's ROWS do not need the leaf, some of its COLUMNS may: mask_kernel then takes just the 128-column stages whose own
+// columns ask for it (LB^2 <= the stage's largest U^2) instead of the whole leaf because of its worst column.
+__device__ __forceinline__ bool col_stage_needed(float lbsq, unsigned ustage_bits) { return lbsq <= __uint_as_float(ustage_bits) * LB_GROW + 1e-12f; }
 __global__ void sched_kernel(int both, float beta_sq, const float* __restrict__ LBsq, const float* __restrict__ u_rb,
-                             const unsigned* __restrict__ u_leaf, int n_rb, int n_leaves, uint8_t* __restrict__ done, uint8_t* __restrict__ sched) {
+                             const unsigned* __restrict__ u_leaf, int n_rb, int n_leaves, int col_partial, uint8_t* __restrict__ done, uint8_t* __restrict__ sched) {
     const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t) n_rb * n_leaves) return;
     const int rb = (int) (idx / n_leaves), g = (int) (idx % n_leaves);
@@ -246,13 +255,14 @@ __global__ void sched_kernel(int both, float beta_sq, const float* __restrict__ 
     if (!d) {
         float lb = LBsq[idx], urb = u_rb[rb];
         bool need = urb >= 0.f && lb <= beta_sq * (urb * LB_GROW + 1e-12f);
-        if (both) { float ug = __uint_as_float(u_leaf[g]); need = need || lb <= beta_sq * (ug * LB_GROW + 1e-12f); }
         s = need ? 1 : 0;
+        if (both && !need) { float ug = __uint_as_float(u_leaf[g]); if (lb <= beta_sq * (ug * LB_GROW + 1e-12f)) s = col_partial ? 2 : 1; }
     }
     sched[idx] = s;
 }
 __global__ void mask_kernel(int pass, const uint8_t* __restrict__ sched, const int* __restrict__ tile_group,
-                            int n_rb, int n_cc, int n_leaves, int n_stage_total, unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
+                            int n_rb, int n_cc, int n_leaves, int n_stage_total, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
+                            unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned m = 0u;
     if (idx < n_rb * n_cc) {
@@ -266,7 +276,8 @@ __global__ void mask_kernel(int pass, const uint8_t* __restrict__ sched, const i
                 int g = tile_group[gst * STAGE_TILES + ct];
                 if (g == gprev) continue;
                 gprev = g;
-                on = on || sched[(size_t) rb * n_leaves + g] != 0;
+                const uint8_t sv = sched[(size_t) rb * n_leaves + g];
+                on = on || (sv & 1) || ((sv & 2) && col_stage_needed(LBsq[(size_t) rb * n_leaves + g], u_stage[gst]));
             }
             if (on) m |= 1u << s;
         }
@@ -286,7 +297,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                              const int* __restrict__ permT, int t_pad, const float* __restrict__ nQ, const int* __restrict__ blkclQ,
                              const float* __restrict__ nQ_sets, const float* __restrict__ gmax, const int* __restrict__ cl_of_group,
                              EpsExtra ex, CompView comp, int stride, const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched,
-                             int n_leaves, unsigned* __restrict__ worst) {
+                             int n_leaves, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage, unsigned* __restrict__ worst) {
     extern __shared__ int list_s[];
     const int i = blockIdx.x * stride;   // sampled padded query position
     // the computed groups of the row block (rows) / of the leaf (columns) this query lives in
@@ -307,7 +318,9 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
             if (permT[j] < 0) continue;
             if (my_leaf >= 0) {
                 size_t t = (size_t) (j / BLOCK_ROWS) * n_leaves + my_leaf;
-                if (!(done[t] | sched[t])) continue;
+                const uint8_t sv = done[t] | sched[t];
+                if (!sv) continue;
+                if (!(sv & 1) && !(u_stage && col_stage_needed(LBsq[t], u_stage[i / STAGE_COLS]))) continue;   // column-partial: this column's stage only
             }
             double d = 0;
             for (int k = 0; k < 33; ++k) { double t = (double) q[k] - (double) Tsorted[(size_t) j * 33 + k]; d += t * t; }
