@@ -11,14 +11,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64"])
+@pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox"])
 def matcher_mode(request, monkeypatch):
     """Every test runs on the automatic path and with the bound-based stage skipping forced on (it is only
     automatic for >= 65536 x 65536 inputs) with 1, 4 and 64 leaves per cluster; results must not depend on it."""
     if request.param != "auto":
         monkeypatch.setenv("LGR_MATCH_PRUNE", "1")
         monkeypatch.setenv("LGR_MATCH_NEAR", "2")       # narrow first pass, so that tiles really are skipped at test sizes
-        monkeypatch.setenv("LGR_MATCH_SUB", request.param.replace("prune_sub", ""))
+        monkeypatch.setenv("LGR_MATCH_SUB", request.param.replace("prune_sub", "").split("_")[0])
+        if request.param.endswith("_leafcols_nobox"):     # the simpler schedule: ball bounds only, whole-leaf column criterion
+            monkeypatch.setenv("LGR_MATCH_COLSTAGE", "0")
+            monkeypatch.setenv("LGR_MATCH_BOX", "0")
         # the minimum tables are initialised only where a pass computes; everything else is pre-filled with 0 (the most
         # harmful stale value) to show that no uninitialised entry is ever read
         monkeypatch.setenv("LGR_MATCH_POISON", "1")
@@ -137,7 +140,7 @@ def test_match_clustered_parity_and_skipping(lgr, oracle, matcher_mode, ma, mb):
     lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 7000)
     lgr.sync()
     w = lgr.match_work()
-    if matcher_mode in ("prune_sub4", "prune_sub64"):
+    if matcher_mode in ("prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox"):
         assert w < 1.0, w
     if matcher_mode == "auto":
         assert w == 1.0
@@ -150,8 +153,8 @@ def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, ki
     minimum (computed in double on the device, LGR_MATCH_CHECK=1) -- on both f16-split operand formats and on f32, for
     FPFH-like rows, tight clusters, tiny and wide dynamic ranges and exact duplicates; results stay oracle-exact."""
     import torch
-    if matcher_mode == "prune_sub1":
-        pytest.skip("same code path as prune_sub4")
+    if matcher_mode in ("prune_sub1", "prune_sub4_leafcols_nobox"):
+        pytest.skip("same filter code path as prune_sub4")
     monkeypatch.setenv("LGR_MATCH_CHECK", "1")
     monkeypatch.setenv("LGR_MATCH_F16", "0" if fmt == "f32" else "1")
     # f16r: the rotated 30-coordinate format forced on ANY data (rows whose blocks do not sum to a constant make its
