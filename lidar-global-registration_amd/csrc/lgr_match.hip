@@ -36,7 +36,7 @@
 
 // statistics of the last match call (bench/diagnostics): candidate (query, group) items and dense-fallback queries
 // per direction, group counts, and the column stages the MFMA passes executed out of all (row block, stage) pairs
-struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; };
+struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; double coarse_tested, coarse_rejected; };
 // diagnostics of the calling thread's last match call (one context per host thread)
 static thread_local lgr_match_stats g_last_stats;
 static thread_local double g_last_check[2] = {-1, -1};
@@ -54,6 +54,11 @@ extern "C" int lgr_match_last_work(double* executed_fraction) {
 
 // MFMA operand format of the last match call: 1 = f16-split operands on v_mfma_f32_32x32x16_f16 (224 FLOP per pair),
 // 0 = f32 operands on v_mfma_f32_32x32x2_f32 (68 FLOP per pair)
+extern "C" int lgr_match_last_coarse(double* out2) {
+    if (!out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = g_last_stats.coarse_tested; out2[1] = g_last_stats.coarse_rejected;
+    return LGR_OK;
+}
 extern "C" int lgr_match_last_format(int* f16) {
     if (!f16) return LGR_ERR_INVALID_ARG;
     *f16 = g_last_stats.f16;
@@ -355,7 +360,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int* xcd_start = ibuf + 4 * (size_t) n_flags;   // [9]
     int* xcd_ctr = xcd_start + 16;                   // [8]
     const int mfma_grid = 8 * (LGR_MM_OCC / 2) * std::max(1, ctx->n_cu / 8);   // resident workgroups: LGR_MM_OCC / 2 per CU
-    auto launch_mfma = [&](const unsigned* mask) -> int {
+    auto launch_mfma = [&](const unsigned* mask, CoarseArgs ca) -> int {
         items_flag_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(mask, n_rb, n_cc, item_rb, n_ir, ccx, iflags);
         size_t sb = 0;
         LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, sb, iflags, ipos, 0, (size_t) n_flags, rocprim::plus<int>(), ctx->stream));
@@ -366,16 +371,19 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_HIP(ctx, hipMemsetAsync(xcd_ctr, 0, 32, ctx->stream));
         LGR_CHECK(ctx, ctx->mfma_timed < 8, LGR_ERR_INVALID_ARG);
         (void) hipEventRecord(ctx->ev[9 + 2 * ctx->mfma_timed], ctx->stream);
-#define LGR_MFMA_ARGS bset_stride, c_scale, out_scale, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin, n_cc, item_rb, ilist, xcd_start, xcd_ctr
-        if (f16 && rot) {
-            if (both) match_mfma<true, FMT_F16R><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
-            else match_mfma<false, FMT_F16R><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+#define LGR_MFMA_ARGS bset_stride, c_scale, out_scale, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin, n_cc, item_rb, ilist, xcd_start, xcd_ctr, ca
+        if (f16 && rot && ca.u_rb) {
+            if (both) match_mfma<true, FMT_F16R, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, FMT_F16R, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+        } else if (f16 && rot) {
+            if (both) match_mfma<true, FMT_F16R, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, FMT_F16R, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
         } else if (f16) {
-            if (both) match_mfma<true, FMT_F16><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
-            else match_mfma<false, FMT_F16><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            if (both) match_mfma<true, FMT_F16, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, FMT_F16, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
         } else {
-            if (both) match_mfma<true, FMT_F32><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
-            else match_mfma<false, FMT_F32><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
+            if (both) match_mfma<true, FMT_F32, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
+            else match_mfma<false, FMT_F32, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const float*) Aop, (const float*) Bop, LGR_MFMA_ARGS);
         }
 #undef LGR_MFMA_ARGS
         (void) hipEventRecord(ctx->ev[10 + 2 * ctx->mfma_timed], ctx->stream);
@@ -402,8 +410,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const uint8_t *chk_done = nullptr, *chk_sched = nullptr;
     const float* chk_lb = nullptr;
     const unsigned* chk_ustage = nullptr;
+    const float* chk_uq_rows = nullptr;
+    const unsigned* chk_uq_cols = nullptr;
     if (!prune) {
-        LGR_TRY(launch_mfma(nullptr));
+        LGR_TRY(launch_mfma(nullptr, CoarseArgs{}));
         g_last_stats.stages_done = g_last_stats.stages_all;
     } else {
         // section 3b: lower bounds, pass 1 (nearest tiles), upper bounds, pass 2 (everything the bounds cannot exclude)
@@ -416,6 +426,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_ust = pcarve((size_t) n_stage_total * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
+        const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(16);
         const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4), o_basis = pcarve((size_t) (34 * 33 + 64) * 4);   // V, mu, count / rmax2
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
@@ -427,6 +438,24 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
         unsigned* u_stage = (unsigned*) (pb + o_ust);
         const bool colstage = both && env_int("LGR_MATCH_COLSTAGE", 1) != 0;
+        // coarse rejection inside match_mfma (rotated format, passes with upper bounds): thresholds from u_rb / u_stage
+        const bool coarse = f16 && rot && env_int("LGR_MATCH_COARSE", 1) != 0;
+        float* smaxB = (float*) (pb + o_smax);
+        unsigned long long* coarse_cnt = (unsigned long long*) (pb + o_ccnt);
+        CoarseArgs ca_on{};
+        if (coarse) {
+            group_max_kernel<<<dim3(n_stage_total, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, STAGE_COLS, nullptr, smaxB);
+            LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 16, ctx->stream));
+            const double c_quad = 9.5367477e-6 * (double) ex.quad * 1.00001;            // eps (group_eps)
+            const double d11 = std::ldexp(1.0, -11) * (1.0 + std::ldexp(1.0, -9));      // delta: 2^-11 (x^2 + y^2) + 2^-10 x y
+            ca_on.xmax = gmaxA; ca_on.ymax = smaxB; ca_on.n_stage_total = n_stage_total;
+            ca_on.quad = (float) ((c_quad + d11) * 1.000001);                          // 2^-11 (x^2 + y^2) = 2^-11 (x + y)^2 - 2^-10 x y
+            ca_on.cross = (float) (2.0 * d11 * 1.000001);                               // 2^-9 x y (a1.b2 and a2.b1) - 2^-10 x y
+            ca_on.lin = (float) (2.0 * (double) ex.lin * 1.00001 + 1e-30);
+            ca_on.abs = (float) (((double) ex.abs * 1.00001 + 2.0 * (double) sc.a_norm[0] * std::ldexp(1.0, -25) * (double) sc.inv_s2) * 1.000001 + 1e-12);
+            ca_on.cnt = coarse_cnt;
+            chk_uq_rows = u_rb; chk_uq_cols = both ? u_stage : nullptr;
+        }
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
         int* group_leaf = (int*) (pb + o_gl);
@@ -485,7 +514,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
                     LGR_HIP(ctx, hipMemsetAsync(u_stage, 0, (size_t) n_stage_total * 4, ctx->stream));
                     col_u_kernel<<<cdiv(mb_pad, 256), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, comp_cols, u_leaf,
-                                                                                                   colstage ? u_stage : nullptr);
+                                                                                                   (colstage || coarse) ? u_stage : nullptr);
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves,
@@ -494,13 +523,20 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             mask_kernel<<<cdiv((long long) n_rb * n_cc, 256), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage, mask, mstats);
             init_tables_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
-            LGR_TRY(launch_mfma(mask));
+            CoarseArgs ca = ca_on;
+            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_stage = both ? u_stage : nullptr; }
+            LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans
         MaskStats* hs;
         LGR_TRY(lgr_pinned(ctx, 256, (void**) &hs));
         LGR_HIP(ctx, hipMemcpyAsync(hs, mstats, sizeof(MaskStats), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long* h_cc = (unsigned long long*) ((char*) hs + 128);
+        h_cc[0] = h_cc[1] = 0ull;
+        if (coarse) LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        g_last_stats.coarse_tested = (double) h_cc[0];
+        g_last_stats.coarse_rejected = (double) h_cc[1];
         g_last_stats.stages_done = 0;
         for (int k = 0; k <= n_beta; ++k) g_last_stats.stages_done += (double) hs->stages[k];
         if (env_int("LGR_MATCH_DEBUG", 0)) {
@@ -545,11 +581,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const int stride = 37;
         check_kernel<true><<<cdiv(ma_pad, stride), 256, (size_t) (n_groups + 8) * 4, ctx->stream>>>(
             (const float*) rowmin, n_groups, ma_pad, 0, group_start, sortedA, A.perm, sortedB, B.perm, mb_pad, nAp, A.blkcl, nullptr, gmaxB, nullptr,
-            ex, comp_rows, stride, nullptr, nullptr, 0, nullptr, nullptr, d_worst);
+            ex, comp_rows, stride, nullptr, nullptr, 0, nullptr, nullptr, chk_uq_rows, chk_uq_cols, d_worst);
         if (both)
             check_kernel<false><<<cdiv(mb_pad, stride), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>(
                 (const float*) colmin, n_rg, mb_pad, rg_rows, nullptr, sortedB, B.perm, sortedA, A.perm, ma_pad, nullptr, nullptr, nBp, gmaxA, cl_of_rg,
-                ex, comp_cols, stride, chk_done, chk_sched, n_leaves, chk_lb, chk_ustage, d_worst + 1);
+                ex, comp_cols, stride, chk_done, chk_sched, n_leaves, chk_lb, chk_ustage, chk_uq_rows, chk_uq_cols, d_worst + 1);
         unsigned* hw;
         LGR_TRY(lgr_pinned(ctx, 64, (void**) &hw));
         LGR_HIP(ctx, hipMemcpyAsync(hw, d_worst, 8, hipMemcpyDeviceToHost, ctx->stream));

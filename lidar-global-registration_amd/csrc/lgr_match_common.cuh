@@ -69,6 +69,26 @@ template <> struct OpFmt<FMT_F16> { typedef f16x8 frag; static constexpr int KS 
 template <> struct OpFmt<FMT_F16R> { typedef f16x8 frag; static constexpr int KS = 6; };
 struct F16Scale { float s_mul; float inv_s2; float a_norm[3]; };   // 2^s, 2^-2s, the three a-side norm-slot constants
 
+// Coarse rejection (rotated format, passes that have upper bounds; DESIGN.md 3b "coarse rejection").  After the first two
+// MFMA steps of a 32 x 32 tile the accumulator holds  c = |a'|^2_lead + |b'|^2_lead - 2 a1.b1  (scaled by 2^2s): the
+// filtered d2~ without the split cross terms a1.b2 + a2.b1 and without the lower norm terms, so
+//     |c 2^-2s - d2| <= eps(x, y) + delta(x, y),   delta = 2^-10 x y + 2^-11 (x^2 + y^2) (1 + 2^-9) + lin (x + y) + abs2
+// with x = max |a'| of the row group, y = max |b'| of the column stage (|h2| <= 2^-11 |h| per element, or the f16 flush
+// limit: the linear / absolute terms).  A tile is abandoned when every c exceeds
+//     T = max(U_rows, U_cols) (1 + 1e-5) + eps + delta
+// -- U_rows = largest U^2 of the row block (u_rb), U_cols = largest U^2 of the 128-column stage (u_stage): no element of
+// the tile can be the nearest neighbour (or tie with it) of its row or of its column, which is the same statement the
+// bound-based skipping makes about a whole (row block, leaf) tile.
+struct CoarseArgs {
+    const float* u_rb;          // [row blocks] or nullptr: no coarse rejection in this launch
+    const unsigned* u_stage;    // [column stages] float bits, or nullptr (row direction only)
+    const float* xmax;          // [row groups] max |a'| (gmaxA)
+    const float* ymax;          // [KCL][column stages] max |b'| per set (group_max_kernel over 128-column windows)
+    int n_stage_total;
+    float quad, cross, lin, abs;   // T = max(U) (1 + 1e-5) + quad (x + y)^2 + cross x y + lin (x + y) + abs
+    unsigned long long* cnt;    // [2]: tiles tested, tiles abandoned (or nullptr)
+};
+
 __device__ __forceinline__ unsigned f2key(float f) {
     unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);

@@ -26,7 +26,7 @@ __device__ unsigned long long g_prof[16];
 __device__ __forceinline__ f32x16 mfma_step(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma_step(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-template <bool COLDIR, int FMT>
+template <bool COLDIR, int FMT, bool CO /* coarse rejection (rotated format, CoarseArgs set) */>
 __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename OpFmt<FMT>::frag* __restrict__ Ap, const typename OpFmt<FMT>::frag* __restrict__ Bp,
                                                      size_t bset_stride /* fragments */, float c_scale /* 2^2s, F16 only */, float out_scale /* 2^-2s */,
                                                      const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
@@ -34,18 +34,26 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                                                      int* __restrict__ rowmin /* [n_groups][ma_pad] */,
                                                      int* __restrict__ colmin /* [ma_pad/rg_rows][mb_pad] */,
                                                      int n_cc, int item_rb, const int2* __restrict__ items, const int* __restrict__ xcd_start,
-                                                     int* __restrict__ xcd_ctr) {
+                                                     int* __restrict__ xcd_ctr, CoarseArgs ca) {
     // column stage double buffered in LDS: the next stage is prefetched into registers while the current one is
     // consumed and written to the other buffer afterwards -> one barrier per stage, global latency hidden
     constexpr bool F16 = FMT != FMT_F32;
+    static_assert(!CO || FMT == FMT_F16R, "the rotated K order puts a coarse d2~ into the first two steps (pack16_kernel)");
+    constexpr bool COARSE = CO, use_coarse = CO;
+    unsigned n_tested = 0u, n_rejected = 0u;   // wave-uniform tile counts
     typedef typename OpFmt<FMT>::frag frag;
     constexpr int KS = OpFmt<FMT>::KS;
     constexpr int STAGE_FRAGS = STAGE_TILES * KS * 64;
     constexpr int STAGE_VEC4 = STAGE_FRAGS * (int) sizeof(frag) / 16;   // 16-byte pieces per stage
-    __shared__ __attribute__((aligned(16))) frag Bs[2][STAGE_FRAGS];
-    __shared__ int cmin_s[CHUNK_COLS];
-    __shared__ int tg_s[CHUNK_COLS / TILE];
-    __shared__ int item_s;
+    // ONE __shared__ object: with a second one beside the LDS-DMA staging array hipcc waits vmcnt(0) before the first
+    // ds_read of every stage, i.e. for the DMA of the NEXT stage it has just issued (cdna_hip_programming.md, projection GEMM
+    // item 4a) -- the staging then never overlaps the stage's own MFMA chains
+    constexpr int BS_BYTES = 2 * STAGE_FRAGS * (int) sizeof(frag);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BS_BYTES + CHUNK_COLS * 4 + (CHUNK_COLS / TILE) * 4 + 16];
+    frag (*Bs)[STAGE_FRAGS] = reinterpret_cast<frag (*)[STAGE_FRAGS]>(smem);
+    int* const cmin_s = reinterpret_cast<int*>(smem + BS_BYTES);
+    int* const tg_s = cmin_s + CHUNK_COLS;
+    int& item_s = tg_s[CHUNK_COLS / TILE];
 
     // Persistent workgroups over a compacted work list.  An item is (column chunk, item_rb row blocks) with at least
     // one stage to compute.  Hardware places workgroup i on XCD i % 8; the list is partitioned per XCD (XCD x owns the
@@ -117,6 +125,18 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
 #pragma unroll
                 for (int g = 0; g < 16; ++g) nav[g] = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
             }
+            // coarse-rejection thresholds of the 32 stages of this (row block, chunk): lane s holds stage s (bit pattern of
+            // a float >= 0, scaled like the accumulator; +inf = keep everything)
+            int t_lane = IINF;
+            if (use_coarse) {
+                const int gst = min(cc * STAGES_PER_CHUNK + (lane & 31), ca.n_stage_total - 1);
+                const float ur = ca.u_rb[rb], us = ca.u_stage ? __uint_as_float(ca.u_stage[gst]) : 0.f;
+                const float x = ca.xmax[rb / rg_blocks], y = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
+                const float s = x + y;
+                float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (x * y) + ca.lin * s + ca.abs);
+                t = (t * 1.0001f) * c_scale;
+                t_lane = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
+            }
             int rmin[16];   // float bit patterns, see the epilogue note
 #pragma unroll
             for (int g = 0; g < 16; ++g) rmin[g] = IINF;
@@ -166,7 +186,11 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                     cm = min(cm, other);
                     // both halves hold the folded minimum: all 64 lanes issue the LDS atomic (no exec-mask branch in
                     // the MFMA block; the two lanes of a column hit the same word with the same value)
-                    atomicMin(&cmin_s[(st * STAGE_TILES + ct) * TILE + (lane & 31)], cm);
+                    // (inline asm: behind a compiler-visible LDS atomic hipcc waits vmcnt(0), i.e. for the LDS-DMA of the
+                    // next stage, in the middle of the current one; the s_waitcnt lgkmcnt(0) before the column flush's
+                    // barrier retires these)
+                    const unsigned lds_addr = (unsigned) (uintptr_t) (__attribute__((address_space(3))) int*) &cmin_s[(st * STAGE_TILES + ct) * TILE + (lane & 31)];
+                    asm volatile("ds_min_i32 %0, %1" : : "v"(lds_addr), "v"(cm));
                 }
             };
             auto tile_ends_group = [&](int st, int ct) {
@@ -237,6 +261,41 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
             // instructions per tile): +13 % at 4 waves/SIMD (spills), -1.4 % at 2 waves/SIMD.
             auto compute = [&](int st, int buf, int nxt) {
                 frag b[KS];
+                if (COARSE && use_coarse) {
+                    // Coarse rejection: the first two steps of a tile give a coarse d2~ (see CoarseArgs); only tiles with an
+                    // element under the stage threshold read their other four B fragments and finish the chain.  Most
+                    // tiles of a final pass end here, with a third of the LDS reads and MFMA steps and no epilogue.
+                    const int t_st = __builtin_amdgcn_readlane(t_lane, st);
+                    b[0] = Bs[buf][lane];
+                    b[1] = Bs[buf][64 + lane];
+#pragma unroll
+                    for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                        f32x16 acc = mfma_step(a[0], b[0], nav);
+                        acc = mfma_step(a[1], b[1], acc);
+                        if (ct + 1 < STAGE_TILES) {
+                            b[0] = Bs[buf][((ct + 1) * KS) * 64 + lane];
+                            b[1] = Bs[buf][((ct + 1) * KS + 1) * 64 + lane];
+                        }
+                        // smallest coarse d2~ of the lane's 16 elements against the stage threshold (bit patterns: the
+                        // signed-int order errs only among negative values, which are below any threshold anyway)
+                        int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
+#pragma unroll
+                        for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
+                        const bool keep = __ballot(m <= t_st) != 0ull;
+                        n_tested += 1u;
+                        if (keep) {
+#pragma unroll
+                            for (int kk = 2; kk < KS; ++kk) b[kk] = Bs[buf][(ct * KS + kk) * 64 + lane];
+#pragma unroll
+                            for (int kk = 2; kk < KS; ++kk) acc = mfma_step(a[kk], b[kk], acc);
+                            epilogue(acc, st, ct, nxt);
+                        } else {
+                            n_rejected += 1u;
+                            maybe_flush(st, ct, nxt);
+                        }
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) b[kk] = Bs[buf][kk * 64 + lane];
 #pragma unroll
@@ -273,6 +332,7 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
     // column minima of this item -> table (the item covers exactly one row group: single owner, plain read-modify-write)
     if (COLDIR && col_dirty) {
         PROF_T(t_c0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");   // the ds_min_i32 of col_min
         __syncthreads();
         int rg = rb0 / rg_blocks;
         int ncols = n_coltiles * TILE;
@@ -298,6 +358,10 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
         PROF_ADD(3, t_c0, t_c1);
     }
   }
+    if (use_coarse && ca.cnt && lane == 0) {
+        if (n_tested) atomicAdd(&ca.cnt[0], (unsigned long long) n_tested);
+        if (n_rejected) atomicAdd(&ca.cnt[1], (unsigned long long) n_rejected);
+    }
     PROF_T(t_wg1);
     PROF_ADD(4, t_wg0, t_wg1);
 }

@@ -116,13 +116,18 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X
 #pragma unroll
         for (int k = 0; k < 30; ++k) n2m = n2m + y[k] * y[k];
     }
+    // K order.  Plain format: [0,nd) a1.b1, [nd,2nd) a1.b2, [2nd,3nd) a2.b1, then the six norm slots.  Rotated format: the
+    // first two MFMA steps (K slots 0..31) hold a1.b1 and the leading norm terms -- a coarse d2~ the kernel tests before
+    // it spends the other four steps on a tile (match_mfma, "coarse rejection") -- then [32,62) a1.b2, [62,92) a2.b1 and
+    // the four remaining norm terms.
+    constexpr int o12 = ROT ? 32 : nd, o21 = ROT ? 62 : 2 * nd;
 #pragma unroll
     for (int k = 0; k < nd; ++k) {
         float x = (ROT ? y[k] : v[k]) * mul;  // exact (power of two)
         _Float16 h1 = (_Float16) x;           // round to nearest
         _Float16 h2 = (_Float16) (x - (float) h1);
-        if (role == 0) { put(k, h1); put(nd + k, h1); put(2 * nd + k, h2); }
-        else { put(k, h1); put(nd + k, h2); put(2 * nd + k, h1); }
+        if (role == 0) { put(k, h1); put(o12 + k, h1); put(o21 + k, h2); }
+        else { put(k, h1); put(o12 + k, h2); put(o21 + k, h1); }
     }
     // norm slots: 3 nd .. 3 nd + 2 carry |b'|^2 (expansion on the column side, constants on the row side), the next three
     // |a'|^2 the other way round, so d2~ 2^2s = |b'|^2 - 2 a'.b' + |a'|^2 comes out of the MFMA chain with C = 0
@@ -140,10 +145,15 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X
         b1 = (_Float16) __uint_as_float(0x7f800000u); b2 = (_Float16) 0.f; b3 = (_Float16) 0.f;   // padding: +inf
     }
     // columns: [expansion | constants], rows: [constants | expansion]
-    put(3 * nd + 0, rows ? c0 : b1); put(3 * nd + 1, rows ? c1 : b2); put(3 * nd + 2, rows ? c2 : b3);
-    put(3 * nd + 3, rows ? b1 : c0); put(3 * nd + 4, rows ? b2 : c1); put(3 * nd + 5, rows ? b3 : c2);
+    if (ROT) {
+        put(30, rows ? c0 : b1); put(31, rows ? b1 : c0);
+        put(92, rows ? c1 : b2); put(93, rows ? c2 : b3); put(94, rows ? b2 : c1); put(95, rows ? b3 : c2);
+    } else {
+        put(3 * nd + 0, rows ? c0 : b1); put(3 * nd + 1, rows ? c1 : b2); put(3 * nd + 2, rows ? c2 : b3);
+        put(3 * nd + 3, rows ? b1 : c0); put(3 * nd + 4, rows ? b2 : c1); put(3 * nd + 5, rows ? b3 : c2);
 #pragma unroll
-    for (int cidx = 3 * nd + 6; cidx < ks * 16; ++cidx) put(cidx, (_Float16) 0.f);
+        for (int cidx = 3 * nd + 6; cidx < ks * 16; ++cidx) put(cidx, (_Float16) 0.f);
+    }
     f16x8* base = reinterpret_cast<f16x8*>(P) + ((size_t) set * (n_pad / TILE) + tile) * ks * 64;
 #pragma unroll
     for (int piece = 0; piece < 2 * ks; ++piece) {

@@ -297,7 +297,9 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                              const int* __restrict__ permT, int t_pad, const float* __restrict__ nQ, const int* __restrict__ blkclQ,
                              const float* __restrict__ nQ_sets, const float* __restrict__ gmax, const int* __restrict__ cl_of_group,
                              EpsExtra ex, CompView comp, int stride, const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched,
-                             int n_leaves, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage, unsigned* __restrict__ worst) {
+                             int n_leaves, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
+                             const float* __restrict__ uq_rows /* coarse rejection: u_rb, or nullptr */,
+                             const unsigned* __restrict__ uq_cols /* coarse rejection: u_stage bits, or nullptr */, unsigned* __restrict__ worst) {
     extern __shared__ int list_s[];
     const int i = blockIdx.x * stride;   // sampled padded query position
     // the computed groups of the row block (rows) / of the leaf (columns) this query lives in
@@ -335,7 +337,15 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
             for (int w = 1; w < (int) (blockDim.x >> 6); ++w) best = sh[w] < best ? sh[w] : best;
             if (best < 1e299) {   // the group has valid rows: the table entry must be finite and within eps
                 float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
-                float ratio = (v < FLT_BIG) ? (float) (fabs((double) v - best) / (double) e) : 1e30f;
+                // coarse rejection leaves out tiles whose elements all lie above the U^2 of their rows and columns: an
+                // entry must still never undercut the exact minimum, but may exceed it (or stay +inf) when that minimum
+                // is above the query's own U^2 (u_rb of its row block / u_stage of its column stage)
+                bool upper = true;
+                if (ROWDIR && uq_rows) upper = best <= (double) uq_rows[i / BLOCK_ROWS];
+                if (!ROWDIR && uq_cols) upper = best <= (double) __uint_as_float(uq_cols[i / STAGE_COLS]);
+                float ratio;
+                if (v < FLT_BIG) ratio = upper ? (float) (fabs((double) v - best) / (double) e) : (float) (fmax(best - (double) v, 0.0) / (double) e);
+                else ratio = upper ? 1e30f : 0.f;
                 atomicMax(worst, __float_as_uint(ratio));
             }
         }

@@ -171,6 +171,12 @@ class Context:
         self.check(_lib.lgr_match_last_work(C.byref(f)))
         return f.value
 
+    def match_coarse(self):
+        """(tiles tested, tiles abandoned) by the coarse rejection inside the MFMA filter kernel in the last match call"""
+        out = (C.c_double * 2)()
+        self.check(_lib.lgr_match_last_coarse(out))
+        return out[0], out[1]
+
     def match_format(self):
         """'f16' (split operands on the f16 MFMA, K = 112), 'f16r' (the same on 30 rotated coordinates, K = 96) or 'f32'
         for the last match call"""
