@@ -27,7 +27,10 @@ __device__ __forceinline__ f32x16 mfma_step(float a, float b, f32x16 c) { return
 __device__ __forceinline__ f32x16 mfma_step(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <bool COLDIR, int FMT, bool CO /* coarse rejection (rotated format, CoarseArgs set) */>
-__global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename OpFmt<FMT>::frag* __restrict__ Ap, const typename OpFmt<FMT>::frag* __restrict__ Bp,
+#ifndef LGR_MM_OCC_CO
+#define LGR_MM_OCC_CO LGR_MM_OCC
+#endif
+__global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_mfma(const typename OpFmt<FMT>::frag* __restrict__ Ap, const typename OpFmt<FMT>::frag* __restrict__ Bp,
                                                      size_t bset_stride /* fragments */, float c_scale /* 2^2s, F16 only */, float out_scale /* 2^-2s */,
                                                      const int* __restrict__ blkcl, const float* __restrict__ nA, int ma_pad, int mb_pad,
                                                      int rg_rows, const int* __restrict__ tile_group, const unsigned* __restrict__ stage_mask,
@@ -48,7 +51,9 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
     // ONE __shared__ object: with a second one beside the LDS-DMA staging array hipcc waits vmcnt(0) before the first
     // ds_read of every stage, i.e. for the DMA of the NEXT stage it has just issued (cdna_hip_programming.md, projection GEMM
     // item 4a) -- the staging then never overlaps the stage's own MFMA chains
-    constexpr int BS_BYTES = 2 * STAGE_FRAGS * (int) sizeof(frag);
+    constexpr int CO_FRAGS = STAGE_TILES * 2 * 64, CO_NB = 4, CO_D = 3;   // coarse kernel: ring slot (fragments), slots, prefetch distance
+    static_assert(CO_D == 3 && CO_NB == CO_D + 1, "the counted waits below are written for three stages in flight");
+    constexpr int BS_BYTES = CO ? CO_NB * CO_FRAGS * (int) sizeof(frag) : 2 * STAGE_FRAGS * (int) sizeof(frag);
     __shared__ __attribute__((aligned(16))) unsigned char smem[BS_BYTES + CHUNK_COLS * 4 + (CHUNK_COLS / TILE) * 4 + 16];
     frag (*Bs)[STAGE_FRAGS] = reinterpret_cast<frag (*)[STAGE_FRAGS]>(smem);
     int* const cmin_s = reinterpret_cast<int*>(smem + BS_BYTES);
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                 t = (t * 1.0001f) * c_scale;
                 t_lane = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
             }
+            unsigned kept[STAGE_TILES] = {0u, 0u, 0u, 0u};   // coarse sweep: bit st of kept[ct] = tile ct of stage st goes on (wave uniform)
             int rmin[16];   // float bit patterns, see the epilogue note
 #pragma unroll
             for (int g = 0; g < 16; ++g) rmin[g] = IINF;
@@ -154,8 +160,10 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
             // first active stage of this row block (barrier first: every wave is past the previous row block's LDS reads)
             int st = __builtin_ctz(mask);
             __syncthreads();
-            stage_dma(st, 0);
-            __syncthreads();   // waits for the DMA (vmcnt(0)) and makes the stage visible
+            if (!COARSE) {
+                stage_dma(st, 0);
+                __syncthreads();   // waits for the DMA (vmcnt(0)) and makes the stage visible
+            }
             PROF_T(t_v1);
             PROF_ADD(0, t_v0, t_v1);
             // Stage loop: the DMA of the next active stage into the other buffer is issued before the current stage is
@@ -197,11 +205,9 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                 const unsigned te = ct == 0 ? tend[0] : ct == 1 ? tend[1] : ct == 2 ? tend[2] : tend[3];
                 return ((te >> st) & 1u) != 0u;
             };
-            auto maybe_flush = [&](int st, int ct, int nxt) {
-                // flush the row minima when the column group (train leaf) ends, or before skipped stages
-                if (tile_ends_group(st, ct) || (ct == STAGE_TILES - 1 && nxt != st + 1)) {
+            auto flush_rows = [&](int grp) {
+                {
                     PROF_CNT(10);
-                    const int grp = tg_s[st * STAGE_TILES + ct];
                     // Halving butterfly over the 32 lanes of each half wave: at every step a lane keeps half of
                     // its registers and receives the partner's copy of them, so 16 registers x 32 lanes reduce to
                     // one value per lane with 16 + 8 + 4 + 2 + 1 exchanges instead of 16 x 5; lane bits 4..1 then
@@ -247,6 +253,10 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                     for (int r = 0; r < 16; ++r) rmin[r] = IINF;
                 }
             };
+            auto maybe_flush = [&](int st, int ct, int nxt) {
+                // flush the row minima when the column group (train leaf) ends, or before skipped stages
+                if (tile_ends_group(st, ct) || (ct == STAGE_TILES - 1 && nxt != st + 1)) flush_rows(tg_s[st * STAGE_TILES + ct]);
+            };
             // Epilogue of one finished 32x32 tile: tile ct of stage st; nxt = the stage computed after st.
             auto epilogue = [&](const f32x16& acc, int st, int ct, int nxt) {
                 row_min1(acc);
@@ -262,19 +272,21 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
             auto compute = [&](int st, int buf, int nxt) {
                 frag b[KS];
                 if (COARSE && use_coarse) {
-                    // Coarse rejection: the first two steps of a tile give a coarse d2~ (see CoarseArgs); only tiles with an
-                    // element under the stage threshold read their other four B fragments and finish the chain.  Most
-                    // tiles of a final pass end here, with a third of the LDS reads and MFMA steps and no epilogue.
+                    // Coarse sweep: the first two steps of a tile give a coarse d2~ (see CoarseArgs); tiles with an element
+                    // under the stage threshold are only RECORDED here (kept[ct] bit st) and finished after the sweep,
+                    // outside the per-stage barriers -- every wave does the same work per stage, so nobody waits at the
+                    // barrier for a wave that happens to hold the few full tiles.
                     const int t_st = __builtin_amdgcn_readlane(t_lane, st);
-                    b[0] = Bs[buf][lane];
-                    b[1] = Bs[buf][64 + lane];
+                    const frag* cs = reinterpret_cast<const frag*>(smem) + buf * CO_FRAGS + lane;   // ring slot `buf`: [tile][2 steps][64]
+                    b[0] = cs[0];
+                    b[1] = cs[64];
 #pragma unroll
                     for (int ct = 0; ct < STAGE_TILES; ++ct) {
                         f32x16 acc = mfma_step(a[0], b[0], nav);
                         acc = mfma_step(a[1], b[1], acc);
                         if (ct + 1 < STAGE_TILES) {
-                            b[0] = Bs[buf][((ct + 1) * KS) * 64 + lane];
-                            b[1] = Bs[buf][((ct + 1) * KS + 1) * 64 + lane];
+                            b[0] = cs[(ct + 1) * 128];
+                            b[1] = cs[(ct + 1) * 128 + 64];
                         }
                         // smallest coarse d2~ of the lane's 16 elements against the stage threshold (bit patterns: the
                         // signed-int order errs only among negative values, which are below any threshold anyway)
@@ -283,16 +295,8 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                         for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
                         const bool keep = __ballot(m <= t_st) != 0ull;
                         n_tested += 1u;
-                        if (keep) {
-#pragma unroll
-                            for (int kk = 2; kk < KS; ++kk) b[kk] = Bs[buf][(ct * KS + kk) * 64 + lane];
-#pragma unroll
-                            for (int kk = 2; kk < KS; ++kk) acc = mfma_step(a[kk], b[kk], acc);
-                            epilogue(acc, st, ct, nxt);
-                        } else {
-                            n_rejected += 1u;
-                            maybe_flush(st, ct, nxt);
-                        }
+                        if (keep) kept[ct] |= 1u << st;
+                        else n_rejected += 1u;
                     }
                     return;
                 }
@@ -310,9 +314,44 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                     epilogue(acc, st, ct, nxt);
                 }
             };
+            if (COARSE) {
+                // Coarse sweep over the active stages.  Only the two coarse fragments of each tile are staged (8 x 1 KB pieces
+                // per stage, one LDS-DMA instruction per wave) into a ring of CO_NB slots, CO_D stages ahead: a stage of the
+                // sweep is too short (eight MFMAs per wave) to cover the latency of a DMA issued one stage earlier.  Per
+                // stage: counted vmcnt (this wave's piece of the stage has landed; newer ones stay in flight), raw barrier
+                // (everybody's pieces have landed, everybody is done with the previous stage), issue the DMA CO_D stages
+                // ahead into the slot the previous stage used, compute.  (__syncthreads() would drain the DMA queue.)
+                static_assert(WAVES == 2 * STAGE_TILES, "one coarse piece per wave");
+                unsigned to_issue = mask, to_do = mask;
+                int issued = 0, done_ = 0;
+                auto dma_coarse = [&]() {
+                    const int s_ = __builtin_ctz(to_issue);
+                    to_issue &= to_issue - 1u;
+                    const char* src = reinterpret_cast<const char*>(Bset + (size_t) s_ * STAGE_FRAGS + (size_t) ((wave >> 1) * KS + (wave & 1)) * 64);
+                    char* dst = reinterpret_cast<char*>(smem) + (issued % CO_NB) * (CO_FRAGS * (int) sizeof(frag)) + wave * 1024;
+                    __builtin_amdgcn_global_load_lds((const void*) (src + lane * 16), (__attribute__((address_space(3))) void*) dst, 16, 0, 0);
+                    ++issued;
+                };
+                // (the thresholds come from ordinary loads: have them in registers before the first DMA is issued -- behind a
+                // DMA in flight hipcc waits for such a load with vmcnt(0), which would drain the ring it has just filled)
+                asm volatile("" : : "v"(t_lane) : "memory");
+                while (issued < CO_D && to_issue) dma_coarse();
+                while (to_do) {
+                    st = __builtin_ctz(to_do);
+                    to_do &= to_do - 1u;
+                    const int newer = issued - done_ - 1;   // DMAs issued after this stage's
+                    if (newer >= 2) asm volatile("s_waitcnt vmcnt(2)" : : : "memory");
+                    else if (newer == 1) asm volatile("s_waitcnt vmcnt(1)" : : : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (to_issue) dma_coarse();
+                    compute(st, done_ % CO_NB, -1);
+                    ++done_;
+                }
+            }
             mask &= mask - 1u;   // st is taken
             int buf = 0;
-            while (true) {
+            while (!COARSE) {
                 int nxt = -1;
                 if (mask) { nxt = __builtin_ctz(mask); mask &= mask - 1u; }
                 if (nxt >= 0) stage_dma(nxt, buf ^ 1);
@@ -324,6 +363,33 @@ __global__ __launch_bounds__(NTHR, LGR_MM_OCC) void match_mfma(const typename Op
                 PROF_ADD(2, t_s0, t_s1);
                 buf ^= 1;
                 st = nxt;
+            }
+            if (COARSE) {
+                // the recorded tiles, in column order: the whole chain on B fragments read straight from memory (the stage
+                // image has the same order there as in LDS), the usual epilogue, row minima flushed when the group changes
+                unsigned any = kept[0] | kept[1] | kept[2] | kept[3];
+                int prev_grp = -1;
+                while (any) {
+                    const int ks_ = __builtin_ctz(any);
+                    any &= any - 1u;
+#pragma unroll
+                    for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                        if (!((kept[ct] >> ks_) & 1u)) continue;
+                        const int grp = __builtin_amdgcn_readfirstlane(tg_s[ks_ * STAGE_TILES + ct]);
+                        if (grp != prev_grp && prev_grp >= 0) flush_rows(prev_grp);
+                        prev_grp = grp;
+                        const frag* bsrc = Bset + (size_t) ks_ * STAGE_FRAGS + (size_t) ct * KS * 64 + lane;
+                        frag b[KS];
+#pragma unroll
+                        for (int kk = 0; kk < KS; ++kk) b[kk] = bsrc[kk * 64];
+                        f32x16 acc = mfma_step(a[0], b[0], nav);
+#pragma unroll
+                        for (int kk = 1; kk < KS; ++kk) acc = mfma_step(a[kk], b[kk], acc);
+                        row_min1(acc);
+                        col_min(acc, ks_, ct);
+                    }
+                }
+                if (prev_grp >= 0) flush_rows(prev_grp);
             }
             PROF_T(t_v2);
             PROF_ADD(1, t_v1, t_v2);

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox"])
+@pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse"])
 def matcher_mode(request, monkeypatch):
     """Every test runs on the automatic path and with the bound-based stage skipping forced on (it is only
     automatic for >= 65536 x 65536 inputs) with 1, 4 and 64 leaves per cluster; results must not depend on it."""
@@ -22,6 +22,8 @@ def matcher_mode(request, monkeypatch):
         if request.param.endswith("_leafcols_nobox"):     # the simpler schedule: ball bounds only, whole-leaf column criterion
             monkeypatch.setenv("LGR_MATCH_COLSTAGE", "0")
             monkeypatch.setenv("LGR_MATCH_BOX", "0")
+        if request.param.endswith("_nocoarse"):           # the final pass without the in-kernel coarse rejection
+            monkeypatch.setenv("LGR_MATCH_COARSE", "0")
         # the minimum tables are initialised only where a pass computes; everything else is pre-filled with 0 (the most
         # harmful stale value) to show that no uninitialised entry is ever read
         monkeypatch.setenv("LGR_MATCH_POISON", "1")
@@ -140,7 +142,7 @@ def test_match_clustered_parity_and_skipping(lgr, oracle, matcher_mode, ma, mb):
     lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 7000)
     lgr.sync()
     w = lgr.match_work()
-    if matcher_mode in ("prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox"):
+    if matcher_mode in ("prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse"):
         assert w < 1.0, w
     if matcher_mode == "auto":
         assert w == 1.0
@@ -153,7 +155,7 @@ def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, ki
     minimum (computed in double on the device, LGR_MATCH_CHECK=1) -- on both f16-split operand formats and on f32, for
     FPFH-like rows, tight clusters, tiny and wide dynamic ranges and exact duplicates; results stay oracle-exact."""
     import torch
-    if matcher_mode in ("prune_sub1", "prune_sub4_leafcols_nobox"):
+    if matcher_mode in ("prune_sub1", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse"):
         pytest.skip("same filter code path as prune_sub4")
     monkeypatch.setenv("LGR_MATCH_CHECK", "1")
     monkeypatch.setenv("LGR_MATCH_F16", "0" if fmt == "f32" else "1")
@@ -184,6 +186,41 @@ def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, ki
     r_rows, r_cols = lgr.match_check()
     assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
     print(f"filter bound ratio [{fmt} {kind} {matcher_mode}]: rows {r_rows:.3g} cols {r_cols:.3g}")
+
+
+def test_coarse_rejection(lgr, oracle, monkeypatch, matcher_mode):
+    """The final pass abandons tiles after their first two MFMA steps when a proven bound on the coarse distance exceeds the
+    upper bounds of the tile's rows and columns (rotated operand format).  The tiles it abandons must not change anything:
+    same matches and distances as the oracle and as the run with the rejection switched off, in both directions and through
+    the single-direction entry point; and on clustered FPFH-like rows it really does abandon tiles."""
+    import torch
+    if matcher_mode not in ("prune_sub4", "prune_sub64"):
+        pytest.skip("needs the skipping passes (upper bounds) and the default schedule")
+    rng = np.random.default_rng(4242)
+    centres = fpfh_like(rng, 40)
+    def cloud(m):
+        x = centres[rng.integers(0, 40, m)].astype(np.float64).reshape(m, 3, 11)
+        x = np.abs(x + rng.normal(0, 1.5, x.shape)) + 1e-3
+        return (100.0 * x / x.sum(2, keepdims=True)).reshape(m, 33).astype(np.float32)
+    # half tight clusters, half one broad distribution (there the bounds exclude little: the final pass has tiles to test)
+    a = np.concatenate([cloud(6000), fpfh_like(rng, 6000)]); b = np.concatenate([fpfh_like(rng, 8000), cloud(7000)])
+    monkeypatch.setenv("LGR_MATCH_CHECK", "1")
+    oi, ri = run_both(lgr, oracle, a, b, 4000)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    on = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
+    lgr.sync()
+    assert lgr.match_format() == "f16r"
+    tested, abandoned = lgr.match_coarse()
+    r_rows, r_cols = lgr.match_check()
+    assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
+    assert tested > 0 and 0 < abandoned <= tested, (tested, abandoned)
+    monkeypatch.setenv("LGR_MATCH_COARSE", "0")
+    off = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
+    lgr.sync()
+    assert lgr.match_coarse() == (0.0, 0.0)
+    for x, y in zip(on, off):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    print(f"coarse rejection [{matcher_mode}]: {abandoned:.0f} of {tested:.0f} tiles abandoned")
 
 
 def test_rotated_format_selection(lgr, oracle, monkeypatch, matcher_mode):
