@@ -315,37 +315,61 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
         const int g = n_list < 0 ? kk : list_s[kk];
         const float v = table[(size_t) g * q_pad + i];
         const int j0 = starts ? starts[g] : g * group_size, j1 = starts ? starts[g + 1] : min(t_pad, j0 + group_size);
-        double best = 1e300;
+        // best: exact minimum over the rows the entry is GUARANTEED to cover; best_all: over every row that MAY have reached it.
+        // Columns: a row block covers the column for sure when (row block, the column's own leaf) was computed for the
+        // column's stage; a stage that straddles two leaves is computed whole, so row blocks scheduled only for the OTHER leaf
+        // reach the column too -- their minima land in the entry when it is already initialised and are lost otherwise
+        // (extra information either way: the rerank only needs the guaranteed rows).
+        double best = 1e300, best_all = 1e300;
         for (int j = j0 + (int) threadIdx.x; j < j1; j += blockDim.x) {
             if (permT[j] < 0) continue;
+            bool sure = true;
             if (my_leaf >= 0) {
-                size_t t = (size_t) (j / BLOCK_ROWS) * n_leaves + my_leaf;
-                const uint8_t sv = done[t] | sched[t];
-                if (!sv) continue;
-                if (!(sv & 1) && !(u_stage && col_stage_needed(LBsq[t], u_stage[i / STAGE_COLS]))) continue;   // column-partial: this column's stage only
+                const int gst = i / STAGE_COLS;
+                bool on = false;
+                sure = false;
+                int gprev = -1;
+                for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                    const int gl = comp.row_of_tile[gst * STAGE_TILES + ct];
+                    if (gl == gprev || gl < 0) continue;
+                    gprev = gl;
+                    const size_t t = (size_t) (j / BLOCK_ROWS) * n_leaves + gl;
+                    const uint8_t sv = done[t] | sched[t];
+                    const bool c = (sv & 1) || ((sv & 2) && u_stage && col_stage_needed(LBsq[t], u_stage[gst]));   // mask_kernel's rule
+                    on = on || c;
+                    if (gl == my_leaf) sure = c;
+                }
+                if (!on) continue;
             }
             double d = 0;
             for (int k = 0; k < 33; ++k) { double t = (double) q[k] - (double) Tsorted[(size_t) j * 33 + k]; d += t * t; }
-            best = d < best ? d : best;
+            best_all = d < best_all ? d : best_all;
+            if (sure) best = d < best ? d : best;
         }
-        for (int o = 32; o > 0; o >>= 1) { double other = __shfl_xor(best, o); best = other < best ? other : best; }
-        __shared__ double sh[4];
+        for (int o = 32; o > 0; o >>= 1) {
+            double other = __shfl_xor(best, o); best = other < best ? other : best;
+            other = __shfl_xor(best_all, o); best_all = other < best_all ? other : best_all;
+        }
+        __shared__ double sh[4], sh_all[4];
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = best;
+        if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = best; sh_all[threadIdx.x >> 6] = best_all; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int w = 1; w < (int) (blockDim.x >> 6); ++w) best = sh[w] < best ? sh[w] : best;
-            if (best < 1e299) {   // the group has valid rows: the table entry must be finite and within eps
+            for (int w = 1; w < (int) (blockDim.x >> 6); ++w) { best = sh[w] < best ? sh[w] : best; best_all = sh_all[w] < best_all ? sh_all[w] : best_all; }
+            if (best_all < 1e299) {   // rows reached the entry
                 float e = group_eps<ROWDIR>(i, g, xq, nQ_sets, gmax, n_groups, p, cl_of_group, q_pad, ex);
-                // coarse rejection leaves out tiles whose elements all lie above the U^2 of their rows and columns: an
-                // entry must still never undercut the exact minimum, but may exceed it (or stay +inf) when that minimum
-                // is above the query's own U^2 (u_rb of its row block / u_stage of its column stage)
-                bool upper = true;
-                if (ROWDIR && uq_rows) upper = best <= (double) uq_rows[i / BLOCK_ROWS];
-                if (!ROWDIR && uq_cols) upper = best <= (double) __uint_as_float(uq_cols[i / STAGE_COLS]);
-                float ratio;
-                if (v < FLT_BIG) ratio = upper ? (float) (fabs((double) v - best) / (double) e) : (float) (fmax(best - (double) v, 0.0) / (double) e);
-                else ratio = upper ? 1e30f : 0.f;
+                // upper side (entry <= guaranteed minimum + eps, and finite): required unless the coarse rejection may have
+                // left the minimum out -- it abandons tiles whose elements all lie above the U^2 of their rows and columns, so
+                // an entry may exceed the exact minimum (or stay +inf) when that minimum is above the query's own U^2 (u_rb of
+                // its row block / u_stage of its column stage).  Lower side (entry >= minimum over all rows - eps): always.
+                bool upper = best < 1e299;
+                if (ROWDIR && uq_rows) upper = upper && best <= (double) uq_rows[i / BLOCK_ROWS];
+                if (!ROWDIR && uq_cols) upper = upper && best <= (double) __uint_as_float(uq_cols[i / STAGE_COLS]);
+                float ratio = 0.f;
+                if (v < FLT_BIG) {
+                    ratio = (float) (fmax(best_all - (double) v, 0.0) / (double) e);
+                    if (upper) ratio = fmaxf(ratio, (float) (fmax((double) v - best, 0.0) / (double) e));
+                } else if (upper) ratio = 1e30f;
                 atomicMax(worst, __float_as_uint(ratio));
             }
         }

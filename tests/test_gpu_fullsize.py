@@ -35,6 +35,38 @@ def test_matcher_1m_permutation_and_mutual_consistency(lgr, monkeypatch):
     assert st["dense_ab"] == 0 and st["dense_ba"] == 0 and st["items_ab"] < 1.5 * m
 
 
+def test_matcher_1m_coarse_rejection_is_invisible(lgr, monkeypatch):
+    """1M x 1M clustered FPFH-like rows: the final MFMA pass abandons most of its tiles after two K steps (coarse rejection);
+    matches and distances are bit-identical to the run without it, in both directions, and the device self-check of the
+    filter bound (sampled queries, exact group minima in double) holds with the rejection rule in force."""
+    import torch
+    monkeypatch.setenv("LGR_MATCH_POISON", "1")
+    monkeypatch.setenv("LGR_MATCH_CHECK", "1")
+    rng = np.random.default_rng(7)
+    m = 1_000_000
+    c = rng.gamma(0.6, 1.0, (3000, 3, 11)) + 1e-3
+    c = 100.0 * c / c.sum(2, keepdims=True)
+    def cloud():
+        x = np.abs(c[rng.integers(0, len(c), m)] + rng.normal(0, 1.0, (m, 3, 11))) + 1e-3
+        return (100.0 * x / x.sum(2, keepdims=True)).reshape(m, 33).astype(np.float32)
+    ta, tb = torch.from_numpy(cloud()).cuda(), torch.from_numpy(cloud()).cuda()
+    on = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 200000)]
+    lgr.sync()
+    assert lgr.match_format() == "f16r"
+    tested, abandoned = lgr.match_coarse()
+    r_rows, r_cols = lgr.match_check()
+    assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
+    assert lgr.match_work() < 0.5 and abandoned > 0.5 * tested > 0, (lgr.match_work(), tested, abandoned)
+    monkeypatch.setenv("LGR_MATCH_COARSE", "0")
+    off = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 200000)]
+    lgr.sync()
+    assert lgr.match_coarse() == (0.0, 0.0)
+    for x, y in zip(on, off):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    print(f"1M coarse rejection: {abandoned:.0f} of {tested:.0f} final-pass tiles abandoned, work {lgr.match_work():.3f}, "
+          f"bound ratios {r_rows:.3g} / {r_cols:.3g}")
+
+
 def test_downsample_1m_sorted_weights_idempotent(lgr, pair1m):
     import torch
     voxel = float(np.float32(np.sqrt(np.pi * 0.25 * 0.25 / 352.0)))
