@@ -13,6 +13,10 @@ namespace {
 //    Row minima are flushed per column group (tile_group[tile], a leaf of the train side) with an integer atomicMin
 //    on the float bits; column minima per row group with a read-modify-write (one owner per entry).  Both tables must
 //    be initialised to +inf bits, so several masked passes accumulate into the same tables.
+//    CO = true (rotated format, launches that have upper bounds: CoarseArgs): per row block a coarse sweep over the active
+//    stages (two of the six K steps per tile, tested against the stage threshold, survivors recorded in bit masks; coarse
+//    fragments only, staged through a ring of four LDS slots three stages ahead) and then the recorded tiles in full,
+//    outside the per-stage barriers, on B fragments read straight from memory.
 #ifdef EXP_PROF
 __device__ unsigned long long g_prof[16];
 #define PROF_T(var) unsigned long long var = wall_clock64()
