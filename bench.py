@@ -163,6 +163,7 @@ def main():
         res = step()
         kernel_ms.append(ctx.match_kernel_ms())
         mstats = ctx.match_stats()
+        mstats["refilter_pairs_ab"], mstats["refilter_pairs_ba"] = ctx.match_pairs()
         work.append(ctx.match_work())
         coarse.append(ctx.match_coarse())
         stage_ms.append(list(res.stage_ms)[:7])

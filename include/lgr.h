@@ -164,6 +164,10 @@ int lgr_match_last_work(double* executed_fraction);
 /* coarse rejection inside the MFMA filter kernel (rotated format only; env LGR_MATCH_COARSE=0 turns it off): 32 x 32 tiles
  * tested after their first two MFMA steps in the last match call, and tiles abandoned there. */
 int lgr_match_last_coarse(double* out2);
+/* exact rerank (f16 operand formats; env LGR_MATCH_REFILTER=0 turns it off): (query, train row) pairs the MFMA re-filter of
+ * the candidate groups passed on to the exact distance in the last match call, query->train and train->query direction; a
+ * count above the pair buffer (8 per candidate group) means that direction fell back to the exact scan of whole groups. */
+int lgr_match_last_pairs(unsigned* out2);
 /* MFMA operand format of the last match call: 1 = two-term f16 splits on v_mfma_f32_32x32x16_f16, K = 112; 2 = the same on
  * 30 Helmert coordinates, K = 96 (chosen when every 11-bin block of all rows has the same sum, as FPFH rows do; env
  * LGR_MATCH_ROT=0/1 forces it off/on); 0 = f32 operands on v_mfma_f32_32x32x2_f32 (env LGR_MATCH_F16=0).  Results do not

@@ -36,7 +36,7 @@
 
 // statistics of the last match call (bench/diagnostics): candidate (query, group) items and dense-fallback queries
 // per direction, group counts, and the column stages the MFMA passes executed out of all (row block, stage) pairs
-struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; double coarse_tested, coarse_rejected; };
+struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; double coarse_tested, coarse_rejected; unsigned pairs_ab, pairs_ba; };
 // diagnostics of the calling thread's last match call (one context per host thread)
 static thread_local lgr_match_stats g_last_stats;
 static thread_local double g_last_check[2] = {-1, -1};
@@ -54,6 +54,11 @@ extern "C" int lgr_match_last_work(double* executed_fraction) {
 
 // MFMA operand format of the last match call: 1 = f16-split operands on v_mfma_f32_32x32x16_f16 (224 FLOP per pair),
 // 0 = f32 operands on v_mfma_f32_32x32x2_f32 (68 FLOP per pair)
+extern "C" int lgr_match_last_pairs(unsigned* out2) {
+    if (!out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = g_last_stats.pairs_ab; out2[1] = g_last_stats.pairs_ba;
+    return LGR_OK;
+}
 extern "C" int lgr_match_last_coarse(double* out2) {
     if (!out2) return LGR_ERR_INVALID_ARG;
     out2[0] = g_last_stats.coarse_tested; out2[1] = g_last_stats.coarse_rejected;
@@ -596,11 +601,13 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     }
 
     // ---- 5. exact rerank
+    // (the MFMA re-filter of the rerank items needs the f16 operand formats and the padded train copies)
+    RefilterArgs ra{(const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, (f16 && env_int("LGR_MATCH_REFILTER", 1)) ? KS : 0, A.blkcl, env_int("LGR_MATCH_PAIR_CAP", -1)};
     LGR_TRY((run_rerank<true>(ctx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
-                              d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab, force_dense)));
+                              d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab, force_dense, ra, &g_last_stats.pairs_ab)));
     if (both)
         LGR_TRY((run_rerank<false>(ctx, ex, comp_cols, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
-                                   d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba, force_dense)));
+                                   d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba, force_dense, ra, &g_last_stats.pairs_ba)));
     return LGR_OK;
 }
 

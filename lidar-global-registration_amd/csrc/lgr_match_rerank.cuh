@@ -522,6 +522,133 @@ __global__ __launch_bounds__(RQ_THREADS) void rerank_grouped(const float* __rest
     if (act && bk != ~0ull) atomicMin(&best[qo], bk);
 }
 
+// 4b'. MFMA re-filter of the items (f16 operand formats).  rerank_grouped computes the exact distance to every train row of
+// an item's group (~660 per query at 1M) to find one neighbour.  The packed operands can say which of those rows matter: a
+// wave takes 32 consecutive items, gathers the queries' operand fragments into one MFMA tile and multiplies it with the
+// group's train tiles; an element (query, train row) goes on to the exact distance only when  filtered - eps <= thr  -- the
+// very criterion that made the GROUP a candidate, applied per element (|filtered - d2| <= eps holds per element), so the
+// nearest neighbour and every tie pass it.  Output: (query position, train position) pairs for rerank_pairs.
+// ROWDIR: queries are rows (gathered A fragments), trains the group's column tiles from the B set of the queries' cluster;
+// the accumulator holds 16 queries per lane.  COLDIR: queries are columns (gathered B fragments of the row group's set),
+// trains the row tiles of the group; the accumulator holds one query per lane.  Items are sorted by group and, inside a
+// group, by query position (clusters are contiguous), so a batch of 32 items is a few runs of equal (group, cluster).
+struct RefilterArgs {
+    const f16x8* Ap; const f16x8* Bp; size_t bset_stride; float out_scale; int ks;   // ks = 6 (rotated) or 7; 0 = re-filter off
+    const int* blkclA;    // cluster of every 256-row block of A (the set a row / a row group is computed against)
+    int pair_cap;         // >= 0: upper limit of the pair buffer (env LGR_MATCH_PAIR_CAP, tests)
+};
+constexpr int RF_THREADS = 256;
+template <bool ROWDIR, int KS>
+__global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, const unsigned* __restrict__ item_g, const unsigned* __restrict__ item_q, unsigned n_items,
+                                                              int n_groups, int q_pad, int t_pad, int group_size, const int* __restrict__ starts,
+                                                              const float* __restrict__ nQ, const int* __restrict__ blkclQ, const float* __restrict__ nQ_sets,
+                                                              const float* __restrict__ gmax, const int* __restrict__ cl_of_group, EpsExtra ex,
+                                                              const float* __restrict__ thr_in, unsigned cap, unsigned* __restrict__ n_pairs,
+                                                              unsigned* __restrict__ pair_q, unsigned* __restrict__ pair_t) {
+    __shared__ float thr_s[RF_THREADS / 64][32], eps_s[RF_THREADS / 64][32];
+    __shared__ int q_s[RF_THREADS / 64][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
+    // passing pairs are collected per wave in LDS and leave with one atomic per flush (an atomic per pair on the one global
+    // counter serialises in L2: 12 ms for 3 M pairs)
+    constexpr int RF_BUF = 256;
+    __shared__ unsigned buf_q[RF_THREADS / 64][RF_BUF], buf_t[RF_THREADS / 64][RF_BUF];
+    int n_buf = 0;   // wave uniform
+    auto flush = [&]() {
+        if (n_buf == 0) return;
+        unsigned pos0 = 0;
+        if (lane == 0) pos0 = atomicAdd(n_pairs, (unsigned) n_buf);
+        pos0 = (unsigned) __builtin_amdgcn_readfirstlane((int) pos0);
+        for (int e = lane; e < n_buf; e += 64)
+            if (pos0 + e < cap) { pair_q[pos0 + e] = buf_q[wave][e]; pair_t[pos0 + e] = buf_t[wave][e]; }
+        n_buf = 0;
+    };
+    const unsigned base = (blockIdx.x * (RF_THREADS / 64) + wave) * 32u;
+    if (base >= n_items) return;
+    // lane c (both halves) owns item base + c
+    const bool have = base + c < n_items;
+    const unsigned my_g = have ? item_g[base + c] : 0xffffffffu;
+    const int my_q = have ? (int) item_q[base + c] : 0;
+    const int my_p = !have ? -1 : ROWDIR ? blkclQ[my_q / BLOCK_ROWS] : cl_of_group[my_g];
+    float my_e = 0.f, my_thr = 0.f;
+    if (have) {
+        const float xq = ROWDIR ? sqrtf(nQ[my_q]) * 1.0000002f : 0.f;
+        my_e = group_eps<ROWDIR>(my_q, (int) my_g, xq, nQ_sets, gmax, n_groups, my_p, cl_of_group, q_pad, ex);
+        my_thr = thr_in[my_q];
+    }
+    bool todo = have;
+    while (__ballot(todo) != 0ull) {
+        // the run of this round: all pending items with the (group, cluster) of the first pending one
+        const int first = __ffsll((long long) __ballot(todo)) - 1;
+        const unsigned g = (unsigned) __builtin_amdgcn_readlane((int) my_g, first);
+        const int p = __builtin_amdgcn_readlane(my_p, first);
+        const bool act = todo && my_g == g && my_p == p;
+        todo = todo && !act;
+        if (ROWDIR) {   // thresholds by accumulator row: inactive rows can never pass
+            if (half == 0) { thr_s[wave][c] = act ? my_thr : -__uint_as_float(0x7f800000u); eps_s[wave][c] = act ? my_e : 0.f; q_s[wave][c] = my_q; }
+        }
+        // the queries' fragments: lane (c, half) reads the 8 halves of its query for every K step
+        f16x8 qf[KS];
+        {
+            const f16x8* src = ROWDIR ? ra.Ap : ra.Bp + (size_t) p * ra.bset_stride;
+            const size_t o = ((size_t) (my_q >> 5) * KS) * 64 + (my_q & 31) + 32 * half;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) qf[kk] = src[o + (size_t) kk * 64];
+        }
+        float thr_r[16], eps_r[16];
+        int q_r[16];
+        if (ROWDIR) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                thr_r[r] = thr_s[wave][row]; eps_r[r] = eps_s[wave][row]; q_r[r] = q_s[wave][row];
+            }
+        }
+        const int j0 = starts ? starts[g] : (int) g * group_size, j1 = starts ? starts[g + 1] : min(t_pad, j0 + group_size);
+        const f16x8* tsrc = ROWDIR ? ra.Bp + (size_t) p * ra.bset_stride : ra.Ap;
+        for (int t0 = j0; t0 < j1; t0 += TILE) {
+            f16x8 tf[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) tf[kk] = tsrc[((size_t) (t0 >> 5) * KS + kk) * 64 + lane];
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc = ROWDIR ? mfma_step(qf[kk], tf[kk], acc) : mfma_step(tf[kk], qf[kk], acc);
+            // ROWDIR: acc[r] = (query row (r&3) + 8 (r>>2) + 4 half, train column c); COLDIR: (train row ..., query column c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r] * ra.out_scale;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool pass = ROWDIR ? (v - eps_r[r] <= thr_r[r]) : (act && v - my_e <= my_thr);
+                const unsigned long long bal = __ballot(pass);
+                if (bal != 0ull) {   // wave uniform
+                    if (pass) {
+                        const int slot = n_buf + __popcll(bal & ((1ull << lane) - 1ull));
+                        buf_q[wave][slot] = ROWDIR ? (unsigned) q_r[r] : (unsigned) my_q;
+                        buf_t[wave][slot] = ROWDIR ? (unsigned) (t0 + c) : (unsigned) (t0 + row);
+                    }
+                    n_buf += __popcll(bal);
+                    if (n_buf > RF_BUF - 64) flush();
+                }
+            }
+        }
+    }
+    flush();
+}
+// exact distances of the re-filtered pairs (a thread per pair; same key as rerank_grouped)
+__global__ void rerank_pairs(const float* __restrict__ Q, const int* __restrict__ permQ, const float* __restrict__ Tsorted, const int* __restrict__ permT,
+                             int block, int nblocks, const unsigned* __restrict__ pair_q, const unsigned* __restrict__ pair_t, unsigned n_pairs,
+                             unsigned long long* __restrict__ best) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const int qo = permQ[pair_q[i]];
+    const int j = (int) pair_t[i], to = permT[j];
+    if (qo < 0 || to < 0) return;
+    float q[33], t[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) { q[k] = Q[(size_t) qo * 33 + k]; t[k] = Tsorted[(size_t) j * 33 + k]; }
+    const float d = exact_l2(q, t);
+    if (d < FLT_BIG) atomicMin(&best[qo], ((unsigned long long) __float_as_uint(d) << 32) | tie_rank(to, block, nblocks));
+}
+
 // 4c. dense fallback (degenerate data: more than half of all groups qualify, e.g. huge sets of identical rows):
 // plain exact brute force over the original train rows, parallel over (256 dense queries) x (column chunk).
 constexpr int DENSE_CHUNK = 8192;
@@ -660,7 +787,7 @@ template <bool ROWDIR>
 int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int n_groups, int group_size, const int* starts, const float* Q, const Side& qs,
                const float* nQ, const float* nQ_sets, const float* gmax, const int* cl_of_group,
                const float* T, const float* Tsorted, const Side& ts, int block, unsigned long long* best, int32_t* d_idx, float* d_dist,
-               unsigned* stat_items, unsigned* stat_dense, bool force_dense) {
+               unsigned* stat_items, unsigned* stat_dense, bool force_dense, RefilterArgs ra, unsigned* stat_pairs) {
     const int q_pad = qs.n_pad;
     unsigned* dense;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_DENSE, (size_t) q_pad * (4 + CAND_KEEP) + 64, &dense));
@@ -703,8 +830,34 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
         void* stmp;
         LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, sb, &stmp));
         LGR_HIP(ctx, rocprim::radix_sort_pairs(stmp, sb, item_g, item_g2, item_q, item_q2, (size_t) n_items, 0, bits, ctx->stream));
-        rerank_grouped<<<cdiv(n_items, RQ_THREADS), RQ_THREADS, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, starts, block, nblocks,
-                                                                                 item_g2, item_q2, n_items, best);
+        bool refiltered = false;
+        *stat_pairs = 0;
+        if (ra.ks) {
+            // MFMA re-filter of the items -> (query, train row) pairs -> exact distances of the pairs only.  The pair buffer
+            // holds 8 per item (1-3 are typical); if it ever overflows, the group scan below does the whole job instead.
+            unsigned cap = 8u * n_items + 1024u;
+            if (ra.pair_cap >= 0) cap = std::min(cap, (unsigned) ra.pair_cap);   // tests: force the overflow fallback
+            unsigned* pb;
+            LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PAIRS, (size_t) 2 * cap + 64, &pb));
+            unsigned *n_pairs = pb, *pair_q = pb + 16, *pair_t = pb + 16 + cap;
+            LGR_HIP(ctx, hipMemsetAsync(n_pairs, 0, 4, ctx->stream));
+            const int rf_grid = cdiv(n_items, 32 * (RF_THREADS / 64));
+#define LGR_RF_ARGS ra, item_g2, item_q2, n_items, n_groups, q_pad, ts.n_pad, group_size, starts, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group, ex, thr, cap, n_pairs, pair_q, pair_t
+            if (ra.ks == 6) rerank_refilter<ROWDIR, 6><<<rf_grid, RF_THREADS, 0, ctx->stream>>>(LGR_RF_ARGS);
+            else rerank_refilter<ROWDIR, 7><<<rf_grid, RF_THREADS, 0, ctx->stream>>>(LGR_RF_ARGS);
+#undef LGR_RF_ARGS
+            LGR_HIP(ctx, hipMemcpyAsync(h + 8, n_pairs, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const unsigned np = (unsigned) h[8];
+            *stat_pairs = np;
+            if (np <= cap) {
+                if (np) rerank_pairs<<<cdiv(np, 256), 256, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, block, nblocks, pair_q, pair_t, np, best);
+                refiltered = true;
+            }
+        }
+        if (!refiltered)
+            rerank_grouped<<<cdiv(n_items, RQ_THREADS), RQ_THREADS, 0, ctx->stream>>>(Q, qs.perm, Tsorted, ts.perm, ts.n_pad, group_size, starts, block, nblocks,
+                                                                                     item_g2, item_q2, n_items, best);
     }
     if (n_dense) {
         dim3 g(std::min(cdiv(n_dense, 256), 64), cdiv(ts.m, DENSE_CHUNK));

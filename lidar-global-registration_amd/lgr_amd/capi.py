@@ -171,6 +171,12 @@ class Context:
         self.check(_lib.lgr_match_last_work(C.byref(f)))
         return f.value
 
+    def match_pairs(self):
+        """(query->train, train->query) pairs the MFMA re-filter of the rerank handed to the exact distance in the last match call"""
+        out = (C.c_uint * 2)()
+        self.check(_lib.lgr_match_last_pairs(out))
+        return out[0], out[1]
+
     def match_coarse(self):
         """(tiles tested, tiles abandoned) by the coarse rejection inside the MFMA filter kernel in the last match call"""
         out = (C.c_double * 2)()

@@ -11,11 +11,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse"])
+@pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse",
+                                      "prune_sub4_groupscan", "auto_groupscan"])
 def matcher_mode(request, monkeypatch):
     """Every test runs on the automatic path and with the bound-based stage skipping forced on (it is only
     automatic for >= 65536 x 65536 inputs) with 1, 4 and 64 leaves per cluster; results must not depend on it."""
-    if request.param != "auto":
+    if request.param.endswith("_groupscan"):              # exact rerank by scanning whole candidate groups (no MFMA re-filter)
+        monkeypatch.setenv("LGR_MATCH_REFILTER", "0")
+    if not request.param.startswith("auto"):
         monkeypatch.setenv("LGR_MATCH_PRUNE", "1")
         monkeypatch.setenv("LGR_MATCH_NEAR", "2")       # narrow first pass, so that tiles really are skipped at test sizes
         monkeypatch.setenv("LGR_MATCH_SUB", request.param.replace("prune_sub", "").split("_")[0])
@@ -142,9 +145,9 @@ def test_match_clustered_parity_and_skipping(lgr, oracle, matcher_mode, ma, mb):
     lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 7000)
     lgr.sync()
     w = lgr.match_work()
-    if matcher_mode in ("prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse"):
+    if matcher_mode in ("prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse", "prune_sub4_groupscan"):
         assert w < 1.0, w
-    if matcher_mode == "auto":
+    if matcher_mode.startswith("auto"):
         assert w == 1.0
 
 
@@ -155,8 +158,8 @@ def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, ki
     minimum (computed in double on the device, LGR_MATCH_CHECK=1) -- on both f16-split operand formats and on f32, for
     FPFH-like rows, tight clusters, tiny and wide dynamic ranges and exact duplicates; results stay oracle-exact."""
     import torch
-    if matcher_mode in ("prune_sub1", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse"):
-        pytest.skip("same filter code path as prune_sub4")
+    if matcher_mode in ("prune_sub1", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse", "prune_sub4_groupscan", "auto_groupscan"):
+        pytest.skip("same filter code path as prune_sub4 / auto")
     monkeypatch.setenv("LGR_MATCH_CHECK", "1")
     monkeypatch.setenv("LGR_MATCH_F16", "0" if fmt == "f32" else "1")
     # f16r: the rotated 30-coordinate format forced on ANY data (rows whose blocks do not sum to a constant make its
@@ -221,6 +224,40 @@ def test_coarse_rejection(lgr, oracle, monkeypatch, matcher_mode):
     for x, y in zip(on, off):
         np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
     print(f"coarse rejection [{matcher_mode}]: {abandoned:.0f} of {tested:.0f} tiles abandoned")
+
+
+def test_rerank_refilter(lgr, oracle, monkeypatch, matcher_mode):
+    """The exact rerank re-filters each candidate group with the MFMA operands and takes the exact distance only for the
+    (query, train row) pairs under the query's threshold.  Same result as scanning the whole groups and as the oracle, in
+    both operand formats; far fewer exact distances than group rows; and when the pair buffer is too small the call falls
+    back to the group scan (forced here) without changing anything."""
+    import torch
+    if matcher_mode not in ("auto", "prune_sub4"):
+        pytest.skip("the rerank does not depend on the other schedule knobs")
+    rng = np.random.default_rng(99)
+    a, b = fpfh_like(rng, 9000), fpfh_like(rng, 11000)
+    a[100] = b[7]; b[6000] = b[7]; a[101] = b[7]      # exact ties across bf blocks
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    outs = {}
+    for fmt in ("f16r", "f16"):
+        monkeypatch.setenv("LGR_MATCH_ROT", "1" if fmt == "f16r" else "0")
+        monkeypatch.delenv("LGR_MATCH_PAIR_CAP", raising=False)
+        run_both(lgr, oracle, a, b, 3000)
+        outs[fmt] = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 3000)]
+        lgr.sync()
+        assert lgr.match_format() == fmt
+        st = lgr.match_stats()
+        p_ab, p_ba = lgr.match_pairs()
+        assert 0 < p_ab < 8 * st["items_ab"] and 0 < p_ba < 8 * st["items_ba"], (p_ab, p_ba, st)
+        monkeypatch.setenv("LGR_MATCH_PAIR_CAP", "100")          # overflow -> whole-group scan
+        small = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 3000)]
+        lgr.sync()
+        assert lgr.match_pairs()[0] > 100
+        for x, y in zip(outs[fmt], small):
+            np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    for x, y in zip(outs["f16r"], outs["f16"]):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    print(f"rerank re-filter [{matcher_mode}]: {p_ab} + {p_ba} pairs for {st['items_ab']} + {st['items_ba']} candidate groups")
 
 
 def test_rotated_format_selection(lgr, oracle, monkeypatch, matcher_mode):
