@@ -45,7 +45,54 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank formation + the record all-gather only (no GPU, no HIP library): proves that --gpus N forms N ranks; used by the CPU tests")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region: check sampled queries of the GPU's 1M x 1M matches against the CPU oracle (parity_sample in the JSON line)")
+    ap.add_argument("--verify-queries", type=int, default=4096)
     return ap.parse_args()
+
+
+def fan_out(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks ourselves, exactly as the
+    driver's own command would (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...).
+    This parent never imports torch or touches HIP (a process that has initialised the GPU must not exec or fork ranks); it
+    relays the children's output (rank 0 prints the one JSON line) and returns their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """Ranks + the one collective of the path, no GPU: every rank packs a record that only it can produce, the records are
+    all-gathered (gloo), and rank 0 checks that it holds one from each of the `--gpus` ranks."""
+    import torch
+    import torch.distributed as dist
+    from lgr_amd import distributed
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    rec = distributed.pack_record(rank, np.eye(4, dtype=np.float32).reshape(16) * (rank + 1), 1, 2**31 - 1 - rank, 1000 + rank, 0.0, 0.0)
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        allr = distributed.gather_records(torch.from_numpy(rec.view(np.int32).copy())[None], world)
+    elapsed = time.perf_counter() - t0
+    got = [distributed.unpack_record(r) for r in np.ascontiguousarray(allr.numpy()).view(np.float32)]
+    ok = [g["pair_id"] for g in got] == list(range(world)) and all(g["iterations"] == 2**31 - 1 - i for i, g in enumerate(got))
+    if rank == 0:
+        print(json.dumps({"metric": "scan-pair registrations/sec", "value": None, "unit": "registrations/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "dry_run": True, "ranks_seen": [g["pair_id"] for g in got], "records_ok": bool(ok)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
 
 
 def make_params(capi, pair, matching):
@@ -115,11 +162,17 @@ def cpu_baseline(pair, gpu_corr, gpu_iterations, args, matching):
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(fan_out(args))              # before anything imports torch / initialises HIP in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher formed WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the product and has no CPU fallback")
     if args.backend == "gloo":
@@ -139,12 +192,12 @@ def main():
     src = torch.from_numpy(pair["src"]).cuda(local)
     tgt = torch.from_numpy(pair["tgt"]).cuda(local)
     coll_dev = f"cuda:{local}" if args.backend == "nccl" else "cpu"
-    record = torch.zeros((1, distributed.RECORD_FLOATS), dtype=torch.float32, device=coll_dev)   # 96-byte per-pair record
+    record = torch.zeros((1, distributed.RECORD_FLOATS), dtype=torch.int32, device=coll_dev)   # 96-byte per-pair record (4-byte words)
 
     def step():
         res = ctx.align(src, tgt, params)
         rec = distributed.pack_record(rank, res.transformation, res.converged, res.iterations, res.n_inliers, res.time_cs, res.time_te)
-        record.copy_(torch.from_numpy(rec)[None])
+        record.copy_(torch.from_numpy(rec.view(np.int32))[None])
         distributed.gather_records(record, world)     # the single collective of the path (RCCL all-gather when N > 1)
         return res
 

@@ -49,11 +49,15 @@ def test_record_roundtrip():
     u = distributed.unpack_record(rec)
     np.testing.assert_array_equal(u["T"], T)
     assert (u["converged"], u["iterations"], u["n_inliers"], u["pair_id"]) == (1, 123456, 789, 17)
+    # integers above 2^24 (max_iterations defaults to INT_MAX) are carried as int32 bit patterns, not rounded through float32
+    big = distributed.unpack_record(distributed.pack_record(2**24 + 1, T.T.reshape(16), 0, 2**31 - 1, 2**30 + 3, 1.5, 2.5))
+    assert (big["iterations"], big["n_inliers"], big["pair_id"]) == (2**31 - 1, 2**30 + 3, 2**24 + 1)
+    assert (big["time_cs"], big["time_te"]) == (1.5, 2.5)
 
 
 def _fake_align(pair_id):
     T = synthetic.random_se3(np.random.default_rng(1000 + pair_id)).astype(np.float32)
-    return distributed.pack_record(pair_id, T.T.reshape(16), pair_id % 2, 10 * pair_id, pair_id + 5, 0.1, 0.2)
+    return distributed.pack_record(pair_id, T.T.reshape(16), pair_id % 2, 2**31 - 1 - 10 * pair_id, pair_id + 5, 0.1, 0.2)
 
 
 def _worker(rank, world, port, n_pairs, q):
@@ -89,3 +93,28 @@ def test_two_ranks_gloo_allgather():
 def test_single_rank_run_pairs():
     out = distributed.run_pairs(5, 1, 0, _fake_align)
     np.testing.assert_array_equal(out, np.stack([_fake_align(i) for i in range(5)]))
+
+
+def _run_bench(*argv, env_extra=None):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_2_forms_two_ranks():
+    """`python bench.py --gpus 2` (no launcher) must start 2 ranks itself and report n_gpus = 2 (pairs shard,
+    one all-gather of the 96-byte records).  --dry-run keeps the GPU out of it; the collective runs over gloo."""
+    r, out = _run_bench("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1                              # rank 0 prints ONE line
+    assert out[0]["n_gpus"] == 2 and out[0]["ranks_seen"] == [0, 1] and out[0]["records_ok"] is True
+
+
+def test_bench_rejects_world_size_mismatch():
+    r, out = _run_bench("--gpus", "1", "--dry-run", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not out
