@@ -40,6 +40,13 @@ def _g(v):
     return "%g" % float(v)
 
 
+def csv_row(line):
+    """Fields of one CSV line as the reference's CSVRow tokenises it (src/csv_parser.cpp:11-25: std::getline, then a plain split
+    at every ',' -- no quoting, empty fields kept, a trailing comma yields a last empty field, '\r' stays in the last field).
+    Pinned against the reference's own code in tests/test_oracle_ref.py."""
+    return line.rstrip("\n").split(",")
+
+
 # ---------------------------------------------------------------------------------------------------------- PLY
 def read_ply(path):
     """-> (points [n x 12 float32], fields [names of the vertex properties that were mapped])."""
@@ -146,7 +153,7 @@ def get_transformation(csv_path, name):
     """getTransformation(csv_path, transformation_name) (src/common.cpp:106-125): the first row whose key matches."""
     with open(csv_path) as f:
         for line in f:
-            tok = line.rstrip("\n").split(",")
+            tok = csv_row(line)
             if tok[0] == name:
                 return np.array([float(v) for v in tok[1:17]], np.float32).reshape(4, 4)
     raise KeyError(name)
@@ -157,7 +164,7 @@ def get_relative_transformation(csv_path, src_filename, tgt_filename):
     pos = {}
     with open(csv_path) as f:
         for line in f:
-            tok = line.rstrip("\n").split(",")
+            tok = csv_row(line)
             if tok[0] in (src_filename, tgt_filename) and len(tok) >= 17:
                 try:
                     pos[tok[0]] = np.array([float(v) for v in tok[1:17]], np.float32).reshape(4, 4)   # later rows overwrite
@@ -183,7 +190,7 @@ def read_correspondences(csv_path):
     with open(csv_path) as f:
         f.readline()
         for line in f:
-            tok = line.split(",")
+            tok = csv_row(line)
             rows.append((int(tok[0]), int(tok[1]), float(tok[2]), float(tok[3])))
     return np.array(rows, dtype=[("index_query", "<i4"), ("index_match", "<i4"), ("distance", "<f4"), ("threshold", "<f4")])
 

@@ -131,6 +131,10 @@ int orc_correspondences(const float* src, int ns, const float* tgt, int nt, cons
 /* ---- RANSAC pieces ---- */
 /* include/utils.h:13-26: first n outputs of UniformRandIntGenerator(0,INT_MAX,seed) */
 int orc_rng_stream(int rng_mode, uint64_t seed, int n, int* out);
+/* restatements pinned against the reference's own code in oracle/_ref (tests/test_oracle_ref.py) */
+int orc_comb_or_max(int n, int k);                       /* include/utils.h:34-43 */
+uint64_t orc_voxel_hash(int ix, int iy, int iz);         /* include/common.h:212-223 over include/utils.h:28-32 semantics */
+uint64_t orc_point_hash(float x, float y, float z);      /* include/common.h:202-210 */
 /* Philox4x32-10: counter=(iter,0,0,0) key=(seed_lo,seed_hi) -> 4 words */
 void orc_philox(uint64_t seed, uint32_t iter, uint32_t out[4]);
 /* src/sac_prerejective_omp.cpp:33-77 given the three raw draws r[3] (already non-negative) */

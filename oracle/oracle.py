@@ -77,6 +77,53 @@ def lib():
     return _lib
 
 
+_REF_SO = os.path.join(_HERE, "_ref", "liblgr_ref_utils.so")
+_ref = None
+
+
+def ref_utils(build_if_possible=True):
+    """The reference's own std-only translation units (src/utils.cpp, src/csv_parser.cpp + headers) behind the extern "C"
+    shim oracle/ref/ref_utils_shim.cpp -> oracle/_ref/liblgr_ref_utils.so (recipe: `make -C oracle ref`; needs
+    /root/reference, so it is built in the authoring container and travels to the GPU box as a built file).
+    Returns the ctypes library or None when it is neither present nor buildable."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(_REF_SO) and build_if_possible and os.path.isdir("/root/reference/include"):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+        if not os.path.exists(_REF_SO):
+            return None
+        _ref = C.CDLL(_REF_SO)
+        _ref.ref_combine_hash_int.restype = C.c_uint64
+        _ref.ref_combine_hash_int.argtypes = [C.c_uint64, C.c_int]
+        _ref.ref_combine_hash_float.restype = C.c_uint64
+        _ref.ref_combine_hash_float.argtypes = [C.c_uint64, C.c_float]
+        for n in ("ref_quantile_float",):
+            getattr(_ref, n).restype = C.c_float
+            getattr(_ref, n).argtypes = [C.c_double, C.c_void_p, C.c_int]
+        for n in ("ref_mean_float", "ref_stddev_float"):
+            getattr(_ref, n).restype = C.c_float
+            getattr(_ref, n).argtypes = [C.c_void_p, C.c_int]
+        _ref.ref_rng_stream.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
+    return _ref
+
+
+def comb_or_max(n, k):
+    return int(lib().orc_comb_or_max(int(n), int(k)))
+
+
+def voxel_hash(ix, iy, iz):
+    f = lib().orc_voxel_hash
+    f.restype = C.c_uint64
+    return int(f(int(ix), int(iy), int(iz)))
+
+
+def point_hash(x, y, z):
+    f = lib().orc_point_hash
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_float, C.c_float, C.c_float]
+    return int(f(x, y, z))
+
+
 def _p(a, t=C.c_void_p):
     return a.ctypes.data_as(t) if a is not None else None
 

@@ -47,6 +47,9 @@ struct HashKey3 {
         return seed;
     }
 };
+}  // namespace
+extern "C" uint64_t orc_voxel_hash(int ix, int iy, int iz) { return (uint64_t) HashKey3()(Key3{ix, iy, iz}); }   // pinned against oracle/_ref
+namespace {
 // include/downsample.h:6-30 AccumulatedPoint
 struct Acc {
     float x = 0, y = 0, z = 0, w = 0, nx = 0, ny = 0, nz = 0;

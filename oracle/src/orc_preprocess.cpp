@@ -28,6 +28,12 @@ struct PtEq {
 };
 }  // namespace
 
+extern "C" uint64_t orc_point_hash(float x, float y, float z) {   // pinned against oracle/_ref (combineHash<float>, include/utils.h:28-32)
+    Pt p{};
+    p.v[0] = x; p.v[1] = y; p.v[2] = z;
+    return (uint64_t) PtHash()(p);
+}
+
 // out holds n points; order as described above
 extern "C" int orc_dedupe(const float* pts, int n, int order, float* out, int* n_out) {
     std::unordered_set<Pt, PtHash, PtEq> set;

@@ -410,6 +410,10 @@ int comb_or_max(int n, int k) {
     return result > mx ? mx : (int) result;
 }
 
+}  // namespace
+extern "C" int orc_comb_or_max(int n, int k) { return comb_or_max(n, k); }   // pinned against oracle/_ref (tests/test_oracle_ref.py)
+namespace {
+
 struct Hyp { bool ok; float T[16]; };
 inline Hyp make_hyp(const float* src, const float* tgt, const lgr_orc_corr* corr, const int sample[3], float edge_thr) {
     Hyp h;
