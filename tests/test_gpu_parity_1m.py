@@ -1,0 +1,159 @@
+"""BASELINE-size parity (-m gpu): the 1M-point pair of BASELINE configs[1] (seed 566), every stage of the hot path checked
+against the CPU ORACLE at that size -- not against the HIP path itself.
+
+The oracle's voxel grid, k-NN normals, FPFH, density filter and RANSAC finish in seconds at 1M points on the box's cores, so
+those stages are compared IN FULL (every row, bit for bit), each fed with the HIP path's output of the stage before (so a
+difference is pinned to one stage).  Only the brute-force matcher (1e12 distance evaluations per direction) is sampled:
+4096 random queries per direction against ALL 1M train rows through oracle.match_bf_subset (matchBF semantics,
+include/matching.h:594-634: bf blocks of 200 000, later block wins a tie, lowest index inside a block, NaN rows skipped) --
+index AND distance bits.  The staged chain is finally tied to the one-call pipeline (lgr_correspondences_dev / lgr_align_dev):
+same correspondences, same transform."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = 0.25
+# include/matching.h:231 `sqrtf(M_PI * search_radius * search_radius / (float) feature_nr_points)`: the product in double, rounded
+# to float, square root in float (python floats on purpose: NumPy 2 would evaluate np.pi * np.float32 in float32)
+VOXEL = float(np.sqrt(np.float32(np.pi * 0.25 * 0.25 / 352.0)))
+assert VOXEL.hex() == "0x1.82f52e0000000p-6"
+BLOCK = 200000
+N_SAMPLE = 4096
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def st(lgr):
+    """HIP-side stages of the 1M pair, computed once; tensors stay on the device, host copies beside them."""
+    import torch
+    from lgr_amd import synthetic
+    pair = synthetic.make_pair(1_000_000, seed=566)
+    s = dict(pair=pair)
+    for side in ("src", "tgt"):
+        cloud = torch.from_numpy(pair[side]).cuda()
+        surf = lgr.downsample(cloud, VOXEL).clone()
+        nrm = lgr.normals_knn(surf.clone(), 30, vp=pair["vp_" + side])       # in place on its argument
+        feat = lgr.fpfh(cloud, nrm, float(R))
+        lgr.sync()
+        s[side] = dict(cloud=cloud, surf=surf, nrm=nrm, feat=feat, surf_h=surf.cpu().numpy(), nrm_h=nrm.cpu().numpy(), feat_h=feat.cpu().numpy())
+    return s
+
+
+@pytest.mark.parametrize("side", ["src", "tgt"])
+def test_downsample_1m_full(st, oracle, side):
+    want = oracle.downsample(st["pair"][side], VOXEL)
+    got = st[side]["surf_h"]
+    assert got.shape == want.shape and got.shape[0] > 500_000
+    np.testing.assert_array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("side", ["src", "tgt"])
+def test_normals_1m_full(st, oracle, side):
+    want = oracle.normals_knn(st[side]["surf_h"], 30, vp=st["pair"]["vp_" + side])
+    np.testing.assert_array_equal(bits(st[side]["nrm_h"]), bits(want))
+    n = want[:, 4:7]
+    assert np.isfinite(n).all() and np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("side", ["src", "tgt"])
+def test_fpfh_1m_full(st, oracle, side):
+    want = oracle.fpfh(st["pair"][side], st[side]["nrm_h"], float(R))
+    got = st[side]["feat_h"]
+    assert got.shape == (1_000_000, 33)
+    np.testing.assert_array_equal(bits(got), bits(want))       # NaN rows included: same bit patterns
+    ok = ~np.isnan(want).any(1)
+    assert ok.mean() > 0.99 and np.abs(want[ok].reshape(-1, 3, 11).sum(2) - 100).max() < 1e-2
+
+
+@pytest.fixture(scope="module")
+def matches(lgr, st):
+    ab_i, ab_d, ba_i, ba_d = lgr.match_bf2(st["src"]["feat"], st["tgt"]["feat"], BLOCK)
+    lgr.sync()
+    stats = lgr.match_stats()
+    return dict(t=(ab_i, ab_d, ba_i, ba_d), h=[x.cpu().numpy() for x in (ab_i, ab_d, ba_i, ba_d)], stats=stats,
+                work=lgr.match_work(), fmt=lgr.match_format())
+
+
+def test_match_1m_sampled_oracle(st, matches, oracle):
+    """the pruned / coarse-rejecting / re-filtered matcher on the pipeline's REAL FPFH rows vs the oracle's exhaustive scan."""
+    assert matches["fmt"] == "f16r" and matches["work"] < 0.5            # the production schedule really ran (not a dense fallback)
+    assert matches["stats"]["dense_ab"] == 0 and matches["stats"]["dense_ba"] == 0
+    fs, ft = st["src"]["feat_h"], st["tgt"]["feat_h"]
+    ab_i, ab_d, ba_i, ba_d = matches["h"]
+    rng = np.random.default_rng(20261004)
+    mism = 0
+    for q, t, gi, gd in ((fs, ft, ab_i, ab_d), (ft, fs, ba_i, ba_d)):
+        sel = np.sort(rng.choice(q.shape[0], N_SAMPLE, replace=False)).astype(np.int32)
+        # always include some NaN query rows if there are any (no match: index -1)
+        nan_rows = np.flatnonzero(np.isnan(q).any(1))[:64].astype(np.int32)
+        sel = np.unique(np.concatenate([sel, nan_rows])).astype(np.int32)
+        oi, od = oracle.match_bf_subset(q, sel, t, BLOCK)
+        valid = oi >= 0
+        mism += int((gi[sel] != oi).sum()) + int((bits(gd[sel])[valid] != bits(od)[valid]).sum())
+        np.testing.assert_array_equal(gi[sel], oi)
+        np.testing.assert_array_equal(bits(gd[sel])[valid], bits(od)[valid])
+        assert (gi[nan_rows] == -1).all()
+    assert mism == 0
+
+
+def test_match_1m_refilter_on_off_identical(lgr, st, matches, monkeypatch):
+    """the rerank's MFMA re-filter + pair path (default) vs the whole-group exact scan, at BASELINE size."""
+    monkeypatch.setenv("LGR_MATCH_REFILTER", "0")
+    off = [x.cpu().numpy() for x in lgr.match_bf2(st["src"]["feat"], st["tgt"]["feat"], BLOCK)]
+    lgr.sync()
+    assert lgr.match_pairs() == (0, 0) or sum(lgr.match_pairs()) == 0
+    for a, b in zip(matches["h"], off):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def corr(lgr, st, matches):
+    from lgr_amd import capi
+    ab_i, ab_d, ba_i, ba_d = matches["t"]
+    return lgr.filter(capi.MATCH_LR, st["src"]["cloud"], st["tgt"]["cloud"], ab_i, ab_d, ba_i, ba_d, 0.1)
+
+
+def test_filter_1m_full(st, matches, corr, oracle):
+    ab_i, ab_d, ba_i, ba_d = matches["h"]
+    want = oracle.filter_matches(oracle.MATCH_LR, st["pair"]["src"], st["pair"]["tgt"], ab_i, ab_d, ba_i, ba_d, 0.1)
+    assert len(corr) == len(want) > 10000
+    np.testing.assert_array_equal(corr["index_query"], want["query"])
+    np.testing.assert_array_equal(corr["index_match"], want["match"])
+    np.testing.assert_array_equal(bits(corr["distance"]), bits(want["distance"]))
+    np.testing.assert_array_equal(bits(corr["threshold"]), bits(want["threshold"]))
+
+
+def _params(mod, pair, **kw):
+    return mod.default_params(matching_id=mod.MATCH_LR, metric_id=mod.METRIC_UNIFORMITY, score_id=mod.SCORE_MSE, feature_radius=0.25,
+                              feature_nr_points=352, normal_nr_points=30, bf_block_size=BLOCK, edge_thr_coef=0.95, confidence=0.999,
+                              max_iterations=1000000, distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"], **kw)
+
+
+def test_ransac_1m_full_and_pipeline(lgr, st, corr, oracle):
+    """RANSAC + refit on the 1M pair's correspondences vs the oracle (whole loop, Philox schedule on both sides), and the
+    one-call pipeline (what bench.py times) == the staged chain."""
+    from lgr_amd import capi
+    pair = st["pair"]
+    p_g = _params(capi, pair)
+    res, mask = lgr.ransac(st["src"]["cloud"], st["tgt"]["cloud"], corr, p_g)
+    oc = np.zeros(len(corr), oracle.CORR_DTYPE)
+    for a, b in (("query", "index_query"), ("match", "index_match"), ("distance", "distance"), ("threshold", "threshold")):
+        oc[a] = corr[b]
+    ores, omask = oracle.ransac(pair["src"], pair["tgt"], oc, _params(oracle, pair, rng_mode=oracle.RNG_PHILOX))
+    assert (res.iterations, res.n_inliers, res.best_iteration, res.converged) == (ores.iterations, ores.n_inliers, ores.best_iteration, ores.converged)
+    np.testing.assert_array_equal(mask, omask)
+    np.testing.assert_array_equal(bits(res.matrix()), bits(ores.matrix()))
+    assert np.abs(res.matrix().astype(np.float64) - ores.matrix().astype(np.float64)).max() <= 1e-4     # north-star tolerance on the 4x4
+    # one-call pipeline == staged chain
+    c2 = lgr.correspondences(st["src"]["cloud"], st["tgt"]["cloud"], p_g).cpu().numpy().view(capi.CORR_DTYPE).reshape(-1)
+    assert len(c2) == len(corr)
+    for f in ("index_query", "index_match"):
+        np.testing.assert_array_equal(c2[f], corr[f])
+    np.testing.assert_array_equal(bits(c2["distance"]), bits(corr["distance"]))
+    full = lgr.align(st["src"]["cloud"], st["tgt"]["cloud"], p_g)
+    np.testing.assert_array_equal(bits(full.matrix()), bits(res.matrix()))
+    assert (full.iterations, full.n_inliers, full.n_correspondences) == (res.iterations, res.n_inliers, len(corr))
