@@ -16,8 +16,12 @@ Rank 0 prints ONE JSON line with the contract keys plus
                    MFMA peak of MI355X; the algorithmic 69 * Mq * Mt over the same time is given beside it
                    ("effective_tflops_algorithmic"); "traffic" = HBM-side bytes from the committed PMC passes;
   "cpu_baseline" : the CPU oracle ("port": the reference itself needs PCL/OpenCV and cannot be built here) timed on
-                   this host on a bounded sample of the same workload, extrapolated linearly where the stage is
-                   linear in the sampled dimension (the sample is stated in the object).
+                   this host's cores on the same pair: every stage in full except the brute-force matcher, which runs a
+                   bounded sample of queries (real FPFH rows) against all train rows and is scaled by M/S;
+  "parity_sample": what those oracle runs say about the timed HIP path (outside the timed region): per stage the number of
+                   compared values and of bit mismatches (each oracle stage is fed with the HIP output of the stage
+                   before), the sampled matcher queries (index and distance bits), and whether the staged chain equals
+                   the timed one-call pipeline.  `--verify` forces this leg even with --no-cpu-baseline.
 """
 import argparse
 import json
@@ -104,60 +108,134 @@ def make_params(capi, pair, matching):
                                vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
 
 
-def cpu_baseline(pair, gpu_corr, gpu_iterations, args, matching):
-    """Oracle timed on the host cores on a bounded sample of the SAME 1M-point pair (see module docstring)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as o
-    o.build()
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _usable_cores():
+    """threads the CPU leg may really use: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU box hands a
+    one-GPU job a share of the host's cores; 256 threads on a 16-core quota only oversubscribe)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            tok = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    cores = min(cores, max(1, int(round(int(tok[0]) / int(tok[1])))))
+            else:
+                q = int(tok[0])
+                if q > 0:
+                    cores = min(cores, max(1, int(round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))))
+            break
+        except Exception:
+            continue
+    return cores
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def gpu_stages(ctx, capi, pair, src, tgt, params, voxel, radius):
+    """the HIP path stage by stage (outside the timed region) so that the CPU leg can check every stage's output."""
+    out = {}
+    for side, cloud in (("src", src), ("tgt", tgt)):
+        surf = ctx.downsample(cloud, voxel).clone()
+        nrm = ctx.normals_knn(surf.clone(), 30, vp=pair["vp_" + side])
+        feat = ctx.fpfh(cloud, nrm, radius)
+        out[side] = dict(surf=surf.cpu().numpy(), nrm=nrm.cpu().numpy(), feat=feat, feat_h=feat.cpu().numpy())
+    m = ctx.match_bf2(out["src"]["feat"], out["tgt"]["feat"], params.bf_block_size)
+    ctx.sync()
+    out["match"] = [x.cpu().numpy() for x in m]
+    corr = ctx.filter(params.matching_id, src, tgt, *m, params.distance_thr)
+    out["corr"] = corr
+    res, mask = ctx.ransac(src, tgt, corr, params)
+    out["ransac"] = (res, mask)
+    return out
+
+
+def cpu_baseline(pair, g, args, matching, capi):
+    """The CPU oracle (the builder's restatement of the reference's algorithm, `kind: "port"` -- the reference itself needs PCL /
+    OpenCV and cannot be built here) on the SAME 1M-point pair on this host's cores.  Every stage but the matcher runs IN FULL
+    on both clouds (timed); the brute-force matcher runs S sampled queries of the pair's REAL FPFH rows against all 1M train
+    rows per direction (train rows reused across 16 queries, bf blocks of 200 000 as include/matching.h:594-634) and is scaled
+    by M / S.  The same runs are the parity check of the timed HIP path (`parity_sample`): each oracle stage is fed with the HIP
+    path's output of the stage before and compared bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as o
+    o.build()
+    cores = _usable_cores()
     o.set_num_threads(cores)
-    src, tgt = pair["src"], pair["tgt"]
-    n = src.shape[0]
-    budget = args.cpu_seconds
-    t = {}
-    # voxel / radius exactly as the pipeline derives them (include/matching.h:172,230-231)
-    r = 0.25
-    voxel = float(np.sqrt(np.pi * r * r / 352.0).astype(np.float32))
-    t0 = time.time(); ds = o.downsample(src, voxel); t["downsample"] = 2 * (time.time() - t0)
-    # normals: a prefix sample of the surface, searched in the full surface (linear in the number of queries)
-    ns = min(ds.shape[0], 40000)
-    t0 = time.time(); o.normals_knn(ds[:ns], 30, surf=ds, vp=pair["vp_src"]); t["normals"] = 2 * (time.time() - t0) * ds.shape[0] / ns
-    dsn = o.normals_knn(ds[: min(ds.shape[0], 60000)], 30, vp=pair["vp_src"])   # oriented normals for the FPFH sample
-    # FPFH on a spatially compact sub-scene (surface prefix is in (z,y,x) voxel order, so take a slab of keypoints)
-    nk = 20000
-    slab = dsn
-    kp_sel = src[:nk]
-    t0 = time.time(); f_s = o.fpfh(kp_sel, slab, r); dt = time.time() - t0
-    # cost model: SPFH is linear in surface points, weighting linear in keypoints; measured together on the slab
-    t["fpfh"] = 2 * dt * max(n / nk, ds.shape[0] / slab.shape[0])
-    # matching: S sampled queries against the full train set of real FPFH rows (O(M) per query), both directions
-    rng = np.random.default_rng(0)
-    feat_t = np.tile(f_s[~np.isnan(f_s).any(1)], (n // max(1, (~np.isnan(f_s).any(1)).sum()) + 1, 1))[:n]
-    feat_t = (feat_t + rng.normal(0, 0.5, feat_t.shape)).astype(np.float32)
-    S = 256
-    t0 = time.time(); o.match_bf_subset(feat_t, np.arange(S, dtype=np.int32), feat_t, 200000); dt = time.time() - t0
-    S2 = int(max(S, min(8192, S * (0.45 * budget) / max(dt, 1e-3))))
-    t0 = time.time(); o.match_bf_subset(feat_t, np.arange(S2, dtype=np.int32), feat_t, 200000); dt = time.time() - t0
+    n = pair["src"].shape[0]
     n_dir = 1 if matching == "one_sided" else 2
-    t["match"] = n_dir * dt * n / S2
-    # filter thresholds (two k=2 density passes over 1M points): prefix sample
-    nd = 100000
-    t0 = time.time(); o.smoothed_densities(src[:nd], 2); t["filter"] = 2 * (time.time() - t0) * n / nd
-    # RANSAC on the correspondences the GPU produced for this pair, Philox schedule, first batches, scaled by iterations
-    corr = np.zeros(gpu_corr.shape[0], o.CORR_DTYPE)
-    corr["query"] = gpu_corr["index_query"]; corr["match"] = gpu_corr["index_match"]
-    corr["distance"] = gpu_corr["distance"]; corr["threshold"] = gpu_corr["threshold"]
-    it_sample = 16384
-    p = o.default_params(rng_mode=o.RNG_PHILOX, metric_id=o.METRIC_UNIFORMITY, max_iterations=it_sample, batch_size=16384)
-    t0 = time.time(); res, _ = o.ransac(src, tgt, corr, p); dt = time.time() - t0
-    t["ransac_sample_iters"] = res.iterations
-    t["ransac"] = dt * max(1.0, gpu_iterations / max(res.iterations, 1))   # linear in the iterations actually needed
-    total = sum(v for k, v in t.items() if k not in ("ransac_sample_iters",))
-    return t, total, cores, S2
+    r = 0.25
+    voxel = float(np.sqrt(np.float32(np.pi * r * r / 352.0)))      # include/matching.h:231 (double product, float sqrt)
+    t = dict(downsample=0.0, normals=0.0, fpfh=0.0)
+    par = {"queries": 0, "mismatches": 0, "stages": {}}
+
+    def check(name, got, want):
+        bad = int((_bits(got) != _bits(want)).sum()) if got.shape == want.shape else -1
+        par["stages"][name] = {"compared": int(want.size), "mismatches": bad}
+
+    feats = {}
+    for side in ("src", "tgt"):
+        t0 = time.time(); ds = o.downsample(pair[side], voxel); t["downsample"] += time.time() - t0
+        check("downsample_" + side, g[side]["surf"], ds)
+        t0 = time.time(); nrm = o.normals_knn(g[side]["surf"], 30, vp=pair["vp_" + side]); t["normals"] += time.time() - t0
+        check("normals_" + side, g[side]["nrm"], nrm)
+        t0 = time.time(); f = o.fpfh(pair[side], g[side]["nrm"], r); t["fpfh"] += time.time() - t0
+        check("fpfh_" + side, g[side]["feat_h"], f)
+        feats[side] = g[side]["feat_h"]
+    # matcher: sampled queries (real rows) x all train rows, both directions; S grows until the sample costs about half the budget
+    rng = np.random.default_rng(566)
+    ab_i, ab_d, ba_i, ba_d = g["match"]
+    S = 512
+    dt = 0.0
+    while True:
+        mism = 0
+        t0 = time.time()
+        for q, tr, gi, gd in ((feats["src"], feats["tgt"], ab_i, ab_d), (feats["tgt"], feats["src"], ba_i, ba_d))[:n_dir]:
+            sel = np.sort(rng.choice(n, S, replace=False)).astype(np.int32)
+            oi, od = o.match_bf_subset(q, sel, tr, 200000)
+            ok = oi >= 0
+            mism += int((gi[sel] != oi).sum()) + int((_bits(gd[sel])[ok] != _bits(od)[ok]).sum())
+        dt = time.time() - t0
+        par["queries"] += n_dir * S
+        par["mismatches"] += mism
+        if dt > 0.3 * args.cpu_seconds or S >= 65536:
+            break
+        S = int(min(65536, max(2 * S, S * 0.5 * args.cpu_seconds / max(dt, 1e-3))))
+    t["match"] = dt * n / S
+    # filter + RANSAC in full on the HIP path's match tables / correspondences
+    mid = {"lr": o.MATCH_LR, "cluster": o.MATCH_CLUSTER, "one_sided": o.MATCH_ONE_SIDED}[matching]
+    t0 = time.time()
+    oc = o.filter_matches(mid, pair["src"], pair["tgt"], ab_i, ab_d, ba_i, ba_d, 0.1)
+    t["filter"] = time.time() - t0
+    gc = g["corr"]
+    same = len(oc) == len(gc) and bool((oc["query"] == gc["index_query"]).all() and (oc["match"] == gc["index_match"]).all()
+                                       and (_bits(oc["distance"]) == _bits(gc["distance"])).all())
+    par["stages"]["filter"] = {"compared": int(len(oc)), "mismatches": 0 if same else -1}
+    p = o.default_params(rng_mode=o.RNG_PHILOX, metric_id=o.METRIC_UNIFORMITY, score_id=o.SCORE_MSE, max_iterations=1000000,
+                         distance_thr=0.1, edge_thr_coef=0.95, confidence=0.999)
+    t0 = time.time(); ores, omask = o.ransac(pair["src"], pair["tgt"], oc, p); t["ransac"] = time.time() - t0
+    gres, gmask = g["ransac"]
+    same = same and (ores.iterations, ores.n_inliers) == (gres.iterations, gres.n_inliers) and bool((omask == gmask).all()) \
+        and bool((_bits(ores.matrix()) == _bits(gres.matrix())).all())
+    par["stages"]["ransac"] = {"compared": int(ores.iterations), "mismatches": 0 if same else -1,
+                               "max_abs_diff_4x4": float(np.abs(ores.matrix().astype(np.float64) - gres.matrix().astype(np.float64)).max())}
+    par["mismatches"] += sum(1 for v in par["stages"].values() if v["mismatches"] != 0)
+    total = sum(t.values())
+    return t, total, cores, S, par
 
 
 def main():
@@ -280,17 +358,24 @@ def main():
             "result": {"converged": int(res.converged), "iterations": int(res.iterations), "n_correspondences": int(res.n_correspondences),
                        "n_inliers": int(res.n_inliers), "max_abs_err_vs_gt": err},
         }
-        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            corr = ctx.correspondences(src, tgt, params).cpu().numpy().view(capi.CORR_DTYPE).reshape(-1)
-            t, total, cores, S2 = cpu_baseline(pair, corr, int(res.iterations), args, args.matching)
-            out["cpu_baseline"] = {
-                "value": 1.0 / total, "unit": "registrations/s", "cores": cores, "kind": "port",
-                "sample": (f"same 1M-pt pair; downsample full; normals 40k-query sample; FPFH 20k keypoints on a 60k-point slab; "
-                           f"matching {S2} sampled queries x 1M train rows x {n_dir} direction(s), scaled by M/S; density filter 100k prefix; "
-                           f"RANSAC first {t['ransac_sample_iters']} iterations of the Philox schedule, scaled to the {int(res.iterations)} the run needed"),
-                "seconds_per_pair_estimate": total, "stage_seconds": {k: float(v) for k, v in t.items()},
-            }
-            out["speedup_vs_cpu_baseline"] = out["value"] / (world * out["cpu_baseline"]["value"])
+        if (not args.no_cpu_baseline or args.verify) and world == 1:   # CPU leg: rank 0 of the 1-GPU run only, outside the timed region
+            voxel = float(np.sqrt(np.float32(np.pi * 0.25 * 0.25 / 352.0)))
+            g = gpu_stages(ctx, capi, pair, src, tgt, params, voxel, 0.25)
+            gres = g["ransac"][0]
+            staged_equals_pipeline = bool((_bits(gres.matrix()) == _bits(res.matrix())).all()) and int(gres.iterations) == int(res.iterations)
+            t, total, cores, S, par = cpu_baseline(pair, g, args, args.matching, capi)
+            par["staged_chain_equals_timed_pipeline"] = staged_equals_pipeline
+            if not staged_equals_pipeline:
+                par["mismatches"] += 1
+            out["parity_sample"] = par
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = {
+                    "value": 1.0 / total, "unit": "registrations/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+                    "sample": (f"same 1M-pt pair; downsample, k-NN normals, FPFH, match filter and RANSAC run IN FULL (both clouds); brute-force matching: "
+                               f"{S} sampled queries of the pair's real FPFH rows x all 1M train rows x {n_dir} direction(s), scaled by M/S"),
+                    "note": "parity oracle in the canonical (non-FMA, SSE-lane) arithmetic order, not a tuned CPU implementation; a reported baseline, not the target",
+                    "seconds_per_pair_estimate": total, "stage_seconds": {k: float(v) for k, v in t.items()},
+                }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

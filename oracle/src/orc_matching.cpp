@@ -65,18 +65,35 @@ inline void merge_block(int bi, float bd, int& best_idx, float& best_dist) {
 }  // namespace
 
 // include/matching.h:594-634 matchBF: the reference loops train blocks INSIDE query blocks and lets OpenCV
-// parallelise over the query rows of one knnMatch call; the same loop order is kept here (one train block, 26 MB at
-// block_size 200000, stays cache resident while all queries visit it), results are independent of the query blocking.
+// parallelise over the query rows of one knnMatch call (cv::batchDistance: one query row against all rows of the train
+// block at a time).  Here a thread takes QB queries through the train block together, so a train row is loaded once per
+// QB queries instead of once per query (the query-at-a-time loop streams the 26 MB block from DRAM for every query);
+// every (query, train) distance is the same canonical l2sqr33 and every query keeps its own first-minimum / merge rule,
+// so results do not depend on QB or on the threading.
 extern "C" int orc_match_bf_subset(const float* q33, const int* qsel, int nsel, const float* t33, int mt, int block, int* idx, float* dist) {
     if (block <= 0) return -1;
+    constexpr int QB = 16;
     for (int s = 0; s < nsel; ++s) { idx[s] = -1; dist[s] = 0.f; }
     for (int j0 = 0; j0 < mt; j0 += block) {
         int j1 = std::min(mt, j0 + block);
-#pragma omp parallel for schedule(dynamic, 4)
-        for (int s = 0; s < nsel; ++s) {
-            int bi; float bd;
-            block_best(q33 + 33 * (size_t) (qsel ? qsel[s] : s), t33, j0, j1, bi, bd);
-            merge_block(bi, bd, idx[s], dist[s]);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int s0 = 0; s0 < nsel; s0 += QB) {
+            const int nq = std::min(QB, nsel - s0);
+            alignas(64) float qrow[QB][36];
+            int bi[QB];
+            float bd[QB];
+            for (int u = 0; u < nq; ++u) {
+                std::memcpy(qrow[u], q33 + 33 * (size_t) (qsel ? qsel[s0 + u] : s0 + u), 33 * sizeof(float));
+                bi[u] = -1; bd[u] = std::numeric_limits<float>::max();   // batchDistance init: FLT_MAX / -1
+            }
+            for (int j = j0; j < j1; ++j) {
+                const float* t = t33 + 33 * (size_t) j;
+                for (int u = 0; u < nq; ++u) {
+                    float d = std::sqrt(l2sqr33(qrow[u], t));
+                    if (d < bd[u]) { bd[u] = d; bi[u] = j; }   // as block_best: strict '<', NaN never enters
+                }
+            }
+            for (int u = 0; u < nq; ++u) merge_block(bi[u], bd[u], idx[s0 + u], dist[s0 + u]);
         }
     }
     return 0;
