@@ -105,6 +105,10 @@ const char* lgr_last_error(lgr_ctx* ctx);
 void lgr_default_params(lgr_params* p);                      /* defaults of src/common.cpp:216-223,335-413 */
 /* on-device stage timers of the last lgr_align*/
 int  lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12);
+/* device bytes the context's workspace currently holds (the sum of its grown-on-demand buffers): what a caller sizes its own
+ * HBM budget against when it pushes many pairs of different sizes through one context (src/main.cpp:384-407 loops pairs in
+ * one process) */
+int  lgr_ctx_workspace_bytes(lgr_ctx* ctx, uint64_t* bytes);
 
 /* ---- include/common.h:266-280 calculateBoundingBox ---- */
 int lgr_bbox_dev(lgr_ctx*, const float* d_pts, int n, float* d_min3_max3 /* 6 floats */);

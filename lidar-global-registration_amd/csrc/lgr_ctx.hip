@@ -97,6 +97,14 @@ extern "C" int lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12) {
     return LGR_OK;
 }
 
+extern "C" int lgr_ctx_workspace_bytes(lgr_ctx* ctx, uint64_t* bytes) {
+    if (!ctx || !bytes) return LGR_ERR_INVALID_ARG;
+    uint64_t t = 0;
+    for (int i = 0; i < WS_COUNT; ++i) t += ctx->ws[i].cap;
+    *bytes = t;
+    return LGR_OK;
+}
+
 // defaults of getParametersFromConfig (src/common.cpp:216-223, 335-413) and include/common.h:38-57
 extern "C" void lgr_default_params(lgr_params* p) {
     memset(p, 0, sizeof(*p));

@@ -129,6 +129,11 @@ class Context:
     def sync(self):
         self.check(_lib.lgr_ctx_sync(self.h))
 
+    def workspace_bytes(self):
+        out = C.c_uint64(0)
+        self.check(_lib.lgr_ctx_workspace_bytes(self.h, C.byref(out)))
+        return int(out.value)
+
     def _dev(self):
         return self.torch.device("cuda", self.device)
 

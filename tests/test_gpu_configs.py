@@ -1,0 +1,161 @@
+"""The BASELINE.json configs that are not the bench line, as -m gpu tests ("configs untested"):
+
+  configs[2]  scan pairs of different sizes sharded over ranks, pushed through ONE context per rank (src/main.cpp:384-407 loops
+              pairs in one process): records equal the single-pair runs in fresh contexts, whatever ran before in the workspace;
+  configs[3]  5M-point pair end to end (properties + sampled matcher parity vs the oracle + workspace budget) and the RANSAC
+              stress: C = 200 000 correspondences, 60 % outliers, 100 000 fixed iterations -- full result equality with the oracle;
+  configs[4]  GROR (src/alignment.cpp:21-35) at C = 50 000, 60 % outliers, K = 800 vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def to_orc_corr(oracle, corr):
+    out = np.zeros(corr.shape[0], oracle.CORR_DTYPE)
+    out["query"] = corr["index_query"]; out["match"] = corr["index_match"]
+    out["distance"] = corr["distance"]; out["threshold"] = corr["threshold"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------ configs[2]
+PAIR_SIZES = [100_000, 1_000_000, 250_000, 600_000, 150_000, 400_000, 1_000_000]
+
+
+def _pair_params(capi, pair):
+    return capi.default_params(matching_id=capi.MATCH_LR, metric_id=capi.METRIC_UNIFORMITY, bf_block_size=200000, max_iterations=200000,
+                               distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
+
+
+def test_config2_sharded_pairs_through_one_context():
+    import torch
+    from lgr_amd import capi, distributed, synthetic
+    pairs = [synthetic.make_pair(n, seed=566 + i) for i, n in enumerate(PAIR_SIZES)]
+
+    def aligner(ctx):
+        def f(p):
+            pr = pairs[p]
+            res = ctx.align(cuda(pr["src"]), cuda(pr["tgt"]), _pair_params(capi, pr))
+            return distributed.pack_record(p, res.transformation, res.converged, res.iterations, res.n_inliers, 0.0, 0.0)   # times zeroed: they differ run to run
+        return f
+
+    # every pair alone, each in a fresh context (nothing stale can reach it)
+    single = []
+    for p in range(len(pairs)):
+        ctx = capi.Context(0)
+        single.append(aligner(ctx)(p))
+        ctx.close()
+    single = np.stack(single)
+    # world = 1: all pairs through one context, sizes going up AND down (a smaller pair runs in buffers a larger one left behind)
+    ctx = capi.Context(0)
+    one = distributed.run_pairs(len(pairs), 1, 0, aligner(ctx))
+    ws = ctx.workspace_bytes()
+    # and again in the same context: warm workspace, no growth, same records
+    again = distributed.run_pairs(len(pairs), 1, 0, aligner(ctx))
+    assert ctx.workspace_bytes() == ws
+    ctx.close()
+    np.testing.assert_array_equal(one.view(np.uint32), single.view(np.uint32))
+    np.testing.assert_array_equal(again.view(np.uint32), single.view(np.uint32))
+    assert ws < 64e9
+    # world = 2 sharding (pair p -> rank p mod 2), each rank with its own context; the union is what the all-gather delivers
+    shards = []
+    for rank in range(2):
+        ctx = capi.Context(0)
+        f = aligner(ctx)
+        shards += [f(p) for p in distributed.shard_pairs(len(pairs), 2, rank)]
+        ctx.close()
+    shards = np.stack(shards)
+    order = np.argsort(distributed.record_pair_ids(shards), kind="stable")
+    np.testing.assert_array_equal(shards[order].view(np.uint32), single.view(np.uint32))
+    for p, pr in enumerate(pairs):      # every pair registers (ground truth within the noise band)
+        u = distributed.unpack_record(single[p])
+        assert u["converged"] == 1 and u["pair_id"] == p
+        R = u["T"][:3, :3].astype(np.float64)
+        ang = np.degrees(np.arccos(np.clip((np.trace(pr["T_gt"][:3, :3].T @ R) - 1) / 2, -1, 1)))
+        assert ang < 1.0 and np.linalg.norm(u["T"][:3, 3] - pr["T_gt"][:3, 3]) < 0.1, (p, ang)
+    del torch
+
+
+# ------------------------------------------------------------------------------------------------------ configs[3]
+def test_config3_ransac_200k_correspondences_100k_iterations(lgr, oracle):
+    from lgr_amd import capi, synthetic
+    pr = synthetic.make_correspondence_problem(n_pts=1_000_000, c=200_000, inlier_frac=0.4, sigma=0.01, thr=0.05, seed=566)
+    src, tgt = cuda(pr["src"]), cuda(pr["tgt"])
+    oc = to_orc_corr(oracle, pr["corr"])
+    assert oracle.comb_or_max(200_000, 3) == 2**31 - 1                # the combination cap does not bind (src/sac_prerejective_omp.cpp:130)
+    for conf, fixed in ((1.0, True), (0.999, False)):                 # throughput form (bound off) and latency form (adaptive bound)
+        kw = dict(max_iterations=100_000, confidence=conf, metric_id=1, score_id=2, distance_thr=0.05)
+        res, mask = lgr.ransac(src, tgt, pr["corr"], capi.default_params(**kw))
+        ores, omask = oracle.ransac(pr["src"], pr["tgt"], oc, oracle.default_params(rng_mode=oracle.RNG_PHILOX, **kw))
+        assert (res.iterations, res.n_inliers, res.best_iteration, res.converged, res.num_rejections) == \
+               (ores.iterations, ores.n_inliers, ores.best_iteration, ores.converged, ores.num_rejections)
+        assert res.iterations == 100_000 if fixed else res.iterations <= 100_000
+        np.testing.assert_array_equal(mask, omask)
+        np.testing.assert_array_equal(bits(res.matrix()), bits(ores.matrix()))
+        assert np.float32(res.metric) == np.float32(ores.metric)
+        assert abs(res.n_inliers - 80_000) < 4_000                    # 40 % of 200 000 true correspondences at sigma = 1 cm, thr 5 cm
+        assert np.abs(res.matrix()[:3, :3] - pr["T_gt"][:3, :3]).max() < 1e-3 and np.abs(res.matrix()[:3, 3] - pr["T_gt"][:3, 3]).max() < 1e-2
+
+
+def test_config3_5m_pair_end_to_end(oracle):
+    """5M points per cloud = 25 x the pair work of the bench line, in a context of its own so the workspace figure is this pair's."""
+    from lgr_amd import capi, synthetic
+    pair = synthetic.make_pair(5_000_000, seed=566)
+    ctx = capi.Context(0)
+    src, tgt = cuda(pair["src"]), cuda(pair["tgt"])
+    p = capi.default_params(matching_id=capi.MATCH_LR, metric_id=capi.METRIC_UNIFORMITY, feature_radius=0.25, bf_block_size=200000,
+                            max_iterations=1000000, distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
+    res = ctx.align(src, tgt, p)
+    st = ctx.match_stats()
+    assert st["dense_ab"] == 0 and st["dense_ba"] == 0 and ctx.match_work() < 0.3 and ctx.match_format() == "f16r"
+    ws = ctx.workspace_bytes()
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    assert ws < 150e9 and ws < 0.6 * total, (ws, total)               # tables are budgeted (row / column minima <= 24 + 24 GB): no cliff at 288 GB
+    T = res.matrix().astype(np.float64)
+    assert res.converged == 1 and res.n_correspondences > 50_000 and res.n_inliers > 2_000
+    Rg = pair["T_gt"][:3, :3]
+    ang = np.degrees(np.arccos(np.clip((np.trace(Rg.T @ T[:3, :3]) - 1) / 2, -1, 1)))
+    assert ang < 0.5 and np.linalg.norm(T[:3, 3] - pair["T_gt"][:3, 3]) < 0.05, (ang, T[:3, 3] - pair["T_gt"][:3, 3])
+    res2 = ctx.align(src, tgt, p)                                      # determinism + warm workspace
+    np.testing.assert_array_equal(bits(res2.matrix()), bits(res.matrix()))
+    assert (res2.n_inliers, res2.n_correspondences, res2.iterations) == (res.n_inliers, res.n_correspondences, res.iterations)
+    assert ctx.workspace_bytes() == ws
+    # sampled matcher parity at 5M x 5M on the pipeline's own FPFH rows (oracle: exhaustive scan of all 5M train rows per query)
+    voxel = float(np.sqrt(np.float32(np.pi * 0.25 * 0.25 / 352.0)))
+    feats = []
+    for cloud, vp in ((src, pair["vp_src"]), (tgt, pair["vp_tgt"])):
+        surf = ctx.normals_knn(ctx.downsample(cloud, voxel).clone(), 30, vp=vp)
+        feats.append(ctx.fpfh(cloud, surf, 0.25))
+    ab_i, ab_d, ba_i, ba_d = [x.cpu().numpy() for x in ctx.match_bf2(feats[0], feats[1], 200000)]
+    ctx.sync()
+    fh = [f.cpu().numpy() for f in feats]
+    rng = np.random.default_rng(5)
+    for q, t, gi, gd in ((fh[0], fh[1], ab_i, ab_d), (fh[1], fh[0], ba_i, ba_d)):
+        sel = np.sort(rng.choice(q.shape[0], 1024, replace=False)).astype(np.int32)
+        oi, od = oracle.match_bf_subset(q, sel, t, 200000)
+        np.testing.assert_array_equal(gi[sel], oi)
+        ok = oi >= 0
+        np.testing.assert_array_equal(bits(gd[sel])[ok], bits(od)[ok])
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------ configs[4]
+def test_config4_gror_50k_correspondences(lgr, oracle):
+    from lgr_amd import synthetic
+    pr = synthetic.make_correspondence_problem(n_pts=2_000_000, c=50_000, inlier_frac=0.4, sigma=0.01, thr=0.05, seed=567)
+    res, mask = lgr.gror(cuda(pr["src"]), cuda(pr["tgt"]), pr["corr"], 0.05)
+    T_o, d = oracle.gror(pr["src"], pr["tgt"], to_orc_corr(oracle, pr["corr"]), 0.05, 800)
+    assert res.estimated_iters == d["K"] == 800 and int(res.metric) == d["best_count"] and res.best_iteration == d["tcfs_rows"]
+    assert res.n_inliers == d["n_inliers"] == int(mask.sum()) and res.n_inliers > 3_000
+    np.testing.assert_array_equal(bits(res.matrix()), bits(T_o))
+    assert np.abs(res.matrix()[:3, :3] - pr["T_gt"][:3, :3]).max() < 1e-3 and np.abs(res.matrix()[:3, 3] - pr["T_gt"][:3, 3]).max() < 1e-2
