@@ -466,11 +466,15 @@ extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const flo
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double time_cs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     tick(ctx, 7);
+    ctx->corr_trusted = true;                  // dc was produced by lgr_correspondences_dev: no range check (lgr_check_corr)
+    int rc_te;
     if (p->alignment_id == LGR_ALIGN_GROR) {   // src/alignment.cpp:21-35: resolution = distance_thr, K_optimal = 800
-        LGR_TRY(lgr_gror_dev(ctx, d_src, ns, d_tgt, nt, dc, c, p->distance_thr, 800, res, nullptr));
+        rc_te = lgr_gror_dev(ctx, d_src, ns, d_tgt, nt, dc, c, p->distance_thr, 800, res, nullptr);
     } else {
-        LGR_TRY(lgr_ransac_dev(ctx, d_src, ns, d_tgt, nt, dc, c, p, res, nullptr));
+        rc_te = lgr_ransac_dev(ctx, d_src, ns, d_tgt, nt, dc, c, p, res, nullptr);
     }
+    ctx->corr_trusted = false;
+    LGR_TRY(rc_te);
     tick(ctx, 8);
     LGR_HIP(ctx, hipEventSynchronize(ctx->ev[8]));
     float t;

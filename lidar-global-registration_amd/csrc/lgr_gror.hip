@@ -367,6 +367,7 @@ extern "C" int lgr_gror_dev(lgr_ctx* ctx, const float* d_src, int ns, const floa
         res->iterations = 1;
         return LGR_OK;
     }
+    LGR_TRY(lgr_check_corr(ctx, d_corr, c, ns, nt));
     GrorBuffers b;
     LGR_TRY(gror_pack(ctx, d_src, d_tgt, d_corr, c, &b));
     int K = c >= k_optimal ? k_optimal : c;

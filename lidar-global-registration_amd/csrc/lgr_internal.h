@@ -30,6 +30,7 @@ struct lgr_ctx {
     float stage_ms[12];
     int n_cu = 256;
     int mfma_timed = 0;
+    bool corr_trusted = false;   // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
 };
 
 int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line);
@@ -101,6 +102,12 @@ int lgr_grid_build(lgr_ctx* ctx, int slot_base, const float* d_pts, int n, float
 // both bounding boxes of a cloud: out12 (host) = true min3, true max3 (finite points only; +-inf when empty),
 // reference-quirk min3, max3 (include/common.h:266-280)
 int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
+
+// caller-supplied correspondences (public lgr_ransac* / lgr_gror* / lgr_evaluate* / lgr_refit_svd entry points): LGR_ERR_INVALID_ARG
+// when an index_query is outside [0, ns) or an index_match outside [0, nt) -- checked on the device BEFORE any kernel gathers
+// points through them (an out-of-range gather is a GPU memory fault, not an error code).  One tiny launch + a 4-byte read-back;
+// skipped when ctx->corr_trusted (lgr_ransac.hip).
+int lgr_check_corr(lgr_ctx* ctx, const lgr_corr* d_corr, int c, int ns, int nt);
 
 // ---- closest-plane metric on the device (lgr_plane.hip) ----
 struct lgr_plane_dev {

@@ -603,7 +603,34 @@ int est_from_support(int count, int c, float confidence, int nr_samples) {
 
 struct Packed { float4* P0; float4* P1; float* sstar; };
 
-int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const lgr_corr* d_corr, int c, Packed* out) {
+__global__ void corr_range_kernel(const lgr_corr* __restrict__ corr, int c, int ns, int nt, int* __restrict__ bad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool b = false;
+    if (i < c) {
+        lgr_corr cr = corr[i];
+        b = (unsigned) cr.index_query >= (unsigned) ns || (unsigned) cr.index_match >= (unsigned) nt;
+    }
+    if (__any(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+}  // namespace
+
+int lgr_check_corr(lgr_ctx* ctx, const lgr_corr* d_corr, int c, int ns, int nt) {
+    if (ctx->corr_trusted || c <= 0) return LGR_OK;
+    int* d_bad;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_STATS, 64, &d_bad));
+    LGR_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    corr_range_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_corr, c, ns, nt, d_bad);
+    int* h;
+    LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
+    LGR_HIP(ctx, hipMemcpyAsync(h, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[0]) return lgr_fail(ctx, LGR_ERR_INVALID_ARG, "a correspondence index is outside its cloud (index_query in [0, ns), index_match in [0, nt))", __FILE__, __LINE__);
+    return LGR_OK;
+}
+
+namespace {
+int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c, Packed* out) {
+    LGR_TRY(lgr_check_corr(ctx, d_corr, c, ns, nt));
     float bb[12];
     LGR_TRY(lgr_bbox_host(ctx, d_src, ns, bb));   // UniformityMetricEstimator::setSourceCloud (src/metric.cpp:167-170)
     float4* P;
@@ -768,7 +795,7 @@ extern "C" int lgr_evaluate_dev(lgr_ctx* ctx, const float* d_src, int ns, const 
     LGR_CHECK(ctx, metric_id == LGR_METRIC_UNIFORMITY || metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     Packed pk;
-    LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+    LGR_TRY(pack(ctx, d_src, ns, d_tgt, nt, d_corr, c, &pk));
     float* dT;
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &dT));
     LGR_HIP(ctx, hipMemcpyAsync(dT, T16, 64, hipMemcpyHostToDevice, ctx->stream));
@@ -877,7 +904,7 @@ extern "C" int lgr_ransac_replay_dev(lgr_ctx* ctx, const float* d_src, int ns, c
     if (n == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     Packed pk;
-    LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+    LGR_TRY(pack(ctx, d_src, ns, d_tgt, nt, d_corr, c, &pk));
     BatchBuffers b;
     LGR_TRY(batch_buffers(ctx, n, &b));
     int n_ok = 0;
@@ -935,7 +962,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     if (c < 3) return LGR_OK;   // selectCorrespondences refuses (src/sac_prerejective_omp.cpp:36-42); identity, not converged
     uint64_t seed = p->fix_seed ? 566ull : p->seed;
     Packed pk;
-    LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+    LGR_TRY(pack(ctx, d_src, ns, d_tgt, nt, d_corr, c, &pk));
     int max_iterations = std::min(comb_or_max(c, p->n_samples), p->max_iterations);
     int batch = std::max(1, p->ransac_batch);
     int bound = max_iterations, done = 0, largest = 0, num_rejections = 0, best_iter = -1;
@@ -1127,6 +1154,7 @@ extern "C" int lgr_refit_svd(lgr_ctx* ctx, const float* src, const float* tgt, i
     LGR_HIP(ctx, hipMemcpyAsync(ds, src, (size_t) ns * 48, hipMemcpyHostToDevice, ctx->stream));
     LGR_HIP(ctx, hipMemcpyAsync(dt, tgt, (size_t) nt * 48, hipMemcpyHostToDevice, ctx->stream));
     if (n) LGR_HIP(ctx, hipMemcpyAsync(dc, inliers, (size_t) n * 16, hipMemcpyHostToDevice, ctx->stream));
+    LGR_TRY(lgr_check_corr(ctx, dc, n, ns, nt));   // the _dev form mirrors estimateOptimalRigidTransformation(src, tgt, inliers, T) and has no sizes to check against
     return lgr_refit_svd_dev(ctx, ds, dt, dc, n, nullptr, T16);
 }
 
@@ -1143,7 +1171,7 @@ extern "C" int lgr_choose_best_hypothesis_dev(lgr_ctx* ctx, const float* d_src, 
     float best = 0.f;
     if (n > 0) {
         Packed pk;
-        LGR_TRY(pack(ctx, d_src, ns, d_tgt, d_corr, c, &pk));
+        LGR_TRY(pack(ctx, d_src, ns, d_tgt, nt, d_corr, c, &pk));
         float* dT;
         LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_T, (size_t) n * 16, &dT));
         LGR_HIP(ctx, hipMemcpyAsync(dT, tns16, (size_t) n * 64, hipMemcpyHostToDevice, ctx->stream));

@@ -119,3 +119,33 @@ def test_invalid_arguments_return_status_not_crash(lgr, pair):
     # the context stays usable after errors
     ok = lgr.align(src, tgt, p)
     assert ok.n_correspondences > 0
+
+
+def test_out_of_range_correspondence_indices_are_an_error_not_a_fault(lgr, pair):
+    """caller-supplied correspondences (alignRansac / alignGror / estimateOptimalRigidTransformation / the metric estimators take
+    them from the caller, src/alignment.cpp:14-35): a stale index must come back as LGR_ERR_INVALID_ARG before any kernel
+    gathers through it, and the context must stay usable."""
+    from lgr_amd import capi, synthetic
+    pr = synthetic.make_correspondence_problem(n_pts=5000, c=600, inlier_frac=0.5, seed=4)
+    src, tgt = cuda(pr["src"]), cuda(pr["tgt"])
+    good = pr["corr"]
+    p = capi.default_params(max_iterations=2000, distance_thr=0.05)
+    for field, value in (("index_query", 5000), ("index_match", 5000), ("index_query", -1), ("index_match", 2**31 - 1)):
+        bad = good.copy()
+        bad[field][317] = value
+        for call in (lambda: lgr.ransac(src, tgt, bad, p), lambda: lgr.gror(src, tgt, bad, 0.05),
+                     lambda: lgr.evaluate(src, tgt, bad, pr["T_gt"]), lambda: lgr.choose_best_hypothesis(src, tgt, bad, [pr["T_gt"]])):
+            with pytest.raises(capi.LgrError) as e:
+                call()
+            assert f"rc={ERR_INVALID_ARG}" in str(e.value)
+        T = (C.c_float * 16)()
+        hb = np.ascontiguousarray(bad)
+        rc = capi.lib().lgr_refit_svd(lgr.h, pr["src"].ctypes.data_as(C.c_void_p), pr["tgt"].ctypes.data_as(C.c_void_p), 5000, 5000,
+                                      hb.ctypes.data_as(C.c_void_p), len(hb), T)
+        assert rc == ERR_INVALID_ARG
+    res, mask = lgr.ransac(src, tgt, good, p)            # the context is fine afterwards, and the good set registers
+    assert res.converged == 1 and np.abs(res.matrix() - pr["T_gt"]).max() < 5e-2
+    # the largest valid indices are accepted
+    edge = good.copy()
+    edge["index_query"][0] = 4999; edge["index_match"][0] = 4999
+    lgr.ransac(src, tgt, edge, p)

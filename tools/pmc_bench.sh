@@ -4,11 +4,12 @@
 # roofline.traffic once copied to profiles/).
 set -e
 cd /tmp && export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the root of the repo copy there)}"
 R=$GRAFT_REPO_ROOT
 i=0
 for grp in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rm -rf $R/gpurun_out/pmcb_$i
+  rm -rf "$R"/gpurun_out/pmcb_$i
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmcb_$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmcb_$i.log 2>&1
   echo "pmc group $i done"
 done

@@ -3,11 +3,12 @@
 set -e
 K=$1
 cd /tmp && export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the root of the repo copy there)}"
 R=$GRAFT_REPO_ROOT
 i=0
 for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD"; do
   i=$((i+1))
-  rm -rf $R/gpurun_out/pmck_$i
+  rm -rf "$R"/gpurun_out/pmck_$i
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmck_$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmck_$i.log 2>&1 || echo "pass $i failed"
 done
 cd $R

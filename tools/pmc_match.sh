@@ -2,6 +2,7 @@
 # PMC passes for the matcher kernel (counters only: --kernel-trace + --pmc, separate runs per counter group)
 set -e
 cd /tmp && export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT is the root of the repo copy there)}"
 R=$GRAFT_REPO_ROOT
 for grp in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $grp | cut -d' ' -f1)
