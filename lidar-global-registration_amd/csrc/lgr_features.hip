@@ -169,11 +169,15 @@ __device__ __forceinline__ int bin11(double t) {
 }
 
 constexpr int SB = 128;
+// SPFH rows are kept in the SORTED order of the grid (row t = the point at sorted position t, so the points of a cell --
+// the candidates the weighting step streams -- are consecutive rows) with a pitch of HP = 48 floats: bins 0..32, then 15
+// zeros.  48 = three 16-column MFMA operand tiles of 64 B each; the zeros make the third tile (bin 32 alone) a plain load.
+constexpr int HP = 48;
 // SPFH rows for the surface points listed in the sorted order of the grid (thread t handles sorted position order[t]).
 // Counters live in LDS as [bin][thread] (bank = thread % 32: conflict-free).
 __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uint8_t* __restrict__ need /* by original index or NULL */,
                                                    const int* __restrict__ order /* processing order of the sorted positions or NULL */,
-                                                   float* __restrict__ spfh /* [n_surface][33] by original index */) {
+                                                   float* __restrict__ spfh /* [n_surface][HP] by SORTED position */) {
     __shared__ int cnt[33 * SB];
     int t = blockIdx.x * SB + threadIdx.x;
     if (t >= g.n) return;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uin
         // no-return LDS adds (ds_add_u32): nothing waits on the counters until the end of the kernel
         atomicAdd(&cnt[b1 * SB + threadIdx.x], 1); atomicAdd(&cnt[b2 * SB + threadIdx.x], 1); atomicAdd(&cnt[b3 * SB + threadIdx.x], 1);
     });
-    float* row = spfh + (size_t) p * 33;
+    float* row = spfh + (size_t) t * HP;
     float incr = 100.0f / (float) (k - 1);
     for (int b = 0; b < 33; ++b) {
         int c = cnt[b * SB + threadIdx.x];
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uin
         for (int i = 0; i < c; ++i) s += incr;
         row[b] = s;
     }
+    for (int b = 33; b < HP; ++b) row[b] = 0.f;
 }
 
 // marks the surface points within r of any keypoint (PCL's spfh_indices set)
@@ -221,46 +226,155 @@ __global__ void need_kernel(GridDev g, const float* __restrict__ kps, int m, flo
     });
 }
 
-// FPFH row of keypoint order[t] (keypoints processed in grid-cell order for locality; output by original index)
-__global__ __launch_bounds__(128) void fpfh_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m,
-                                                    float r2, const float* __restrict__ spfh, float* __restrict__ out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    int i = order ? order[t] : t;
-    float x = kps[(size_t) i * 12], y = kps[(size_t) i * 12 + 1], z = kps[(size_t) i * 12 + 2];
-    float fp[33];
+// FPFH rows of 16 key points per wave on the f32 matrix cores (include/common.h:322-332 -> pcl::FPFHEstimation::weightPointSPFHSignature).
+//
+//   out[kp][bin] = sum over the neighbours q of kp (d2 < r2, d2 != 0, canonical order)  (1 / d2) * SPFH[q][bin]
+//
+// is the product W (key points x candidates) . SPFH (candidates x 33) with W masked to the accepted pairs.  The canonical
+// definition (oracle orc_fpfh) is one fmaf chain per bin over the accepted neighbours in grid order -- which is bit for bit what
+// v_mfma_f32_16x16x4_f32 computes along k (a k-ordered fmaf chain, one rounding per product), and a masked pair (weight +0,
+// SPFH finite) leaves the accumulator untouched: fma(+0, h, acc) == acc.  So ANY superset of a key point's neighbours, fed in
+// ascending (cell z, y, x; sorted position) order, gives the canonical row.
+//
+// A wave takes 16 consecutive key points of the cell-sorted order (fine_keys: cell, then Morton code).  Per run of key points
+// that share a cell: the points of the 27 surrounding cells are streamed 64 at a time, kept when they lie within r of the
+// run's bounding box (a superset test), compacted in order into a ring in LDS, and consumed four at a time: lane (i, k) =
+// (key point i, candidate k) computes d2 in the canonical op order, the mask, 1.0f / d2 (IEEE), and the wave issues three
+// 16x16x4 MFMAs against the candidates' SPFH rows (three 16-bin column tiles; pitch-48 rows, third tile = bin 32 + zeros).
+// Lanes of other runs in the same wave are masked (+0), so a tile may straddle cells.  Epilogue: accumulators -> LDS, one lane
+// per (key point, 11-bin block): block sum in double (ascending bins), 100 / sum, scaled bins to the key point's output row.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int FT = 16;        // key points per wave
+constexpr int FRING = 128;    // live-candidate ring entries (float4: x, y, z, bits(sorted position))
+constexpr int FP_PITCH = 36;  // LDS pitch of the epilogue rows (4 * 36 mod 32 == 16: the four row groups of a store hit different banks)
+
+__global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m, float r2,
+                                                       const float* __restrict__ Hs /* [g.n + 1][HP], last row zero */, float* __restrict__ out) {
+    __shared__ float4 ring[FRING];
+    __shared__ float fpl[FT * FP_PITCH];
+    const int l = threadIdx.x, i = l & 15, k = l >> 4;
+    const int r = blockIdx.x * FT + i;
+    const float nanv = __uint_as_float(0x7fc00000u);
+    int kp = -1;
+    float x = nanv, y = nanv, z = nanv;
+    if (r < m) {
+        kp = order[r];
+        x = kps[(size_t) kp * 12]; y = kps[(size_t) kp * 12 + 1]; z = kps[(size_t) kp * 12 + 2];
+    }
+    const bool fin = lgr_finite3(x, y, z);
+    int cell = -1;   // clamped cell of the key point (the ordering key of fine_keys); -1: no neighbours at all
+    if (fin && g.n > 0) {
+        int cx = min(max(lgr_cellc(x, g.ox, g.h), 0), g.dx - 1), cy = min(max(lgr_cellc(y, g.oy, g.h), 0), g.dy - 1), cz = min(max(lgr_cellc(z, g.oz, g.h), 0), g.dz - 1);
+        cell = (cz * g.dy + cy) * g.dx + cx;
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    bool found = false;
+    const float r2box = r2 * 1.0001f + 1e-30f;
+    const float* hbase = Hs + i;   // lane (i, k) supplies column i of every 16-bin tile
+    // runs of key points with the same cell (the tile is sorted by cell; -1 cells are skipped)
+    for (int p = 0; p < FT;) {
+        const int c = __builtin_amdgcn_readlane(cell, p);
+        const bool active = cell == c;
+        const unsigned long long am = __ballot(active) & 0xffffull;
+        p += __popcll(am);
+        if (c < 0) continue;
+        // bounding box of the run's key points
+        float bx0 = active ? x : 3.4e38f, bx1 = active ? x : -3.4e38f, by0 = active ? y : 3.4e38f, by1 = active ? y : -3.4e38f;
+        float bz0 = active ? z : 3.4e38f, bz1 = active ? z : -3.4e38f;
 #pragma unroll
-    for (int b = 0; b < 33; ++b) fp[b] = 0.f;
-    double sum0 = 0, sum1 = 0, sum2 = 0;
-    int found = 0;
-    if (lgr_finite3(x, y, z)) {
-        lgr_visit27(g, x, y, z, [&](int s, float4 Q) {
-            float d2 = lgr_dist2(x, y, z, Q.x, Q.y, Q.z);
-            if (!(d2 < r2)) return;
-            ++found;
-            if (d2 == 0.f) return;
-            float weight = 1.0f / d2;
-            const float* h = spfh + (size_t) __float_as_int(Q.w) * 33;
-#pragma unroll
-            for (int b = 0; b < 33; ++b) {
-                float val = h[b] * weight;
-                if (b < 11) sum0 += (double) val; else if (b < 22) sum1 += (double) val; else sum2 += (double) val;
-                fp[b] += val;
+        for (int o = 1; o < 16; o <<= 1) {
+            bx0 = fminf(bx0, __shfl_xor(bx0, o)); bx1 = fmaxf(bx1, __shfl_xor(bx1, o));
+            by0 = fminf(by0, __shfl_xor(by0, o)); by1 = fmaxf(by1, __shfl_xor(by1, o));
+            bz0 = fminf(bz0, __shfl_xor(bz0, o)); bz1 = fmaxf(bz1, __shfl_xor(bz1, o));
+        }
+        const int cz = c / (g.dx * g.dy), cy = (c / g.dx) % g.dy, cx = c % g.dx;
+        int head = 0, tail = 0;   // ring positions (monotone; entry e lives at e & (FRING - 1))
+        auto consume = [&](int n_groups) {
+            for (int gq = 0; gq < n_groups; ++gq, head += 4) {
+                const float4 e = ring[(head + k) & (FRING - 1)];
+                const float d2 = lgr_dist2(x, y, z, e.x, e.y, e.z);
+                const bool in = active && d2 < r2;
+                found = found || in;
+                const bool use = in && d2 != 0.f;
+                if (__ballot(use) == 0ull) continue;
+                const float w = use ? 1.0f / d2 : 0.f;
+                const float* h = hbase + (size_t) __float_as_int(e.w) * HP;
+                const float b0 = h[0], b1 = h[16], b2 = h[32];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b2, acc2, 0, 0, 0);
             }
-        });
+        };
+        for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dz - 1); ++zz)
+            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dy - 1); ++yy) {
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
+                const size_t c0 = ((size_t) zz * g.dy + yy) * g.dx;
+                const int b = g.cell_start[c0 + x0], e = g.cell_start[c0 + x1 + 1];   // three x-cells are contiguous
+                for (int t0 = b; t0 < e; t0 += 64) {
+                    const int t = t0 + l;
+                    bool live = false;
+                    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (t < e) {
+                        P = g.pxyz[t];
+                        const float ddx = fmaxf(fmaxf(bx0 - P.x, P.x - bx1), 0.f), ddy = fmaxf(fmaxf(by0 - P.y, P.y - by1), 0.f), ddz = fmaxf(fmaxf(bz0 - P.z, P.z - bz1), 0.f);
+                        live = (ddx * ddx + ddy * ddy) + ddz * ddz <= r2box;
+                    }
+                    const unsigned long long lm = __ballot(live);
+                    if (lm == 0ull) continue;
+                    if (live) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) lm, 0u));
+                        ring[(tail + rank) & (FRING - 1)] = make_float4(P.x, P.y, P.z, __int_as_float(t));
+                    }
+                    tail += __popcll(lm);
+                    __syncthreads();   // one wave per workgroup: orders the LDS stores before the reads below
+                    consume((tail - head) >> 2);
+                    __syncthreads();   // ... and those reads before the next chunk's stores
+                }
+            }
+        // the last 1..3 candidates of the run: pad the group with the all-zero SPFH row (position g.n) far away
+        if (tail > head) {
+            if (l < 4 - (tail - head)) ring[(tail + l) & (FRING - 1)] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(g.n));
+            __syncthreads();
+            consume(1);
+            __syncthreads();
+        }
     }
-    float* o = out + (size_t) i * 33;
-    if (found == 0) {
-        const float nanv = __uint_as_float(0x7fc00000u);
+    // The last MFMAs were issued in another basic block (end of the run loop): hipcc's hazard recognizer does not carry their
+    // "XDL write -> VALU read" wait states across the branches in between, and the v_accvgpr_read below then returns the
+    // accumulators WITHOUT the last group's products (seen on gfx950 / ROCm 7.2: every row off by a few ulp after normalisation;
+    // any build that happened to put more instructions in between was exact).  18 wait states cover an 8-pass MFMA.
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    // key point i found a neighbour in any of its four candidate slots?
+    const unsigned long long fm = __ballot(found);
+    // accumulators -> LDS: lane l holds rows 4 * (l >> 4) + q, column l & 15 of every tile
 #pragma unroll
-        for (int b = 0; b < 33; ++b) o[b] = nanv;
-        return;
+    for (int q = 0; q < 4; ++q) {
+        const int row = 4 * k + q;
+        fpl[row * FP_PITCH + i] = acc0[q];
+        fpl[row * FP_PITCH + 16 + i] = acc1[q];
+        if (i == 0) fpl[row * FP_PITCH + 32] = acc2[q];
     }
-    if (sum0 != 0) sum0 = 100.0 / sum0;
-    if (sum1 != 0) sum1 = 100.0 / sum1;
-    if (sum2 != 0) sum2 = 100.0 / sum2;
+    __syncthreads();
+    if (l < 3 * FT) {
+        const int kq = l / 3, blk = l % 3;
+        const int rr = blockIdx.x * FT + kq;
+        if (rr < m) {
+            const bool any = ((fm >> kq) | (fm >> (kq + 16)) | (fm >> (kq + 32)) | (fm >> (kq + 48))) & 1ull;
+            float* o = out + (size_t) order[rr] * 33 + 11 * blk;
+            const float* f = fpl + kq * FP_PITCH + 11 * blk;
+            if (!any) {
 #pragma unroll
-    for (int b = 0; b < 33; ++b) o[b] = (float) ((double) fp[b] * (b < 11 ? sum0 : (b < 22 ? sum1 : sum2)));
+                for (int q = 0; q < 11; ++q) o[q] = nanv;
+            } else {
+                double sum = 0.0;
+#pragma unroll
+                for (int q = 0; q < 11; ++q) sum += (double) f[q];
+                if (sum != 0) sum = 100.0 / sum;
+#pragma unroll
+                for (int q = 0; q < 11; ++q) o[q] = (float) ((double) f[q] * sum);
+            }
+        }
+    }
 }
 
 // Processing order of key points / surface points: grid cell, then a Morton code of the position inside the cell
@@ -465,8 +579,9 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     GridDev g;
     LGR_TRY(lgr_grid_build(ctx, WS_GRID_B, d_surf, n, radius * 1.001f, 0.f, &g));
     float r2 = radius * radius;
-    float* spfh;
-    LGR_TRY(lgr_ws_t(ctx, WS_SPFH, (size_t) n * 33 + 64 + (size_t) n, &spfh));
+    float* spfh;   // [g.n + 1][HP] in the grid's sorted order; row g.n is all zero (padding candidates of the MFMA weighting)
+    LGR_TRY(lgr_ws_t(ctx, WS_SPFH, ((size_t) n + 1) * HP + 64, &spfh));
+    LGR_HIP(ctx, hipMemsetAsync(spfh + (size_t) g.n * HP, 0, HP * sizeof(float), ctx->stream));
     // PCL computes SPFH only for surface points within r of some keypoint (spfh_indices); rows outside that set are
     // never read by the weighting step, so computing all rows gives the same FPFH output and saves the marking pass.
     // processing orders (fine_keys): cell bits + 3 * sb Morton bits must fit the 32-bit sort key
@@ -491,7 +606,7 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     }
     fine_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, 12, m, sb, keys, vals);
     LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, key_bits, ctx->stream));
-    fpfh_kernel<<<cdiv(m, 128), 128, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
+    fpfh_mfma_kernel<<<cdiv(m, FT), 64, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }

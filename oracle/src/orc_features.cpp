@@ -286,8 +286,14 @@ extern "C" int orc_spfh(const float* surf, int n, float radius, float* out33, in
 //   radius search: strict d2 < r*r (FLANN RadiusResultSet), d2 = ((dx*dx)+dy*dy)+dz*dz.
 //   neighbour visiting order: PCL visits by ascending distance; the oracle visits by (grid cell z,y,x; index) with
 //   cell = 1.001*r anchored at the surface AABB min -- DEVIATION in float summation order only (documented).
-//   weight = 1/d2 (squared distance); val = hist*weight (float); fpfh += val (float); sum (double) += val;
-//   final: fpfh[b] = float(double(fpfh[b]) * (100.0/sum)).
+//   weight = 1.0f / d2 (squared distance, IEEE division).  CANONICAL weighting (DEVIATION from PCL in float rounding only, see
+//   DESIGN.md section 4): PCL rounds val = hist * weight, adds it to the float bin and to a double block sum, in its
+//   ascending-distance neighbour order.  Here every bin is ONE fused chain over the accepted neighbours in grid order,
+//       fp[b] = fmaf(weight, hist[b], fp[b])            (one rounding per neighbour)
+//   -- which is bit for bit what the gfx950 f32 MFMA computes (v_mfma_f32_16x16x4_f32 = k-ordered fmaf chain), so the HIP
+//   path can run the weighting W(keypoints x neighbours) . SPFH(neighbours x 33) on the matrix cores -- and the block
+//   normaliser is taken from the finished bins: sum_j = sum over the block's 11 bins, ascending, in double;
+//   fpfh[b] = float(double(fp[b]) * (100.0 / sum_j)).
 extern "C" int orc_fpfh(const float* kps, int m, const float* surf, int n, float radius, float* out33, int libm_mode) {
     Grid g;
     g.build(surf, n, radius * 1.001f);
@@ -310,7 +316,6 @@ extern "C" int orc_fpfh(const float* kps, int m, const float* surf, int n, float
         float* o = out33 + 33 * (size_t) i;
         int found = 0;
         float fp[33];
-        double sum[3] = {0, 0, 0};
         for (int b = 0; b < 33; ++b) fp[b] = 0.f;
         if (finite3(P)) {
             g.visit27(P, [&](int q) {
@@ -320,17 +325,15 @@ extern "C" int orc_fpfh(const float* kps, int m, const float* surf, int n, float
                 if (d2 == 0.f) return;
                 float weight = 1.0f / d2;
                 const float* h = spfh.data() + 33 * (size_t) q;
-                for (int b = 0; b < 33; ++b) {
-                    float val = h[b] * weight;
-                    sum[b / 11] += val;
-                    fp[b] += val;
-                }
+                for (int b = 0; b < 33; ++b) fp[b] = std::fmaf(weight, h[b], fp[b]);
             });
         }
         if (found == 0) {
             for (int b = 0; b < 33; ++b) o[b] = std::numeric_limits<float>::quiet_NaN();
             continue;
         }
+        double sum[3] = {0, 0, 0};
+        for (int b = 0; b < 33; ++b) sum[b / 11] += (double) fp[b];
         for (int s = 0; s < 3; ++s) if (sum[s] != 0) sum[s] = 100.0 / sum[s];
         for (int b = 0; b < 33; ++b) o[b] = (float) ((double) fp[b] * sum[b / 11]);
     }
