@@ -215,6 +215,145 @@ __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uin
     for (int b = 33; b < HP; ++b) row[b] = 0.f;
 }
 
+// SPFH rows of 16 surface points per wave with the expensive part (pcl::computePairFeatures: two square roots, three divisions,
+// an atan2, three bin indices) run on COMPACTED work: a thread-per-point loop over the 27-cell candidates keeps only the ~35 % of
+// its lanes busy that accept their current candidate.  Here lane = candidate: the points of the 27 cells around a run of tile
+// points (same cell) are streamed 64 at a time, kept when within r of the run's bounding box and staged in LDS; for every tile
+// point all lanes test their candidate (d2 < r2, the k count of the point = popcount of the ballot) and the accepted
+// (point, candidate) pairs are appended to a queue in LDS; whenever 64 pairs are queued every lane takes one and does the
+// pair-feature arithmetic -- all 64 lanes busy -- and three LDS atomic increments into the point's histogram.  Counts are
+// order free (the canonical value of a bin is the sequential float sum of `count` copies of the increment), so any
+// enumeration that meets every (point, neighbour) pair exactly once gives the oracle's rows bit for bit.
+constexpr int ST = 16;          // surface points per wave
+constexpr int SQ = 128;         // pair queue entries: (tile point << 8) | candidate slot
+constexpr int SHP = 36;         // histogram pitch (33 bins + pad)
+
+__global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, const int* __restrict__ order, float* __restrict__ spfh /* [n][HP], sorted positions */) {
+    __shared__ float4 tp[ST], tn[ST];
+    __shared__ float4 cp[64], cn[64];
+    __shared__ unsigned short queue[SQ];
+    __shared__ int hist[2][ST][SHP];
+    __shared__ int kcnt[ST];
+    const int l = threadIdx.x;
+    int pos = -1, cell = -1;   // sorted position / cell of tile point l (lanes 0..15)
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (l < ST) {
+        const int rnk = blockIdx.x * ST + l;
+        if (rnk < g.n) {
+            pos = order ? order[rnk] : rnk;
+            const float4 P = g.pxyz[pos];
+            x = P.x; y = P.y; z = P.z;
+            tp[l] = make_float4(P.x, P.y, P.z, __int_as_float(pos));
+            tn[l] = g.pnrm[pos];
+            const int cx = min(max(lgr_cellc(x, g.ox, g.h), 0), g.dx - 1), cy = min(max(lgr_cellc(y, g.oy, g.h), 0), g.dy - 1), cz = min(max(lgr_cellc(z, g.oz, g.h), 0), g.dz - 1);
+            cell = (cz * g.dy + cy) * g.dx + cx;
+        }
+        kcnt[l] = 0;
+    }
+    for (int q = l; q < 2 * ST * SHP; q += 64) (&hist[0][0][0])[q] = 0;
+    __syncthreads();
+    const float r2box = r2 * 1.0001f + 1e-30f;
+    const float d_pi = 1.0f / (2.0f * 3.14159274101257324f);   // 1.0f / (2.0f * static_cast<float>(M_PI))
+    const double MPI = 3.14159265358979323846;
+    int qh = 0, qt = 0;
+    auto process = [&](int nb) {   // the first nb queued pairs, one per lane
+        if (l < nb) {
+            const unsigned e = queue[(qh + l) & (SQ - 1)];
+            const int i = (int) (e >> 8), sl = (int) (e & 255u);
+            const float4 P = tp[i], N = tn[i], Q = cp[sl], M = cn[sl];
+            float f1, f2, f3;
+            if (pair_features(P.x, P.y, P.z, N.x, N.y, N.z, Q.x, Q.y, Q.z, M.x, M.y, M.z, f1, f2, f3)) {
+                const int b1 = bin11(((double) f1 + MPI) * (double) d_pi);
+                const int b2 = 11 + bin11(((double) f2 + 1.0) * 0.5);
+                const int b3 = 22 + bin11(((double) f3 + 1.0) * 0.5);
+                int* h = &hist[l & 1][i][0];
+                atomicAdd(h + b1, 1); atomicAdd(h + b2, 1); atomicAdd(h + b3, 1);
+            }
+        }
+        qh += nb;
+    };
+    for (int p = 0; p < ST;) {
+        const int c = __builtin_amdgcn_readlane(cell, p);
+        const bool active = l < ST && cell == c;
+        const int n_run = __popcll(__ballot(active));
+        const int p0 = p;
+        p += n_run;
+        if (c < 0) break;   // the rest of the tile lies beyond g.n
+        float bx0 = active ? x : 3.4e38f, bx1 = active ? x : -3.4e38f, by0 = active ? y : 3.4e38f, by1 = active ? y : -3.4e38f;
+        float bz0 = active ? z : 3.4e38f, bz1 = active ? z : -3.4e38f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            bx0 = fminf(bx0, __shfl_xor(bx0, o)); bx1 = fmaxf(bx1, __shfl_xor(bx1, o));
+            by0 = fminf(by0, __shfl_xor(by0, o)); by1 = fmaxf(by1, __shfl_xor(by1, o));
+            bz0 = fminf(bz0, __shfl_xor(bz0, o)); bz1 = fmaxf(bz1, __shfl_xor(bz1, o));
+        }
+        const int cz = c / (g.dx * g.dy), cy = (c / g.dx) % g.dy, cx = c % g.dx;
+        for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dz - 1); ++zz)
+            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dy - 1); ++yy) {
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
+                const size_t c0 = ((size_t) zz * g.dy + yy) * g.dx;
+                const int b = g.cell_start[c0 + x0], e = g.cell_start[c0 + x1 + 1];
+                for (int t0 = b; t0 < e; t0 += 64) {
+                    const int t = t0 + l;
+                    bool live = false;
+                    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (t < e) {
+                        P = g.pxyz[t];
+                        const float ddx = fmaxf(fmaxf(bx0 - P.x, P.x - bx1), 0.f), ddy = fmaxf(fmaxf(by0 - P.y, P.y - by1), 0.f), ddz = fmaxf(fmaxf(bz0 - P.z, P.z - bz1), 0.f);
+                        live = (ddx * ddx + ddy * ddy) + ddz * ddz <= r2box;
+                    }
+                    const unsigned long long lm = __ballot(live);
+                    if (lm == 0ull) continue;
+                    const int n_live = __popcll(lm);
+                    if (live) {
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) lm, 0u));
+                        cp[rank] = make_float4(P.x, P.y, P.z, __int_as_float(t));
+                        cn[rank] = g.pnrm[t];
+                    }
+                    __syncthreads();
+                    float4 Q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (l < n_live) Q = cp[l];
+                    for (int i = p0; i < p0 + n_run; ++i) {
+                        const float4 P_i = tp[i];
+                        const float d2 = lgr_dist2(P_i.x, P_i.y, P_i.z, Q.x, Q.y, Q.z);
+                        const bool acc = l < n_live && d2 < r2;
+                        const unsigned long long am = __ballot(acc);
+                        if (am == 0ull) continue;
+                        if (l == 0) kcnt[i] += __popcll(am);
+                        const bool enq = acc && __float_as_int(Q.w) != __float_as_int(P_i.w);   // if (s == t) return: the point itself
+                        const unsigned long long em = __ballot(enq);
+                        if (enq) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) em, 0u));
+                            queue[(qt + rank) & (SQ - 1)] = (unsigned short) ((i << 8) | l);
+                        }
+                        qt += __popcll(em);
+                        if (qt - qh >= 64) {
+                            __syncthreads();
+                            process(64);
+                        }
+                    }
+                    __syncthreads();
+                    process(qt - qh);     // the queue refers to this chunk's candidate slots: drain it before they are overwritten
+                    __syncthreads();
+                }
+            }
+    }
+    __syncthreads();
+    // rows: bin value = sequential float sum of `count` copies of 100 / (k - 1); zero padding up to the pitch
+    for (int q = l; q < ST * HP; q += 64) {
+        const int i = q / HP, b = q % HP;
+        const int ps = __float_as_int(tp[i].w);
+        if (blockIdx.x * ST + i >= g.n) continue;
+        float v = 0.f;
+        if (b < 33) {
+            const int cnt = hist[0][i][b] + hist[1][i][b];
+            const float incr = 100.0f / (float) (kcnt[i] - 1);
+            for (int k = 0; k < cnt; ++k) v += incr;
+        }
+        spfh[(size_t) ps * HP + b] = v;
+    }
+}
+
 // marks the surface points within r of any keypoint (PCL's spfh_indices set)
 __global__ void need_kernel(GridDev g, const float* __restrict__ kps, int m, float r2, uint8_t* __restrict__ need) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -602,7 +741,7 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     if (g.n > 0) {
         fine_keys<<<cdiv(g.n, 256), 256, 0, ctx->stream>>>(g, reinterpret_cast<const float*>(g.pxyz), 4, g.n, sb, keys, vals);
         LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) g.n, 0, key_bits, ctx->stream));
-        spfh_kernel<<<cdiv(g.n, SB), SB, 0, ctx->stream>>>(g, r2, nullptr, vals2, spfh);
+        spfh_tile_kernel<<<cdiv(g.n, ST), 64, 0, ctx->stream>>>(g, r2, vals2, spfh);
     }
     fine_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, 12, m, sb, keys, vals);
     LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, key_bits, ctx->stream));
