@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: check sampled queries of the GPU's 1M x 1M matches against the CPU oracle (parity_sample in the JSON line)")
     ap.add_argument("--verify-queries", type=int, default=4096)
+    ap.add_argument("--match-opt", action="append", default=[], metavar="FIELD=VALUE",
+                    help="lgr_match_options override for ablations / profiles (e.g. coarse_rejection=0); never changes results")
     return ap.parse_args()
 
 
@@ -264,6 +266,8 @@ def main():
     torch.cuda.set_device(local)
     from lgr_amd import capi, synthetic, distributed
     ctx = capi.Context(local)
+    if args.match_opt:
+        ctx.set_match_options(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.match_opt)})
 
     pair = synthetic.make_pair(args.points, seed=synthetic.SEED + rank)
     params = make_params(capi, pair, args.matching)

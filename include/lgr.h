@@ -72,7 +72,12 @@ typedef struct {
     uint64_t seed;
     int32_t keypoint_id;         /* LGR_KEYPOINT_ANY (every point, BASELINE configs) or LGR_KEYPOINT_ISS */
     float   iss_radius_src, iss_radius_tgt;   /* include/common.h:139; salient = non-maxima radius */
-    int32_t reserved0;
+    int32_t use_bfmatcher;       /* 1 (ALIGNMENT_USE_BFMATCHER include/common.h:41); 0: matchFLANN (include/matching.h:309) */
+    /* include/common.h:158-160: "cannot be set in config, set before alignment steps" */
+    int32_t has_guess;           /* 1: matching is matchLocal around guess * p (include/matching.h:294-299) and the guess is the
+                                  *    hypothesis RANSAC has to beat (src/sac_prerejective_omp.cpp:134-147) */
+    float   match_search_radius;
+    float   guess[16];           /* column-major */
 } lgr_params;
 
 /* mirrors AlignmentResult (include/common.h:165-174) + diagnostics */
@@ -93,6 +98,24 @@ typedef struct {
 
 typedef struct lgr_ctx lgr_ctx;
 
+/* How the brute-force matcher runs (NEVER what it returns: every setting gives the same matches and distance bits).  The
+ * defaults are the production schedule; the other values exist so that tests can drive every path at small sizes and so that
+ * profiles can switch single mechanisms off.  Held by the context: lgr_ctx_set_match_options. */
+typedef struct {
+    int32_t prune;            /* exact bound-based tile skipping: -1 auto (on from 65536 x 65536 pairs), 0 off (dense), 1 on */
+    int32_t leaves;           /* second-level k-means leaves per cluster: 0 auto (about 1024 rows per leaf), else 1 .. 64 */
+    int32_t near;             /* pass-0 width: nearest leaves per row block / row blocks per leaf; 0 = default (32) */
+    int32_t operand_format;   /* -1 auto (f16 two-term splits, rotated to 30 coordinates when the rows allow it), 0 f32, 1 f16, 2 f16 rotated */
+    int32_t box_bounds;       /* bounding-box lower bounds beside the ball bounds: 1 PCA basis (default), 2 raw coordinates, 0 off */
+    int32_t column_stage;     /* per-stage column criterion in the final schedule: 1 (default) / 0 */
+    int32_t coarse_rejection; /* two-step coarse test inside the final MFMA pass: 1 (default) / 0 */
+    int32_t rerank_refilter;  /* MFMA re-filter of the rerank's candidate groups: 1 (default) / 0 (whole-group exact scan) */
+    int32_t pair_cap;         /* pairs per rerank item the re-filter may emit before falling back to the group scan: -1 default (8) */
+    int32_t poison_tables;    /* diagnostics: fill never-computed minimum-table entries with 0 (nothing may read them) */
+    int32_t self_check;       /* diagnostics: device check of the proven filter bound on sampled queries (lgr_match_last_check) */
+    int32_t reserved[5];
+} lgr_match_options;
+
 /* ---- context ---- */
 int  lgr_version(void);
 /* device: HIP ordinal.  stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's null
@@ -105,6 +128,10 @@ const char* lgr_last_error(lgr_ctx* ctx);
 void lgr_default_params(lgr_params* p);                      /* defaults of src/common.cpp:216-223,335-413 */
 /* on-device stage timers of the last lgr_align*/
 int  lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12);
+void lgr_match_default_options(lgr_match_options* opt);
+/* opt == NULL restores the defaults.  Applies to every later matcher call of this context, stand-alone or inside lgr_align*. */
+int  lgr_ctx_set_match_options(lgr_ctx* ctx, const lgr_match_options* opt);
+int  lgr_ctx_get_match_options(lgr_ctx* ctx, lgr_match_options* opt);
 /* device bytes the context's workspace currently holds (the sum of its grown-on-demand buffers): what a caller sizes its own
  * HBM budget against when it pushes many pairs of different sizes through one context (src/main.cpp:384-407 loops pairs in
  * one process) */
@@ -157,6 +184,21 @@ int lgr_match_bf_dev(lgr_ctx*, const float* d_q33, int mq, const float* d_t33, i
 /* both directions in one MFMA pass (what LeftToRight/Cluster matchers need, include/matching.h:431-432,495-496) */
 int lgr_match_bf2_dev(lgr_ctx*, const float* d_a33, int ma, const float* d_b33, int mb, int block,
                       int32_t* d_ab_idx, float* d_ab_dist, int32_t* d_ba_idx, float* d_ba_dist);
+/* ---- include/matching.h:373-376 matchFLANN<FPFH>(query_features, train_features, parameters), randomness 1 (:565-592):
+ *      pcl::KdTreeFLANN is an exact search, so the nearest row is the one matchBF finds (the reference's own test asserts that,
+ *      tests/flann_bf_matcher.h:82-83); what differs is the reported distance: sqrt of FLANN's L2_Simple (sequential sum of
+ *      squares) instead of OpenCV's lane-ordered norm.  idx = -1 for invalid query rows. ---- */
+int lgr_match_flann(lgr_ctx*, const float* q33, int mq, const float* t33, int mt, int32_t* idx, float* dist);
+int lgr_match_flann_dev(lgr_ctx*, const float* d_q33, int mq, const float* d_t33, int mt, int32_t* d_idx, float* d_dist);
+/* ---- include/matching.h:383-387 matchLocal<FPFH>(query_pcd, train_tree, query_features, train_features, parameters, guess)
+ *      (:637-678): for every valid query row, the train row with the nearest descriptor (pcl::L2_Norm: sequential sum, sqrtf)
+ *      among the train POINTS within match_search_radius of guess * query point (strict d2 < r*r; FLT_MAX radius = all points);
+ *      equal descriptor distances: the spatially nearer point, then the lower index (KNNResult keeps the first, radiusSearch
+ *      visits by ascending distance).  guess16: column-major, host. ---- */
+int lgr_match_local(lgr_ctx*, const float* query_pts, int mq, const float* train_pts, int mt, const float* q33, const float* t33,
+                    const float guess16[16], float match_search_radius, int32_t* idx, float* dist);
+int lgr_match_local_dev(lgr_ctx*, const float* d_query_pts, int mq, const float* d_train_pts, int mt, const float* d_q33, const float* d_t33,
+                        const float guess16[16] /* host */, float match_search_radius, int32_t* d_idx, float* d_dist);
 
 /* diagnostics of the last match call: [items_ab, dense_ab, items_ba, dense_ba, sub_cols, rg_rows] and the duration of
  * its MFMA filter kernel (hipEvents on the ctx stream) -- what bench.py's roofline object is computed from */

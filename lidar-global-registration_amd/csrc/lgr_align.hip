@@ -266,6 +266,47 @@ static void ms_vote(const MsSide& tr, const std::vector<std::vector<int>>& mi, c
     }
 }
 
+// inverse of a column-major 4x4 by Gauss-Jordan with partial pivoting in double, rounded to float: the canonical stand-in for
+// Eigen's Matrix4f::inverse() (include/matching.h:296), same as the oracle's orc_inverse4
+static void inverse4(const float* m16, float* out16) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = m16[4 * c + r]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (piv != col) for (int c = 0; c < 8; ++c) std::swap(a[piv][c], a[col][c]);
+        double d = a[col][col];
+        for (int c = 0; c < 8; ++c) a[col][c] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            double f = a[r][col];
+            for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out16[4 * c + r] = (float) a[r][4 + c];
+}
+
+// the matcher dispatch of match_multiscale (include/matching.h:294-312): guess -> matchLocal in both directions (the inverse guess
+// for train -> query, :296), else bf -> matchBF (one MFMA pass serves both directions), else matchFLANN
+static int match_dispatch(lgr_ctx* ctx, const lgr_params* p, const float* a_pts, const float* fa, int ma, const float* b_pts, const float* fb, int mb,
+                          bool need_ba, int32_t* ab_i, float* ab_d, int32_t* ba_i, float* ba_d) {
+    if (p->has_guess) {
+        LGR_TRY(lgr_match_local_dev(ctx, a_pts, ma, b_pts, mb, fa, fb, p->guess, p->match_search_radius, ab_i, ab_d));
+        if (need_ba) {
+            float inv[16];
+            inverse4(p->guess, inv);
+            LGR_TRY(lgr_match_local_dev(ctx, b_pts, mb, a_pts, ma, fb, fa, inv, p->match_search_radius, ba_i, ba_d));
+        }
+    } else if (p->use_bfmatcher) {
+        if (need_ba) LGR_TRY(lgr_match_bf2_dev(ctx, fa, ma, fb, mb, p->bf_block_size, ab_i, ab_d, ba_i, ba_d));
+        else LGR_TRY(lgr_match_bf_dev(ctx, fa, ma, fb, mb, p->bf_block_size, ab_i, ab_d));
+    } else {
+        LGR_TRY(lgr_match_flann_dev(ctx, fa, ma, fb, mb, ab_i, ab_d));
+        if (need_ba) LGR_TRY(lgr_match_flann_dev(ctx, fb, mb, fa, ma, ba_i, ba_d));
+    }
+    return LGR_OK;
+}
+
 static int ms_match_tables(lgr_ctx* ctx, const float* const* clouds, const int* sizes, const float* const* kclouds, const int* ksizes,
                            const lgr_params* p, int32_t* d_ij, float* d_dij, int32_t* d_ji, float* d_dji, float* ms) {
     MsSide st[2];
@@ -291,8 +332,15 @@ static int ms_match_tables(lgr_ctx* ctx, const float* const* clouds, const int* 
         float *ab_d = (float*) (r + ma + mb), *ba_d = ab_d + ma;
         const float* fa = st[0].feat + st[0].feat_off[ia] * 33;
         const float* fb = st[1].feat + st[1].feat_off[ib] * 33;
-        if (need_ji) LGR_TRY(lgr_match_bf2_dev(ctx, fa, ma, fb, mb, p->bf_block_size, ab_i, ab_d, ba_i, ba_d));
-        else LGR_TRY(lgr_match_bf_dev(ctx, fa, ma, fb, mb, p->bf_block_size, ab_i, ab_d));
+        const float *pa = nullptr, *pb = nullptr;
+        if (p->has_guess) {   // matchLocal works on the level's key-point sub-clouds (kps_multiscale, include/matching.h:243)
+            float* sub;
+            LGR_TRY(lgr_ws_t(ctx, WS_MS_SUB, (size_t) (ma + mb) * 12 + 4, &sub));
+            gather_rows12_kernel<<<cdiv((long long) ma * 12, 256), 256, 0, ctx->stream>>>(kclouds[0], st[0].d_lists + st[0].feat_off[ia], ma, sub);
+            gather_rows12_kernel<<<cdiv((long long) mb * 12, 256), 256, 0, ctx->stream>>>(kclouds[1], st[1].d_lists + st[1].feat_off[ib], mb, sub + (size_t) ma * 12);
+            pa = sub; pb = sub + (size_t) ma * 12;
+        }
+        LGR_TRY(match_dispatch(ctx, p, pa, fa, ma, pb, fb, mb, need_ji, ab_i, ab_d, ba_i, ba_d));
         std::vector<int32_t> h((size_t) 2 * (ma + mb));
         LGR_HIP(ctx, hipMemcpyAsync(h.data(), r, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -410,8 +458,7 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
         for (int s = 0; s < 3; ++s) { (void) hipEventElapsedTime(&t, ctx->ev[s], ctx->ev[s + 1]); ms[s] += t; }
     }
     tick(ctx, 4);
-    if (p->matching_id == LGR_MATCH_ONE_SIDED) LGR_TRY(lgr_match_bf_dev(ctx, feat[0], ns, feat[1], nt, p->bf_block_size, ij, dij));
-    else LGR_TRY(lgr_match_bf2_dev(ctx, feat[0], ns, feat[1], nt, p->bf_block_size, ij, dij, ji, dji));
+    LGR_TRY(match_dispatch(ctx, p, kclouds[0], feat[0], ns, kclouds[1], feat[1], nt, p->matching_id != LGR_MATCH_ONE_SIDED, ij, dij, ji, dji));
     }
     tick(ctx, 5);
     LGR_TRY(lgr_filter_dev(ctx, p->matching_id, kclouds[0], ns, kclouds[1], nt, ij, dij, ji, dji, p->distance_thr, p->cluster_k, d_out, n_out));

@@ -97,6 +97,28 @@ extern "C" int lgr_ctx_stage_ms(lgr_ctx* ctx, float* out12) {
     return LGR_OK;
 }
 
+extern "C" void lgr_match_default_options(lgr_match_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->prune = -1; o->leaves = 0; o->near = 0; o->operand_format = -1; o->box_bounds = 1; o->column_stage = 1;
+    o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0;
+}
+
+extern "C" int lgr_ctx_set_match_options(lgr_ctx* ctx, const lgr_match_options* opt) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    if (!opt) { lgr_match_default_options(&ctx->mopt); return LGR_OK; }
+    LGR_CHECK(ctx, opt->prune >= -1 && opt->prune <= 1 && opt->leaves >= 0 && opt->leaves <= 64 && opt->near >= 0 &&
+                   opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2, LGR_ERR_INVALID_ARG);
+    ctx->mopt = *opt;
+    return LGR_OK;
+}
+
+extern "C" int lgr_ctx_get_match_options(lgr_ctx* ctx, lgr_match_options* opt) {
+    if (!ctx || !opt) return LGR_ERR_INVALID_ARG;
+    *opt = ctx->mopt;
+    return LGR_OK;
+}
+
 extern "C" int lgr_ctx_workspace_bytes(lgr_ctx* ctx, uint64_t* bytes) {
     if (!ctx || !bytes) return LGR_ERR_INVALID_ARG;
     uint64_t t = 0;
@@ -129,4 +151,6 @@ extern "C" void lgr_default_params(lgr_params* p) {
     p->fix_seed = 1;
     p->ransac_batch = 65536;
     p->seed = 566;
+    p->use_bfmatcher = 1;                // ALIGNMENT_USE_BFMATCHER include/common.h:41
+    for (int i = 0; i < 4; ++i) p->guess[5 * i] = 1.f;
 }

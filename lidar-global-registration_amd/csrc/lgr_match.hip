@@ -70,7 +70,7 @@ extern "C" int lgr_match_last_format(int* f16) {
     return LGR_OK;
 }
 
-// LGR_MATCH_CHECK=1 (tests): worst |filtered - exact| / eps over the sampled table entries of the last call, per direction
+// lgr_match_options.self_check (tests): worst |filtered - exact| / eps over the sampled table entries of the last call, per direction
 // (rows, columns); -1 when the check did not run.  A proven bound: must be <= 1.
 extern "C" int lgr_match_last_check(double* out2) {
     if (!out2) return LGR_ERR_INVALID_ARG;
@@ -78,16 +78,17 @@ extern "C" int lgr_match_last_check(double* out2) {
     return LGR_OK;
 }
 
+// environment: debug dumps only (LGR_MATCH_DEBUG); everything that selects a path is an lgr_match_options field
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
 
 // Orthonormal basis for the box bounds: principal axes of the k-means sample (both sets).  Covariance on the device,
-// cyclic Jacobi on the host (33 x 33), rows of V = eigenvectors, mu = sample mean.  LGR_MATCH_BOX=2: raw coordinates.
+// cyclic Jacobi on the host (33 x 33), rows of V = eigenvectors, mu = sample mean.  box_bounds == 2: raw coordinates.
 static int box_basis(lgr_ctx* ctx, const float* smp, const int* smp_ok, int ns, float* d_basis /* [34][33] + 1: V rows, then mu */) {
     std::vector<float> h(34 * 33 + 1, 0.f);
-    const bool raw = env_int("LGR_MATCH_BOX", 1) == 2;
+    const bool raw = ctx->mopt.box_bounds == 2;
     if (!raw) {
         const int nb = cdiv(ns, COV_ROWS);
         float* part;
@@ -154,15 +155,16 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     if (mb && d_ba_idx) { LGR_HIP(ctx, hipMemsetAsync(d_ba_idx, 0xff, (size_t) mb * 4, ctx->stream)); LGR_HIP(ctx, hipMemsetAsync(d_ba_dist, 0, (size_t) mb * 4, ctx->stream)); }
     if (ma == 0 || mb == 0) return LGR_OK;
 
-    // leaves per cluster: about 1024 rows per leaf on the larger side.  LGR_MATCH_SUB / LGR_MATCH_PRUNE override the
-    // automatic choices, LGR_MATCH_NEAR the pass-0 width (tests force the skipping path on small inputs); results never
-    // depend on them.
+    // leaves per cluster: about 1024 rows per leaf on the larger side.  lgr_match_options (ctx->mopt: leaves / prune / near)
+    // override the automatic choices (tests force the skipping path on small inputs); results never depend on them.
+    const lgr_match_options& mo = ctx->mopt;
     int sub = 1;
     while (sub < SUBMAX && (long long) KCL * sub * 1024 < std::max(ma, mb)) sub *= 2;
-    sub = std::min(SUBMAX, std::max(1, env_int("LGR_MATCH_SUB", sub)));
+    if (mo.leaves > 0) sub = mo.leaves;
+    sub = std::min(SUBMAX, std::max(1, sub));
     const int n_leaves = KCL * sub;
-    const int prune_mode = env_int("LGR_MATCH_PRUNE", -1);   // -1 auto, 0 off, 1 on
-    const int near_t = std::max(1, env_int("LGR_MATCH_NEAR", NEAR_T));
+    const int prune_mode = mo.prune;   // -1 auto, 0 off, 1 on
+    const int near_t = mo.near > 0 ? mo.near : NEAR_T;
     const bool prune = prune_mode == 1 || (prune_mode != 0 && (double) ma * mb >= 65536.0 * 65536.0);
 
     // ---- 1. k-means centres on a sample: KCL clusters, then `sub` leaves inside every cluster
@@ -216,7 +218,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const int n_rb = ma_pad / BLOCK_ROWS, n_stage_total = mb_pad / STAGE_COLS;
 
     // ---- 3. pack operands, group maxima, stage -> leaf map
-    const bool f16 = env_int("LGR_MATCH_F16", 1) != 0;
+    const bool f16 = mo.operand_format != 0;
     g_last_stats.f16 = f16 ? 1 : 0;
     EpsExtra ex{0.f, 0.f, 1.f};
     float c_scale = 1.f, out_scale = 1.f;
@@ -246,7 +248,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         // Rotated format (FMT_F16R) when what it drops is negligible: with u the dropped coordinates of a row relative to a
         // centre, d2 = d2_30 + |u_a - u_b|^2 and 0 <= |u_a - u_b|^2 <= 4 max |u|^2 -- that bound joins the absolute error
         // term, so the choice below only trades speed.  FPFH rows: every block sums to 100 -> max |u|^2 ~ 1e-7.
-        const int rot_env = env_int("LGR_MATCH_ROT", -1);
+        const int rot_env = mo.operand_format < 0 ? -1 : (mo.operand_format == 2 ? 1 : 0);
         rot = rot_env >= 0 ? rot_env != 0 : (4.0 * (double) drop2 <= 1e-8 * (double) r2);
         double R = std::sqrt((double) r2);
         int sexp = R > 0 ? (int) std::floor(std::log2(16384.0 / R)) : 14;
@@ -353,7 +355,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // dense mode: +inf everywhere; skipping mode: init_tables_kernel covers what each pass computes (LGR_MATCH_POISON=1, tests: the
     // rest is filled with 0 -- the most harmful value a stale entry could have -- to show that nothing reads it)
     if (!prune) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
-    else if (env_int("LGR_MATCH_POISON", 0)) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0, tab_floats, ctx->stream));
+    else if (mo.poison_tables) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0, tab_floats, ctx->stream));
     const int n_cc = cdiv(mb_pad, CHUNK_COLS);
     // work items of the persistent MFMA kernel: one row group (the owner of its column minima) x one column chunk
     const int item_rb = both ? std::min(rg_rows / BLOCK_ROWS, 16) : 4;
@@ -442,9 +444,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
         unsigned* u_stage = (unsigned*) (pb + o_ust);
-        const bool colstage = both && env_int("LGR_MATCH_COLSTAGE", 1) != 0;
+        const bool colstage = both && mo.column_stage != 0;
         // coarse rejection inside match_mfma (rotated format, passes with upper bounds): thresholds from u_rb / u_stage
-        const bool coarse = f16 && rot && env_int("LGR_MATCH_COARSE", 1) != 0;
+        const bool coarse = f16 && rot && mo.coarse_rejection != 0;
         float* smaxB = (float*) (pb + o_smax);
         unsigned long long* coarse_cnt = (unsigned long long*) (pb + o_ccnt);
         CoarseArgs ca_on{};
@@ -483,7 +485,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
         lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
-        if (env_int("LGR_MATCH_BOX", 1)) {
+        if (mo.box_bounds) {
             float* boxA = (float*) (pb + o_boxa);
             float* boxBt = (float*) (pb + o_boxb);
             float* basis = (float*) (pb + o_basis);              // V [33][33], mu [33]
@@ -580,7 +582,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     }
     LGR_HIP(ctx, hipGetLastError());
 
-    if (env_int("LGR_MATCH_CHECK", 0) && sortedA) {
+    if (mo.self_check && sortedA) {
         unsigned* d_worst = (unsigned*) (misc + 192);
         LGR_HIP(ctx, hipMemsetAsync(d_worst, 0, 8, ctx->stream));
         const int stride = 37;
@@ -602,7 +604,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
 
     // ---- 5. exact rerank
     // (the MFMA re-filter of the rerank items needs the f16 operand formats and the padded train copies)
-    RefilterArgs ra{(const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, (f16 && env_int("LGR_MATCH_REFILTER", 1)) ? KS : 0, A.blkcl, env_int("LGR_MATCH_PAIR_CAP", -1)};
+    RefilterArgs ra{(const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, (f16 && mo.rerank_refilter) ? KS : 0, A.blkcl, mo.pair_cap};
     LGR_TRY((run_rerank<true>(ctx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
                               d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab, force_dense, ra, &g_last_stats.pairs_ab)));
     if (both)

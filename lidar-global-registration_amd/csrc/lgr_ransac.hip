@@ -976,6 +976,19 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const bool plane_metric = p->metric_id == LGR_METRIC_CLOSEST_PLANE || p->metric_id == LGR_METRIC_COMBINATION;
+    lgr_plane_dev plane;
+    if (plane_metric) LGR_TRY(lgr_plane_setup(ctx, d_src, ns, d_tgt, nt, seed, &plane));
+    if (p->has_guess) {
+        // src/sac_prerejective_omp.cpp:134-147: the guess is the hypothesis to beat (final_tn / final_metric).  Its inliers only seed
+        // the global largest_inlier_set, which the loop never reads (thread-local sets start empty, :177): the bound is unaffected.
+        LGR_HIP(ctx, hipMemcpyAsync(d_best, p->guess, 64, hipMemcpyHostToDevice, ctx->stream));
+        uint8_t* d_gm;
+        LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASK, (size_t) c + 16, &d_gm));
+        EvalOut eg;
+        if (plane_metric) LGR_TRY(evaluate_one_plane(ctx, d_best, pk, c, p->metric_id, p->score_id, d_gm, plane, 0xFFFFFFFDu, &eg, nullptr));
+        else LGR_TRY(evaluate_one(ctx, d_best, pk, c, p->metric_id, p->score_id, d_gm, &eg, false));
+        final_metric = eg.metric;
+    }
     // Rounds.  The schedule is defined per batch (bound and best hypothesis are updated after every `batch` iterations).
     // Only ~0.2 % of the samples survive the prerejection, so one batch is a few hundred hypotheses -- far too few to
     // fill the chip, and every batch costs three host round trips.  Several batches are therefore evaluated by one round
@@ -985,8 +998,6 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     const int round_cap = plane_metric ? 1 : MAX_ROUND_BATCHES;   // the plane metrics key their subsets by batch: one at a time
     BatchBuffers b;
     LGR_TRY(batch_buffers(ctx, (int) std::min<long long>((long long) batch * round_cap, std::max(max_iterations, 1)), &b));
-    lgr_plane_dev plane;
-    if (plane_metric) LGR_TRY(lgr_plane_setup(ctx, d_src, ns, d_tgt, nt, seed, &plane));
     const bool ransac_debug = getenv("LGR_RANSAC_DEBUG") != nullptr;
     bool first_round = true;
     while (done < bound) {

@@ -162,6 +162,9 @@ inline lgr_params to_abi(const AlignmentParameters& p) {
     a.max_iterations = p.max_iterations; a.normals_available = p.normals_available; a.fix_seed = p.fix_seed;
     if (p.vp_src) { a.has_vp_src = 1; std::memcpy(a.vp_src, p.vp_src->data(), 12); }
     if (p.vp_tgt) { a.has_vp_tgt = 1; std::memcpy(a.vp_tgt, p.vp_tgt->data(), 12); }
+    a.use_bfmatcher = p.use_bfmatcher ? 1 : 0;
+    a.match_search_radius = p.match_search_radius;
+    if (p.guess) { a.has_guess = 1; std::memcpy(a.guess, p.guess->data(), 64); }
     return a;
 }
 inline const float* raw(const PointNCloud& c) { return reinterpret_cast<const float*>(c.points.data()); }
@@ -212,6 +215,45 @@ inline std::vector<MultivaluedCorrespondence> matchBF(const typename Cloud<Featu
     check(lgr_match_bf(context(), reinterpret_cast<const float*>(query_features->points.data()), mq,
                        reinterpret_cast<const float*>(train_features->points.data()), mt, parameters.bf_block_size, idx.data(), dist.data()),
           "matchBF");
+    std::vector<MultivaluedCorrespondence> out(mq);
+    for (int i = 0; i < mq; ++i)
+        if (idx[i] >= 0) { out[i].match_indices.push_back(idx[i]); out[i].distances.push_back(dist[i]); }
+    return out;
+}
+
+// ---- include/matching.h:367-370 (randomness = 1; exact search, so the rows matchBF finds -- tests/flann_bf_matcher.h:82-83)
+template <class FeatureT>
+inline std::vector<MultivaluedCorrespondence> matchFLANN(const typename Cloud<FeatureT>::ConstPtr& query_features,
+                                                         const typename Cloud<FeatureT>::ConstPtr& train_features,
+                                                         const AlignmentParameters& parameters) {
+    static_assert(sizeof(FeatureT) == 132, "only FPFH is built on this path");
+    if (parameters.randomness != 1) throw std::runtime_error("lgr: randomness != 1 is not supported (data/test.yaml:14)");
+    int mq = (int) query_features->size(), mt = (int) train_features->size();
+    std::vector<int32_t> idx(mq);
+    std::vector<float> dist(mq);
+    check(lgr_match_flann(context(), reinterpret_cast<const float*>(query_features->points.data()), mq,
+                          reinterpret_cast<const float*>(train_features->points.data()), mt, idx.data(), dist.data()), "matchFLANN");
+    std::vector<MultivaluedCorrespondence> out(mq);
+    for (int i = 0; i < mq; ++i)
+        if (idx[i] >= 0) { out[i].match_indices.push_back(idx[i]); out[i].distances.push_back(dist[i]); }
+    return out;
+}
+
+// ---- include/matching.h:378-382: the reference takes the train cloud as a pcl::search::KdTree; here it is the cloud itself
+template <class FeatureT>
+inline std::vector<MultivaluedCorrespondence> matchLocal(const PointNCloud::ConstPtr& query_pcd, const PointNCloud::ConstPtr& train_pcd,
+                                                         const typename Cloud<FeatureT>::ConstPtr& query_features,
+                                                         const typename Cloud<FeatureT>::ConstPtr& train_features,
+                                                         const AlignmentParameters& parameters, const Matrix4f& guess) {
+    static_assert(sizeof(FeatureT) == 132, "only FPFH is built on this path");
+    if (parameters.randomness != 1) throw std::runtime_error("lgr: randomness != 1 is not supported (data/test.yaml:14)");
+    int mq = (int) query_features->size(), mt = (int) train_features->size();
+    if ((int) query_pcd->size() != mq || (int) train_pcd->size() != mt) throw std::runtime_error("lgr: matchLocal: clouds and feature clouds differ in size");
+    std::vector<int32_t> idx(mq);
+    std::vector<float> dist(mq);
+    check(lgr_match_local(context(), raw(*query_pcd), mq, raw(*train_pcd), mt, reinterpret_cast<const float*>(query_features->points.data()),
+                          reinterpret_cast<const float*>(train_features->points.data()), guess.data(), parameters.match_search_radius,
+                          idx.data(), dist.data()), "matchLocal");
     std::vector<MultivaluedCorrespondence> out(mq);
     for (int i = 0; i < mq; ++i)
         if (idx[i] >= 0) { out[i].match_indices.push_back(idx[i]); out[i].distances.push_back(dist[i]); }

@@ -36,7 +36,8 @@ class Params(C.Structure):
         ("max_iterations", C.c_int32), ("normals_available", C.c_int32), ("fix_seed", C.c_int32),
         ("has_vp_src", C.c_int32), ("has_vp_tgt", C.c_int32), ("vp_src", C.c_float * 3), ("vp_tgt", C.c_float * 3),
         ("ransac_batch", C.c_int32), ("seed", C.c_uint64),
-        ("keypoint_id", C.c_int32), ("iss_radius_src", C.c_float), ("iss_radius_tgt", C.c_float), ("reserved0", C.c_int32),
+        ("keypoint_id", C.c_int32), ("iss_radius_src", C.c_float), ("iss_radius_tgt", C.c_float), ("use_bfmatcher", C.c_int32),
+        ("has_guess", C.c_int32), ("match_search_radius", C.c_float), ("guess", C.c_float * 16),
     ]
 
 
@@ -51,6 +52,16 @@ class Result(C.Structure):
 
     def matrix(self):
         return np.array(self.transformation, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class MatchOptions(C.Structure):
+    """lgr_match_options (include/lgr.h): how the matcher runs, never what it returns."""
+    _fields_ = [("prune", C.c_int32), ("leaves", C.c_int32), ("near", C.c_int32), ("operand_format", C.c_int32), ("box_bounds", C.c_int32),
+                ("column_stage", C.c_int32), ("coarse_rejection", C.c_int32), ("rerank_refilter", C.c_int32), ("pair_cap", C.c_int32),
+                ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+FORMAT_AUTO, FORMAT_F32, FORMAT_F16, FORMAT_F16R = -1, 0, 1, 2
 
 
 class LgrError(RuntimeError):
@@ -81,6 +92,9 @@ def default_params(**kw):
         if k in ("vp_src", "vp_tgt"):
             setattr(p, k, (C.c_float * 3)(*[float(x) for x in v]))
             setattr(p, "has_" + k, 1)
+        elif k == "guess":      # 4x4, row/col indexed normally -> column-major 16
+            p.guess = (C.c_float * 16)(*np.asarray(v, np.float32).T.reshape(16).tolist())
+            p.has_guess = 1
         else:
             assert hasattr(p, k), k
             setattr(p, k, v)
@@ -129,6 +143,21 @@ class Context:
     def sync(self):
         self.check(_lib.lgr_ctx_sync(self.h))
 
+    def set_match_options(self, **kw):
+        """defaults + overrides (no arguments: back to the defaults); returns the options now in force"""
+        o = MatchOptions()
+        _lib.lgr_match_default_options(C.byref(o))
+        for k, v in kw.items():
+            assert hasattr(o, k), k
+            setattr(o, k, int(v))
+        self.check(_lib.lgr_ctx_set_match_options(self.h, C.byref(o)))
+        return o
+
+    def match_options(self):
+        o = MatchOptions()
+        self.check(_lib.lgr_ctx_get_match_options(self.h, C.byref(o)))
+        return o
+
     def workspace_bytes(self):
         out = C.c_uint64(0)
         self.check(_lib.lgr_ctx_workspace_bytes(self.h, C.byref(out)))
@@ -158,6 +187,25 @@ class Context:
         self.check(_lib.lgr_match_bf2_dev(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], int(block),
                                           _ptr(ab_i), _ptr(ab_d), _ptr(ba_i), _ptr(ba_d)))
         return ab_i, ab_d, ba_i, ba_d
+
+    def match_flann(self, q, t):
+        """matchFLANN<FPFH> (include/matching.h:565-592): cuda float32 [m,33] -> (idx, dist)"""
+        torch = self.torch
+        q = q.contiguous(); t = t.contiguous()
+        idx = self.empty((q.shape[0],), torch.int32)
+        dist = self.empty((q.shape[0],), torch.float32)
+        self.check(_lib.lgr_match_flann_dev(self.h, _ptr(q), q.shape[0], _ptr(t), t.shape[0], _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def match_local(self, qpts, tpts, qf, tf, guess, radius):
+        """matchLocal<FPFH> (include/matching.h:637-678): points [m,12], descriptors [m,33] on the device; guess 4x4 (numpy)"""
+        torch = self.torch
+        g = (C.c_float * 16)(*np.asarray(guess, np.float32).T.reshape(16).tolist())
+        idx = self.empty((qpts.shape[0],), torch.int32)
+        dist = self.empty((qpts.shape[0],), torch.float32)
+        self.check(_lib.lgr_match_local_dev(self.h, _ptr(qpts), qpts.shape[0], _ptr(tpts), tpts.shape[0], _ptr(qf.contiguous()), _ptr(tf.contiguous()),
+                                            g, C.c_float(radius), _ptr(idx), _ptr(dist)))
+        return idx, dist
 
     def match_bf_host(self, q, t, block=10000):
         q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)

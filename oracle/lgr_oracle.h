@@ -61,6 +61,11 @@ typedef struct {
     int   n_threads;           /* reference schedule (mt19937 modes): emulated OpenMP team size */
     int   batch_size;          /* philox schedule: iterations per batch */
     uint64_t seed;             /* 566 */
+    /* matcher dispatch of match_multiscale (include/matching.h:300-312) + the RANSAC seed (src/sac_prerejective_omp.cpp:134-147) */
+    int   use_bfmatcher;       /* 1 (ALIGNMENT_USE_BFMATCHER); 0 -> matchFLANN */
+    int   has_guess;           /* 1 -> matchLocal around guess * p, and the guess is RANSAC's first hypothesis */
+    float match_search_radius;
+    float guess[16];           /* column-major */
 } lgr_orc_params;
 
 typedef struct {
@@ -98,6 +103,18 @@ int orc_spfh(const float* surf, int n, float radius, float* out33, int libm_mode
 int orc_match_bf(const float* q33, int mq, const float* t33, int mt, int block, int* idx, float* dist);
 /* same, only for the queries listed in qsel (bounded CPU baseline sample) */
 int orc_match_bf_subset(const float* q33, const int* qsel, int nsel, const float* t33, int mt, int block, int* idx, float* dist);
+
+/* include/matching.h:565-592 matchFLANN (pcl::KdTreeFLANN<FPFH>, exact search, randomness 1): nearest train row under FLANN's
+ * L2_Simple (sequential sum of squared differences), distance = sqrt of it; ties -> lowest index (FLANN: unspecified). */
+int orc_match_flann(const float* q33, int mq, const float* t33, int mt, int* idx, float* dist);
+/* include/matching.h:637-678 matchLocal: query points moved by guess (pcl::transformPointCloudWithNormals), radius search in the
+ * train cloud (strict d2 < r*r, visited by ascending (d2, index)), nearest valid train descriptor by pcl::L2_Norm (sequential
+ * sum, sqrtf), KNNResult k = 1 (first of equal distances stays). guess16 column-major. */
+int orc_match_local(const float* qpts, int mq, const float* tpts, int mt, const float* q33, const float* t33, const float* guess16,
+                    float radius, int* idx, float* dist);
+/* inverse of a 4x4 (column-major) by Gauss-Jordan with partial pivoting in double, rounded to float: the canonical stand-in for
+ * Eigen's Matrix4f::inverse() (include/matching.h:293) */
+void orc_inverse4(const float* m16, float* out16);
 
 /* exact k-NN in 3-D, sorted by (d2, index); idx/d2 are n*k. Used by several stages and by tests. */
 int orc_knn(const float* qpts, int nq, const float* pts, int n, int k, int* idx, float* d2);

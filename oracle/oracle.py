@@ -32,6 +32,7 @@ class Params(C.Structure):
         ("vp_src", C.c_float * 3), ("vp_tgt", C.c_float * 3),
         ("keypoint_id", C.c_int), ("iss_radius_src", C.c_float), ("iss_radius_tgt", C.c_float),
         ("rng_mode", C.c_int), ("n_threads", C.c_int), ("batch_size", C.c_int), ("seed", C.c_uint64),
+        ("use_bfmatcher", C.c_int), ("has_guess", C.c_int), ("match_search_radius", C.c_float), ("guess", C.c_float * 16),
     ]
 
 
@@ -154,6 +155,9 @@ def default_params(**kw):
         if k in ("vp_src", "vp_tgt"):
             setattr(p, k, (C.c_float * 3)(*v))
             setattr(p, "has_" + k, 1)
+        elif k == "guess":      # 4x4, row/col indexed normally -> column-major 16
+            p.guess = (C.c_float * 16)(*np.asarray(v, np.float32).T.reshape(16).tolist())
+            p.has_guess = 1
         else:
             assert hasattr(p, k), k
             setattr(p, k, v)
@@ -229,6 +233,33 @@ def match_bf_subset(q, qsel, t, block=10000):
     rc = lib().orc_match_bf_subset(_p(q), _p(qsel), qsel.shape[0], _p(t), t.shape[0], block, _p(idx), _p(dist))
     assert rc == 0
     return idx, dist
+
+
+def match_flann(q, t):
+    q = np.ascontiguousarray(q, np.float32)
+    t = np.ascontiguousarray(t, np.float32)
+    idx = np.zeros(q.shape[0], np.int32)
+    dist = np.zeros(q.shape[0], np.float32)
+    assert lib().orc_match_flann(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist)) == 0
+    return idx, dist
+
+
+def match_local(qpts, tpts, qf, tf, guess, radius):
+    qpts, tpts = _pts(qpts), _pts(tpts)
+    qf = np.ascontiguousarray(qf, np.float32)
+    tf = np.ascontiguousarray(tf, np.float32)
+    g = (C.c_float * 16)(*np.asarray(guess, np.float32).T.reshape(16).tolist())
+    idx = np.zeros(qpts.shape[0], np.int32)
+    dist = np.zeros(qpts.shape[0], np.float32)
+    assert lib().orc_match_local(_p(qpts), qpts.shape[0], _p(tpts), tpts.shape[0], _p(qf), _p(tf), g, C.c_float(radius), _p(idx), _p(dist)) == 0
+    return idx, dist
+
+
+def inverse4(T):
+    a = (C.c_float * 16)(*np.asarray(T, np.float32).T.reshape(16).tolist())
+    out = (C.c_float * 16)()
+    lib().orc_inverse4(a, out)
+    return np.array(out, np.float32).reshape(4, 4).T.copy()
 
 
 def knn(qpts, pts, k):

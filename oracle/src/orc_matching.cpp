@@ -103,6 +103,94 @@ extern "C" int orc_match_bf(const float* q33, int mq, const float* t33, int mt, 
     return orc_match_bf_subset(q33, nullptr, mq, t33, mt, block, idx, dist);
 }
 
+namespace {
+// FLANN L2_Simple / pcl::L2_Norm_SQR: result += diff * diff, sequentially from dimension 0
+inline float l2sqr33_seq(const float* a, const float* b) {
+    float s = 0.f;
+    for (int i = 0; i < 33; ++i) { float d = a[i] - b[i]; s += d * d; }
+    return s;
+}
+}  // namespace
+
+// include/matching.h:565-592 matchFLANN<FPFH>: pcl::KdTreeFLANN<FPFHSignature33>::nearestKSearch(k = 1) is an EXACT search
+//  under L2_Simple, returning the squared distance; the reference takes std::sqrt of it (:587).  The nearest row is
+// therefore the argmin of the sequential squared distance; equal distances: lowest index (FLANN's order is unspecified).
+// Invalid (non-finite) query rows get no match (:576); non-finite train rows cannot be nearest to anything (their distance is NaN).
+extern "C" int orc_match_flann(const float* q33, int mq, const float* t33, int mt, int* idx, float* dist) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < mq; ++i) {
+        idx[i] = -1; dist[i] = 0.f;
+        const float* q = q33 + 33 * (size_t) i;
+        if (!row_valid(q)) continue;
+        float best = 0.f;
+        int bi = -1;
+        for (int j = 0; j < mt; ++j) {
+            float d = l2sqr33_seq(q, t33 + 33 * (size_t) j);
+            if (d == d && (bi < 0 || d < best)) { best = d; bi = j; }
+        }
+        if (bi >= 0) { idx[i] = bi; dist[i] = std::sqrt(best); }
+    }
+    return 0;
+}
+
+extern "C" void orc_inverse4(const float* m16, float* out16) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = m16[4 * c + r]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (piv != col) for (int c = 0; c < 8; ++c) std::swap(a[piv][c], a[col][c]);
+        double d = a[col][col];
+        for (int c = 0; c < 8; ++c) a[col][c] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            double f = a[r][col];
+            for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out16[4 * c + r] = (float) a[r][4 + c];
+}
+
+// include/matching.h:637-678 matchLocal<FPFH> with randomness = 1.
+//   transformed query point: pcl::transformPointCloudWithNormals -> Transformer::se3 (x*c0 + (y*c1 + (z*c2 + c3)), as orc_gror.cpp)
+//   radiusSearch(p, match_search_radius): strict d2 < r*r, r*r in float (FLT_MAX -> inf: every finite train point), results by
+//   ascending (d2, index); only train rows with valid descriptors are offered to KNNResult (:664); dist = pcl::L2_Norm =
+//   sqrtf(sequential sum) (:665); KNNResult(1).addPoint keeps the FIRST of equal distances (include/matching.h:69-93) -> the
+//   winner is the lexicographic minimum of (descriptor distance, spatial d2, index).
+extern "C" int orc_match_local(const float* qpts, int mq, const float* tpts, int mt, const float* q33, const float* t33, const float* G,
+                               float radius, int* idx, float* dist) {
+    const float r2 = radius * radius;
+    Grid g;
+    const bool use_grid = std::isfinite(r2) && radius > 0.f;
+    if (use_grid) g.build(tpts, mt, radius * 1.001f);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < mq; ++i) {
+        idx[i] = -1; dist[i] = 0.f;
+        const float* qf = q33 + 33 * (size_t) i;
+        if (!row_valid(qf)) continue;
+        const float* P = qpts + 12 * (size_t) i;
+        float T[3];
+        for (int a = 0; a < 3; ++a) T[a] = G[a] * P[0] + (G[4 + a] * P[1] + (G[8 + a] * P[2] + G[12 + a]));
+        float bd = 0.f, bs = 0.f;
+        int bi = -1;
+        auto offer = [&](int j) {
+            const float* Q = tpts + 12 * (size_t) j;
+            if (!finite3(Q)) return;
+            float s = dist2(T, Q);
+            if (!(s < r2)) return;
+            const float* tf = t33 + 33 * (size_t) j;
+            if (!row_valid(tf)) return;
+            float d = std::sqrt(l2sqr33_seq(qf, tf));
+            if (bi < 0 || d < bd || (d == bd && (s < bs || (s == bs && j < bi)))) { bd = d; bs = s; bi = j; }
+        };
+        if (!std::isfinite(T[0]) || !std::isfinite(T[1]) || !std::isfinite(T[2])) continue;   // FLANN: no neighbours of a NaN point
+        if (use_grid) g.visit27(T, offer);
+        else for (int j = 0; j < mt; ++j) offer(j);
+        if (bi >= 0) { idx[i] = bi; dist[i] = bd; }
+    }
+    return 0;
+}
+
 // src/common.cpp:531-547 calculateSmoothedDensities: k-NN of point i (itself included, sorted by (d2, index));
 // density = sqrt(d2[k-1]); then the same for nn_indices[1] and take the min.
 extern "C" int orc_smoothed_densities(const float* pts, int n, int k, float* out) {
@@ -217,6 +305,20 @@ extern "C" int orc_filter(int matching_id, const float* src, int ns, const float
 // stage_seconds: [0] downsample [1] normals [2] fpfh [3] match [4] filter
 // ---- multi-scale matching (feature_radius unset): include/matching.h:163-262 (initialize) and :264-352 (match_multiscale)
 namespace {
+// the matcher dispatch of match_multiscale (include/matching.h:294-312): guess -> matchLocal (inverse guess for the
+// train -> query direction, :296), else bf -> matchBF, else matchFLANN
+void match_dispatch(const lgr_orc_params* p, const float* qpts, int mq, const float* tpts, int mt, const float* qf, const float* tf,
+                    bool inverse_tn, int* idx, float* dist) {
+    if (p->has_guess) {
+        float G[16];
+        if (inverse_tn) orc_inverse4(p->guess, G); else std::memcpy(G, p->guess, 64);
+        orc_match_local(qpts, mq, tpts, mt, qf, tf, G, p->match_search_radius, idx, dist);
+    } else if (p->use_bfmatcher) {
+        orc_match_bf(qf, mq, tf, mt, p->bf_block_size, idx, dist);
+    } else {
+        orc_match_flann(qf, mq, tf, mt, idx, dist);
+    }
+}
 struct MsStorage {
     const float* kps = nullptr;       // key-point cloud, 12 floats per point
     int n_kps = 0;
@@ -286,7 +388,7 @@ int ms_initialize(MsStorage& st, const float* pcd, int n, const float* kps, int 
 }
 
 // :264-352: per common level brute-force matches, then one match per query by the proximity vote
-void ms_match(const MsStorage& q, const MsStorage& tr, const lgr_orc_params* p, std::vector<int>& out_idx, std::vector<float>& out_dist) {
+void ms_match(const MsStorage& q, const MsStorage& tr, const lgr_orc_params* p, bool inverse_tn, std::vector<int>& out_idx, std::vector<float>& out_dist) {
     std::vector<std::vector<int>> mi(q.n_kps);
     std::vector<std::vector<float>> md(q.n_kps);
     int lo = std::max(q.min_l2, tr.min_l2), hi = std::min(q.max_l2, tr.max_l2);
@@ -297,7 +399,12 @@ void ms_match(const MsStorage& q, const MsStorage& tr, const lgr_orc_params* p, 
         const std::vector<float>& tf = tr.feat_ms[level - tr.min_l2];
         std::vector<int> idx(qs.size());
         std::vector<float> dist(qs.size());
-        orc_match_bf(qf.data(), (int) qs.size(), tf.data(), (int) ts.size(), p->bf_block_size, idx.data(), dist.data());
+        {   // key-point sub-clouds of this level (kps_multiscale[idx], include/matching.h:243)
+            std::vector<float> qp(qs.size() * 12), tp(ts.size() * 12);
+            for (size_t r = 0; r < qs.size(); ++r) memcpy(qp.data() + 12 * r, q.kps + 12 * (size_t) qs[r], 48);
+            for (size_t r = 0; r < ts.size(); ++r) memcpy(tp.data() + 12 * r, tr.kps + 12 * (size_t) ts[r], 48);
+            match_dispatch(p, qp.data(), (int) qs.size(), tp.data(), (int) ts.size(), qf.data(), tf.data(), inverse_tn, idx.data(), dist.data());
+        }
         for (size_t i = 0; i < qs.size(); ++i) {
             if (!row_valid(qf.data() + 33 * i) || idx[i] < 0) continue;
             mi[qs[i]].push_back(ts[idx[i]]);
@@ -382,8 +489,8 @@ extern "C" int orc_correspondences(const float* src_all, int ns_all, const float
             t[0] += tb - ta; t[1] += tc - tb; t[2] += td - tc;
         }
         t0 = now_s();
-        orc_match_bf(feat[0].data(), ns, feat[1].data(), nt, p->bf_block_size, ij.data(), dij.data());
-        if (need_ji) orc_match_bf(feat[1].data(), nt, feat[0].data(), ns, p->bf_block_size, ji.data(), dji.data());
+        match_dispatch(p, src, ns, tgt, nt, feat[0].data(), feat[1].data(), false, ij.data(), dij.data());
+        if (need_ji) match_dispatch(p, tgt, nt, src, ns, feat[1].data(), feat[0].data(), true, ji.data(), dji.data());
         // NaN query rows have no match (include/matching.h:576,614)
         for (int i = 0; i < ns; ++i) if (!row_valid(feat[0].data() + 33 * (size_t) i)) ij[i] = -1;
         if (need_ji) for (int i = 0; i < nt; ++i) if (!row_valid(feat[1].data() + 33 * (size_t) i)) ji[i] = -1;
@@ -398,8 +505,8 @@ extern "C" int orc_correspondences(const float* src_all, int ns_all, const float
             if (rc) return rc;
         }
         t0 = now_s();
-        ms_match(st[0], st[1], p, ij, dij);
-        if (need_ji) ms_match(st[1], st[0], p, ji, dji);
+        ms_match(st[0], st[1], p, false, ij, dij);
+        if (need_ji) ms_match(st[1], st[0], p, true, ji, dji);
         t1 = now_s();
     }
     int rc = orc_filter(p->matching_id, src, ns, tgt, nt, ij.data(), dij.data(), ji.data(), dji.data(),

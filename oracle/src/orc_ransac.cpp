@@ -37,6 +37,8 @@ extern "C" void orc_default_params(lgr_orc_params* p) {
     p->n_threads = 8;
     p->batch_size = 65536;
     p->seed = 566;                // SEED include/common.h:25
+    p->use_bfmatcher = 1;         // ALIGNMENT_USE_BFMATCHER :41
+    for (int i = 0; i < 4; ++i) p->guess[5 * i] = 1.f;
 }
 
 // ---------------------------------------------------------------- RNG
@@ -517,6 +519,17 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
     for (int i = 0; i < 16; ++i) final_T[i] = (i % 5 == 0) ? 1.f : 0.f;
     float final_metric = 0.f;
     int ransac_iterations = 0, num_rejections = 0, best_iter = -1;
+
+    if (p->has_guess) {
+        // :134-147: the guess is the hypothesis to beat (final_tn / final_metric).  Its inliers seed only the GLOBAL largest_inlier_set,
+        // which the loop never reads (the threads start from empty local sets, :177), so the iteration bound is unaffected.
+        // The reference evaluates it with a fresh generator (:138); here the plane metrics' subset counter is 0xFFFFFFFD.
+        std::vector<int> hist(30000);
+        std::vector<uint32_t> visited;
+        Eval e = evaluate(src, tgt, corr, c, p->guess, p->metric_id, p->score_id, mn, mx, nullptr, hist, &pc, 0xFFFFFFFDu, &visited);
+        std::memcpy(final_T, p->guess, 64);
+        final_metric = e.metric;
+    }
 
     if (p->rng_mode == ORC_RNG_PHILOX) {
         int bound = max_iterations, done = 0, largest = 0;

@@ -2,6 +2,7 @@
 // style): build two clouds, alignPointClouds, check the transform.  Run by tests/test_host_shim.py on the GPU box.
 #include <cmath>
 #include <cstdio>
+#include <limits>
 #include <random>
 
 #include "../../lidar-global-registration_amd/host/lgr_compat.hpp"
@@ -34,5 +35,32 @@ int main() {
     downsamplePointCloud(src, down, 0.05f);
     std::vector<float> dens = calculateSmoothedDensities(src);
     std::printf("downsampled %zu -> %zu, density[0]=%g\n", src->size(), down->size(), dens[0]);
-    return (r.converged && err < 0.05f && down->size() > 100 && down->size() < src->size()) ? 0 : 1;
+    // the reference's tests/flann_bf_matcher.h:40-97 through the shim: matchBF == matchFLANN == matchLocal(identity, FLT_MAX)
+    estimateNormalsPoints(30, down, nullptr, p.vp_src, false);
+    auto fsrc = std::make_shared<FPFHCloud>(), ftgt = std::make_shared<FPFHCloud>();
+    auto down_t = std::make_shared<PointNCloud>();
+    downsamplePointCloud(tgt, down_t, 0.05f);
+    estimateNormalsPoints(30, down_t, nullptr, p.vp_tgt, false);
+    estimateFeatures<FPFH>(down, down, fsrc, 0.25f, p);
+    estimateFeatures<FPFH>(down_t, down_t, ftgt, 0.25f, p);
+    AlignmentParameters pl = p;
+    pl.guess = Matrix4f::Identity();
+    pl.match_search_radius = std::numeric_limits<float>::max();
+    auto bf = matchBF<FPFH>(fsrc, ftgt, p), fl = matchFLANN<FPFH>(fsrc, ftgt, p);
+    auto lo = matchLocal<FPFH>(down, down_t, fsrc, ftgt, pl, *pl.guess);
+    size_t differ = 0, matched = 0;
+    for (size_t i = 0; i < bf.size(); ++i) {
+        if (bf[i].match_indices != fl[i].match_indices || bf[i].match_indices != lo[i].match_indices) ++differ;
+        matched += !bf[i].match_indices.empty();
+    }
+    std::printf("flann_bf_matcher: %zu queries, %zu matched, %zu differ\n", bf.size(), matched, differ);
+    // guided second step: the pose found above as the guess, matchLocal inside alignPointClouds
+    AlignmentParameters p2 = p;
+    p2.guess = T; p2.match_search_radius = 0.3f; p2.max_iterations = 5000;
+    AlignmentResult r2 = alignPointClouds(src, tgt, p2);
+    const Matrix4f& T2 = r2.transformation;
+    float err2 = std::fabs(T2(0, 0) - c) + std::fabs(T2(1, 0) - s) + std::fabs(T2(0, 3) - 1.f) + std::fabs(T2(1, 3) + 2.f) + std::fabs(T2(2, 3) - 0.5f);
+    std::printf("guided: converged=%d err=%g\n", (int) r2.converged, err2);
+    return (r.converged && err < 0.05f && down->size() > 100 && down->size() < src->size() && differ == 0 && matched > bf.size() / 2 &&
+            r2.converged && err2 < 0.05f) ? 0 : 1;
 }

@@ -13,8 +13,15 @@ def pair1m():
     return synthetic.make_pair(1_000_000, seed=566)
 
 
-def test_matcher_1m_permutation_and_mutual_consistency(lgr, monkeypatch):
-    monkeypatch.setenv("LGR_MATCH_POISON", "1")   # never-computed table entries hold 0: nothing may read them
+@pytest.fixture
+def opts(lgr):
+    """lgr_match_options for one test; the context goes back to the defaults afterwards"""
+    yield lambda **kw: lgr.set_match_options(**kw)
+    lgr.set_match_options()
+
+
+def test_matcher_1m_permutation_and_mutual_consistency(lgr, opts):
+    opts(poison_tables=1)   # never-computed table entries hold 0: nothing may read them
     import torch
     rng = np.random.default_rng(1)
     m = 1_000_000
@@ -35,13 +42,12 @@ def test_matcher_1m_permutation_and_mutual_consistency(lgr, monkeypatch):
     assert st["dense_ab"] == 0 and st["dense_ba"] == 0 and st["items_ab"] < 1.5 * m
 
 
-def test_matcher_1m_coarse_rejection_is_invisible(lgr, monkeypatch):
+def test_matcher_1m_coarse_rejection_is_invisible(lgr, opts):
     """1M x 1M clustered FPFH-like rows: the final MFMA pass abandons most of its tiles after two K steps (coarse rejection);
     matches and distances are bit-identical to the run without it, in both directions, and the device self-check of the
     filter bound (sampled queries, exact group minima in double) holds with the rejection rule in force."""
     import torch
-    monkeypatch.setenv("LGR_MATCH_POISON", "1")
-    monkeypatch.setenv("LGR_MATCH_CHECK", "1")
+    opts(poison_tables=1, self_check=1)
     rng = np.random.default_rng(7)
     m = 1_000_000
     c = rng.gamma(0.6, 1.0, (3000, 3, 11)) + 1e-3
@@ -57,7 +63,7 @@ def test_matcher_1m_coarse_rejection_is_invisible(lgr, monkeypatch):
     r_rows, r_cols = lgr.match_check()
     assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
     assert lgr.match_work() < 0.5 and abandoned > 0.5 * tested > 0, (lgr.match_work(), tested, abandoned)
-    monkeypatch.setenv("LGR_MATCH_COARSE", "0")
+    opts(poison_tables=1, self_check=1, coarse_rejection=0)
     off = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 200000)]
     lgr.sync()
     assert lgr.match_coarse() == (0.0, 0.0)
@@ -84,8 +90,8 @@ def test_downsample_1m_sorted_weights_idempotent(lgr, pair1m):
     assert ds2.shape[0] >= 0.99 * ds.shape[0]
 
 
-def test_align_1m_recovers_ground_truth(lgr, pair1m, monkeypatch):
-    monkeypatch.setenv("LGR_MATCH_POISON", "1")
+def test_align_1m_recovers_ground_truth(lgr, pair1m, opts):
+    opts(poison_tables=1)
     import torch
     from lgr_amd import capi
     p = capi.default_params(matching_id=capi.MATCH_LR, bf_block_size=200000, max_iterations=1000000, distance_thr=0.1,

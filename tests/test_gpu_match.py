@@ -13,24 +13,38 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["auto", "prune_sub1", "prune_sub4", "prune_sub64", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse",
                                       "prune_sub4_groupscan", "auto_groupscan"])
-def matcher_mode(request, monkeypatch):
+def matcher_mode(request, lgr):
     """Every test runs on the automatic path and with the bound-based stage skipping forced on (it is only
-    automatic for >= 65536 x 65536 inputs) with 1, 4 and 64 leaves per cluster; results must not depend on it."""
+    automatic for >= 65536 x 65536 inputs) with 1, 4 and 64 leaves per cluster; results must not depend on it.
+    The paths are selected through lgr_match_options (include/lgr.h) held by the context."""
+    base = {}
     if request.param.endswith("_groupscan"):              # exact rerank by scanning whole candidate groups (no MFMA re-filter)
-        monkeypatch.setenv("LGR_MATCH_REFILTER", "0")
+        base["rerank_refilter"] = 0
     if not request.param.startswith("auto"):
-        monkeypatch.setenv("LGR_MATCH_PRUNE", "1")
-        monkeypatch.setenv("LGR_MATCH_NEAR", "2")       # narrow first pass, so that tiles really are skipped at test sizes
-        monkeypatch.setenv("LGR_MATCH_SUB", request.param.replace("prune_sub", "").split("_")[0])
+        base["prune"] = 1
+        base["near"] = 2                                  # narrow first pass, so that tiles really are skipped at test sizes
+        base["leaves"] = int(request.param.replace("prune_sub", "").split("_")[0])
         if request.param.endswith("_leafcols_nobox"):     # the simpler schedule: ball bounds only, whole-leaf column criterion
-            monkeypatch.setenv("LGR_MATCH_COLSTAGE", "0")
-            monkeypatch.setenv("LGR_MATCH_BOX", "0")
+            base["column_stage"] = 0
+            base["box_bounds"] = 0
         if request.param.endswith("_nocoarse"):           # the final pass without the in-kernel coarse rejection
-            monkeypatch.setenv("LGR_MATCH_COARSE", "0")
+            base["coarse_rejection"] = 0
         # the minimum tables are initialised only where a pass computes; everything else is pre-filled with 0 (the most
         # harmful stale value) to show that no uninitialised entry is ever read
-        monkeypatch.setenv("LGR_MATCH_POISON", "1")
-    return request.param
+        base["poison_tables"] = 1
+    lgr._base_opts = base
+    lgr.set_match_options(**base)
+    yield request.param
+    lgr._base_opts = {}
+    lgr.set_match_options()
+
+
+def opts(lgr, **extra):
+    """the mode's options plus overrides"""
+    lgr.set_match_options(**{**getattr(lgr, "_base_opts", {}), **extra})
+
+
+FMT = {"f32": 0, "f16": 1, "f16r": 2}
 
 
 def fpfh_like(rng, m, spread=1.0):
@@ -153,18 +167,16 @@ def test_match_clustered_parity_and_skipping(lgr, oracle, matcher_mode, ma, mb):
 
 @pytest.mark.parametrize("fmt", ["f16", "f16r", "f32"])
 @pytest.mark.parametrize("kind", ["fpfh", "clustered", "tiny", "wide", "duplicates"])
-def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, kind):
+def test_filter_bound_self_check(lgr, oracle, matcher_mode, fmt, kind):
     """The MFMA filter value of every computed (query, group) entry must lie within the proven eps of the exact group
-    minimum (computed in double on the device, LGR_MATCH_CHECK=1) -- on both f16-split operand formats and on f32, for
+    minimum (computed in double on the device, lgr_match_options.self_check) -- on both f16-split operand formats and on f32, for
     FPFH-like rows, tight clusters, tiny and wide dynamic ranges and exact duplicates; results stay oracle-exact."""
     import torch
     if matcher_mode in ("prune_sub1", "prune_sub4_leafcols_nobox", "prune_sub4_nocoarse", "prune_sub4_groupscan", "auto_groupscan"):
         pytest.skip("same filter code path as prune_sub4 / auto")
-    monkeypatch.setenv("LGR_MATCH_CHECK", "1")
-    monkeypatch.setenv("LGR_MATCH_F16", "0" if fmt == "f32" else "1")
     # f16r: the rotated 30-coordinate format forced on ANY data (rows whose blocks do not sum to a constant make its
     # dropped-coordinate term large: the bound must still hold and the result stay exact); f16: forced off
-    monkeypatch.setenv("LGR_MATCH_ROT", "1" if fmt == "f16r" else "0")
+    opts(lgr, self_check=1, operand_format=FMT[fmt])
     rng = np.random.default_rng(77)
     ma, mb = 6000, 9000
     if kind == "fpfh":
@@ -191,7 +203,7 @@ def test_filter_bound_self_check(lgr, oracle, monkeypatch, matcher_mode, fmt, ki
     print(f"filter bound ratio [{fmt} {kind} {matcher_mode}]: rows {r_rows:.3g} cols {r_cols:.3g}")
 
 
-def test_coarse_rejection(lgr, oracle, monkeypatch, matcher_mode):
+def test_coarse_rejection(lgr, oracle, matcher_mode):
     """The final pass abandons tiles after their first two MFMA steps when a proven bound on the coarse distance exceeds the
     upper bounds of the tile's rows and columns (rotated operand format).  The tiles it abandons must not change anything:
     same matches and distances as the oracle and as the run with the rejection switched off, in both directions and through
@@ -207,7 +219,7 @@ def test_coarse_rejection(lgr, oracle, monkeypatch, matcher_mode):
         return (100.0 * x / x.sum(2, keepdims=True)).reshape(m, 33).astype(np.float32)
     # half tight clusters, half one broad distribution (there the bounds exclude little: the final pass has tiles to test)
     a = np.concatenate([cloud(6000), fpfh_like(rng, 6000)]); b = np.concatenate([fpfh_like(rng, 8000), cloud(7000)])
-    monkeypatch.setenv("LGR_MATCH_CHECK", "1")
+    opts(lgr, self_check=1)
     oi, ri = run_both(lgr, oracle, a, b, 4000)
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     on = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
@@ -217,7 +229,7 @@ def test_coarse_rejection(lgr, oracle, monkeypatch, matcher_mode):
     r_rows, r_cols = lgr.match_check()
     assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
     assert tested > 0 and 0 < abandoned <= tested, (tested, abandoned)
-    monkeypatch.setenv("LGR_MATCH_COARSE", "0")
+    opts(lgr, self_check=1, coarse_rejection=0)
     off = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
     lgr.sync()
     assert lgr.match_coarse() == (0.0, 0.0)
@@ -226,7 +238,7 @@ def test_coarse_rejection(lgr, oracle, monkeypatch, matcher_mode):
     print(f"coarse rejection [{matcher_mode}]: {abandoned:.0f} of {tested:.0f} tiles abandoned")
 
 
-def test_rerank_refilter(lgr, oracle, monkeypatch, matcher_mode):
+def test_rerank_refilter(lgr, oracle, matcher_mode):
     """The exact rerank re-filters each candidate group with the MFMA operands and takes the exact distance only for the
     (query, train row) pairs under the query's threshold.  Same result as scanning the whole groups and as the oracle, in
     both operand formats; far fewer exact distances than group rows; and when the pair buffer is too small the call falls
@@ -240,8 +252,7 @@ def test_rerank_refilter(lgr, oracle, monkeypatch, matcher_mode):
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     outs = {}
     for fmt in ("f16r", "f16"):
-        monkeypatch.setenv("LGR_MATCH_ROT", "1" if fmt == "f16r" else "0")
-        monkeypatch.delenv("LGR_MATCH_PAIR_CAP", raising=False)
+        opts(lgr, operand_format=FMT[fmt])
         run_both(lgr, oracle, a, b, 3000)
         outs[fmt] = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 3000)]
         lgr.sync()
@@ -249,7 +260,7 @@ def test_rerank_refilter(lgr, oracle, monkeypatch, matcher_mode):
         st = lgr.match_stats()
         p_ab, p_ba = lgr.match_pairs()
         assert 0 < p_ab < 8 * st["items_ab"] and 0 < p_ba < 8 * st["items_ba"], (p_ab, p_ba, st)
-        monkeypatch.setenv("LGR_MATCH_PAIR_CAP", "100")          # overflow -> whole-group scan
+        opts(lgr, operand_format=FMT[fmt], pair_cap=100)          # overflow -> whole-group scan
         small = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 3000)]
         lgr.sync()
         assert lgr.match_pairs()[0] > 100
@@ -260,13 +271,12 @@ def test_rerank_refilter(lgr, oracle, monkeypatch, matcher_mode):
     print(f"rerank re-filter [{matcher_mode}]: {p_ab} + {p_ba} pairs for {st['items_ab']} + {st['items_ba']} candidate groups")
 
 
-def test_rotated_format_selection(lgr, oracle, monkeypatch, matcher_mode):
+def test_rotated_format_selection(lgr, oracle, matcher_mode):
     """FPFH-like rows (every 11-bin block sums to 100) take the 30-coordinate operand format on their own; one row with a
     different block sum switches the call back to 33 coordinates; both give the oracle's result."""
     import torch
     if matcher_mode != "auto":
         pytest.skip("format selection does not depend on the skipping mode")
-    monkeypatch.delenv("LGR_MATCH_ROT", raising=False)
     rng = np.random.default_rng(123)
     a, b = fpfh_like(rng, 3000), fpfh_like(rng, 4000)
     run_both(lgr, oracle, a, b, 1000)

@@ -100,11 +100,14 @@ def test_match_1m_sampled_oracle(st, matches, oracle):
     assert mism == 0
 
 
-def test_match_1m_refilter_on_off_identical(lgr, st, matches, monkeypatch):
+def test_match_1m_refilter_on_off_identical(lgr, st, matches):
     """the rerank's MFMA re-filter + pair path (default) vs the whole-group exact scan, at BASELINE size."""
-    monkeypatch.setenv("LGR_MATCH_REFILTER", "0")
-    off = [x.cpu().numpy() for x in lgr.match_bf2(st["src"]["feat"], st["tgt"]["feat"], BLOCK)]
-    lgr.sync()
+    lgr.set_match_options(rerank_refilter=0)
+    try:
+        off = [x.cpu().numpy() for x in lgr.match_bf2(st["src"]["feat"], st["tgt"]["feat"], BLOCK)]
+        lgr.sync()
+    finally:
+        lgr.set_match_options()
     assert lgr.match_pairs() == (0, 0) or sum(lgr.match_pairs()) == 0
     for a, b in zip(matches["h"], off):
         np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
