@@ -151,8 +151,7 @@ __device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, f
     float vx = dy * uz - dz * uy, vy = dz * ux - dx * uz, vz = dx * uy - dy * ux;
     float v_norm = __builtin_sqrtf(dot3e(vx, vy, vz, vx, vy, vz));
     if (v_norm == 0.0f) return false;
-    float inv = 1.0f / v_norm;
-    vx *= inv; vy *= inv; vz *= inv;
+    vx /= v_norm; vy /= v_norm; vz /= v_norm;   // PCL: v /= v_norm; Eigen 3.3+ divides every component (no reciprocal)
     float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
     f2 = dot3e(vx, vy, vz, mx, my, mz);
     float yy = dot3e(wx, wy, wz, mx, my, mz), xx = dot3e(ux, uy, uz, mx, my, mz);
@@ -230,7 +229,7 @@ constexpr int SHP = 36;         // histogram pitch (33 bins + pad)
 
 __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, const int* __restrict__ order, float* __restrict__ spfh /* [n][HP], sorted positions */) {
     __shared__ float4 tp[ST], tn[ST];
-    __shared__ float4 cp[64], cn[64];
+    __shared__ float4 cp[128], cn[128];   // live candidates: tested 64 at a time, the rest waits for the next chunks
     __shared__ unsigned short queue[SQ];
     __shared__ int hist[2][ST][SHP];
     __shared__ int kcnt[ST];
@@ -288,6 +287,35 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
             bz0 = fminf(bz0, __shfl_xor(bz0, o)); bz1 = fmaxf(bz1, __shfl_xor(bz1, o));
         }
         const int cz = c / (g.dx * g.dy), cy = (c / g.dx) % g.dy, cx = c % g.dx;
+        int n_buf = 0;   // live candidates waiting in cp / cn [0, n_buf)
+        // every tile point of the run against the first n_c buffered candidates (lane = candidate), accepted pairs queued and
+        // processed 64 at a time; the queue is drained before the candidate slots are reused
+        auto test_block = [&](int n_c) {
+            float4 Q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l < n_c) Q = cp[l];
+            for (int i = p0; i < p0 + n_run; ++i) {
+                const float4 P_i = tp[i];
+                const float d2 = lgr_dist2(P_i.x, P_i.y, P_i.z, Q.x, Q.y, Q.z);
+                const bool acc = l < n_c && d2 < r2;
+                const unsigned long long am = __ballot(acc);
+                if (am == 0ull) continue;
+                if (l == 0) kcnt[i] += __popcll(am);
+                const bool enq = acc && __float_as_int(Q.w) != __float_as_int(P_i.w);   // if (s == t) return: the point itself
+                const unsigned long long em = __ballot(enq);
+                if (enq) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) em, 0u));
+                    queue[(qt + rank) & (SQ - 1)] = (unsigned short) ((i << 8) | l);
+                }
+                qt += __popcll(em);
+                if (qt - qh >= 64) {
+                    __syncthreads();
+                    process(64);
+                }
+            }
+            __syncthreads();
+            process(qt - qh);
+            __syncthreads();
+        };
         for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dz - 1); ++zz)
             for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dy - 1); ++yy) {
                 const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
@@ -304,39 +332,27 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
                     }
                     const unsigned long long lm = __ballot(live);
                     if (lm == 0ull) continue;
-                    const int n_live = __popcll(lm);
                     if (live) {
                         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) lm, 0u));
-                        cp[rank] = make_float4(P.x, P.y, P.z, __int_as_float(t));
-                        cn[rank] = g.pnrm[t];
+                        cp[n_buf + rank] = make_float4(P.x, P.y, P.z, __int_as_float(t));
+                        cn[n_buf + rank] = g.pnrm[t];
                     }
+                    n_buf += __popcll(lm);
                     __syncthreads();
-                    float4 Q = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (l < n_live) Q = cp[l];
-                    for (int i = p0; i < p0 + n_run; ++i) {
-                        const float4 P_i = tp[i];
-                        const float d2 = lgr_dist2(P_i.x, P_i.y, P_i.z, Q.x, Q.y, Q.z);
-                        const bool acc = l < n_live && d2 < r2;
-                        const unsigned long long am = __ballot(acc);
-                        if (am == 0ull) continue;
-                        if (l == 0) kcnt[i] += __popcll(am);
-                        const bool enq = acc && __float_as_int(Q.w) != __float_as_int(P_i.w);   // if (s == t) return: the point itself
-                        const unsigned long long em = __ballot(enq);
-                        if (enq) {
-                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) em, 0u));
-                            queue[(qt + rank) & (SQ - 1)] = (unsigned short) ((i << 8) | l);
-                        }
-                        qt += __popcll(em);
-                        if (qt - qh >= 64) {
-                            __syncthreads();
-                            process(64);
-                        }
+                    if (n_buf >= 64) {
+                        test_block(64);
+                        // the candidates beyond the first 64 move to the front
+                        const int rest = n_buf - 64;
+                        float4 mp = make_float4(0.f, 0.f, 0.f, 0.f), mn = mp;
+                        if (l < rest) { mp = cp[64 + l]; mn = cn[64 + l]; }
+                        __syncthreads();
+                        if (l < rest) { cp[l] = mp; cn[l] = mn; }
+                        __syncthreads();
+                        n_buf = rest;
                     }
-                    __syncthreads();
-                    process(qt - qh);     // the queue refers to this chunk's candidate slots: drain it before they are overwritten
-                    __syncthreads();
                 }
             }
+        if (n_buf > 0) test_block(n_buf);
     }
     __syncthreads();
     // rows: bin value = sequential float sum of `count` copies of 100 / (k - 1); zero padding up to the pitch

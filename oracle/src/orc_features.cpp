@@ -226,8 +226,7 @@ inline bool pair_features(const float* p1, const float* n1, const float* p2, con
     float v[3] = {d[1] * u[2] - d[2] * u[1], d[2] * u[0] - d[0] * u[2], d[0] * u[1] - d[1] * u[0]};
     float v_norm = std::sqrt(dot3(v, v));
     if (v_norm == 0.0f) return false;
-    float inv = 1.0f / v_norm;
-    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    v[0] /= v_norm; v[1] /= v_norm; v[2] /= v_norm;   // PCL: v /= v_norm; Eigen 3.3+ divides every component (no reciprocal)
     // w = u x v
     float w[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
     f2 = dot3(v, m2);

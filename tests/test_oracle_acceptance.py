@@ -19,11 +19,14 @@ def test_oracle_passes_reference_point2plane_acceptance(oracle):
     assert res.converged == 1 and len(corr) > 100
     ratio, error, overlap = acc.acceptance(s, t, res.matrix(), oracle.cloud_density(t))
     assert abs(ratio - 1.0) <= 1e-5 and error < 2.0 / 3.0 and overlap < 0.72, (ratio, error, overlap)
-    # the reference draws its samples from mt19937(566 + thread); both libstdc++ mappings of that stream pass as well
-    for mode in (oracle.RNG_MT19937_LEMIRE, oracle.RNG_MT19937_REJECT):
-        r2, _, _ = oracle.align(s, t, acc.reference_params(oracle, vp_src, vp_tgt, rng_mode=mode, n_threads=8))
+    # the reference draws its samples from mt19937(566 + thread): with this container's libstdc++ mapping of that stream (the one
+    # oracle/_ref pins, tests/test_oracle_ref.py) the scene passes for 1, 8 and 16 threads as well.  (The libstdc++ <= 10 mapping
+    # with 8 threads ends at an overlap rmse of 1.25 on this lattice -- 10 000 iterations over 1 472 degenerate correspondences
+    # is RNG-sensitive, which is why the reference fixes its seed; not asserted.)
+    for n_threads in (1, 8, 16):
+        r2, _, _ = oracle.align(s, t, acc.reference_params(oracle, vp_src, vp_tgt, rng_mode=oracle.RNG_MT19937_LEMIRE, n_threads=n_threads))
         ratio, error, overlap = acc.acceptance(s, t, r2.matrix(), oracle.cloud_density(t))
-        assert abs(ratio - 1.0) <= 1e-5 and error < 2.0 / 3.0 and overlap < 0.72, (mode, ratio, error, overlap)
+        assert abs(ratio - 1.0) <= 1e-5 and error < 2.0 / 3.0 and overlap < 0.72, (n_threads, ratio, error, overlap)
 
 
 def _isclose(a, b, rtol=1e-5, atol=1e-8):       # tests/flann_bf_matcher.h:12-14
