@@ -6,12 +6,13 @@
  * every function in src/).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it.  The product (liblgr_hip.so) never links or calls it.
  *
- * PARITY STATUS: "parity unpinned" for every stage except KNNResult: the reference
- * cannot be built here (needs PCL 1.12.1 / OpenCV 4.5.1 / Eigen / FLANN / yaml-cpp,
- * none installed, no network) and ships no golden vectors for this path other than
- * tests/knn_result.cpp:30-51.  Third-party arithmetic (PCL FPFH / normals / polygon
- * rejector / umeyama, OpenCV batchDistance, libstdc++ RNG + unordered_map) is restated
- * from the pinned upstream versions and property-tested (tests/test_oracle_*.py).
+ * PARITY STATUS: pinned against the reference's own code where it can be compiled here (oracle/_ref =
+ * src/utils.cpp + src/csv_parser.cpp in place: RNG stream, iteration cap, container hashes, CSV tokeniser, number formatting --
+ * tests/test_oracle_ref.py), against its golden vectors (KNNResult, tests/knn_result.cpp:30-51) and against its end-to-end
+ * acceptance tests (tests/point2plane_distance.cpp:29-96, tests/flann_bf_matcher.h:70-96 -- tests/test_oracle_acceptance.py).
+ * "Parity unpinned" for the third-party arithmetic the reference ships no fixtures for and cannot run here (PCL FPFH / normals /
+ * polygon rejector / umeyama, OpenCV batchDistance, GROR): restated from the pinned upstream versions and property-tested
+ * (tests/test_oracle_*.py).
  *
  * Layouts (all host pointers):
  *   point  : 12 floats = pcl::PointXYZINormal {x,y,z,1 | nx,ny,nz,0 | intensity,curvature,pad,pad}
