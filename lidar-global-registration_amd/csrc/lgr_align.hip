@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <thread>
 
 #include <climits>
 
@@ -441,21 +442,54 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     if (multiscale) {
         LGR_TRY(ms_match_tables(ctx, clouds, sizes, kclouds, ksizes, p, ij, dij, ji, dji, ms));
     } else {
-    for (int c = 0; c < 2; ++c) {
+    // The two clouds' feature stages are independent until the matcher: the source cloud runs on this context, the target cloud
+    // on a second context (own stream and workspace) driven by a second host thread, so that the ~20 host read-backs per cloud
+    // (voxel counts, grid extents) and the short sort / scan launches of one cloud hide behind the other cloud's kernels.
+    // Results cannot depend on it (disjoint outputs; every kernel is deterministic).
+    auto cloud_features = [&](lgr_ctx* cx, int c, float* out_ms) -> int {
+        LGR_HIP(cx, hipSetDevice(cx->device));
         int nd = 0;
-        tick(ctx, 0);
-        LGR_TRY(lgr_downsample_dev(ctx, clouds[c], sizes[c], voxel, surf[c], &nd));                       // :234
-        tick(ctx, 1);
+        tick(cx, 0);
+        LGR_TRY(lgr_downsample_dev(cx, clouds[c], sizes[c], voxel, surf[c], &nd));                       // :234
+        tick(cx, 1);
         const float* vp = c == 0 ? (p->has_vp_src ? p->vp_src : nullptr) : (p->has_vp_tgt ? p->vp_tgt : nullptr);
-        LGR_TRY(lgr_normals_knn_dev(ctx, surf[c], nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available));   // :235
-        tick(ctx, 2);
+        LGR_TRY(lgr_normals_knn_dev(cx, surf[c], nd, nullptr, 0, p->normal_nr_points, vp, p->normals_available));   // :235
+        tick(cx, 2);
         // :243-246 re-estimates the normals of the key-point COPY; FPFH reads only the surface normals
         // (include/common.h:329), so that step has no observable effect and is not executed.
-        LGR_TRY(lgr_fpfh_dev(ctx, kclouds[c], ksizes[c], surf[c], nd, search_radius, feat[c]));            // :248
-        tick(ctx, 3);
-        LGR_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+        LGR_TRY(lgr_fpfh_dev(cx, kclouds[c], ksizes[c], surf[c], nd, search_radius, feat[c]));            // :248
+        tick(cx, 3);
+        LGR_HIP(cx, hipEventSynchronize(cx->ev[3]));
         float t;
-        for (int s = 0; s < 3; ++s) { (void) hipEventElapsedTime(&t, ctx->ev[s], ctx->ev[s + 1]); ms[s] += t; }
+        for (int s = 0; s < 3; ++s) { (void) hipEventElapsedTime(&t, cx->ev[s], cx->ev[s + 1]); out_ms[s] += t; }
+        return LGR_OK;
+    };
+    if (!ctx->aux) {
+        LGR_CHECK(ctx, lgr_ctx_create(ctx->device, LGR_STREAM_OWN, &ctx->aux) == LGR_OK, LGR_ERR_HIP);
+        LGR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
+    }
+    // what the caller enqueued on this context's stream (the clouds) is visible to the second stream
+    LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
+    LGR_HIP(ctx, hipStreamWaitEvent(ctx->aux->stream, ctx->aux_ev, 0));
+    float ms_t[3] = {0, 0, 0};
+    int rc_t = LGR_OK;
+    const auto t_feat0 = std::chrono::steady_clock::now();
+    std::thread worker([&]() {
+        rc_t = cloud_features(ctx->aux, 1, ms_t);
+        if (rc_t == LGR_OK && hipStreamSynchronize(ctx->aux->stream) != hipSuccess) rc_t = LGR_ERR_HIP;
+    });
+    const int rc_s = cloud_features(ctx, 0, ms);
+    worker.join();
+    (void) hipSetDevice(ctx->device);
+    if (rc_t != LGR_OK) { ctx->err = ctx->aux->err; return rc_t; }
+    LGR_TRY(rc_s);
+    {
+        // the two clouds overlap in wall time: report the wall time of the feature stages, split in proportion to the stage times
+        // the two streams measured (each of which includes the other stream's interleaved kernels)
+        const float wall = 1e3f * std::chrono::duration<float>(std::chrono::steady_clock::now() - t_feat0).count();
+        float sum = 0.f;
+        for (int s = 0; s < 3; ++s) { ms[s] += ms_t[s]; sum += ms[s]; }
+        if (sum > 0.f) for (int s = 0; s < 3; ++s) ms[s] *= wall / sum;
     }
     tick(ctx, 4);
     LGR_TRY(match_dispatch(ctx, p, kclouds[0], feat[0], ns, kclouds[1], feat[1], nt, p->matching_id != LGR_MATCH_ONE_SIDED, ij, dij, ji, dji));

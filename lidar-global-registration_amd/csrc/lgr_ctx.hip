@@ -74,6 +74,8 @@ extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     if (!ctx) return LGR_OK;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->aux) { (void) lgr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
+    if (ctx->aux_ev) { (void) hipEventDestroy(ctx->aux_ev); ctx->aux_ev = nullptr; }
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i].p) (void) hipFree(ctx->ws[i].p);
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
@@ -123,6 +125,7 @@ extern "C" int lgr_ctx_workspace_bytes(lgr_ctx* ctx, uint64_t* bytes) {
     if (!ctx || !bytes) return LGR_ERR_INVALID_ARG;
     uint64_t t = 0;
     for (int i = 0; i < WS_COUNT; ++i) t += ctx->ws[i].cap;
+    if (ctx->aux) for (int i = 0; i < WS_COUNT; ++i) t += ctx->aux->ws[i].cap;
     *bytes = t;
     return LGR_OK;
 }

@@ -31,7 +31,10 @@ struct lgr_ctx {
     int n_cu = 256;
     int mfma_timed = 0;
     lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, {0, 0, 0, 0, 0}};   // lgr_match_default_options
-    bool corr_trusted = false;   // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
+    bool corr_trusted = false;
+    lgr_ctx* aux = nullptr;      // second context (own stream + workspace, same device): the target cloud's feature stages run on it
+                                 // from a second host thread while this one does the source cloud (lgr_align.hip)
+    hipEvent_t aux_ev = nullptr;   // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
 };
 
 int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line);
