@@ -106,17 +106,23 @@ extern "C" int lgr_filter_dev(lgr_ctx* ctx, int matching_id, const float* d_src,
     float *thr_s, *thr_t;
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_MISC, (size_t) ns + nt + 16, &thr_s));
     thr_t = thr_s + ns;
-    LGR_TRY(lgr_smoothed_densities_dev(ctx, d_src, ns, 2, thr_s));
-    LGR_TRY(lgr_smoothed_densities_dev(ctx, d_tgt, nt, 2, thr_t));
     int32_t *knn_s = nullptr, *knn_t = nullptr;
     if (matching_id == LGR_MATCH_CLUSTER) {
-        float* d2;
         LGR_TRY(lgr_ws_t(ctx, WS_PIPE_KNN_S, (size_t) ns * cluster_k, &knn_s));
         LGR_TRY(lgr_ws_t(ctx, WS_PIPE_KNN_T, (size_t) nt * cluster_k, &knn_t));
-        LGR_TRY(lgr_ws_t(ctx, WS_DENS_C, (size_t) std::max(ns, nt) * cluster_k, &d2));
-        LGR_TRY(lgr_knn_dev(ctx, d_src, ns, d_src, ns, cluster_k, knn_s, d2));
-        LGR_TRY(lgr_knn_dev(ctx, d_tgt, nt, d_tgt, nt, cluster_k, knn_t, d2));
     }
+    // the per-cloud tables (densities; k-NN lists of the cluster filter) of the two clouds side by side on the two contexts
+    auto cloud_tables = [&](lgr_ctx* cx, const float* pts, int n, float* thr, int32_t* knn) -> int {
+        LGR_TRY(lgr_smoothed_densities_dev(cx, pts, n, 2, thr));
+        if (knn) {
+            float* d2;
+            LGR_TRY(lgr_ws_t(cx, WS_DENS_C, (size_t) n * cluster_k, &d2));
+            LGR_TRY(lgr_knn_dev(cx, pts, n, pts, n, cluster_k, knn, d2));
+        }
+        return LGR_OK;
+    };
+    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return cloud_tables(cx, d_src, ns, thr_s, knn_s); },
+                         [&](lgr_ctx* cx) { return cloud_tables(cx, d_tgt, nt, thr_t, knn_t); }));
     int *flags, *pos;
     float* dist;
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_FLAGS, (size_t) ns * 3 + 16, &flags));
@@ -464,25 +470,9 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
         for (int s = 0; s < 3; ++s) { (void) hipEventElapsedTime(&t, cx->ev[s], cx->ev[s + 1]); out_ms[s] += t; }
         return LGR_OK;
     };
-    if (!ctx->aux) {
-        LGR_CHECK(ctx, lgr_ctx_create(ctx->device, LGR_STREAM_OWN, &ctx->aux) == LGR_OK, LGR_ERR_HIP);
-        LGR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
-    }
-    // what the caller enqueued on this context's stream (the clouds) is visible to the second stream
-    LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
-    LGR_HIP(ctx, hipStreamWaitEvent(ctx->aux->stream, ctx->aux_ev, 0));
     float ms_t[3] = {0, 0, 0};
-    int rc_t = LGR_OK;
     const auto t_feat0 = std::chrono::steady_clock::now();
-    std::thread worker([&]() {
-        rc_t = cloud_features(ctx->aux, 1, ms_t);
-        if (rc_t == LGR_OK && hipStreamSynchronize(ctx->aux->stream) != hipSuccess) rc_t = LGR_ERR_HIP;
-    });
-    const int rc_s = cloud_features(ctx, 0, ms);
-    worker.join();
-    (void) hipSetDevice(ctx->device);
-    if (rc_t != LGR_OK) { ctx->err = ctx->aux->err; return rc_t; }
-    LGR_TRY(rc_s);
+    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return cloud_features(cx, 0, ms); }, [&](lgr_ctx* cx) { return cloud_features(cx, 1, ms_t); }));
     {
         // the two clouds overlap in wall time: report the wall time of the feature stages, split in proportion to the stage times
         // the two streams measured (each of which includes the other stream's interleaved kernels)

@@ -70,6 +70,13 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
     return LGR_OK;
 }
 
+int lgr_ctx_aux(lgr_ctx* ctx) {
+    if (ctx->aux) return LGR_OK;
+    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, LGR_STREAM_OWN, &ctx->aux) == LGR_OK, LGR_ERR_HIP);
+    LGR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
+    return LGR_OK;
+}
+
 extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     if (!ctx) return LGR_OK;
     (void) hipSetDevice(ctx->device);

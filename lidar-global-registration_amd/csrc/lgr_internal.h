@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lgr.h"
@@ -106,6 +107,30 @@ int lgr_grid_build(lgr_ctx* ctx, int slot_base, const float* d_pts, int n, float
 // both bounding boxes of a cloud: out12 (host) = true min3, true max3 (finite points only; +-inf when empty),
 // reference-quirk min3, max3 (include/common.h:266-280)
 int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
+
+// Two independent pieces of host-driven GPU work side by side: fa(ctx) on this context, fb(ctx->aux) on the second context (own
+// stream and workspace, same device; created on first use) from a second host thread.  Everything enqueued on ctx->stream before
+// the call is visible to both; the call returns when both have finished and the aux stream has drained, so the caller simply goes
+// on using ctx->stream.  The pieces must write disjoint outputs; buffers they allocate belong to the context they ran on.
+// What it buys: the host read-backs (counts, extents) and short launches of one piece hide behind the other piece's kernels.
+int lgr_ctx_aux(lgr_ctx* ctx);   // makes sure ctx->aux exists
+template <class FA, class FB>
+static inline int lgr_run_pair(lgr_ctx* ctx, FA&& fa, FB&& fb) {
+    LGR_TRY(lgr_ctx_aux(ctx));
+    LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
+    LGR_HIP(ctx, hipStreamWaitEvent(ctx->aux->stream, ctx->aux_ev, 0));
+    int rc_b = LGR_OK;
+    std::thread worker([&]() {
+        if (hipSetDevice(ctx->aux->device) != hipSuccess) { rc_b = LGR_ERR_HIP; return; }
+        rc_b = fb(ctx->aux);
+        if (rc_b == LGR_OK && hipStreamSynchronize(ctx->aux->stream) != hipSuccess) rc_b = LGR_ERR_HIP;
+    });
+    const int rc_a = fa(ctx);
+    worker.join();
+    (void) hipSetDevice(ctx->device);
+    if (rc_b != LGR_OK) { ctx->err = ctx->aux->err; return rc_b; }
+    return rc_a;
+}
 
 // caller-supplied correspondences (public lgr_ransac* / lgr_gror* / lgr_evaluate* / lgr_refit_svd entry points): LGR_ERR_INVALID_ARG
 // when an index_query is outside [0, ns) or an index_match outside [0, nt) -- checked on the device BEFORE any kernel gathers

@@ -86,9 +86,8 @@ static int env_int(const char* name, int dflt) {
 
 // Orthonormal basis for the box bounds: principal axes of the k-means sample (both sets).  Covariance on the device,
 // cyclic Jacobi on the host (33 x 33), rows of V = eigenvectors, mu = sample mean.  box_bounds == 2: raw coordinates.
-static int box_basis(lgr_ctx* ctx, const float* smp, const int* smp_ok, int ns, float* d_basis /* [34][33] + 1: V rows, then mu */) {
+static int box_basis(lgr_ctx* ctx, bool raw, const float* smp, const int* smp_ok, int ns, float* d_basis /* [34][33] + 1: V rows, then mu */) {
     std::vector<float> h(34 * 33 + 1, 0.f);
-    const bool raw = ctx->mopt.box_bounds == 2;
     if (!raw) {
         const int nb = cdiv(ns, COV_ROWS);
         float* part;
@@ -209,8 +208,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int rg_rows = both ? pick_group((size_t) mb, (size_t) ma) : BLOCK_ROWS;   // row groups (column direction table)
     if (ma <= 65536) rg_rows = BLOCK_ROWS;                                     // small inputs: keep the cluster padding small
     Side A, B;
-    LGR_TRY(build_side(ctx, d_a, ma, cen, cen2, sub, 1, rg_rows, WS_MATCH_NA, WS_MATCH_AP, &A));
-    LGR_TRY(build_side(ctx, d_b, mb, cen, cen2, sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B));
+    // the two sides are independent (assign, sort, two host read-backs each): side by side on the two contexts
+    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, cen, cen2, sub, 1, rg_rows, WS_MATCH_NA, WS_MATCH_AP, &A); },
+                         [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, cen, cen2, sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B); }));
     if (A.n_valid == 0 || B.n_valid == 0) return LGR_OK;
     const int ma_pad = A.n_pad, mb_pad = B.n_pad;
     g_last_stats.rg_rows = rg_rows;
@@ -484,17 +484,29 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         chk_done = done; chk_sched = sched; chk_lb = LBsq; chk_ustage = colstage ? u_stage : nullptr;
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
-        lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
         if (mo.box_bounds) {
             float* boxA = (float*) (pb + o_boxa);
             float* boxBt = (float*) (pb + o_boxb);
             float* basis = (float*) (pb + o_basis);              // V [33][33], mu [33]
             unsigned* rmax2 = (unsigned*) (basis + 34 * 33 + 8);
-            LGR_TRY(box_basis(ctx, smp, smp_ok, ns, basis));
-            LGR_HIP(ctx, hipMemsetAsync(rmax2, 0, 4, ctx->stream));
-            box_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
-            box_kernel<<<n_leaves, 256, 0, ctx->stream>>>(sortedB, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
+            // ball bounds on this context; basis (device covariance, host Jacobi) and boxes on the second one, side by side
+            LGR_TRY(lgr_run_pair(ctx,
+                [&](lgr_ctx* cx) {
+                    lb_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
+                    LGR_HIP(cx, hipGetLastError());
+                    return (int) LGR_OK;
+                },
+                [&](lgr_ctx* cx) {
+                    LGR_TRY(box_basis(cx, mo.box_bounds == 2, smp, smp_ok, ns, basis));
+                    LGR_HIP(cx, hipMemsetAsync(rmax2, 0, 4, cx->stream));
+                    box_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
+                    box_kernel<<<n_leaves, 256, 0, cx->stream>>>(sortedB, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
+                    LGR_HIP(cx, hipGetLastError());
+                    return (int) LGR_OK;
+                }));
             box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
+        } else {
+            lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
         }
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
         auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {
@@ -605,11 +617,17 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // ---- 5. exact rerank
     // (the MFMA re-filter of the rerank items needs the f16 operand formats and the padded train copies)
     RefilterArgs ra{(const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, (f16 && mo.rerank_refilter) ? KS : 0, A.blkcl, mo.pair_cap};
-    LGR_TRY((run_rerank<true>(ctx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
-                              d_ab_idx, d_ab_dist, &g_last_stats.items_ab, &g_last_stats.dense_ab, force_dense, ra, &g_last_stats.pairs_ab)));
-    if (both)
-        LGR_TRY((run_rerank<false>(ctx, ex, comp_cols, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
-                                   d_ba_idx, d_ba_dist, &g_last_stats.items_ba, &g_last_stats.dense_ba, force_dense, ra, &g_last_stats.pairs_ba)));
+    lgr_match_stats* st = &g_last_stats;   // (thread_local: the second host thread writes through this pointer)
+    auto rerank_ab = [&](lgr_ctx* cx) {
+        return run_rerank<true>(cx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
+                                d_ab_idx, d_ab_dist, &st->items_ab, &st->dense_ab, force_dense, ra, &st->pairs_ab);
+    };
+    auto rerank_ba = [&](lgr_ctx* cx) {
+        return run_rerank<false>(cx, ex, comp_cols, (const float*) colmin, n_rg, rg_rows, nullptr, d_b, B, nullptr, nBp, gmaxA, cl_of_rg, d_a, sortedA, A, block, bestB,
+                                 d_ba_idx, d_ba_dist, &st->items_ba, &st->dense_ba, force_dense, ra, &st->pairs_ba);
+    };
+    if (both) LGR_TRY(lgr_run_pair(ctx, rerank_ab, rerank_ba));   // the two directions' exact reranks are independent
+    else LGR_TRY(rerank_ab(ctx));
     return LGR_OK;
 }
 
