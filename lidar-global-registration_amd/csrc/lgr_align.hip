@@ -92,6 +92,30 @@ __global__ void invalidate_nan_rows(const float* __restrict__ feat, int m, int32
 
 }  // namespace
 
+// the filter's per-cloud tables: smoothed densities (thresholds) of both key-point clouds and, for the cluster filter, their
+// k-NN lists.  They depend on the clouds only, not on the matches.
+struct FilterTables { float *thr_s = nullptr, *thr_t = nullptr; int32_t *knn_s = nullptr, *knn_t = nullptr; };
+static int filter_tables_alloc(lgr_ctx* ctx, int matching_id, int ns, int nt, int cluster_k, FilterTables* ft) {
+    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_MISC, (size_t) ns + nt + 16, &ft->thr_s));
+    ft->thr_t = ft->thr_s + ns;
+    if (matching_id == LGR_MATCH_CLUSTER) {
+        LGR_TRY(lgr_ws_t(ctx, WS_PIPE_KNN_S, (size_t) ns * cluster_k, &ft->knn_s));
+        LGR_TRY(lgr_ws_t(ctx, WS_PIPE_KNN_T, (size_t) nt * cluster_k, &ft->knn_t));
+    }
+    return LGR_OK;
+}
+static int filter_cloud_tables(lgr_ctx* cx, const float* pts, int n, int cluster_k, float* thr, int32_t* knn) {
+    LGR_TRY(lgr_smoothed_densities_dev(cx, pts, n, 2, thr));   // calculateSmoothedDensities(kps) (include/matching.h:396-397 etc.)
+    if (knn) {
+        float* d2;
+        LGR_TRY(lgr_ws_t(cx, WS_DENS_C, (size_t) n * cluster_k, &d2));
+        LGR_TRY(lgr_knn_dev(cx, pts, n, pts, n, cluster_k, knn, d2));
+    }
+    return LGR_OK;
+}
+static int filter_core(lgr_ctx* ctx, int matching_id, int ns, const int32_t* d_ij_idx, const float* d_ij_dist, const int32_t* d_ji_idx, const float* d_ji_dist,
+                       float distance_thr, int cluster_k, const FilterTables& ft, lgr_corr* d_out, int* n_out);
+
 extern "C" int lgr_filter_dev(lgr_ctx* ctx, int matching_id, const float* d_src, int ns, const float* d_tgt, int nt,
                               const int32_t* d_ij_idx, const float* d_ij_dist, const int32_t* d_ji_idx, const float* d_ji_dist,
                               float distance_thr, int cluster_k, lgr_corr* d_out, int* n_out) {
@@ -102,27 +126,19 @@ extern "C" int lgr_filter_dev(lgr_ctx* ctx, int matching_id, const float* d_src,
     if (matching_id == LGR_MATCH_CLUSTER) LGR_CHECK(ctx, cluster_k >= 1 && cluster_k <= 64, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     *n_out = 0;
-    // thresholds: calculateSmoothedDensities(kps) of both clouds (include/matching.h:396-397 etc.)
-    float *thr_s, *thr_t;
-    LGR_TRY(lgr_ws_t(ctx, WS_PIPE_MISC, (size_t) ns + nt + 16, &thr_s));
-    thr_t = thr_s + ns;
-    int32_t *knn_s = nullptr, *knn_t = nullptr;
-    if (matching_id == LGR_MATCH_CLUSTER) {
-        LGR_TRY(lgr_ws_t(ctx, WS_PIPE_KNN_S, (size_t) ns * cluster_k, &knn_s));
-        LGR_TRY(lgr_ws_t(ctx, WS_PIPE_KNN_T, (size_t) nt * cluster_k, &knn_t));
-    }
-    // the per-cloud tables (densities; k-NN lists of the cluster filter) of the two clouds side by side on the two contexts
-    auto cloud_tables = [&](lgr_ctx* cx, const float* pts, int n, float* thr, int32_t* knn) -> int {
-        LGR_TRY(lgr_smoothed_densities_dev(cx, pts, n, 2, thr));
-        if (knn) {
-            float* d2;
-            LGR_TRY(lgr_ws_t(cx, WS_DENS_C, (size_t) n * cluster_k, &d2));
-            LGR_TRY(lgr_knn_dev(cx, pts, n, pts, n, cluster_k, knn, d2));
-        }
-        return LGR_OK;
-    };
-    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return cloud_tables(cx, d_src, ns, thr_s, knn_s); },
-                         [&](lgr_ctx* cx) { return cloud_tables(cx, d_tgt, nt, thr_t, knn_t); }));
+    FilterTables ft;
+    LGR_TRY(filter_tables_alloc(ctx, matching_id, ns, nt, cluster_k, &ft));
+    // the two clouds' tables side by side on the two contexts
+    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return filter_cloud_tables(cx, d_src, ns, cluster_k, ft.thr_s, ft.knn_s); },
+                         [&](lgr_ctx* cx) { return filter_cloud_tables(cx, d_tgt, nt, cluster_k, ft.thr_t, ft.knn_t); }));
+    return filter_core(ctx, matching_id, ns, d_ij_idx, d_ij_dist, d_ji_idx, d_ji_dist, distance_thr, cluster_k, ft, d_out, n_out);
+}
+
+static int filter_core(lgr_ctx* ctx, int matching_id, int ns, const int32_t* d_ij_idx, const float* d_ij_dist, const int32_t* d_ji_idx, const float* d_ji_dist,
+                       float distance_thr, int cluster_k, const FilterTables& ft, lgr_corr* d_out, int* n_out) {
+    float *thr_s = ft.thr_s, *thr_t = ft.thr_t;
+    int32_t *knn_s = ft.knn_s, *knn_t = ft.knn_t;
+    *n_out = 0;
     int *flags, *pos;
     float* dist;
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_FLAGS, (size_t) ns * 3 + 16, &flags));
@@ -445,6 +461,22 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_JI, (size_t) nt, &ji));
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_DIJ, (size_t) ns, &dij));
     LGR_TRY(lgr_ws_t(ctx, WS_PIPE_DJI, (size_t) nt, &dji));
+    // The filter's per-cloud tables do not depend on the matches: a third context computes them from a host thread of its own
+    // while the feature stages and the matcher run (their sorts and k-NN kernels fill the matcher's low-occupancy phases).
+    FilterTables ftab;
+    LGR_TRY(filter_tables_alloc(ctx, p->matching_id, ns, nt, p->cluster_k, &ftab));
+    LGR_TRY(lgr_ctx_aux2(ctx));
+    LGR_HIP(ctx, hipEventRecord(ctx->aux2_ev, ctx->stream));
+    LGR_HIP(ctx, hipStreamWaitEvent(ctx->aux2->stream, ctx->aux2_ev, 0));
+    int rc_tab = LGR_OK;
+    std::thread tables_worker([&]() {
+        lgr_ctx* cx = ctx->aux2;
+        if (hipSetDevice(cx->device) != hipSuccess) { rc_tab = LGR_ERR_HIP; return; }
+        rc_tab = filter_cloud_tables(cx, kclouds[0], ns, p->cluster_k, ftab.thr_s, ftab.knn_s);
+        if (rc_tab == LGR_OK) rc_tab = filter_cloud_tables(cx, kclouds[1], nt, p->cluster_k, ftab.thr_t, ftab.knn_t);
+        if (rc_tab == LGR_OK && hipStreamSynchronize(cx->stream) != hipSuccess) rc_tab = LGR_ERR_HIP;
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{tables_worker};   // every exit path waits for the worker
     if (multiscale) {
         LGR_TRY(ms_match_tables(ctx, clouds, sizes, kclouds, ksizes, p, ij, dij, ji, dji, ms));
     } else {
@@ -485,7 +517,11 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     LGR_TRY(match_dispatch(ctx, p, kclouds[0], feat[0], ns, kclouds[1], feat[1], nt, p->matching_id != LGR_MATCH_ONE_SIDED, ij, dij, ji, dji));
     }
     tick(ctx, 5);
-    LGR_TRY(lgr_filter_dev(ctx, p->matching_id, kclouds[0], ns, kclouds[1], nt, ij, dij, ji, dji, p->distance_thr, p->cluster_k, d_out, n_out));
+    tables_worker.join();
+    (void) hipSetDevice(ctx->device);
+    if (rc_tab != LGR_OK) { ctx->err = ctx->aux2->err; return rc_tab; }
+    LGR_CHECK(ctx, p->matching_id == LGR_MATCH_LR || p->matching_id == LGR_MATCH_ONE_SIDED || p->matching_id == LGR_MATCH_CLUSTER, LGR_ERR_INVALID_ARG);
+    LGR_TRY(filter_core(ctx, p->matching_id, ns, ij, dij, ji, dji, p->distance_thr, p->cluster_k, ftab, d_out, n_out));
     if (iss && *n_out) finalize_kernel<<<cdiv(*n_out, 256), 256, 0, ctx->stream>>>(d_out, *n_out, kidx[0], kidx[1]);
     tick(ctx, 6);
     LGR_HIP(ctx, hipEventSynchronize(ctx->ev[6]));

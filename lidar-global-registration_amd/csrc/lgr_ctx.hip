@@ -77,12 +77,21 @@ int lgr_ctx_aux(lgr_ctx* ctx) {
     return LGR_OK;
 }
 
+int lgr_ctx_aux2(lgr_ctx* ctx) {
+    if (ctx->aux2) return LGR_OK;
+    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, LGR_STREAM_OWN, &ctx->aux2) == LGR_OK, LGR_ERR_HIP);
+    LGR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux2_ev, hipEventDisableTiming));
+    return LGR_OK;
+}
+
 extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     if (!ctx) return LGR_OK;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     if (ctx->aux) { (void) lgr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     if (ctx->aux_ev) { (void) hipEventDestroy(ctx->aux_ev); ctx->aux_ev = nullptr; }
+    if (ctx->aux2) { (void) lgr_ctx_destroy(ctx->aux2); ctx->aux2 = nullptr; }
+    if (ctx->aux2_ev) { (void) hipEventDestroy(ctx->aux2_ev); ctx->aux2_ev = nullptr; }
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i].p) (void) hipFree(ctx->ws[i].p);
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
@@ -133,6 +142,7 @@ extern "C" int lgr_ctx_workspace_bytes(lgr_ctx* ctx, uint64_t* bytes) {
     uint64_t t = 0;
     for (int i = 0; i < WS_COUNT; ++i) t += ctx->ws[i].cap;
     if (ctx->aux) for (int i = 0; i < WS_COUNT; ++i) t += ctx->aux->ws[i].cap;
+    if (ctx->aux2) for (int i = 0; i < WS_COUNT; ++i) t += ctx->aux2->ws[i].cap;
     *bytes = t;
     return LGR_OK;
 }

@@ -35,7 +35,10 @@ struct lgr_ctx {
     bool corr_trusted = false;
     lgr_ctx* aux = nullptr;      // second context (own stream + workspace, same device): the target cloud's feature stages run on it
                                  // from a second host thread while this one does the source cloud (lgr_align.hip)
-    hipEvent_t aux_ev = nullptr;   // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
+    hipEvent_t aux_ev = nullptr;
+    lgr_ctx* aux2 = nullptr;     // third context: the match filter's per-cloud tables (densities, cluster k-NN lists) are computed on it
+                                 // while the matcher runs on this one (lgr_correspondences_dev)
+    hipEvent_t aux2_ev = nullptr;   // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
 };
 
 int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line);
@@ -114,6 +117,7 @@ int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
 // on using ctx->stream.  The pieces must write disjoint outputs; buffers they allocate belong to the context they ran on.
 // What it buys: the host read-backs (counts, extents) and short launches of one piece hide behind the other piece's kernels.
 int lgr_ctx_aux(lgr_ctx* ctx);   // makes sure ctx->aux exists
+int lgr_ctx_aux2(lgr_ctx* ctx);  // makes sure ctx->aux2 exists
 template <class FA, class FB>
 static inline int lgr_run_pair(lgr_ctx* ctx, FA&& fa, FB&& fb) {
     LGR_TRY(lgr_ctx_aux(ctx));
