@@ -117,9 +117,10 @@ def read_ply(path):
 
 
 def has_normals(fields):
-    """pointCloudHasNormals (the loader's `normals_available`): all three normal components present."""
+    """pointCloudHasNormals (include/common.h:465-480, the loader's `normals_available`) with what it actually tests: its
+    z flag is set by a normal_x field as well, so normal_x and normal_y decide."""
     s = set(fields)
-    return all((a in s) or (b in s) for a, b in (("normal_x", "nx"), ("normal_y", "ny"), ("normal_z", "nz")))
+    return all((a in s) or (b in s) for a, b in (("normal_x", "nx"), ("normal_y", "ny")))
 
 
 def write_ply(path, pts, binary=True, with_normals=True):
@@ -136,7 +137,7 @@ def write_ply(path, pts, binary=True, with_normals=True):
             np.stack(cols, 1).astype("<f4").tofile(f)
         else:
             for row in np.stack(cols, 1):
-                f.write((" ".join(repr(float(v)) for v in row) + "\n").encode())
+                f.write((" ".join("%.9g" % float(v) for v in row) + "\n").encode())   # 9 digits: reads back to the same float
 
 
 # ---------------------------------------------------------------------------------------------------------- CSV
