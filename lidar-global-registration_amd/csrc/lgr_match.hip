@@ -171,31 +171,37 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     char* misc;
     size_t off = 8192;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
-    const size_t o_cen2 = carve((size_t) MAXLEAF * 33 * 4), o_sums2 = carve((size_t) MAXLEAF * 34 * 4);
+    const size_t o_cen2 = carve((size_t) MAXLEAF * 33 * 4);
     const size_t o_smp = carve((size_t) ns * 33 * 4), o_ok = carve((size_t) ns * 4), o_label = carve((size_t) ns * 4);
+    const size_t o_cbuf = carve((size_t) 2 * KCL * 33 * 4);
+    const size_t o_zero = off;   // zeroed once per call: largest sample magnitude, one set of level-1 sums per Lloyd step, the level-2 sums
+    const size_t o_kmax = carve(256), o_acc1 = carve((size_t) KM_ITERS * KCL * sizeof(KmAcc)), o_acc2 = carve((size_t) MAXLEAF * sizeof(KmAcc));
+    const size_t zero_bytes = off - o_zero;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, off, &misc));
     float* cen = (float*) (misc + 256);                 // [KCL][33]
     float* cen2 = (float*) (misc + o_cen2);             // [n_leaves][33]
-    float* sums2 = (float*) (misc + o_sums2);
     float* smp = (float*) (misc + o_smp);
     int* smp_ok = (int*) (misc + o_ok);
     int* label = (int*) (misc + o_label);
-    km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok);
-    km_init<<<1, 64, 0, ctx->stream>>>(smp, smp_ok, ns, cen);
-    for (int it = 0; it < KM_ITERS; ++it) {   // Lloyd, deterministic (no float atomics)
-        km_label<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, cen, label);
-        km_centres<<<KCL, KMC_THREADS, 0, ctx->stream>>>(smp, label, ns, cen);
+    float* cbuf = (float*) (misc + o_cbuf);             // two scratch copies of the level-1 centres (read one, write the other)
+    unsigned* kmax = (unsigned*) (misc + o_kmax);
+    KmAcc* acc1 = (KmAcc*) (misc + o_acc1);
+    KmAcc* acc2 = (KmAcc*) (misc + o_acc2);
+    LGR_HIP(ctx, hipMemsetAsync(misc + o_zero, 0, zero_bytes, ctx->stream));
+    km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok, kmax);
+    km_init<<<1, 64, 0, ctx->stream>>>(smp, smp_ok, ns, cbuf);
+    for (int it = 0; it <= KM_ITERS; ++it) {   // Lloyd with order-free integer sums; the last launch labels with the final centres
+        const bool last = it == KM_ITERS;
+        km1_step<<<cdiv(ns, KM1_THREADS), KM1_THREADS, 0, ctx->stream>>>(smp, smp_ok, ns, kmax, cbuf + (it & 1) * KCL * 33, it ? acc1 + (size_t) (it - 1) * KCL : nullptr,
+                                                                         last ? nullptr : acc1 + (size_t) it * KCL, last ? cen : cbuf + ((it + 1) & 1) * KCL * 33, label);
     }
-    km_label<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(smp, smp_ok, ns, cen, label);
-    km2_init<<<KCL, 64, 0, ctx->stream>>>(smp, label, ns, cen, sub, cen2);
+    km2_init<<<KCL, KM2I_THREADS, 0, ctx->stream>>>(smp, label, ns, cen, sub, cen2);
     if (sub > 1) {
-        int* leaf_of = (int*) sums2;   // [ns] (the slab of the former atomic sums: MAXLEAF * 34 floats >= 2 * KM_SAMPLE)
-        static_assert((size_t) MAXLEAF * 34 >= 2 * (size_t) KM_SAMPLE, "leaf_of fits the sums2 slab");
         const size_t km2_lds = (size_t) KCL * (sub * 33 + 1) * 4;
-        if (km2_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) km2_label, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
+        if (km2_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) km2_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
         for (int it = 0; it < KM2_ITERS; ++it) {
-            km2_label<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, ctx->stream>>>(smp, label, ns, cen2, sub, leaf_of);
-            km2_centres<<<n_leaves, 64, 0, ctx->stream>>>(smp, leaf_of, ns, cen2);
+            km2_step<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, ctx->stream>>>(smp, label, ns, kmax, cen2, sub, acc2);
+            km2_finalize<<<n_leaves, 64, 0, ctx->stream>>>(acc2, kmax, cen2);
         }
     }
 

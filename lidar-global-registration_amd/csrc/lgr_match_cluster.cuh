@@ -6,10 +6,17 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
-// 1. clustering (any centres are valid -- they only shape the error bounds and the tile schedule; the Lloyd steps are
-//    deterministic all the same, so that schedule and timing repeat from run to run)
+// 1. clustering (any centres are valid -- they only shape the error bounds and the tile schedule).  Lloyd steps with
+//    ORDER-FREE sums: every sample coordinate is turned into a 64-bit integer on a per-call power-of-two grid
+//    (2^40 steps up to the largest sample magnitude) and added with integer atomics, so the centres -- hence the tile
+//    schedule and the timing -- repeat from run to run whatever order the atomics land in, and a Lloyd step is one
+//    kernel (label + accumulate) instead of a labelling kernel plus a deterministic tree reduction per centre.
+struct KmAcc { long long sum[33]; long long cnt; };
+__device__ __forceinline__ double km_scale(unsigned kmax_bits) {   // 2^(40 - e), 2^e <= largest |sample value| < 2^(e+1)
+    return kmax_bits ? ldexp(1.0, 40 - ((int) (kmax_bits >> 23) - 127)) : 1.0;
+}
 __global__ void km_sample(const float* __restrict__ A, int ma, const float* __restrict__ B, int mb, int per_side,
-                          float* __restrict__ smp, int* __restrict__ smp_ok) {
+                          float* __restrict__ smp, int* __restrict__ smp_ok, unsigned* __restrict__ kmax /* zeroed: max |v| bits */) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= 2 * per_side) return;
     const float* X = s < per_side ? A : B;
@@ -21,8 +28,11 @@ __global__ void km_sample(const float* __restrict__ A, int ma, const float* __re
         long long i = (long long) t * m / per_side;
         ok = row_finite(X + (size_t) i * 33, v);
     }
-    for (int k = 0; k < 33; ++k) smp[(size_t) s * 33 + k] = ok ? v[k] : 0.f;
+    float mx = 0.f;
+    for (int k = 0; k < 33; ++k) { smp[(size_t) s * 33 + k] = ok ? v[k] : 0.f; if (ok) mx = fmaxf(mx, fabsf(v[k])); }
     smp_ok[s] = ok ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(kmax, __float_as_uint(mx));
 }
 __global__ void km_init(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, float* __restrict__ cen) {
     int c = threadIdx.x;
@@ -44,46 +54,74 @@ __device__ __forceinline__ int nearest_centre(const float* v, const float* __res
     }
     return bi;
 }
-// second level: `sub` centres inside every cluster, seeded with evenly spaced sample members of the cluster
-__global__ void km_label(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, const float* __restrict__ cen,
-                         int* __restrict__ label) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ns) return;
-    int c = -1;
-    if (smp_ok[s]) {
-        float v[33], d;
-#pragma unroll
-        for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
-        c = nearest_centre(v, cen, d);
+// One Lloyd step of the first level: the centres of this step come from the previous step's sums (an empty cluster keeps
+// its centre), every sample is labelled and, when acc_out is given, added to its centre's sums.  The last launch
+// (acc_out = nullptr) only labels and leaves the final centres in cen_out.
+constexpr int KM1_THREADS = 256;
+__global__ __launch_bounds__(KM1_THREADS) void km1_step(const float* __restrict__ smp, const int* __restrict__ smp_ok, int ns, const unsigned* __restrict__ kmax,
+                                                        const float* __restrict__ cen_prev, const KmAcc* __restrict__ acc_prev, KmAcc* __restrict__ acc_out,
+                                                        float* __restrict__ cen_out, int* __restrict__ label) {
+    __shared__ float cen_s[KCL * 33];
+    __shared__ long long acc_s[KCL * 34];
+    const double scale = km_scale(*kmax);
+    for (int e = threadIdx.x; e < KCL * 33; e += KM1_THREADS) {
+        const int c = e / 33, k = e % 33;
+        float v = cen_prev[e];
+        if (acc_prev && acc_prev[c].cnt > 0) v = (float) (((double) acc_prev[c].sum[k] / scale) / (double) acc_prev[c].cnt);
+        cen_s[e] = v;
+        if (blockIdx.x == 0) cen_out[e] = v;
     }
-    label[s] = c;
-}
-__global__ void km2_init(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen, int sub,
-                         float* __restrict__ cen2) {
-    const int p = blockIdx.x, lane = threadIdx.x;   // one wave per cluster
-    for (int e = lane; e < sub * 33; e += 64) cen2[(size_t) p * sub * 33 + e] = cen[p * 33 + e % 33];
-    __threadfence_block();
+    for (int e = threadIdx.x; e < KCL * 34; e += KM1_THREADS) acc_s[e] = 0;
     __syncthreads();
-    int cnt = 0;
-    for (int base = 0; base < ns; base += 64) {
-        int s = base + lane;
-        bool m = s < ns && label[s] == p;
-        cnt += __popcll(__ballot(m));
-    }
-    if (cnt == 0) return;
-    int rank0 = 0;
-    for (int base = 0; base < ns; base += 64) {
-        int s = base + lane;
-        bool m = s < ns && label[s] == p;
-        unsigned long long bal = __ballot(m);
-        if (m) {
-            int r = rank0 + __popcll(bal & ((1ull << lane) - 1ull));
-            int j = (int) ((long long) r * sub / cnt);
-            bool first = r == 0 || (int) ((long long) (r - 1) * sub / cnt) != j;
-            if (first)
-                for (int k = 0; k < 33; ++k) cen2[((size_t) p * sub + j) * 33 + k] = smp[(size_t) s * 33 + k];
+    const int s = blockIdx.x * KM1_THREADS + threadIdx.x;
+    if (s < ns) {
+        int c = -1;
+        if (smp_ok[s]) {
+            float v[33], d;
+#pragma unroll
+            for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
+            c = nearest_centre(v, cen_s, d);
+            if (acc_out) {
+#pragma unroll
+                for (int k = 0; k < 33; ++k) atomicAdd((unsigned long long*) &acc_s[c * 34 + k], (unsigned long long) (long long) rint((double) v[k] * scale));
+                atomicAdd((unsigned long long*) &acc_s[c * 34 + 33], 1ull);
+            }
         }
-        rank0 += __popcll(bal);
+        label[s] = c;
+    }
+    if (!acc_out) return;
+    __syncthreads();
+    long long* out = (long long*) acc_out;
+    for (int e = threadIdx.x; e < KCL * 34; e += KM1_THREADS)
+        if (acc_s[e] != 0) atomicAdd((unsigned long long*) &out[e], (unsigned long long) acc_s[e]);
+}
+// second level: `sub` centres inside every cluster, seeded with evenly spaced sample members of the cluster (in sample
+// order).  One workgroup per cluster; thread t owns the samples [t * per, (t + 1) * per), ranks by a workgroup scan.
+constexpr int KM2I_THREADS = 1024;
+__global__ __launch_bounds__(KM2I_THREADS) void km2_init(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen, int sub,
+                                                         float* __restrict__ cen2) {
+    __shared__ int wsum[KM2I_THREADS / 64];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < sub * 33; e += KM2I_THREADS) cen2[(size_t) p * sub * 33 + e] = cen[p * 33 + e % 33];
+    const int per = (ns + KM2I_THREADS - 1) / KM2I_THREADS;
+    const int s0 = min(ns, tid * per), s1 = min(ns, s0 + per);
+    int mine = 0;
+    for (int s = s0; s < s1; ++s) mine += label[s] == p;
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();   // also: the default centres above are written before any seed below
+    int before = incl - mine, cnt = 0;
+    for (int w = 0; w < KM2I_THREADS / 64; ++w) { if (w < wave) before += wsum[w]; cnt += wsum[w]; }
+    if (cnt == 0) return;
+    int r = before;
+    for (int s = s0; s < s1; ++s) {
+        if (label[s] != p) continue;
+        const int j = (int) ((long long) r * sub / cnt);
+        const bool first = r == 0 || (int) ((long long) (r - 1) * sub / cnt) != j;
+        if (first)
+            for (int k = 0; k < 33; ++k) cen2[((size_t) p * sub + j) * 33 + k] = smp[(size_t) s * 33 + k];
+        ++r;
     }
 }
 __device__ __forceinline__ int nearest_sub(const float* v, const float* __restrict__ c2 /* [sub][33] of the row's cluster */, int sub, float& best) {
@@ -99,11 +137,11 @@ __device__ __forceinline__ int nearest_sub(const float* v, const float* __restri
     return bj;
 }
 constexpr int KM2_THREADS = 512;
-// Lloyd step of the second level in two deterministic kernels (no float atomics: the same centres, hence the same tile
-// schedule and timing, on every run).  km2_label: leaf of every sample (sub-centres of all clusters in LDS, odd pitch per
-// cluster as in assign_kernel).  km2_centres: one wave per leaf sums its samples in sample order and writes the new centre.
-__global__ __launch_bounds__(KM2_THREADS) void km2_label(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen2, int sub,
-                                                         int* __restrict__ leaf_of /* [ns], -1: no cluster */) {
+// Lloyd step of the second level: km2_step labels every sample with the nearest sub-centre of its cluster (sub-centres of
+// all clusters in LDS, odd pitch per cluster as in assign_kernel) and adds it to the leaf's integer sums; km2_finalize turns
+// the sums into the new centres (an empty leaf keeps its centre) and clears them for the next step.
+__global__ __launch_bounds__(KM2_THREADS) void km2_step(const float* __restrict__ smp, const int* __restrict__ label, int ns, const unsigned* __restrict__ kmax,
+                                                        const float* __restrict__ cen2, int sub, KmAcc* __restrict__ acc2) {
     extern __shared__ float c2s[];
     const int pitch = sub * 33 + 1;
     for (int e = threadIdx.x; e < KCL * sub * 33; e += blockDim.x) c2s[(e / (sub * 33)) * pitch + e % (sub * 33)] = cen2[e];
@@ -111,79 +149,25 @@ __global__ __launch_bounds__(KM2_THREADS) void km2_label(const float* __restrict
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ns) return;
     int p = label[s];
-    int leaf = -1;
-    if (p >= 0) {
-        float v[33], d;
+    if (p < 0) return;
+    const double scale = km_scale(*kmax);
+    float v[33], d;
 #pragma unroll
-        for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
-        leaf = p * sub + nearest_sub(v, c2s + p * pitch, sub, d);
-    }
-    leaf_of[s] = leaf;
+    for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
+    const int leaf = p * sub + nearest_sub(v, c2s + p * pitch, sub, d);
+    long long* out = (long long*) &acc2[leaf];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) atomicAdd((unsigned long long*) &out[k], (unsigned long long) (long long) rint((double) v[k] * scale));
+    atomicAdd((unsigned long long*) &out[33], 1ull);
 }
-// level 1: 16 centres over the whole sample -> 1024 threads per centre, the 16 wave sums combined in a fixed order
-constexpr int KMC_THREADS = 1024;
-__global__ __launch_bounds__(KMC_THREADS) void km_centres(const float* __restrict__ smp, const int* __restrict__ label, int ns, float* __restrict__ cen) {
-    __shared__ float part[KMC_THREADS / 64][34];
-    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float acc[33];
-#pragma unroll
-    for (int k = 0; k < 33; ++k) acc[k] = 0.f;
-    int n = 0;
-    for (int s0 = threadIdx.x; s0 < ns; s0 += KMC_THREADS * 8) {
-        int lb[8];   // eight label loads in flight (a label per iteration is one exposed load latency per iteration)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) lb[u] = s0 + KMC_THREADS * u < ns ? label[s0 + KMC_THREADS * u] : -1;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (lb[u] != c) continue;
-            const int s = s0 + KMC_THREADS * u;
-            ++n;
-#pragma unroll
-            for (int k = 0; k < 33; ++k) acc[k] += smp[(size_t) s * 33 + k];
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
-#pragma unroll
-    for (int k = 0; k < 33; ++k) {
-        float a = acc[k];
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) part[wave][k] = a;
-    }
-    if (lane == 0) part[wave][33] = (float) n;
+__global__ __launch_bounds__(64) void km2_finalize(KmAcc* __restrict__ acc2, const unsigned* __restrict__ kmax, float* __restrict__ cen2) {
+    const int leaf = blockIdx.x, k = threadIdx.x;
+    const long long cnt = acc2[leaf].cnt;
     __syncthreads();
-    if (threadIdx.x < 33) {
-        float cnt = 0.f, sum = 0.f;
-        for (int w = 0; w < KMC_THREADS / 64; ++w) { cnt += part[w][33]; sum += part[w][threadIdx.x]; }
-        if (cnt > 0.f) cen[c * 33 + threadIdx.x] = sum / cnt;
-    }
-}
-__global__ __launch_bounds__(64) void km2_centres(const float* __restrict__ smp, const int* __restrict__ leaf_of, int ns, float* __restrict__ cen2) {
-    const int leaf = blockIdx.x, lane = threadIdx.x;
-    float acc[33];
-#pragma unroll
-    for (int k = 0; k < 33; ++k) acc[k] = 0.f;
-    int n = 0;
-    for (int s0 = lane; s0 < ns; s0 += 64 * 16) {
-        int lb[16];   // sixteen label loads in flight
-#pragma unroll
-        for (int u = 0; u < 16; ++u) lb[u] = s0 + 64 * u < ns ? leaf_of[s0 + 64 * u] : -1;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (lb[u] != leaf) continue;
-            const int s = s0 + 64 * u;
-            ++n;
-#pragma unroll
-            for (int k = 0; k < 33; ++k) acc[k] += smp[(size_t) s * 33 + k];
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
-    if (n == 0) return;   // empty leaf: the centre stays
-#pragma unroll
-    for (int k = 0; k < 33; ++k) {
-        float a = acc[k];
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) cen2[(size_t) leaf * 33 + k] = a / (float) n;
-    }
+    if (k < 33) {
+        if (cnt > 0) cen2[(size_t) leaf * 33 + k] = (float) (((double) acc2[leaf].sum[k] / km_scale(*kmax)) / (double) cnt);
+        acc2[leaf].sum[k] = 0;
+    } else if (k == 33) acc2[leaf].cnt = 0;
 }
 
 // key = (leaf << 22) | (bits(r2) >> 9), leaf = cluster * sub + sub-centre: sort by cluster, leaf, then distance to the
