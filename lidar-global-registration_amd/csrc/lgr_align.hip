@@ -504,7 +504,17 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     };
     float ms_t[3] = {0, 0, 0};
     const auto t_feat0 = std::chrono::steady_clock::now();
-    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return cloud_features(cx, 0, ms); }, [&](lgr_ctx* cx) { return cloud_features(cx, 1, ms_t); }));
+    // The source cloud is done first (this thread): the matcher's query-side half (clustering, assignment, sort) runs right behind
+    // its features, under the target cloud's feature kernels on the second context.
+    const bool both_dirs = p->matching_id != LGR_MATCH_ONE_SIDED;
+    const bool prepare_query = p->use_bfmatcher && !p->has_guess;   // match_dispatch: the brute-force matcher will be called
+    struct PrepGuard { lgr_ctx* c; ~PrepGuard() { lgr_match_prepare_cancel(c); } } prep_guard{ctx};
+    LGR_TRY(lgr_run_pair(ctx,
+        [&](lgr_ctx* cx) {
+            LGR_TRY(cloud_features(cx, 0, ms));
+            return prepare_query ? lgr_match_prepare(cx, feat[0], ns, nt, both_dirs) : (int) LGR_OK;
+        },
+        [&](lgr_ctx* cx) { return cloud_features(cx, 1, ms_t); }));
     {
         // the two clouds overlap in wall time: report the wall time of the feature stages, split in proportion to the stage times
         // the two streams measured (each of which includes the other stream's interleaved kernels)

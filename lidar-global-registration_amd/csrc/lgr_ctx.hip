@@ -88,6 +88,7 @@ extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     if (!ctx) return LGR_OK;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->match_prep && ctx->match_prep_free) { ctx->match_prep_free(ctx->match_prep); ctx->match_prep = nullptr; }
     if (ctx->aux) { (void) lgr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     if (ctx->aux_ev) { (void) hipEventDestroy(ctx->aux_ev); ctx->aux_ev = nullptr; }
     if (ctx->aux2) { (void) lgr_ctx_destroy(ctx->aux2); ctx->aux2 = nullptr; }

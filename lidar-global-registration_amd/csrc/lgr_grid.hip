@@ -75,17 +75,53 @@ __global__ void cell_keys(const float* __restrict__ pts, int n, float ox, float 
     keys[i] = k; vals[i] = i;
 }
 
-// counts[c] = number of sorted entries with key c (written once, by the thread at the run's first element);
-// cell_start = exclusive scan of counts (rocPRIM), so empty cells cost nothing
-__global__ void cell_counts(const unsigned* __restrict__ keys, int n, int ncell, int* __restrict__ counts) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned k = keys[i];
-    if (k >= (unsigned) ncell) return;                  // invalid points (sorted last)
-    if (i > 0 && keys[i - 1] == k) return;              // not the head of its run
-    int j = i + 1;
-    while (j < n && keys[j] == k) ++j;
-    counts[k] = j - i;
+// cell_start[c] = number of sorted keys below c, for every cell c in [0, ncell] (cell_start[ncell] = number of valid points; invalid
+// points carry the key ncell and sort last).  The dense table can have 100+ cells per point (a surface scan in its 3-D bounding box), so
+// it is WRITTEN ONCE, straight from the sorted keys, instead of memset + per-cell counts + a scan over all cells (three more passes
+// over up to 1 GB): a coarse table (one entry per CSF_CELLS cells) is filled from the keys, then every workgroup of cell_start_fill
+// finds the few keys of its CSF_CELLS cells between two coarse entries and writes its piece of the table.
+constexpr int CSF_T = 256, CSF_SHIFT = 10, CSF_CELLS = 1 << CSF_SHIFT;   // 4 cells per thread
+static_assert(CSF_CELLS == 4 * CSF_T, "one int4 store per thread");
+// coarse[b] = number of keys below b * CSF_CELLS, b in [0, nblk].  Keys driven: lane <-> boundary i between keys i-1 and i; the
+// coarse entries in (key[i-1] >> shift, key[i] >> shift] all equal i and are filled by the whole wave (gaps can be long).
+__global__ __launch_bounds__(256) void coarse_start_fill(const unsigned* __restrict__ keys, int n, int nblk, int* __restrict__ coarse) {
+    const int lane = threadIdx.x & 63;
+    const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const int i = base + lane;
+    int lo = 1, hi = 0;
+    if (i <= n) {
+        lo = i == 0 ? 0 : (int) (keys[i - 1] >> CSF_SHIFT) + 1;
+        hi = i == n ? nblk : (int) (keys[i] >> CSF_SHIFT);
+    }
+    unsigned long long todo = __ballot(lo <= hi);
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int lo_j = __builtin_amdgcn_readlane(lo, j), hi_j = __builtin_amdgcn_readlane(hi, j);
+        for (int c = lo_j + lane; c <= hi_j; c += 64) coarse[c] = base + j;
+    }
+}
+__global__ __launch_bounds__(CSF_T) void cell_start_fill(const unsigned* __restrict__ keys, const int* __restrict__ coarse, unsigned ncell, int* __restrict__ start) {
+    const int k0 = coarse[blockIdx.x], k1 = coarse[blockIdx.x + 1];   // the keys of this workgroup's cells: [k0, k1)
+    const unsigned c = (unsigned) blockIdx.x * CSF_CELLS + 4u * threadIdx.x;
+    if (c > ncell) return;
+    int lo = k0, hi = k1;                                             // first key >= c
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < c) lo = mid + 1; else hi = mid; }
+    int4 v;
+    v.x = lo;
+    while (lo < k1 && keys[lo] < c + 1u) ++lo;
+    v.y = lo;
+    while (lo < k1 && keys[lo] < c + 2u) ++lo;
+    v.z = lo;
+    while (lo < k1 && keys[lo] < c + 3u) ++lo;
+    v.w = lo;
+    if (c + 3u <= ncell) {
+        *reinterpret_cast<int4*>(start + c) = v;
+    } else {
+        start[c] = v.x;
+        if (c + 1u <= ncell) start[c + 1] = v.y;
+        if (c + 2u <= ncell) start[c + 2] = v.z;
+    }
 }
 
 __global__ void gather_points(const float* __restrict__ pts, const int* __restrict__ vals, int nvalid,
@@ -199,7 +235,7 @@ int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, flo
     unsigned *keys, *keys2;
     int *vals, *vals2, *start;
     float4 *pxyz, *pnrm;
-    LGR_TRY(lgr_ws_t(ctx, sb + 0, (size_t) std::max(n, ncell + 1) + 1, &keys));
+    LGR_TRY(lgr_ws_t(ctx, sb + 0, (size_t) n + 1, &keys));
     LGR_TRY(lgr_ws_t(ctx, sb + 1, (size_t) n + 1, &vals));
     LGR_TRY(lgr_ws_t(ctx, sb + 2, (size_t) n + 1, &keys2));
     LGR_TRY(lgr_ws_t(ctx, sb + 3, (size_t) n + 1, &vals2));
@@ -216,14 +252,12 @@ int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, flo
         void* tmp;
         LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tmp_bytes, &tmp));
         LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, bits, ctx->stream));
-        int* counts = (int*) keys;    // the unsorted key buffer is free again; ncell + 1 <= capacity is ensured below
-        LGR_HIP(ctx, hipMemsetAsync(counts, 0, ((size_t) ncell + 1) * 4, ctx->stream));
-        cell_counts<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys2, n, ncell, counts);
-        size_t sb = 0;
-        LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, sb, counts, start, 0, (size_t) ncell + 1, rocprim::plus<int>(), ctx->stream));
-        void* stmp;
-        LGR_TRY(lgr_ws(ctx, WS_GRID_MISC, std::max<size_t>(sb, 256) + 256, &stmp));
-        LGR_HIP(ctx, rocprim::exclusive_scan((char*) stmp + 256, sb, counts, start, 0, (size_t) ncell + 1, rocprim::plus<int>(), ctx->stream));
+        const int nblk = (int) (((size_t) ncell + 1 + CSF_CELLS - 1) >> CSF_SHIFT);   // workgroups of cell_start_fill; cells 0..ncell
+        int* coarse;
+        LGR_TRY(lgr_ws_t(ctx, WS_GRID_MISC, (size_t) nblk + 1 + 64, &coarse));
+        coarse += 64;   // (the first 256 bytes of the slot belong to lgr_bbox_host)
+        coarse_start_fill<<<cdiv(n + 1, 256), 256, 0, ctx->stream>>>(keys2, n, nblk, coarse);
+        cell_start_fill<<<nblk, CSF_T, 0, ctx->stream>>>(keys2, coarse, (unsigned) ncell, start);
         int* h_n;
         LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_n));
         LGR_HIP(ctx, hipMemcpyAsync(h_n, start + ncell, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -33,6 +33,8 @@ struct lgr_ctx {
     int mfma_timed = 0;
     lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, {0, 0, 0, 0, 0}};   // lgr_match_default_options
     bool corr_trusted = false;
+    void* match_prep = nullptr;                 // the matcher's clustering / prepared query side (lgr_match.hip: MatchPrep)
+    void (*match_prep_free)(void*) = nullptr;
     lgr_ctx* aux = nullptr;      // second context (own stream + workspace, same device): the target cloud's feature stages run on it
                                  // from a second host thread while this one does the source cloud (lgr_align.hip)
     hipEvent_t aux_ev = nullptr;
@@ -141,6 +143,11 @@ static inline int lgr_run_pair(lgr_ctx* ctx, FA&& fa, FB&& fb) {
 // points through them (an out-of-range gather is a GPU memory fault, not an error code).  One tiny launch + a 4-byte read-back;
 // skipped when ctx->corr_trusted (lgr_ransac.hip).
 int lgr_check_corr(lgr_ctx* ctx, const lgr_corr* d_corr, int c, int ns, int nt);
+// lgr_match.hip: the query-side half of a coming brute-force match (clustering + assignment / sort / placement of d_a33), run ahead
+// of the call while the train side's descriptors are still being computed; consumed by the next lgr_match_bf*_dev on the same
+// (d_a33, ma, mb, both directions) or dropped by lgr_match_prepare_cancel.
+int lgr_match_prepare(lgr_ctx* ctx, const float* d_a33, int ma, int mb, bool both);
+void lgr_match_prepare_cancel(lgr_ctx* ctx);
 
 // ---- closest-plane metric on the device (lgr_plane.hip) ----
 struct lgr_plane_dev {

@@ -139,6 +139,119 @@ static int box_basis(lgr_ctx* ctx, bool raw, const float* smp, const int* smp_ok
     return LGR_OK;
 }
 
+// Clustering of one call: centres, leaves, the box basis, and -- when the query side was prepared ahead of the call -- the built
+// query side.  lgr_match_prepare (below) fills it while the train side's descriptors are still being computed; match_impl consumes it.
+struct MatchPrep {
+    bool armed = false;            // prepared ahead of the call and not yet consumed
+    const float* d_a = nullptr;    // what it was prepared for
+    int ma = 0, mb = 0;
+    bool both = false;
+    lgr_match_options mopt{};
+    int sub = 1, rg_rows = BLOCK_ROWS, ns = 0;
+    float *cen = nullptr, *cen2 = nullptr, *smp = nullptr, *basis = nullptr;   // in WS_MATCH_MISC
+    int* smp_ok = nullptr;
+    bool basis_ready = false;
+    Side A;
+};
+static void match_prep_free(void* p) { delete (MatchPrep*) p; }
+static MatchPrep* match_prep_of(lgr_ctx* ctx) {
+    if (!ctx->match_prep) { ctx->match_prep = new MatchPrep(); ctx->match_prep_free = match_prep_free; }
+    return (MatchPrep*) ctx->match_prep;
+}
+
+// ---- 1. k-means centres on a sample: KCL clusters, then `sub` leaves inside every cluster; the basis of the box bounds from the
+// same sample.  d_b == nullptr: the train side does not exist yet, the sample comes from the query side alone (any centres are
+// valid; the two sides of a registration pair are scans of the same scene).  basis_side_by_side: covariance + host Jacobi on the
+// second context while the Lloyd steps run on this one (only when the second context is free).
+static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, int mb, bool both, bool basis_side_by_side, MatchPrep* P) {
+    const lgr_match_options& mo = ctx->mopt;
+    // leaves per cluster: about 1024 rows per leaf on the larger side.  lgr_match_options (ctx->mopt: leaves / prune / near)
+    // override the automatic choices (tests force the skipping path on small inputs); results never depend on them.
+    int sub = 1;
+    while (sub < SUBMAX && (long long) KCL * sub * 1024 < std::max(ma, mb)) sub *= 2;
+    if (mo.leaves > 0) sub = mo.leaves;
+    sub = std::min(SUBMAX, std::max(1, sub));
+    const int n_leaves = KCL * sub;
+    const int ns = 2 * KM_SAMPLE;
+    char* misc;
+    size_t off = 8192;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
+    const size_t o_cen2 = carve((size_t) MAXLEAF * 33 * 4);
+    const size_t o_smp = carve((size_t) ns * 33 * 4), o_ok = carve((size_t) ns * 4), o_label = carve((size_t) ns * 4);
+    const size_t o_cbuf = carve((size_t) 2 * KCL * 33 * 4), o_basis = carve((size_t) (34 * 33 + 64) * 4);
+    const size_t o_zero = off;   // zeroed once per call: largest sample magnitude, one set of level-1 sums per Lloyd step, the level-2 sums
+    const size_t o_kmax = carve(256), o_acc1 = carve((size_t) KM_ITERS * KCL * sizeof(KmAcc)), o_acc2 = carve((size_t) MAXLEAF * sizeof(KmAcc));
+    const size_t zero_bytes = off - o_zero;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, off, &misc));
+    float* cen = (float*) (misc + 256);                 // [KCL][33]
+    float* cen2 = (float*) (misc + o_cen2);             // [n_leaves][33]
+    float* smp = (float*) (misc + o_smp);
+    int* smp_ok = (int*) (misc + o_ok);
+    int* label = (int*) (misc + o_label);
+    float* cbuf = (float*) (misc + o_cbuf);             // two scratch copies of the level-1 centres (read one, write the other)
+    float* basis = (float*) (misc + o_basis);           // V [33][33], mu [33], count; + 8: rmax2
+    unsigned* kmax = (unsigned*) (misc + o_kmax);
+    KmAcc* acc1 = (KmAcc*) (misc + o_acc1);
+    KmAcc* acc2 = (KmAcc*) (misc + o_acc2);
+    LGR_HIP(ctx, hipMemsetAsync(misc + o_zero, 0, zero_bytes, ctx->stream));
+    km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok, kmax);
+    auto lloyd = [&](lgr_ctx* cx) -> int {
+        km_init<<<1, 64, 0, cx->stream>>>(smp, smp_ok, ns, cbuf);
+        for (int it = 0; it <= KM_ITERS; ++it) {   // Lloyd with order-free integer sums; the last launch labels with the final centres
+            const bool last = it == KM_ITERS;
+            km1_step<<<cdiv(ns, KM1_THREADS), KM1_THREADS, 0, cx->stream>>>(smp, smp_ok, ns, kmax, cbuf + (it & 1) * KCL * 33, it ? acc1 + (size_t) (it - 1) * KCL : nullptr,
+                                                                            last ? nullptr : acc1 + (size_t) it * KCL, last ? cen : cbuf + ((it + 1) & 1) * KCL * 33, label);
+        }
+        km2_init<<<KCL, KM2I_THREADS, 0, cx->stream>>>(smp, label, ns, cen, sub, cen2);
+        if (sub > 1) {
+            const size_t km2_lds = (size_t) KCL * (sub * 33 + 1) * 4;
+            if (km2_lds > 64 * 1024) LGR_HIP(cx, hipFuncSetAttribute((const void*) km2_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
+            for (int it = 0; it < KM2_ITERS; ++it) {
+                km2_step<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, cx->stream>>>(smp, label, ns, kmax, cen2, sub, acc2);
+                km2_finalize<<<n_leaves, 64, 0, cx->stream>>>(acc2, kmax, cen2);
+            }
+        }
+        LGR_HIP(cx, hipGetLastError());
+        return LGR_OK;
+    };
+    const bool want_basis = mo.box_bounds != 0;
+    if (want_basis && basis_side_by_side) {
+        LGR_TRY(lgr_run_pair(ctx, lloyd, [&](lgr_ctx* cx) { return box_basis(cx, mo.box_bounds == 2, smp, smp_ok, ns, basis); }));
+    } else {
+        LGR_TRY(lloyd(ctx));
+        if (want_basis) LGR_TRY(box_basis(ctx, mo.box_bounds == 2, smp, smp_ok, ns, basis));
+    }
+    auto pick_group = [](size_t q_count, size_t t_count) {   // table [t/g][q] floats kept under ~6 GB
+        int g = 1024;
+        while (g < 4096 && (t_count / g + 1) * q_count * 4 > ((size_t) 6 << 30)) g *= 2;
+        return g;
+    };
+    int rg_rows = both ? pick_group((size_t) mb, (size_t) ma) : BLOCK_ROWS;   // row groups (column direction table)
+    if (ma <= 65536) rg_rows = BLOCK_ROWS;                                     // small inputs: keep the cluster padding small
+    P->d_a = d_a; P->ma = ma; P->mb = mb; P->both = both; P->mopt = mo;
+    P->sub = sub; P->rg_rows = rg_rows; P->ns = ns;
+    P->cen = cen; P->cen2 = cen2; P->smp = smp; P->smp_ok = smp_ok; P->basis = basis; P->basis_ready = want_basis;
+    return LGR_OK;
+}
+
+// Query-side half of a coming lgr_match_bf*_dev(ctx, d_a, ma, <train side of mb rows>, both directions or not): clustering from the
+// query side's descriptors and the query side's assignment / sort / placement, so that the caller can run it while the train
+// side's descriptors are still being computed on another context.  Consumed by the next matcher call on this context when
+// (d_a, ma, mb, both, options) agree; lgr_match_prepare_cancel drops it (every exit path of the caller).
+int lgr_match_prepare(lgr_ctx* ctx, const float* d_a, int ma, int mb, bool both) {
+    MatchPrep* P = match_prep_of(ctx);
+    P->armed = false;
+    if (!d_a || ma <= 0 || mb <= 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    LGR_TRY(match_cluster(ctx, d_a, ma, nullptr, mb, both, false, P));
+    LGR_TRY(build_side(ctx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, &P->A));
+    P->armed = true;
+    return LGR_OK;
+}
+void lgr_match_prepare_cancel(lgr_ctx* ctx) {
+    if (ctx && ctx->match_prep) ((MatchPrep*) ctx->match_prep)->armed = false;
+}
+
 static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, int mb, int block,
                       int32_t* d_ab_idx, float* d_ab_dist, int32_t* d_ba_idx, float* d_ba_dist) {
     LGR_CHECK(ctx, ctx && (d_a || ma == 0) && (d_b || mb == 0) && (d_ab_idx || ma == 0) && (d_ab_dist || ma == 0), LGR_ERR_INVALID_ARG);
@@ -154,69 +267,31 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     if (mb && d_ba_idx) { LGR_HIP(ctx, hipMemsetAsync(d_ba_idx, 0xff, (size_t) mb * 4, ctx->stream)); LGR_HIP(ctx, hipMemsetAsync(d_ba_dist, 0, (size_t) mb * 4, ctx->stream)); }
     if (ma == 0 || mb == 0) return LGR_OK;
 
-    // leaves per cluster: about 1024 rows per leaf on the larger side.  lgr_match_options (ctx->mopt: leaves / prune / near)
-    // override the automatic choices (tests force the skipping path on small inputs); results never depend on them.
     const lgr_match_options& mo = ctx->mopt;
-    int sub = 1;
-    while (sub < SUBMAX && (long long) KCL * sub * 1024 < std::max(ma, mb)) sub *= 2;
-    if (mo.leaves > 0) sub = mo.leaves;
-    sub = std::min(SUBMAX, std::max(1, sub));
-    const int n_leaves = KCL * sub;
     const int prune_mode = mo.prune;   // -1 auto, 0 off, 1 on
     const int near_t = mo.near > 0 ? mo.near : NEAR_T;
     const bool prune = prune_mode == 1 || (prune_mode != 0 && (double) ma * mb >= 65536.0 * 65536.0);
 
-    // ---- 1. k-means centres on a sample: KCL clusters, then `sub` leaves inside every cluster
-    const int ns = 2 * KM_SAMPLE;
+    // ---- 1. + 2. clustering, then assign / sort / place both sides -- unless the query side was prepared ahead of this call
+    MatchPrep* P = match_prep_of(ctx);
+    const bool prepared = P->armed && P->d_a == d_a && P->ma == ma && P->mb == mb && P->both == both && memcmp(&P->mopt, &mo, sizeof mo) == 0;
+    P->armed = false;
+    Side B;
+    if (prepared) {
+        LGR_TRY(build_side(ctx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B));
+    } else {
+        LGR_TRY(match_cluster(ctx, d_a, ma, d_b, mb, both, true, P));
+        // the two sides are independent (assign, sort, two host read-backs each): side by side on the two contexts
+        LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, &P->A); },
+                             [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B); }));
+    }
+    const Side& A = P->A;
+    const int sub = P->sub, n_leaves = KCL * sub, rg_rows = P->rg_rows, ns = P->ns;
+    float *const cen = P->cen, *const cen2 = P->cen2, *const smp = P->smp;
+    int* const smp_ok = P->smp_ok;
+    (void) smp; (void) smp_ok; (void) ns;
     char* misc;
-    size_t off = 8192;
-    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t) 255; return o; };
-    const size_t o_cen2 = carve((size_t) MAXLEAF * 33 * 4);
-    const size_t o_smp = carve((size_t) ns * 33 * 4), o_ok = carve((size_t) ns * 4), o_label = carve((size_t) ns * 4);
-    const size_t o_cbuf = carve((size_t) 2 * KCL * 33 * 4);
-    const size_t o_zero = off;   // zeroed once per call: largest sample magnitude, one set of level-1 sums per Lloyd step, the level-2 sums
-    const size_t o_kmax = carve(256), o_acc1 = carve((size_t) KM_ITERS * KCL * sizeof(KmAcc)), o_acc2 = carve((size_t) MAXLEAF * sizeof(KmAcc));
-    const size_t zero_bytes = off - o_zero;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, off, &misc));
-    float* cen = (float*) (misc + 256);                 // [KCL][33]
-    float* cen2 = (float*) (misc + o_cen2);             // [n_leaves][33]
-    float* smp = (float*) (misc + o_smp);
-    int* smp_ok = (int*) (misc + o_ok);
-    int* label = (int*) (misc + o_label);
-    float* cbuf = (float*) (misc + o_cbuf);             // two scratch copies of the level-1 centres (read one, write the other)
-    unsigned* kmax = (unsigned*) (misc + o_kmax);
-    KmAcc* acc1 = (KmAcc*) (misc + o_acc1);
-    KmAcc* acc2 = (KmAcc*) (misc + o_acc2);
-    LGR_HIP(ctx, hipMemsetAsync(misc + o_zero, 0, zero_bytes, ctx->stream));
-    km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok, kmax);
-    km_init<<<1, 64, 0, ctx->stream>>>(smp, smp_ok, ns, cbuf);
-    for (int it = 0; it <= KM_ITERS; ++it) {   // Lloyd with order-free integer sums; the last launch labels with the final centres
-        const bool last = it == KM_ITERS;
-        km1_step<<<cdiv(ns, KM1_THREADS), KM1_THREADS, 0, ctx->stream>>>(smp, smp_ok, ns, kmax, cbuf + (it & 1) * KCL * 33, it ? acc1 + (size_t) (it - 1) * KCL : nullptr,
-                                                                         last ? nullptr : acc1 + (size_t) it * KCL, last ? cen : cbuf + ((it + 1) & 1) * KCL * 33, label);
-    }
-    km2_init<<<KCL, KM2I_THREADS, 0, ctx->stream>>>(smp, label, ns, cen, sub, cen2);
-    if (sub > 1) {
-        const size_t km2_lds = (size_t) KCL * (sub * 33 + 1) * 4;
-        if (km2_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) km2_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
-        for (int it = 0; it < KM2_ITERS; ++it) {
-            km2_step<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, ctx->stream>>>(smp, label, ns, kmax, cen2, sub, acc2);
-            km2_finalize<<<n_leaves, 64, 0, ctx->stream>>>(acc2, kmax, cen2);
-        }
-    }
-
-    // ---- 2. assign / sort / place
-    auto pick_group = [](size_t q_count, size_t t_count) {   // table [t/g][q] floats kept under ~6 GB
-        int g = 1024;
-        while (g < 4096 && (t_count / g + 1) * q_count * 4 > ((size_t) 6 << 30)) g *= 2;
-        return g;
-    };
-    int rg_rows = both ? pick_group((size_t) mb, (size_t) ma) : BLOCK_ROWS;   // row groups (column direction table)
-    if (ma <= 65536) rg_rows = BLOCK_ROWS;                                     // small inputs: keep the cluster padding small
-    Side A, B;
-    // the two sides are independent (assign, sort, two host read-backs each): side by side on the two contexts
-    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, cen, cen2, sub, 1, rg_rows, WS_MATCH_NA, WS_MATCH_AP, &A); },
-                         [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, cen, cen2, sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B); }));
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, 8192, &misc));   // (grown by match_cluster; the first 8 KB hold small per-call scalars)
     if (A.n_valid == 0 || B.n_valid == 0) return LGR_OK;
     const int ma_pad = A.n_pad, mb_pad = B.n_pad;
     g_last_stats.rg_rows = rg_rows;
@@ -440,7 +515,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(16);
-        const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4), o_basis = pcarve((size_t) (34 * 33 + 64) * 4);   // V, mu, count / rmax2
+        const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4);
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
@@ -493,9 +568,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         if (mo.box_bounds) {
             float* boxA = (float*) (pb + o_boxa);
             float* boxBt = (float*) (pb + o_boxb);
-            float* basis = (float*) (pb + o_basis);              // V [33][33], mu [33]
+            float* basis = P->basis;                             // V [33][33], mu [33] (match_cluster)
             unsigned* rmax2 = (unsigned*) (basis + 34 * 33 + 8);
-            // ball bounds on this context; basis (device covariance, host Jacobi) and boxes on the second one, side by side
+            // ball bounds on this context, boxes on the second one, side by side
             LGR_TRY(lgr_run_pair(ctx,
                 [&](lgr_ctx* cx) {
                     lb_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
@@ -503,7 +578,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                     return (int) LGR_OK;
                 },
                 [&](lgr_ctx* cx) {
-                    LGR_TRY(box_basis(cx, mo.box_bounds == 2, smp, smp_ok, ns, basis));
                     LGR_HIP(cx, hipMemsetAsync(rmax2, 0, 4, cx->stream));
                     box_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
                     box_kernel<<<n_leaves, 256, 0, cx->stream>>>(sortedB, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);

@@ -19,13 +19,14 @@ __global__ void km_sample(const float* __restrict__ A, int ma, const float* __re
                           float* __restrict__ smp, int* __restrict__ smp_ok, unsigned* __restrict__ kmax /* zeroed: max |v| bits */) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= 2 * per_side) return;
-    const float* X = s < per_side ? A : B;
-    int m = s < per_side ? ma : mb;
-    int t = s < per_side ? s : s - per_side;
+    // B == nullptr: all 2 * per_side samples from A (evenly spaced), otherwise per_side from each set
+    const float* X = (!B || s < per_side) ? A : B;
+    int m = (!B || s < per_side) ? ma : mb;
+    int t = (!B || s < per_side) ? s : s - per_side;
     float v[33];
     bool ok = false;
     if (m > 0) {
-        long long i = (long long) t * m / per_side;
+        long long i = (long long) t * m / (B ? per_side : 2 * per_side);
         ok = row_finite(X + (size_t) i * 33, v);
     }
     float mx = 0.f;
