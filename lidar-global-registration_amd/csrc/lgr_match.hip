@@ -516,6 +516,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(16);
         const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4);
+        const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
+        const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
@@ -565,6 +567,30 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         chk_done = done; chk_sched = sched; chk_lb = LBsq; chk_ustage = colstage ? u_stage : nullptr;
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
+        // ball bounds: on the matrix cores from the packed operands (f16 formats), with packed FMAs from the sorted rows otherwise
+        const int n_cpad = pad_to(n_leaves, TILE);
+        const size_t cset_stride = (size_t) (n_cpad / TILE) * KS * 64;
+        auto launch_lb = [&](lgr_ctx* cx) -> int {
+            if (!f16) {
+                lb_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
+            } else {
+                int* cperm = (int*) (pb + o_cperm);
+                float* nC = (float*) (pb + o_cnrm);
+                f16x8* Cop = (f16x8*) (pb + o_cop);
+                centre_perm_kernel<<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(n_leaves, n_cpad, cperm);
+                if (rot) {
+                    pack16_kernel<true, false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
+                    lb_mfma_kernel<OpFmt<FMT_F16R>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
+                                                                                             B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
+                } else {
+                    pack16_kernel<false, false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
+                    lb_mfma_kernel<OpFmt<FMT_F16>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
+                                                                                            B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
+                }
+            }
+            LGR_HIP(cx, hipGetLastError());
+            return (int) LGR_OK;
+        };
         if (mo.box_bounds) {
             float* boxA = (float*) (pb + o_boxa);
             float* boxBt = (float*) (pb + o_boxb);
@@ -572,11 +598,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             unsigned* rmax2 = (unsigned*) (basis + 34 * 33 + 8);
             // ball bounds on this context, boxes on the second one, side by side
             LGR_TRY(lgr_run_pair(ctx,
-                [&](lgr_ctx* cx) {
-                    lb_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
-                    LGR_HIP(cx, hipGetLastError());
-                    return (int) LGR_OK;
-                },
+                launch_lb,
                 [&](lgr_ctx* cx) {
                     LGR_HIP(cx, hipMemsetAsync(rmax2, 0, 4, cx->stream));
                     box_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
@@ -586,7 +608,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 }));
             box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
         } else {
-            lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
+            LGR_TRY(launch_lb(ctx));
         }
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
         auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {

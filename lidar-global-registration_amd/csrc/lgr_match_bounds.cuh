@@ -74,6 +74,80 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
     }
 }
 
+// The same table from the packed f16 operands (f16 formats): the leaf centres are packed like train rows (one copy per column set,
+// pack16_kernel with role 1), a workgroup multiplies the 8 row tiles of its block with the centre tiles of the block's set on the
+// matrix cores and keeps the row minimum -- 6 (7) MFMA steps per 32 x 32 (row, centre) tile instead of 33 packed FMAs per pair.
+// The filtered value is within eps(x, y) of |a - c|^2 (x = largest |a'| of the block, y = |c'|: the matcher's own proven bound),
+// so  dmin - eps  is a valid lower bound of the smallest distance; eps is ~1e-5 (x + y)^2, far below what the bound is used for.
+constexpr int LBM_THREADS = 512, LBM_CHUNK = 8;   // 8 waves = the 8 row tiles of a block; centre tiles staged through LDS 8 at a time
+template <int KS>
+__global__ __launch_bounds__(LBM_THREADS) void lb_mfma_kernel(const f16x8* __restrict__ Ap, const f16x8* __restrict__ Cp, size_t cset_stride /* fragments */,
+                                                              float out_scale, const int* __restrict__ blkcl, const float* __restrict__ nA,
+                                                              const float* __restrict__ nC /* [KCL][n_cpad] */, EpsExtra ex,
+                                                              const unsigned* __restrict__ r2max, const int* __restrict__ leaf_count, int n_leaves, int n_cpad,
+                                                              float* __restrict__ LBsq) {
+    __shared__ __attribute__((aligned(16))) f16x8 cs[LBM_CHUNK * KS * 64];
+    __shared__ int dmin_s[MAXLEAF + TILE];
+    __shared__ float xw[LBM_THREADS / 64];
+    const int rb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int p = blkcl[rb];
+    constexpr int IINF = 0x7f800000;
+    for (int g = tid; g < n_cpad; g += LBM_THREADS) dmin_s[g] = IINF;
+    // largest |a'| of the block's valid rows (padding rows carry +inf)
+    {
+        float n2 = tid < BLOCK_ROWS ? nA[(size_t) rb * BLOCK_ROWS + tid] : 0.f;
+        if (!(n2 < FLT_BIG)) n2 = 0.f;
+        for (int o = 32; o > 0; o >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, o));
+        if (lane == 0) xw[wave] = n2;
+    }
+    f16x8 a[KS];
+    const int row_tile = rb * (BLOCK_ROWS / TILE) + wave;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) a[kk] = Ap[((size_t) row_tile * KS + kk) * 64 + lane];
+    const f16x8* Cset = Cp + (size_t) p * cset_stride;
+    const int n_ct = n_cpad / TILE;
+    for (int ct0 = 0; ct0 < n_ct; ct0 += LBM_CHUNK) {
+        const int nt = min(LBM_CHUNK, n_ct - ct0);
+        __syncthreads();   // everybody is done with the previous chunk (and, the first time, dmin_s / xw are written)
+        for (int e = tid; e < nt * KS * 64; e += LBM_THREADS) cs[e] = Cset[(size_t) ct0 * KS * 64 + e];
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc = mfma_step(a[kk], cs[(t * KS + kk) * 64 + lane], acc);
+            // minimum over the wave's 32 rows, on the bit patterns (a negative value -- a distance within eps of zero -- stays
+            // negative under the signed-integer order, whichever negative it is; it ends as a bound of 0 below)
+            int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
+#pragma unroll
+            for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
+            auto sw = __builtin_amdgcn_permlane32_swap((unsigned) m, (unsigned) m, false, false);
+            m = min(m, (int) (half ? sw[0] : sw[1]));
+            if (half == 0) atomicMin(&dmin_s[(ct0 + t) * TILE + lane], m);
+        }
+    }
+    __syncthreads();
+    float x2 = xw[0];
+#pragma unroll
+    for (int w = 1; w < LBM_THREADS / 64; ++w) x2 = fmaxf(x2, xw[w]);
+    const float x = sqrtf(x2) * 1.0000002f;
+    for (int g = tid; g < n_leaves; g += LBM_THREADS) {
+        float out = __uint_as_float(0x7f800000u);
+        const float d = __int_as_float(dmin_s[g]) * out_scale;   // NaN never occurs (padding rows: +inf)
+        if (leaf_count[g] > 0 && d < FLT_BIG) {
+            const float y = sqrtf(nC[(size_t) p * n_cpad + g]) * 1.0000002f;
+            const float dm = fmaxf(d - eps_xy(x, y, ex), 0.f);
+            float lb = sqrtf(dm) * LB_SHRINK - sqrtf(__uint_as_float(r2max[g])) * LB_GROW;
+            lb = lb > 0.f ? lb : 0.f;
+            out = lb * lb * LB_SHRINK;
+        }
+        LBsq[(size_t) rb * n_leaves + g] = out;
+    }
+}
+__global__ void centre_perm_kernel(int n_leaves, int n_cpad, int* __restrict__ perm) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_cpad) perm[g] = g < n_leaves ? g : -1;
+}
+
 // ---- bounding-box bounds (section 3b).  A leaf's ball is a poor container in 33 dimensions; its axis-aligned box in a
 // fixed orthonormal basis (the principal axes of a sample of both sets) excludes a fifth more tiles at 1M x 1M.  For a row
 // block with box [amin, amax] and a leaf with box [blo, bhi] every pair is at least sqrt(sum_k gap_k^2) apart,

@@ -92,6 +92,15 @@ struct CoarseArgs {
     unsigned long long* cnt;    // [2]: tiles tested, tiles abandoned (or nullptr)
 };
 
+// proven bound of |filtered - d2| for a pair whose operands have |a'| <= x and |b'| <= y: evaluated in float,
+// inflated by 1e-5 (its five roundings are worth 3e-7)
+struct EpsExtra { float lin, abs, quad; };   // quad: multiplier of the 4 g40 (x + y)^2 term (1 on the f32 path)
+__device__ __forceinline__ float eps_xy(float x, float y, EpsExtra ex) {
+    const float c_quad = 9.5367477e-6f * ex.quad;   // 4 g40 = 4 * 40 u / (1 - 40 u) = 9.53677e-6, rounded up
+    const float s = x + y;
+    return ((c_quad * s) * s + ex.lin * s + ex.abs) * 1.00001f + 1e-30f;
+}
+
 __device__ __forceinline__ unsigned f2key(float f) {
     unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);

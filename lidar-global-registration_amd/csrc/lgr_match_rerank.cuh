@@ -52,7 +52,6 @@ __device__ __forceinline__ unsigned tie_rank(int j, int block, int nblocks) {
 struct RerankCounters { unsigned n_items; unsigned n_dense; unsigned pad0; unsigned pad1; };
 
 // extra terms of the f16-split operand path (0 on the f32 path): eps += lin * (x + y) + abs
-struct EpsExtra { float lin, abs, quad; };   // quad: multiplier of the 4 g40 (x + y)^2 term (1 on the f32 path)
 
 template <bool ROWDIR>
 __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* __restrict__ nT_sets, const float* __restrict__ gmax,
@@ -67,9 +66,7 @@ __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* 
         x = gmax[g];
         y = sqrtf(nT_sets[(size_t) p * t_pad + i]) * 1.0000002f;
     }
-    const float c_quad = 9.5367477e-6f * ex.quad;   // 4 g40 = 4 * 40 u / (1 - 40 u) = 9.53677e-6, rounded up
-    const float s = x + y;
-    return ((c_quad * s) * s + ex.lin * s + ex.abs) * 1.00001f + 1e-30f;
+    return eps_xy(x, y, ex);
 }
 
 // Table scan of one query: calls f(group, value) for every computed, finite entry table[g][i].  Four loads are in flight
