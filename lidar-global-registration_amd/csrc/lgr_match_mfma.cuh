@@ -216,22 +216,23 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     // its registers and receives the partner's copy of them, so 16 registers x 32 lanes reduce to
                     // one value per lane with 16 + 8 + 4 + 2 + 1 exchanges instead of 16 x 5; lane bits 4..1 then
                     // select the register (= row) the lane ends up holding, and one atomic instruction with 16
-                    // active lanes per half wave writes all rows.
+                    // active lanes per half wave writes all rows.  All exchanges stay in the VALU (no LDS round trip):
+                    // lane ^ 16 is v_permlane16_swap -- swapping the odd 16-lane rows of rmin[j] with the even rows of
+                    // rmin[8 + j] hands every lane exactly the partner copy of the register it keeps, in both directions
+                    // at once -- and lane ^ 8 / 4 / 2 / 1 are DPP operands of the v_min (row_ror:8; row_half_mirror then
+                    // quad_perm [3,2,1,0] = ^7 ^3; quad_perm [2,3,0,1]; quad_perm [1,0,3,2]).
                     int w8[8], w4[4], w2[2], w1;
-                    {
-                        const bool up = (lane & 16) != 0;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            int keep = up ? rmin[8 + j] : rmin[j], send = up ? rmin[j] : rmin[8 + j];
-                            w8[j] = min(keep, __shfl_xor(send, 16));
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        auto sw = __builtin_amdgcn_permlane16_swap((unsigned) rmin[j], (unsigned) rmin[8 + j], false, false);
+                        w8[j] = min((int) sw[0], (int) sw[1]);
                     }
                     {
                         const bool up = (lane & 8) != 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             int keep = up ? w8[4 + j] : w8[j], send = up ? w8[j] : w8[4 + j];
-                            w4[j] = min(keep, __shfl_xor(send, 8));
+                            w4[j] = min(keep, __builtin_amdgcn_update_dpp(0, send, 0x128 /* row_ror:8 */, 0xf, 0xf, true));
                         }
                     }
                     {
@@ -239,15 +240,16 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             int keep = up ? w4[2 + j] : w4[j], send = up ? w4[j] : w4[2 + j];
-                            w2[j] = min(keep, __shfl_xor(send, 4));
+                            const int t = __builtin_amdgcn_update_dpp(0, send, 0x141 /* row_half_mirror */, 0xf, 0xf, true);
+                            w2[j] = min(keep, __builtin_amdgcn_update_dpp(0, t, 0x1b /* quad_perm [3,2,1,0] */, 0xf, 0xf, true));
                         }
                     }
                     {
                         const bool up = (lane & 2) != 0;
                         int keep = up ? w2[1] : w2[0], send = up ? w2[0] : w2[1];
-                        w1 = min(keep, __shfl_xor(send, 2));
+                        w1 = min(keep, __builtin_amdgcn_update_dpp(0, send, 0x4e /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
                     }
-                    w1 = min(w1, __shfl_xor(w1, 1));
+                    w1 = min(w1, __builtin_amdgcn_update_dpp(0, w1, 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
                     // register index held by this lane: bit 3 <- lane bit 4, bit 2 <- bit 3, bit 1 <- bit 2, bit 0 <- bit 1
                     const int g = (lane >> 1) & 15;
                     if (F16) w1 = __float_as_int(__int_as_float(w1) * out_scale);   // back to d2~ (monotonic)
