@@ -23,6 +23,7 @@
  */
 #ifndef LGR_H
 #define LGR_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -136,6 +137,15 @@ int  lgr_ctx_get_match_options(lgr_ctx* ctx, lgr_match_options* opt);
  * HBM budget against when it pushes many pairs of different sizes through one context (src/main.cpp:384-407 loops pairs in
  * one process) */
 int  lgr_ctx_workspace_bytes(lgr_ctx* ctx, uint64_t* bytes);
+
+/* ---- building block under every grid / voxel / placement step (the reference has no counterpart: its containers are hash maps and
+ *      kd-trees): stable LSD radix sort of (key, 32-bit value) pairs on the context's stream, out of place (in != out, input kept).
+ *      u32: key bits [begin_bit, end_bit).  u64: bit ranges (shift, width), least significant first; bits outside the ranges must be
+ *      equal in all keys.  Exported for tests and for callers that build their own orderings on the device. ---- */
+int lgr_sort_pairs_u32_dev(lgr_ctx*, const uint32_t* d_keys_in, uint32_t* d_keys_out, const int32_t* d_vals_in, int32_t* d_vals_out,
+                           size_t n, int begin_bit, int end_bit);
+int lgr_sort_pairs_u64_dev(lgr_ctx*, const uint64_t* d_keys_in, uint64_t* d_keys_out, const int32_t* d_vals_in, int32_t* d_vals_out,
+                           size_t n, const int* shifts, const int* widths, int n_ranges);
 
 /* ---- include/common.h:266-280 calculateBoundingBox ---- */
 int lgr_bbox_dev(lgr_ctx*, const float* d_pts, int n, float* d_min3_max3 /* 6 floats */);

@@ -592,13 +592,26 @@ static int downsample_core(lgr_ctx* ctx, const float* d_pts, int n, float voxel,
     bad = rank + n;
     LGR_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
     voxel_keys<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_pts, n, bx, by, bz, voxel, keys, vals, bad);
-    size_t tb = 0;
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) n, 0, 64, ctx->stream));
     size_t tb2 = 0;
     LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb2, flags, rank, 0, (size_t) n, rocprim::plus<int>(), ctx->stream));
     void* tmp;
-    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, std::max(tb, tb2), &tmp));
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) n, 0, 64, ctx->stream));
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb2, &tmp));
+    {
+        // only the bits a voxel index of this cloud can set are sorted: index <= floor((max - bound) / voxel), the kernel's own
+        // expression on the largest coordinate (float subtraction, division and floor are monotone).  The z field is sorted one
+        // bit wider: that bit is 0 in every valid key and 1 in the all-ones key of an invalid point, which therefore sorts last.
+        const float bnd[3] = {bx, by, bz};
+        int shifts[3] = {0, 21, 42}, widths[3];
+        for (int a = 0; a < 3; ++a) {
+            const float q = std::floor((bb[9 + a] - bnd[a]) / voxel);
+            long long imax = (q >= 0.f && q < 2097152.f) ? (long long) q : 2097151;
+            int b = 1;
+            while ((1ll << b) <= imax) ++b;
+            widths[a] = std::min(21, b);
+        }
+        widths[2] = std::min(22, widths[2] + 1);
+        LGR_TRY(lgr_sort_pairs_u64(ctx, keys, keys2, vals, vals2, (size_t) n, shifts, widths, 3));
+    }
     head_flags<<<cdiv(n, 256), 256, 0, ctx->stream>>>(keys2, n, flags);
     LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb2, flags, rank, 0, (size_t) n, rocprim::plus<int>(), ctx->stream));
     int* h;
@@ -750,17 +763,13 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     int *vals, *vals2;
     LGR_TRY(lgr_ws_t(ctx, WS_KP_ORDER, (size_t) mx * 4 + 16, &keys));
     keys2 = keys + mx; vals = (int*) (keys2 + mx); vals2 = vals + mx;
-    size_t tb = 0;
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) mx, 0, key_bits, ctx->stream));
-    void* tmp;
-    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
     if (g.n > 0) {
         fine_keys<<<cdiv(g.n, 256), 256, 0, ctx->stream>>>(g, reinterpret_cast<const float*>(g.pxyz), 4, g.n, sb, keys, vals);
-        LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) g.n, 0, key_bits, ctx->stream));
+        LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) g.n, 0, key_bits));
         spfh_tile_kernel<<<cdiv(g.n, ST), 64, 0, ctx->stream>>>(g, r2, vals2, spfh);
     }
     fine_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, 12, m, sb, keys, vals);
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, key_bits, ctx->stream));
+    LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) m, 0, key_bits));
     fpfh_mfma_kernel<<<cdiv(m, FT), 64, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;

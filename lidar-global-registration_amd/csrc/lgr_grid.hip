@@ -247,11 +247,7 @@ int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, flo
         cell_keys<<<cdiv(n, 256), 256, 0, ctx->stream>>>(d_pts, n, mn[0], mn[1], mn[2], h, dim[0], dim[1], dim[2], (unsigned) ncell, keys, vals);
         int bits = 1;
         while (((unsigned long long) 1 << bits) <= (unsigned long long) ncell) ++bits;
-        size_t tmp_bytes = 0;
-        LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, bits, ctx->stream));
-        void* tmp;
-        LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tmp_bytes, &tmp));
-        LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t) n, 0, bits, ctx->stream));
+        LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) n, 0, bits));
         const int nblk = (int) (((size_t) ncell + 1 + CSF_CELLS - 1) >> CSF_SHIFT);   // workgroups of cell_start_fill; cells 0..ncell
         int* coarse;
         LGR_TRY(lgr_ws_t(ctx, WS_GRID_MISC, (size_t) nblk + 1 + 64, &coarse));

@@ -77,7 +77,7 @@ enum {
     WS_RANSAC_T, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK, WS_RANSAC_MASKT,
     WS_PIPE_SURF_S, WS_PIPE_SURF_T, WS_PIPE_FEAT_S, WS_PIPE_FEAT_T, WS_PIPE_IJ, WS_PIPE_JI, WS_PIPE_DIJ, WS_PIPE_DJI,
     WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_FLAGS, WS_PIPE_MISC, WS_PIPE_KIDX_S, WS_PIPE_KIDX_T, WS_PIPE_KPS_S, WS_PIPE_KPS_T,
-    WS_MS_KNN_I, WS_MS_KNN_D, WS_MS_LIST_S, WS_MS_LIST_T, WS_MS_SUB, WS_MS_FEAT_S, WS_MS_FEAT_T, WS_MS_SURF2, WS_MS_RES, WS_PLANE_VISITED, WS_PLANE_CLAIMED, WS_PLANE_OUT, WS_LOCAL_G,
+    WS_MS_KNN_I, WS_MS_KNN_D, WS_MS_LIST_S, WS_MS_LIST_T, WS_MS_SUB, WS_MS_FEAT_S, WS_MS_FEAT_T, WS_MS_SURF2, WS_MS_RES, WS_PLANE_VISITED, WS_PLANE_CLAIMED, WS_PLANE_OUT, WS_LOCAL_G, WS_SORT_TMP,
     WS_HOST_A, WS_HOST_B, WS_HOST_C, WS_HOST_D, WS_HOST_E, WS_HOST_F,
     WS_COUNT
 };
@@ -143,6 +143,12 @@ static inline int lgr_run_pair(lgr_ctx* ctx, FA&& fa, FB&& fb) {
 // points through them (an out-of-range gather is a GPU memory fault, not an error code).  One tiny launch + a 4-byte read-back;
 // skipped when ctx->corr_trusted (lgr_ransac.hip).
 int lgr_check_corr(lgr_ctx* ctx, const lgr_corr* d_corr, int c, int ns, int nt);
+// lgr_sort.hip: stable radix sort of (key, 32-bit value) pairs, out of place (in and out must differ; the input is preserved), on
+// ctx->stream.  u32: the key bits [begin_bit, end_bit); u64: the bit ranges (shift, width) listed from the least significant up --
+// bits outside the ranges must be equal in all keys.
+int lgr_sort_pairs_u32(lgr_ctx* ctx, const unsigned* kin, unsigned* kout, const int* vin, int* vout, size_t n, int begin_bit, int end_bit);
+int lgr_sort_pairs_u64(lgr_ctx* ctx, const unsigned long long* kin, unsigned long long* kout, const int* vin, int* vout, size_t n,
+                       const int* shifts, const int* widths, int n_ranges);
 // lgr_match.hip: the query-side half of a coming brute-force match (clustering + assignment / sort / placement of d_a33), run ahead
 // of the call while the train side's descriptors are still being computed; consumed by the next lgr_match_bf*_dev on the same
 // (d_a33, ma, mb, both directions) or dropped by lgr_match_prepare_cancel.

@@ -738,11 +738,7 @@ int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const fl
     const size_t assign_lds = ((size_t) KCL * (sub * 33 + 1) + 2 * MAXLEAF + 1) * 4;
     if (assign_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) assign_lds));
     assign_kernel<<<cdiv(m, ASSIGN_THREADS), ASSIGN_THREADS, assign_lds, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax);
-    size_t tb = 0;
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
-    void* tmp;
-    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
-    LGR_HIP(ctx, rocprim::radix_sort_pairs(tmp, tb, keys, keys2, vals, vals2, (size_t) m, 0, 32, ctx->stream));
+    LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) m, 0, 32));
     int* h;
     LGR_TRY(lgr_pinned(ctx, 8192, (void**) &h));
     LGR_HIP(ctx, hipMemcpyAsync(h, counts, (MAXLEAF + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -822,11 +818,7 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
                                                                       ex, comp, thr, counts, cand, offs, item_q, item_g);
         int bits = 1;
         while ((1 << bits) < n_groups) ++bits;
-        size_t sb = 0;
-        LGR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sb, item_g, item_g2, item_q, item_q2, (size_t) n_items, 0, bits, ctx->stream));
-        void* stmp;
-        LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, sb, &stmp));
-        LGR_HIP(ctx, rocprim::radix_sort_pairs(stmp, sb, item_g, item_g2, item_q, item_q2, (size_t) n_items, 0, bits, ctx->stream));
+        LGR_TRY(lgr_sort_pairs_u32(ctx, item_g, item_g2, (const int*) item_q, (int*) item_q2, (size_t) n_items, 0, bits));
         bool refiltered = false;
         *stat_pairs = 0;
         if (ra.ks) {

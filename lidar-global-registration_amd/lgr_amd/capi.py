@@ -188,6 +188,24 @@ class Context:
                                           _ptr(ab_i), _ptr(ab_d), _ptr(ba_i), _ptr(ba_d)))
         return ab_i, ab_d, ba_i, ba_d
 
+    def sort_pairs_u32(self, keys, vals, begin_bit=0, end_bit=32):
+        """lgr_sort_pairs_u32_dev: cuda int32 keys (bit patterns of the uint32 keys) and int32 values -> (keys, values) stably sorted
+        by the key bits [begin_bit, end_bit)"""
+        torch = self.torch
+        keys = keys.contiguous(); vals = vals.contiguous()
+        ko = self.empty((keys.shape[0],), torch.int32); vo = self.empty((keys.shape[0],), torch.int32)
+        self.check(_lib.lgr_sort_pairs_u32_dev(self.h, _ptr(keys), _ptr(ko), _ptr(vals), _ptr(vo), C.c_size_t(keys.shape[0]), int(begin_bit), int(end_bit)))
+        return ko, vo
+
+    def sort_pairs_u64(self, keys, vals, ranges):
+        """lgr_sort_pairs_u64_dev: cuda int64 keys (bit patterns), int32 values, ranges = [(shift, width), ...] least significant first"""
+        torch = self.torch
+        keys = keys.contiguous(); vals = vals.contiguous()
+        ko = self.empty((keys.shape[0],), torch.int64); vo = self.empty((keys.shape[0],), torch.int32)
+        sh = (C.c_int * max(1, len(ranges)))(*[r[0] for r in ranges]); wd = (C.c_int * max(1, len(ranges)))(*[r[1] for r in ranges])
+        self.check(_lib.lgr_sort_pairs_u64_dev(self.h, _ptr(keys), _ptr(ko), _ptr(vals), _ptr(vo), C.c_size_t(keys.shape[0]), sh, wd, len(ranges)))
+        return ko, vo
+
     def match_flann(self, q, t):
         """matchFLANN<FPFH> (include/matching.h:565-592): cuda float32 [m,33] -> (idx, dist)"""
         torch = self.torch
