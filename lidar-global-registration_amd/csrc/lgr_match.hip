@@ -179,6 +179,7 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
     const size_t o_cen2 = carve((size_t) MAXLEAF * 33 * 4);
     const size_t o_smp = carve((size_t) ns * 33 * 4), o_ok = carve((size_t) ns * 4), o_label = carve((size_t) ns * 4);
     const size_t o_cbuf = carve((size_t) 2 * KCL * 33 * 4), o_basis = carve((size_t) (34 * 33 + 64) * 4);
+    const size_t o_skeys = carve((size_t) 2 * ns * 4), o_svals = carve((size_t) ns * 4), o_sidx = carve((size_t) ns * 4), o_coff = carve(256);
     const size_t o_zero = off;   // zeroed once per call: largest sample magnitude, one set of level-1 sums per Lloyd step, the level-2 sums
     const size_t o_kmax = carve(256), o_acc1 = carve((size_t) KM_ITERS * KCL * sizeof(KmAcc)), o_acc2 = carve((size_t) MAXLEAF * sizeof(KmAcc));
     const size_t zero_bytes = off - o_zero;
@@ -190,6 +191,10 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
     int* label = (int*) (misc + o_label);
     float* cbuf = (float*) (misc + o_cbuf);             // two scratch copies of the level-1 centres (read one, write the other)
     float* basis = (float*) (misc + o_basis);           // V [33][33], mu [33], count; + 8: rmax2
+    unsigned* skeys = (unsigned*) (misc + o_skeys);      // [2][ns]: level-1 labels as sort keys, sorted copy
+    int* svals = (int*) (misc + o_svals);
+    int* sidx = (int*) (misc + o_sidx);                  // sample indices in cluster order
+    int* coff = (int*) (misc + o_coff);                  // [KCL + 1]
     unsigned* kmax = (unsigned*) (misc + o_kmax);
     KmAcc* acc1 = (KmAcc*) (misc + o_acc1);
     KmAcc* acc2 = (KmAcc*) (misc + o_acc2);
@@ -202,12 +207,14 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
             km1_step<<<cdiv(ns, KM1_THREADS), KM1_THREADS, 0, cx->stream>>>(smp, smp_ok, ns, kmax, cbuf + (it & 1) * KCL * 33, it ? acc1 + (size_t) (it - 1) * KCL : nullptr,
                                                                             last ? nullptr : acc1 + (size_t) it * KCL, last ? cen : cbuf + ((it + 1) & 1) * KCL * 33, label);
         }
-        km2_init<<<KCL, KM2I_THREADS, 0, cx->stream>>>(smp, label, ns, cen, sub, cen2);
+        // the samples in cluster order (stable: sample order inside a cluster)
+        km_label_keys<<<cdiv(ns, 256), 256, 0, cx->stream>>>(label, ns, skeys, svals);
+        LGR_TRY(lgr_sort_pairs_u32(cx, skeys, skeys + ns, svals, sidx, (size_t) ns, 0, 5));
+        km_cluster_offsets<<<1, 64, 0, cx->stream>>>(skeys + ns, ns, coff);
+        km2_init<<<KCL, 64, 0, cx->stream>>>(smp, sidx, coff, cen, sub, cen2);
         if (sub > 1) {
-            const size_t km2_lds = (size_t) KCL * (sub * 33 + 1) * 4;
-            if (km2_lds > 64 * 1024) LGR_HIP(cx, hipFuncSetAttribute((const void*) km2_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int) km2_lds));
             for (int it = 0; it < KM2_ITERS; ++it) {
-                km2_step<<<cdiv(ns, KM2_THREADS), KM2_THREADS, km2_lds, cx->stream>>>(smp, label, ns, kmax, cen2, sub, acc2);
+                km2_step<<<dim3(cdiv(ns, KM2_THREADS), KCL), KM2_THREADS, 0, cx->stream>>>(smp, sidx, coff, kmax, cen2, sub, acc2);
                 km2_finalize<<<n_leaves, 64, 0, cx->stream>>>(acc2, kmax, cen2);
             }
         }

@@ -96,33 +96,37 @@ __global__ __launch_bounds__(KM1_THREADS) void km1_step(const float* __restrict_
     for (int e = threadIdx.x; e < KCL * 34; e += KM1_THREADS)
         if (acc_s[e] != 0) atomicAdd((unsigned long long*) &out[e], (unsigned long long) acc_s[e]);
 }
-// second level: `sub` centres inside every cluster, seeded with evenly spaced sample members of the cluster (in sample
-// order).  One workgroup per cluster; thread t owns the samples [t * per, (t + 1) * per), ranks by a workgroup scan.
-constexpr int KM2I_THREADS = 1024;
-__global__ __launch_bounds__(KM2I_THREADS) void km2_init(const float* __restrict__ smp, const int* __restrict__ label, int ns, const float* __restrict__ cen, int sub,
-                                                         float* __restrict__ cen2) {
-    __shared__ int wsum[KM2I_THREADS / 64];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < sub * 33; e += KM2I_THREADS) cen2[(size_t) p * sub * 33 + e] = cen[p * 33 + e % 33];
-    const int per = (ns + KM2I_THREADS - 1) / KM2I_THREADS;
-    const int s0 = min(ns, tid * per), s1 = min(ns, s0 + per);
-    int mine = 0;
-    for (int s = s0; s < s1; ++s) mine += label[s] == p;
-    int incl = mine;
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();   // also: the default centres above are written before any seed below
-    int before = incl - mine, cnt = 0;
-    for (int w = 0; w < KM2I_THREADS / 64; ++w) { if (w < wave) before += wsum[w]; cnt += wsum[w]; }
-    if (cnt == 0) return;
-    int r = before;
-    for (int s = s0; s < s1; ++s) {
-        if (label[s] != p) continue;
-        const int j = (int) ((long long) r * sub / cnt);
-        const bool first = r == 0 || (int) ((long long) (r - 1) * sub / cnt) != j;
-        if (first)
-            for (int k = 0; k < 33; ++k) cen2[((size_t) p * sub + j) * 33 + k] = smp[(size_t) s * 33 + k];
-        ++r;
+// second level: `sub` centres inside every cluster.  The samples are first put in cluster order (stable sort of the sample
+// indices by their level-1 label, lgr_sort_pairs_u32; coff[p] = first sorted position of cluster p, coff[KCL] = number of
+// labelled samples), so a cluster's samples are a contiguous range: seeding is a direct index, and a workgroup of the Lloyd
+// step sees one cluster only -- its sub-centres and its integer sums fit in a few KB of LDS.
+__global__ void km_label_keys(const int* __restrict__ label, int ns, unsigned* __restrict__ keys, int* __restrict__ vals) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    const int l = label[s];
+    keys[s] = l < 0 ? (unsigned) KCL : (unsigned) l;   // unlabelled (non-finite) samples last
+    vals[s] = s;
+}
+__global__ void km_cluster_offsets(const unsigned* __restrict__ keys_sorted, int ns, int* __restrict__ coff /* [KCL + 1] */) {
+    const int p = threadIdx.x;
+    if (p > KCL) return;
+    int lo = 0, hi = ns;   // first position with key >= p
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys_sorted[mid] < (unsigned) p) lo = mid + 1; else hi = mid; }
+    coff[p] = lo;
+}
+// seeds: evenly spaced members of the cluster in sample order -- leaf j starts from the member of rank ceil(j cnt / sub) (the
+// first rank r with floor(r sub / cnt) == j); leaves without such a member (cnt < sub) start from the cluster centre
+__global__ __launch_bounds__(64) void km2_init(const float* __restrict__ smp, const int* __restrict__ sidx, const int* __restrict__ coff,
+                                               const float* __restrict__ cen, int sub, float* __restrict__ cen2) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int c0 = coff[p], cnt = coff[p + 1] - c0;
+    for (int j = lane; j < sub; j += 64) {
+        const float* src = cen + p * 33;
+        if (cnt > 0) {
+            const long long r = ((long long) j * cnt + sub - 1) / sub;
+            if (r < cnt && (int) (r * sub / cnt) == j) src = smp + (size_t) sidx[c0 + (int) r] * 33;
+        }
+        for (int k = 0; k < 33; ++k) cen2[((size_t) p * sub + j) * 33 + k] = src[k];
     }
 }
 __device__ __forceinline__ int nearest_sub(const float* v, const float* __restrict__ c2 /* [sub][33] of the row's cluster */, int sub, float& best) {
@@ -137,29 +141,37 @@ __device__ __forceinline__ int nearest_sub(const float* v, const float* __restri
     }
     return bj;
 }
-constexpr int KM2_THREADS = 512;
-// Lloyd step of the second level: km2_step labels every sample with the nearest sub-centre of its cluster (sub-centres of
-// all clusters in LDS, odd pitch per cluster as in assign_kernel) and adds it to the leaf's integer sums; km2_finalize turns
-// the sums into the new centres (an empty leaf keeps its centre) and clears them for the next step.
-__global__ __launch_bounds__(KM2_THREADS) void km2_step(const float* __restrict__ smp, const int* __restrict__ label, int ns, const unsigned* __restrict__ kmax,
-                                                        const float* __restrict__ cen2, int sub, KmAcc* __restrict__ acc2) {
-    extern __shared__ float c2s[];
-    const int pitch = sub * 33 + 1;
-    for (int e = threadIdx.x; e < KCL * sub * 33; e += blockDim.x) c2s[(e / (sub * 33)) * pitch + e % (sub * 33)] = cen2[e];
+constexpr int KM2_THREADS = 256;
+// Lloyd step of the second level: a workgroup takes 256 consecutive samples of ONE cluster (grid: x = piece, y = cluster; pieces
+// past the cluster's end leave at once), labels them with the nearest of the cluster's sub-centres and adds them to the leaves'
+// integer sums in LDS; one global atomic per touched sum at the end.  km2_finalize turns the sums into the new centres (an empty
+// leaf keeps its centre) and clears them for the next step.
+__global__ __launch_bounds__(KM2_THREADS) void km2_step(const float* __restrict__ smp, const int* __restrict__ sidx, const int* __restrict__ coff,
+                                                        const unsigned* __restrict__ kmax, const float* __restrict__ cen2, int sub, KmAcc* __restrict__ acc2) {
+    __shared__ float c2s[SUBMAX * 33];
+    __shared__ long long acc_s[SUBMAX * 34];
+    const int p = blockIdx.y;
+    const int s0 = coff[p] + blockIdx.x * KM2_THREADS, s1 = coff[p + 1];
+    if (s0 >= s1) return;
+    for (int e = threadIdx.x; e < sub * 33; e += KM2_THREADS) c2s[e] = cen2[(size_t) p * sub * 33 + e];
+    for (int e = threadIdx.x; e < sub * 34; e += KM2_THREADS) acc_s[e] = 0;
     __syncthreads();
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= ns) return;
-    int p = label[s];
-    if (p < 0) return;
-    const double scale = km_scale(*kmax);
-    float v[33], d;
+    const int s = s0 + threadIdx.x;
+    if (s < s1) {
+        const double scale = km_scale(*kmax);
+        const float* row = smp + (size_t) sidx[s] * 33;
+        float v[33], d;
 #pragma unroll
-    for (int k = 0; k < 33; ++k) v[k] = smp[(size_t) s * 33 + k];
-    const int leaf = p * sub + nearest_sub(v, c2s + p * pitch, sub, d);
-    long long* out = (long long*) &acc2[leaf];
+        for (int k = 0; k < 33; ++k) v[k] = row[k];
+        const int j = nearest_sub(v, c2s, sub, d);
 #pragma unroll
-    for (int k = 0; k < 33; ++k) atomicAdd((unsigned long long*) &out[k], (unsigned long long) (long long) rint((double) v[k] * scale));
-    atomicAdd((unsigned long long*) &out[33], 1ull);
+        for (int k = 0; k < 33; ++k) atomicAdd((unsigned long long*) &acc_s[j * 34 + k], (unsigned long long) (long long) rint((double) v[k] * scale));
+        atomicAdd((unsigned long long*) &acc_s[j * 34 + 33], 1ull);
+    }
+    __syncthreads();
+    long long* out = (long long*) (acc2 + (size_t) p * sub);
+    for (int e = threadIdx.x; e < sub * 34; e += KM2_THREADS)
+        if (acc_s[e] != 0) atomicAdd((unsigned long long*) &out[e], (unsigned long long) acc_s[e]);
 }
 __global__ __launch_bounds__(64) void km2_finalize(KmAcc* __restrict__ acc2, const unsigned* __restrict__ kmax, float* __restrict__ cen2) {
     const int leaf = blockIdx.x, k = threadIdx.x;
