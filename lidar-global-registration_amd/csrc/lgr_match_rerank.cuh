@@ -559,8 +559,13 @@ __global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, c
             if (pos0 + e < cap) { pair_q[pos0 + e] = buf_q[wave][e]; pair_t[pos0 + e] = buf_t[wave][e]; }
         n_buf = 0;
     };
+    // The four waves of a workgroup hold 4 x 32 consecutive items, which mostly belong to one or two (group, cluster) runs: the
+    // run is chosen for the whole workgroup and its train tiles go through LDS once for all four waves (every wave fetching
+    // its own copy made the kernel a re-reader of operand tiles: 5-6 GB per launch at 1M).  A wave without items in the run
+    // only joins the barriers.
+    __shared__ __attribute__((aligned(16))) f16x8 tile_s[KS * 64];
+    __shared__ unsigned long long runkey_s[RF_THREADS / 64];
     const unsigned base = (blockIdx.x * (RF_THREADS / 64) + wave) * 32u;
-    if (base >= n_items) return;
     // lane c (both halves) owns item base + c
     const bool have = base + c < n_items;
     const unsigned my_g = have ? item_g[base + c] : 0xffffffffu;
@@ -572,43 +577,76 @@ __global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, c
         my_e = group_eps<ROWDIR>(my_q, (int) my_g, xq, nQ_sets, gmax, n_groups, my_p, cl_of_group, q_pad, ex);
         my_thr = thr_in[my_q];
     }
+    const unsigned long long my_key = have ? (((unsigned long long) my_g << 8) | (unsigned) my_p) : ~0ull;
     bool todo = have;
-    while (__ballot(todo) != 0ull) {
-        // the run of this round: all pending items with the (group, cluster) of the first pending one
-        const int first = __ffsll((long long) __ballot(todo)) - 1;
-        const unsigned g = (unsigned) __builtin_amdgcn_readlane((int) my_g, first);
-        const int p = __builtin_amdgcn_readlane(my_p, first);
-        const bool act = todo && my_g == g && my_p == p;
-        todo = todo && !act;
-        if (ROWDIR) {   // thresholds by accumulator row: inactive rows can never pass
-            if (half == 0) { thr_s[wave][c] = act ? my_thr : -__uint_as_float(0x7f800000u); eps_s[wave][c] = act ? my_e : 0.f; q_s[wave][c] = my_q; }
-        }
-        // the queries' fragments: lane (c, half) reads the 8 halves of its query for every K step
-        f16x8 qf[KS];
+    constexpr int PIECES = KS * 64;   // 16-byte pieces of a train tile
+    for (;;) {
+        // the run of this round: all pending items of the workgroup with the smallest pending (group, cluster)
         {
+            const unsigned long long pend = __ballot(todo);
+            unsigned long long first_key = ~0ull;
+            if (pend) {   // items are sorted: the first pending lane holds the wave's smallest key
+                const int first = __ffsll((long long) pend) - 1;
+                const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) my_key, first);
+                const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (my_key >> 32), first);
+                first_key = ((unsigned long long) hi << 32) | lo;
+            }
+            __syncthreads();   // the previous round's readers of runkey_s / tile_s are done
+            if (lane == 0) runkey_s[wave] = first_key;
+            __syncthreads();
+        }
+        unsigned long long rk = runkey_s[0];
+#pragma unroll
+        for (int w = 1; w < RF_THREADS / 64; ++w) rk = runkey_s[w] < rk ? runkey_s[w] : rk;
+        if (rk == ~0ull) break;
+        const unsigned g = (unsigned) (rk >> 8);
+        const int p = (int) (rk & 0xffull);
+        const bool act = todo && my_key == rk;
+        todo = todo && !act;
+        const bool wave_on = __ballot(act) != 0ull;
+        f16x8 qf[KS];
+        float thr_r[16], eps_r[16];
+        int q_r[16];
+        if (wave_on) {
+            if (ROWDIR) {   // thresholds by accumulator row: inactive rows can never pass
+                if (half == 0) { thr_s[wave][c] = act ? my_thr : -__uint_as_float(0x7f800000u); eps_s[wave][c] = act ? my_e : 0.f; q_s[wave][c] = my_q; }
+            }
+            // the queries' fragments: lane (c, half) reads the 8 halves of its query for every K step
             const f16x8* src = ROWDIR ? ra.Ap : ra.Bp + (size_t) p * ra.bset_stride;
             const size_t o = ((size_t) (my_q >> 5) * KS) * 64 + (my_q & 31) + 32 * half;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) qf[kk] = src[o + (size_t) kk * 64];
-        }
-        float thr_r[16], eps_r[16];
-        int q_r[16];
-        if (ROWDIR) {
+            if (ROWDIR) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                thr_r[r] = thr_s[wave][row]; eps_r[r] = eps_s[wave][row]; q_r[r] = q_s[wave][row];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    thr_r[r] = thr_s[wave][row]; eps_r[r] = eps_s[wave][row]; q_r[r] = q_s[wave][row];
+                }
             }
         }
         const int j0 = starts ? starts[g] : (int) g * group_size, j1 = starts ? starts[g + 1] : min(t_pad, j0 + group_size);
         const f16x8* tsrc = ROWDIR ? ra.Bp + (size_t) p * ra.bset_stride : ra.Ap;
+        // train tiles: fetched by the whole workgroup (the next one into registers while the current one is consumed), one LDS copy
+        f16x8 nx0, nx1;
+        auto fetch = [&](int t0) {
+            const f16x8* tb = tsrc + (size_t) (t0 >> 5) * KS * 64;
+            nx0 = tb[threadIdx.x];
+            if ((int) threadIdx.x + RF_THREADS < PIECES) nx1 = tb[threadIdx.x + RF_THREADS];
+        };
+        if (j0 < j1) fetch(j0);
         for (int t0 = j0; t0 < j1; t0 += TILE) {
-            f16x8 tf[KS];
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) tf[kk] = tsrc[((size_t) (t0 >> 5) * KS + kk) * 64 + lane];
+            __syncthreads();   // the previous tile has been read by every wave
+            tile_s[threadIdx.x] = nx0;
+            if ((int) threadIdx.x + RF_THREADS < PIECES) tile_s[threadIdx.x + RF_THREADS] = nx1;
+            __syncthreads();
+            if (t0 + TILE < j1) fetch(t0 + TILE);
+            if (!wave_on) continue;
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) acc = ROWDIR ? mfma_step(qf[kk], tf[kk], acc) : mfma_step(tf[kk], qf[kk], acc);
+            for (int kk = 0; kk < KS; ++kk) {
+                const f16x8 tf = tile_s[kk * 64 + lane];
+                acc = ROWDIR ? mfma_step(qf[kk], tf, acc) : mfma_step(tf, qf[kk], acc);
+            }
             // ROWDIR: acc[r] = (query row (r&3) + 8 (r>>2) + 4 half, train column c); COLDIR: (train row ..., query column c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
