@@ -708,7 +708,9 @@ extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const floa
         S = snap; ns = n;
     }
     GridDev g;
-    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, S, ns, 0.f, 4.f, &g));
+    // cell size for about 6 points per cell (measured at 1M, k = 30: 2 / 3 / 4 / 6 / 8 / 12 / 16 points per cell -> 6.2 / 5.3 / 4.8 / 4.1 / 4.0 /
+    // 4.1 / 4.0 ms for the two clouds' normals, the later stages slowing down slightly from 8 on; the neighbours do not depend on it)
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, S, ns, 0.f, 6.f, &g));
     size_t sm = (size_t) k * NB * 8;
     const float vx = vp3 ? vp3[0] : 0.f, vy = vp3 ? vp3[1] : 0.f, vz = vp3 ? vp3[2] : 0.f;
     if (!d_surf) {
