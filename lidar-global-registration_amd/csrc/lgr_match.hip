@@ -110,7 +110,13 @@ static int box_basis(lgr_ctx* ctx, bool raw, const float* smp, const int* smp_ok
             }
         // cyclic Jacobi; rows of Vd become the eigenvectors.  Whatever it converges to, Vd stays a product of plane
         // rotations, i.e. orthonormal -- which is all the bound needs.
-        for (int sweep = 0; sweep < 12; ++sweep)
+        double tr = 0.0;
+        for (int i = 0; i < 33; ++i) tr += std::fabs(C[i * 33 + i]);
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            double off = 0.0;   // converged: the off-diagonal part is at rounding level (more sweeps would only cost host time)
+            for (int p = 0; p < 32; ++p)
+                for (int q = p + 1; q < 33; ++q) off = std::max(off, std::fabs(C[p * 33 + q]));
+            if (off <= 1e-13 * tr) break;
             for (int p = 0; p < 32; ++p)
                 for (int q = p + 1; q < 33; ++q) {
                     double apq = C[p * 33 + q];
@@ -131,6 +137,7 @@ static int box_basis(lgr_ctx* ctx, bool raw, const float* smp, const int* smp_ok
                         Vd[p * 33 + k] = c * vpk - sn * vqk; Vd[q * 33 + k] = sn * vpk + c * vqk;
                     }
                 }
+        }
     }
     for (int i = 0; i < 33 * 33; ++i) h[i] = (float) Vd[i];
     for (int k = 0; k < 33; ++k) h[33 * 33 + k] = (float) mu[k];
@@ -139,8 +146,8 @@ static int box_basis(lgr_ctx* ctx, bool raw, const float* smp, const int* smp_ok
     return LGR_OK;
 }
 
-// Clustering of one call: centres, leaves, the box basis, and -- when the query side was prepared ahead of the call -- the built
-// query side.  lgr_match_prepare (below) fills it while the train side's descriptors are still being computed; match_impl consumes it.
+// Clustering of one call: centres, leaves, the box basis.  lgr_match_prepare (below) computes it from the query side ahead of the
+// call, while the train side's descriptors are still being computed; match_impl consumes it.
 struct MatchPrep {
     bool armed = false;            // prepared ahead of the call and not yet consumed
     const float* d_a = nullptr;    // what it was prepared for
@@ -241,9 +248,9 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
     return LGR_OK;
 }
 
-// Query-side half of a coming lgr_match_bf*_dev(ctx, d_a, ma, <train side of mb rows>, both directions or not): clustering from the
-// query side's descriptors and the query side's assignment / sort / placement, so that the caller can run it while the train
-// side's descriptors are still being computed on another context.  Consumed by the next matcher call on this context when
+// Clustering for a coming lgr_match_bf*_dev(ctx, d_a, ma, <train side of mb rows>, both directions or not) from the query side's
+// descriptors alone (a chain of ~60 short launches and one host Jacobi), so that the caller can run it while the train side's
+// descriptors are still being computed on another context.  Consumed by the next matcher call on this context when
 // (d_a, ma, mb, both, options) agree; lgr_match_prepare_cancel drops it (every exit path of the caller).
 int lgr_match_prepare(lgr_ctx* ctx, const float* d_a, int ma, int mb, bool both) {
     MatchPrep* P = match_prep_of(ctx);
@@ -251,7 +258,6 @@ int lgr_match_prepare(lgr_ctx* ctx, const float* d_a, int ma, int mb, bool both)
     if (!d_a || ma <= 0 || mb <= 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     LGR_TRY(match_cluster(ctx, d_a, ma, nullptr, mb, both, false, P));
-    LGR_TRY(build_side(ctx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, &P->A));
     P->armed = true;
     return LGR_OK;
 }
@@ -284,14 +290,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const bool prepared = P->armed && P->d_a == d_a && P->ma == ma && P->mb == mb && P->both == both && memcmp(&P->mopt, &mo, sizeof mo) == 0;
     P->armed = false;
     Side B;
-    if (prepared) {
-        LGR_TRY(build_side(ctx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B));
-    } else {
-        LGR_TRY(match_cluster(ctx, d_a, ma, d_b, mb, both, true, P));
-        // the two sides are independent (assign, sort, two host read-backs each): side by side on the two contexts
-        LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, &P->A); },
-                             [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B); }));
-    }
+    if (!prepared) LGR_TRY(match_cluster(ctx, d_a, ma, d_b, mb, both, true, P));
+    // the two sides are independent (assign, sort, two host read-backs each): side by side on the two contexts
+    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, &P->A); },
+                         [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B); }));
     const Side& A = P->A;
     const int sub = P->sub, n_leaves = KCL * sub, rg_rows = P->rg_rows, ns = P->ns;
     float *const cen = P->cen, *const cen2 = P->cen2, *const smp = P->smp;
@@ -304,6 +306,36 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     g_last_stats.rg_rows = rg_rows;
     const int ta = ma_pad / TILE, tb = mb_pad / TILE;
     const int n_rb = ma_pad / BLOCK_ROWS, n_stage_total = mb_pad / STAGE_COLS;
+
+    // The rows in sorted order (exact rerank, box bounds) and the bounding boxes of the row blocks / leaves need nothing of the operand
+    // packing below: four launches on the second stream, which run under the packing passes (joined before section 4).
+    float *sortedA = nullptr, *sortedB;
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_B, (size_t) mb_pad * 33, &sortedB));
+    if (both || prune) LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_A, (size_t) ma_pad * 33, &sortedA));
+    const bool boxes = prune && mo.box_bounds != 0;
+    float *boxA = nullptr, *boxBt = nullptr;
+    unsigned* rmax2 = nullptr;
+    if (boxes) {
+        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BOX, (size_t) n_rb * 66 + (size_t) n_leaves * 66 + 64, &boxA));
+        boxBt = boxA + (size_t) n_rb * 66;
+        rmax2 = (unsigned*) (boxBt + (size_t) n_leaves * 66);
+    }
+    {
+        LGR_TRY(lgr_ctx_aux(ctx));
+        hipStream_t s2 = ctx->aux->stream;
+        LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
+        LGR_HIP(ctx, hipStreamWaitEvent(s2, ctx->aux_ev, 0));
+        gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, s2>>>(d_b, B.perm, mb_pad, sortedB);
+        if (sortedA) gather_rows_kernel<<<cdiv((long long) ma_pad * 33, 256), 256, 0, s2>>>(d_a, A.perm, ma_pad, sortedA);
+        if (boxes) {
+            const float* basis = P->basis;   // V [33][33], mu [33] (match_cluster)
+            LGR_HIP(ctx, hipMemsetAsync(rmax2, 0, 4, s2));
+            box_kernel<<<n_rb, 256, 0, s2>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
+            box_kernel<<<n_leaves, 256, 0, s2>>>(sortedB, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
+        }
+        LGR_HIP(ctx, hipGetLastError());
+        LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, s2));
+    }
 
     // ---- 3. pack operands, group maxima, stage -> leaf map
     const bool f16 = mo.operand_format != 0;
@@ -424,13 +456,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     }
     group_max_kernel<<<dim3(n_groups, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, 0, group_start, gmaxB);
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
-    float *sortedA = nullptr, *sortedB;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_B, (size_t) mb_pad * 33, &sortedB));
-    gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, sortedB);
-    if (both || prune) {
-        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_SORTED_A, (size_t) ma_pad * 33, &sortedA));
-        gather_rows_kernel<<<cdiv((long long) ma_pad * 33, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, sortedA);
-    }
+    // (sortedA / sortedB / the boxes: forked onto the second stream above) -- from here on this stream may read them
+    LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev, 0));
 
     // ---- 4. MFMA passes into the two minimum tables (+inf initialised)
     int *rowmin, *colmin = nullptr;
@@ -522,7 +549,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(16);
-        const size_t o_boxa = pcarve((size_t) n_rb * 66 * 4), o_boxb = pcarve((size_t) n_leaves * 66 * 4);
         const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
         const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
@@ -598,25 +624,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             LGR_HIP(cx, hipGetLastError());
             return (int) LGR_OK;
         };
-        if (mo.box_bounds) {
-            float* boxA = (float*) (pb + o_boxa);
-            float* boxBt = (float*) (pb + o_boxb);
-            float* basis = P->basis;                             // V [33][33], mu [33] (match_cluster)
-            unsigned* rmax2 = (unsigned*) (basis + 34 * 33 + 8);
-            // ball bounds on this context, boxes on the second one, side by side
-            LGR_TRY(lgr_run_pair(ctx,
-                launch_lb,
-                [&](lgr_ctx* cx) {
-                    LGR_HIP(cx, hipMemsetAsync(rmax2, 0, 4, cx->stream));
-                    box_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
-                    box_kernel<<<n_leaves, 256, 0, cx->stream>>>(sortedB, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
-                    LGR_HIP(cx, hipGetLastError());
-                    return (int) LGR_OK;
-                }));
-            box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
-        } else {
-            LGR_TRY(launch_lb(ctx));
-        }
+        LGR_TRY(launch_lb(ctx));
+        if (boxes) box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
         auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {
             if (len <= NEAR_LDS_MAX) {
