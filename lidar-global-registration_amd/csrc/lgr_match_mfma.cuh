@@ -373,6 +373,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
             if (COARSE) {
                 // the recorded tiles, in column order: the whole chain on B fragments read straight from memory (the stage
                 // image has the same order there as in LDS), the usual epilogue, row minima flushed when the group changes
+                PROF_T(t_k0);
                 unsigned any = kept[0] | kept[1] | kept[2] | kept[3];
                 int prev_grp = -1;
                 while (any) {
@@ -396,6 +397,8 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     }
                 }
                 if (prev_grp >= 0) flush_rows(prev_grp);
+                PROF_T(t_k1);
+                PROF_ADD(5, t_k0, t_k1);
             }
             PROF_T(t_v2);
             PROF_ADD(1, t_v1, t_v2);
