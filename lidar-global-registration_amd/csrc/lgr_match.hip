@@ -302,8 +302,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     Side B;
     if (!prepared) LGR_TRY(match_cluster(ctx, d_a, ma, d_b, mb, both, true, P));
     // the two sides are independent (assign, sort, two host read-backs each): side by side on the two contexts
-    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, &P->A); },
-                         [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, &B); }));
+    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, 0, &P->A); },
+                         [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, 1, &B); }));
     const Side& A = P->A;
     const int sub = P->sub, n_leaves = KCL * sub, rg_rows = P->rg_rows, ns = P->ns;
     float *const cen = P->cen, *const cen2 = P->cen2, *const smp = P->smp;
@@ -361,20 +361,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 12, ctx->stream));
     bool force_dense = false;
     if (f16) {
-        // norms first: the power-of-two scale 2^s puts the largest operand (2 |a'| 2^s, |b'| 2^s) just under 2^15; the same
-        // pass measures the largest energy of the three coordinates the rotated 30-D format would drop
-        pack16_kernel<false, true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, nullptr, nAp, d_max + 1);
-        pack16_kernel<false, true><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, nullptr, nBp, d_max + 1);
-        norm_max_kernel<<<std::min(cdiv(ma_pad, 256), 2048), 256, 0, ctx->stream>>>(nAp, (size_t) ma_pad, d_max);
-        norm_max_kernel<<<std::min(cdiv((long long) KCL * mb_pad, 256), 2048), 256, 0, ctx->stream>>>(nBp, (size_t) KCL * mb_pad, d_max);
-        unsigned* h_max;
-        LGR_TRY(lgr_pinned(ctx, 64, (void**) &h_max));
-        LGR_HIP(ctx, hipMemcpyAsync(h_max, d_max, 12, hipMemcpyDeviceToHost, ctx->stream));
-        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        float r2, drop2;
-        memcpy(&r2, h_max, 4);
-        memcpy(&drop2, h_max + 1, 4);
-        force_dense = h_max[2] != 0u;
+        // the power-of-two scale 2^s puts the largest operand (2 |a'| 2^s, |b'| 2^s) just under 2^15; the largest |x - c|^2 and the
+        // largest energy of the three coordinates the rotated 30-D format would drop come from assign_kernel (build_side)
+        const float r2 = std::max(A.nstat_n2, B.nstat_n2), drop2 = std::max(A.nstat_drop, B.nstat_drop);
+        force_dense = A.nstat_ovf || B.nstat_ovf;
         // Rotated format (FMT_F16R) when what it drops is negligible: with u the dropped coordinates of a row relative to a
         // centre, d2 = d2_30 + |u_a - u_b|^2 and 0 <= |u_a - u_b|^2 <= 4 max |u|^2 -- that bound joins the absolute error
         // term, so the choice below only trades speed.  FPFH rows: every block sums to 100 -> max |u|^2 ~ 1e-7.

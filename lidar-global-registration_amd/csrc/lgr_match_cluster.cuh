@@ -187,9 +187,15 @@ __global__ __launch_bounds__(64) void km2_finalize(KmAcc* __restrict__ acc2, con
 // cluster centre.  Invalid rows: 0xffffffff.  counts[leaf] / counts[MAXLEAF] (invalid) and the squared leaf radii
 // rmax[leaf] = max |x - c_leaf|^2 (float bits) are accumulated through LDS.
 constexpr int ASSIGN_THREADS = 512;
+// nstat (the operand statistics the f16 packing needs before it can choose its scale; they used to cost a pass of their own over
+// both sets): [0] largest finite |x - c|^2 (float bits) over the centres the row will be packed against -- its own cluster's
+// (role 0, query side) or all KCL (role 1, train side: one operand copy per column set) --, [1] the largest energy of the three
+// coordinates the rotated 30-D format drops (u_j = block sum of x - c over sqrt(11); summed in double, rounded up: the same
+// expression as the packing kernel's), [2] set when such a |x - c|^2 overflows float.
 __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __restrict__ X, int m, const float* __restrict__ cen, const float* __restrict__ cen2, int sub,
                                                                 unsigned* __restrict__ keys, int* __restrict__ vals, uint8_t* __restrict__ valid,
-                                                                int* __restrict__ counts /* [MAXLEAF+1] */, unsigned* __restrict__ rmax /* [MAXLEAF] */) {
+                                                                int* __restrict__ counts /* [MAXLEAF+1] */, unsigned* __restrict__ rmax /* [MAXLEAF] */,
+                                                                int role, unsigned* __restrict__ nstat /* [3] */) {
     // All sub-centres live in LDS (dynamic; up to 16 x 64 x 33 floats = 135 KB): every lane walks the sub-centres of ITS
     // cluster, which from global memory is a per-lane gather of 33 x sub words.  The odd pitch per cluster keeps lanes of
     // different clusters on different banks; lanes of one cluster read the same word (broadcast).
@@ -201,6 +207,8 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
     for (int i = threadIdx.x; i <= MAXLEAF; i += blockDim.x) { lc[i] = 0; if (i < MAXLEAF) lr[i] = 0u; }
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float st_n2 = 0.f, st_drop = 0.f;
+    bool st_ovf = false;
     if (i < m) {
         float v[33], r2;
         bool ok = row_finite(X + (size_t) i * 33, v);
@@ -209,7 +217,31 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
             // a finite row whose squared distance to every centre overflows float stays a valid row (its exact distance to
             // a duplicate of itself is 0 in the reference); it lands in leaf 0 of cluster 0 with an infinite radius, and
             // the overflow sends the whole call down the exact dense path (match_impl, force_dense)
-            int c = nearest_centre(v, cen, r2);
+            // nearest centre (as nearest_centre) with the packing statistics of every centre on the way
+            int c = 0;
+            r2 = __uint_as_float(0x7f800000u);
+            float own_drop = 0.f;
+#pragma unroll 1
+            for (int cc = 0; cc < KCL; ++cc) {
+                float d = 0.f;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 33; ++k) {
+                    const float t = v[k] - cen[cc * 33 + k];
+                    d = d + t * t;
+                    if (k < 11) s0 += (double) t; else if (k < 22) s1 += (double) t; else s2 += (double) t;
+                }
+                const float dr = (float) (((s0 * s0 + s1 * s1) + s2 * s2) * (1.0001 / 11.0)) * 1.000001f + 1e-20f * d;
+                if (d < r2) { r2 = d; c = cc; own_drop = dr; }
+                if (role == 1) {
+                    if (d < FLT_BIG) st_n2 = fmaxf(st_n2, d); else st_ovf = true;
+                    st_drop = fmaxf(st_drop, dr);
+                }
+            }
+            if (role == 0) {
+                if (r2 < FLT_BIG) st_n2 = r2; else st_ovf = true;
+                st_drop = own_drop;
+            }
             float rl2;
             int j = nearest_sub(v, c2s + c * pitch, sub, rl2);
             if (!(r2 < FLT_BIG)) r2 = __uint_as_float(0x7f800000u);
@@ -226,6 +258,13 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
     for (int l = threadIdx.x; l <= MAXLEAF; l += blockDim.x) {
         if (lc[l]) atomicAdd(&counts[l], lc[l]);
         if (l < MAXLEAF && lr[l]) atomicMax(&rmax[l], lr[l]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { st_n2 = fmaxf(st_n2, __shfl_xor(st_n2, o)); st_drop = fmaxf(st_drop, __shfl_xor(st_drop, o)); }
+    const bool any_ovf = __ballot(st_ovf) != 0ull;
+    if ((threadIdx.x & 63) == 0) {   // (a plain look first: same-address atomics from every wave would serialise in L2)
+        if (st_n2 > 0.f && __float_as_uint(st_n2) > *(volatile unsigned*) &nstat[0]) atomicMax(&nstat[0], __float_as_uint(st_n2));
+        if (st_drop > 0.f && __float_as_uint(st_drop) > *(volatile unsigned*) &nstat[1]) atomicMax(&nstat[1], __float_as_uint(st_drop));
+        if (any_ovf) nstat[2] = 1u;
     }
 }
 

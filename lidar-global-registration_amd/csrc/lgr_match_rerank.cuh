@@ -752,6 +752,8 @@ struct Side {
     int* leaf_start = nullptr;    // [n_leaves + 1] padded start of every leaf (device); leaf l covers [start[l], start[l+1])
     int* leaf_count = nullptr;    // [MAXLEAF + 1] valid rows per leaf (device; [MAXLEAF] = invalid rows)
     unsigned* r2max = nullptr;    // [MAXLEAF] squared leaf radius bits (device)
+    float nstat_n2 = 0.f, nstat_drop = 0.f;   // assign_kernel's packing statistics of this side (largest |x - c|^2, dropped energy)
+    bool nstat_ovf = false;
     std::vector<int> h_blkcl;     // host copies
     std::vector<int> h_leaf_start;
 };
@@ -759,7 +761,7 @@ struct Side {
 // assign + sort + place one side.  Leaves start at multiples of leaf_unit, clusters at multiples of cluster_unit
 // (a multiple of 256 and of leaf_unit); padding positions carry perm = -1.
 int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const float* cen2, int sub, int leaf_unit, int cluster_unit,
-               int ws_keys, int ws_perm, Side* s) {
+               int ws_keys, int ws_perm, int role, Side* s) {
     s->m = m;
     const int n_leaves = KCL * sub;
     unsigned *keys, *keys2;
@@ -775,12 +777,17 @@ int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const fl
     LGR_HIP(ctx, hipMemsetAsync(counts, 0, 16384, ctx->stream));
     const size_t assign_lds = ((size_t) KCL * (sub * 33 + 1) + 2 * MAXLEAF + 1) * 4;
     if (assign_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) assign_lds));
-    assign_kernel<<<cdiv(m, ASSIGN_THREADS), ASSIGN_THREADS, assign_lds, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax);
+    unsigned* nstat = (unsigned*) (kbuf + body + 12288);   // [3], inside the 16 KB cleared above
+    assign_kernel<<<cdiv(m, ASSIGN_THREADS), ASSIGN_THREADS, assign_lds, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax, role, nstat);
     LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) m, 0, 32));
     int* h;
     LGR_TRY(lgr_pinned(ctx, 8192, (void**) &h));
     LGR_HIP(ctx, hipMemcpyAsync(h, counts, (MAXLEAF + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + MAXLEAF + 8, nstat, 12, hipMemcpyDeviceToHost, ctx->stream));
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(&s->nstat_n2, h + MAXLEAF + 8, 4);
+    memcpy(&s->nstat_drop, h + MAXLEAF + 9, 4);
+    s->nstat_ovf = h[MAXLEAF + 10] != 0;
     std::vector<int> starts(2 * (size_t) MAXLEAF + 2, 0);   // [0..MAXLEAF): sorted start, [MAXLEAF..2*MAXLEAF]: padded start
     int acc = 0, pacc = 0;
     s->h_blkcl.clear();
