@@ -357,7 +357,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     float *nAp, *nBp;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_NORMS, (size_t) ma_pad + (size_t) KCL * mb_pad + 64, &nAp));
     nBp = nAp + ma_pad;
-    unsigned* d_max = (unsigned*) (misc + 128);   // [0] largest finite norm, [1] dropped energy, [2] norm overflow flag
+    unsigned* d_max = (unsigned*) (misc + 128);   // [2]: norm overflow flag of the f32 packing (the f16 statistics come from assign_kernel)
     LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 12, ctx->stream));
     bool force_dense = false;
     if (f16) {
@@ -416,11 +416,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         force_dense = h_ovf[0] != 0u;
     } else {
         if (rot) {
-            pack16_kernel<true, false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, nullptr);
-            pack16_kernel<true, false><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
+            pack16_kernel<true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
+            pack16_kernel<true><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
         } else {
-            pack16_kernel<false, false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, nullptr);
-            pack16_kernel<false, false><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, nullptr);
+            pack16_kernel<false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
+            pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
         }
     }
     const int n_rg = cdiv(ma_pad, rg_rows);
@@ -612,11 +612,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 f16x8* Cop = (f16x8*) (pb + o_cop);
                 centre_perm_kernel<<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(n_leaves, n_cpad, cperm);
                 if (rot) {
-                    pack16_kernel<true, false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
+                    pack16_kernel<true><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC);
                     lb_mfma_kernel<OpFmt<FMT_F16R>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
                                                                                              B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
                 } else {
-                    pack16_kernel<false, false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
+                    pack16_kernel<false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC);
                     lb_mfma_kernel<OpFmt<FMT_F16>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
                                                                                             B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
                 }

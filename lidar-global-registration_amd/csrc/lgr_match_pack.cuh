@@ -60,20 +60,19 @@ __device__ __forceinline__ void helmert11(const float* __restrict__ x, float* __
     *u = pre * 0.30151134457776363f;
 }
 
-template <bool ROT, bool NORMS_ONLY>
+template <bool ROT>
 __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
                               const float* __restrict__ cen, const int* __restrict__ blkcl, F16Scale sc,
-                              _Float16* __restrict__ P, float* __restrict__ nrm, unsigned* __restrict__ drop_max) {
+                              _Float16* __restrict__ P, float* __restrict__ nrm) {
     int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = pos < n_pad;
-    if (!in_range) pos = n_pad - 1;           // keep whole waves alive for the reduction below; nothing is stored
+    if (!in_range) pos = n_pad - 1;           // (nothing is stored for these lanes)
     // the row is read once (a 132-byte gather) and packed for every set: 16 column sets, one per centre, or the row set
     const int n_sets = role == 1 ? KCL : 1;
     const int o = perm[pos];
     float x0[33];
 #pragma unroll
     for (int k = 0; k < 33; ++k) x0[k] = o >= 0 ? X[(size_t) o * 33 + k] : 0.f;
-    float drop = 0.f;
 #pragma unroll 1
     for (int set = 0; set < n_sets; ++set) {
     const int c = role == 1 ? set : blkcl[pos / BLOCK_ROWS];
@@ -88,18 +87,6 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X
         n2 = __uint_as_float(0x7f800000u);
     }
     if (in_range) nrm[(size_t) set * n_pad + pos] = n2;   // |x'|^2 in all 33 coordinates: the magnitude the error bounds are stated in
-    if (NORMS_ONLY) {
-        // first pass: norms (the scale is chosen from the largest one) and the largest energy of the three coordinates
-        // the rotated format drops, u_k = (sum of block k of x') / sqrt(11): summed in double (exact for any realistic
-        // exponent spread), rounded up; one atomic per wave
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { s0 += (double) v[k]; s1 += (double) v[11 + k]; s2 += (double) v[22 + k]; }
-        float d2 = (o >= 0 && in_range) ? (float) (((s0 * s0 + s1 * s1) + s2 * s2) * (1.0001 / 11.0)) * 1.000001f + 1e-20f * n2 : 0.f;
-        drop = fmaxf(drop, d2);
-        if (o >= 0 && in_range && !(n2 < FLT_BIG)) drop_max[1] = 1u;   // |x'|^2 overflows float: the filter cannot represent this row
-        continue;
-    }
     float y[30], u0, u1, u2;
     if (ROT) { helmert11(v, y, &u0); helmert11(v + 11, y + 10, &u1); helmert11(v + 22, y + 20, &u2); }
     if (!in_range) continue;
@@ -163,28 +150,6 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X
         base[(piece >> 1) * 64 + ((piece & 1) << 5) + r] = w;
     }
     }   // sets
-    if (NORMS_ONLY) {
-        for (int sh = 32; sh > 0; sh >>= 1) drop = fmaxf(drop, __shfl_xor(drop, sh));
-        // (a plain look first: same-address atomics from every wave would serialise in L2; a stale value only costs an atomic)
-        if ((threadIdx.x & 63) == 0 && drop > 0.f && __float_as_uint(drop) > *(volatile unsigned*) drop_max) atomicMax(drop_max, __float_as_uint(drop));
-    }
-}
-
-// largest finite |x - c|^2 over all rows and sets (float bits through atomicMax; values are >= 0): one atomic per block
-__global__ __launch_bounds__(256) void norm_max_kernel(const float* __restrict__ nrm, size_t n, unsigned* __restrict__ out) {
-    float v = 0.f;
-    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) {
-        float t = nrm[i];
-        if (t < FLT_BIG) v = fmaxf(v, t);
-    }
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    __shared__ float sh[4];
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-        if (v > 0.f) atomicMax(out, __float_as_uint(v));
-    }
 }
 
 // original rows in padded (cluster-sorted) order, contiguous, for the exact rerank (padding rows are never read)
