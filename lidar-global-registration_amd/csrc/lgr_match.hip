@@ -543,7 +543,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         size_t poff = 0;
         auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
         const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
-        const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
+        const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
         const size_t o_ust = pcarve((size_t) n_stage_total * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
@@ -557,6 +557,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         uint8_t* sched = (uint8_t*) (pb + o_sched);
         unsigned* mask = (unsigned*) (pb + o_mask);
         float* u_rb = (float*) (pb + o_urb);
+        float* u_rt = (float*) (pb + o_urt);
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
         unsigned* u_stage = (unsigned*) (pb + o_ust);
@@ -577,7 +578,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             ca_on.lin = (float) (2.0 * (double) ex.lin * 1.00001 + 1e-30);
             ca_on.abs = (float) (((double) ex.abs * 1.00001 + 2.0 * (double) sc.a_norm[0] * std::ldexp(1.0, -25) * (double) sc.inv_s2) * 1.000001 + 1e-12);
             ca_on.cnt = coarse_cnt;
-            chk_uq_rows = u_rb; chk_uq_cols = both ? u_stage : nullptr;
+            chk_uq_rows = u_rt; chk_uq_cols = both ? u_stage : nullptr;
         }
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
@@ -646,7 +647,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         for (int pass = 0; pass <= n_beta; ++pass) {
             if (pass > 0) {
                 build_comp();
-                row_u_kernel<<<n_rb, BLOCK_ROWS, (size_t) (n_groups + 8) * 4, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, comp_rows, u_rb);
+                row_u_kernel<<<n_rb, BLOCK_ROWS, (size_t) (n_groups + 8) * 4, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, comp_rows, u_rb, u_rt);
                 if (both) {
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
                     LGR_HIP(ctx, hipMemsetAsync(u_stage, 0, (size_t) n_stage_total * 4, ctx->stream));
@@ -661,7 +662,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             init_tables_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             CoarseArgs ca = ca_on;
-            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_stage = both ? u_stage : nullptr; }
+            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_stage = both ? u_stage : nullptr; }
             LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans

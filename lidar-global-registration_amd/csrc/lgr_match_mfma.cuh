@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
             int t_lane = IINF;
             if (use_coarse) {
                 const int gst = min(cc * STAGES_PER_CHUNK + (lane & 31), ca.n_stage_total - 1);
-                const float ur = ca.u_rb[rb], us = ca.u_stage ? __uint_as_float(ca.u_stage[gst]) : 0.f;
+                const float ur = ca.u_rt[rb * (BLOCK_ROWS / TILE) + wave], us = ca.u_stage ? __uint_as_float(ca.u_stage[gst]) : 0.f;   // this wave's 32 rows
                 const float x = ca.xmax[rb / rg_blocks], y = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
                 const float s = x + y;
                 float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (x * y) + ca.lin * s + ca.abs);

@@ -149,7 +149,8 @@ __global__ void comp_cols_kernel(const uint8_t* __restrict__ done, const uint8_t
 // upper bounds after a masked pass (section 3b): largest over the row block / the leaf of  min_g (filtered + eps)
 __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                                                             const float* __restrict__ nQ, const int* __restrict__ blkclQ,
-                                                            const float* __restrict__ gmax, EpsExtra ex, CompView comp, float* __restrict__ u_rb) {
+                                                            const float* __restrict__ gmax, EpsExtra ex, CompView comp, float* __restrict__ u_rb,
+                                                            float* __restrict__ u_rt /* [row tiles]: the same maximum per 32-row tile */) {
     extern __shared__ int list_s[];
     const int i = blockIdx.x * BLOCK_ROWS + threadIdx.x;
     const int n_list = comp_list(comp, blockIdx.x * BLOCK_ROWS, q_pad, n_groups, list_s);
@@ -163,7 +164,9 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
             ub = fminf(ub, v + e);
         });
     }
-    for (int o = 32; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
+    for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
+    if ((threadIdx.x & 31) == 0 && i < q_pad) u_rt[i / TILE] = ub;
+    ub = fmaxf(ub, __shfl_xor(ub, 32));
     __shared__ float sh[BLOCK_ROWS / 64];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ub;
     __syncthreads();
@@ -295,7 +298,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                              const float* __restrict__ nQ_sets, const float* __restrict__ gmax, const int* __restrict__ cl_of_group,
                              EpsExtra ex, CompView comp, int stride, const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched,
                              int n_leaves, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
-                             const float* __restrict__ uq_rows /* coarse rejection: u_rb, or nullptr */,
+                             const float* __restrict__ uq_rows /* coarse rejection: u_rt (per 32-row tile), or nullptr */,
                              const unsigned* __restrict__ uq_cols /* coarse rejection: u_stage bits, or nullptr */, unsigned* __restrict__ worst) {
     extern __shared__ int list_s[];
     const int i = blockIdx.x * stride;   // sampled padded query position
@@ -360,7 +363,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                 // an entry may exceed the exact minimum (or stay +inf) when that minimum is above the query's own U^2 (u_rb of
                 // its row block / u_stage of its column stage).  Lower side (entry >= minimum over all rows - eps): always.
                 bool upper = best < 1e299;
-                if (ROWDIR && uq_rows) upper = upper && best <= (double) uq_rows[i / BLOCK_ROWS];
+                if (ROWDIR && uq_rows) upper = upper && best <= (double) uq_rows[i / TILE];
                 if (!ROWDIR && uq_cols) upper = upper && best <= (double) __uint_as_float(uq_cols[i / STAGE_COLS]);
                 float ratio = 0.f;
                 if (v < FLT_BIG) {
