@@ -545,7 +545,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
-        const size_t o_ust = pcarve((size_t) n_stage_total * 4);
+        const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
         const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(16);
@@ -561,6 +561,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
         unsigned* u_stage = (unsigned*) (pb + o_ust);
+        unsigned* u_ct = (unsigned*) (pb + o_uct);
         const bool colstage = both && mo.column_stage != 0;
         // coarse rejection inside match_mfma (rotated format, passes with upper bounds): thresholds from u_rb / u_stage
         const bool coarse = f16 && rot && mo.coarse_rejection != 0;
@@ -578,7 +579,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             ca_on.lin = (float) (2.0 * (double) ex.lin * 1.00001 + 1e-30);
             ca_on.abs = (float) (((double) ex.abs * 1.00001 + 2.0 * (double) sc.a_norm[0] * std::ldexp(1.0, -25) * (double) sc.inv_s2) * 1.000001 + 1e-12);
             ca_on.cnt = coarse_cnt;
-            chk_uq_rows = u_rt; chk_uq_cols = both ? u_stage : nullptr;
+            chk_uq_rows = u_rt; chk_uq_cols = both ? u_ct : nullptr;
         }
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
@@ -652,7 +653,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
                     LGR_HIP(ctx, hipMemsetAsync(u_stage, 0, (size_t) n_stage_total * 4, ctx->stream));
                     col_u_kernel<<<cdiv(mb_pad, 256), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, comp_cols, u_leaf,
-                                                                                                   (colstage || coarse) ? u_stage : nullptr);
+                                                                                                   (colstage || coarse) ? u_stage : nullptr, coarse ? u_ct : nullptr);
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves,
@@ -662,7 +663,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             init_tables_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             CoarseArgs ca = ca_on;
-            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_stage = both ? u_stage : nullptr; }
+            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.n_ct_total = tb; }
             LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans

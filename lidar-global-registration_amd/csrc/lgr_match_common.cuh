@@ -79,13 +79,15 @@ struct F16Scale { float s_mul; float inv_s2; float a_norm[3]; };   // 2^s, 2^-2s
 // with x = max |a'| of the row group, y = max |b'| of the column stage (|h2| <= 2^-11 |h| per element, or the f16 flush
 // limit: the linear / absolute terms).  A tile is abandoned when every c exceeds
 //     T = max(U_rows, U_cols) (1 + 1e-5) + eps + delta
-// -- U_rows = largest U^2 of the tile's 32 rows (u_rt), U_cols = largest U^2 of the 128-column stage (u_stage): no element of
+// -- U_rows = largest U^2 of the tile's 32 rows (u_rt), U_cols = largest U^2 of the tile's 32 columns (u_ct): no element of
 // the tile can be the nearest neighbour (or tie with it) of its row or of its column, which is the same statement the
 // bound-based skipping makes about a whole (row block, leaf) tile.
 struct CoarseArgs {
     const float* u_rb;          // [row blocks] or nullptr: no coarse rejection in this launch
     const float* u_rt;          // [row tiles]: largest U^2 of the 32 rows of a tile (the row side of a wave's threshold)
     const unsigned* u_stage;    // [column stages] float bits, or nullptr (row direction only)
+    const unsigned* u_ct;       // [column tiles] float bits: largest U^2 of the 32 columns of a tile (with u_stage)
+    int n_ct_total;
     const float* xmax;          // [row groups] max |a'| (gmaxA)
     const float* ymax;          // [KCL][column stages] max |b'| per set (group_max_kernel over 128-column windows)
     int n_stage_total;

@@ -134,17 +134,24 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
 #pragma unroll
                 for (int g = 0; g < 16; ++g) nav[g] = nA[row_tile * TILE + (g & 3) + 8 * (g >> 2) + 4 * half];
             }
-            // coarse-rejection thresholds of the 32 stages of this (row block, chunk): lane s holds stage s (bit pattern of
-            // a float >= 0, scaled like the accumulator; +inf = keep everything)
-            int t_lane = IINF;
+            // coarse-rejection thresholds of the 128 column tiles of this (row block, chunk) for this wave's 32 rows: tile q = 4 stage + ct
+            // sits in lane q & 63 of t_lane[q >> 6] (bit pattern of a float >= 0, scaled like the accumulator; +inf = keep everything)
+            int t_lane[2] = {IINF, IINF};
             if (use_coarse) {
-                const int gst = min(cc * STAGES_PER_CHUNK + (lane & 31), ca.n_stage_total - 1);
-                const float ur = ca.u_rt[rb * (BLOCK_ROWS / TILE) + wave], us = ca.u_stage ? __uint_as_float(ca.u_stage[gst]) : 0.f;   // this wave's 32 rows
-                const float x = ca.xmax[rb / rg_blocks], y = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
-                const float s = x + y;
-                float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (x * y) + ca.lin * s + ca.abs);
-                t = (t * 1.0001f) * c_scale;
-                t_lane = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
+                const float ur = ca.u_rt[rb * (BLOCK_ROWS / TILE) + wave];   // this wave's 32 rows
+                const float x = ca.xmax[rb / rg_blocks];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int q = lane + 64 * r;
+                    const int gst = min(cc * STAGES_PER_CHUNK + (q >> 2), ca.n_stage_total - 1);
+                    const int gct = min(col_tile0 + q, ca.n_ct_total - 1);
+                    const float us = ca.u_stage ? __uint_as_float(ca.u_ct[gct]) : 0.f;
+                    const float y = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
+                    const float s = x + y;
+                    float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (x * y) + ca.lin * s + ca.abs);
+                    t = (t * 1.0001f) * c_scale;
+                    t_lane[r] = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
+                }
             }
             unsigned kept[STAGE_TILES] = {0u, 0u, 0u, 0u};   // coarse sweep: bit st of kept[ct] = tile ct of stage st goes on (wave uniform)
             int rmin[16];   // float bit patterns, see the epilogue note
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     // under the stage threshold are only RECORDED here (kept[ct] bit st) and finished after the sweep,
                     // outside the per-stage barriers -- every wave does the same work per stage, so nobody waits at the
                     // barrier for a wave that happens to hold the few full tiles.
-                    const int t_st = __builtin_amdgcn_readlane(t_lane, st);
+                    const int t_sel = st < 16 ? t_lane[0] : t_lane[1];   // (st is wave uniform)
                     const frag* cs = reinterpret_cast<const frag*>(smem) + buf * CO_FRAGS + lane;   // ring slot `buf`: [tile][2 steps][64]
                     b[0] = cs[0];
                     b[1] = cs[64];
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                         int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
                         for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
+                        const int t_st = __builtin_amdgcn_readlane(t_sel, (st * STAGE_TILES + ct) & 63);
                         const bool keep = __ballot(m <= t_st) != 0ull;
                         n_tested += 1u;
                         if (keep) kept[ct] |= 1u << st;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                 };
                 // (the thresholds come from ordinary loads: have them in registers before the first DMA is issued -- behind a
                 // DMA in flight hipcc waits for such a load with vmcnt(0), which would drain the ring it has just filled)
-                asm volatile("" : : "v"(t_lane) : "memory");
+                asm volatile("" : : "v"(t_lane[0]), "v"(t_lane[1]) : "memory");
                 while (issued < CO_D && to_issue) dma_coarse();
                 while (to_do) {
                     st = __builtin_ctz(to_do);

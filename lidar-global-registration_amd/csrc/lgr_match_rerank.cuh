@@ -178,7 +178,8 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
 __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pad, const int* __restrict__ permT,
                              const float* __restrict__ nT_sets, const float* __restrict__ gmaxA, const int* __restrict__ cl_of_rg,
                              const int* __restrict__ tile_group, EpsExtra ex, CompView comp, unsigned* __restrict__ u_leaf /* float bits, >= 0 */,
-                             unsigned* __restrict__ u_stage /* [stages] or nullptr: the same maximum per 128-column stage */) {
+                             unsigned* __restrict__ u_stage /* [stages] or nullptr: the same maximum per 128-column stage */,
+                             unsigned* __restrict__ u_ct /* [column tiles] or nullptr: per 32-column tile (plain store: one writer) */) {
     extern __shared__ int list_s[];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     bool several;
@@ -194,6 +195,7 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
     }
     // the 32 columns of a tile share a leaf: one atomic per tile (t_pad is a multiple of the block size, so whole waves get here)
     for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
+    if (u_ct && (threadIdx.x & 31) == 0 && j < t_pad) u_ct[j / TILE] = ub > 0.f ? __float_as_uint(ub) : 0u;
     if ((threadIdx.x & 31) == 0 && j < t_pad && ub > 0.f) {
         atomicMax(&u_leaf[tile_group[j / TILE]], __float_as_uint(ub));
         if (u_stage) atomicMax(&u_stage[j / STAGE_COLS], __float_as_uint(ub));
@@ -364,7 +366,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                 // its row block / u_stage of its column stage).  Lower side (entry >= minimum over all rows - eps): always.
                 bool upper = best < 1e299;
                 if (ROWDIR && uq_rows) upper = upper && best <= (double) uq_rows[i / TILE];
-                if (!ROWDIR && uq_cols) upper = upper && best <= (double) __uint_as_float(uq_cols[i / STAGE_COLS]);
+                if (!ROWDIR && uq_cols) upper = upper && best <= (double) __uint_as_float(uq_cols[i / TILE]);
                 float ratio = 0.f;
                 if (v < FLT_BIG) {
                     ratio = (float) (fmax(best_all - (double) v, 0.0) / (double) e);
