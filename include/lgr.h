@@ -105,7 +105,7 @@ typedef struct lgr_ctx lgr_ctx;
 typedef struct {
     int32_t prune;            /* exact bound-based tile skipping: -1 auto (on from 65536 x 65536 pairs), 0 off (dense), 1 on */
     int32_t leaves;           /* second-level k-means leaves per cluster: 0 auto (about 1024 rows per leaf), else 1 .. 64 */
-    int32_t near;             /* pass-0 width: nearest leaves per row block / row blocks per leaf; 0 = default (32) */
+    int32_t near;             /* pass-0 width: nearest leaves per row block / row blocks per leaf; 0 = default (28) */
     int32_t operand_format;   /* -1 auto (f16 two-term splits, rotated to 30 coordinates when the rows allow it), 0 f32, 1 f16, 2 f16 rotated */
     int32_t box_bounds;       /* bounding-box lower bounds beside the ball bounds: 1 PCA basis (default), 2 raw coordinates, 0 off */
     int32_t column_stage;     /* per-stage column criterion in the final schedule: 1 (default) / 0 */

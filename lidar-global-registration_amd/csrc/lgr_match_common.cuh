@@ -40,9 +40,9 @@ constexpr int KM2_ITERS = LGR_KM2_ITERS;
 #define LGR_MM_OCC 4          // waves per SIMD of match_mfma (2: 256 VGPRs, one workgroup per CU; 4: 128 VGPRs, two)
 #endif
 #ifndef LGR_NEAR_T
-#define LGR_NEAR_T 32
+#define LGR_NEAR_T 28
 #endif
-constexpr int NEAR_T = LGR_NEAR_T;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured at 1M with box bounds and the per-stage column criterion: 16 / 24 / 32 / 48 / 64 -> 75.5 / 73.1 / 72.2 / 73.7 / 76.4 ms per pair)
+constexpr int NEAR_T = LGR_NEAR_T;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured at 1M: 16 / 24 / 32 / 48 / 64 -> 75.5 / 73.1 / 72.2 / 73.7 / 76.4 ms per pair in round 1; with the per-tile coarse thresholds of round 2 the final pass is cheaper per tile: 16 / 20 / 24 / 28 / 32 -> 40.4 / 39.8 / 39.4 / 39.45 / 39.8-40.1)
 #ifndef LGR_PRUNE_BETAS
 #define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
 #endif
