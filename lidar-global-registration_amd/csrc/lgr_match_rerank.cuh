@@ -263,32 +263,46 @@ __global__ void sched_kernel(int both, float beta_sq, const float* __restrict__ 
     }
     sched[idx] = s;
 }
-__global__ void mask_kernel(int pass, const uint8_t* __restrict__ sched, const int* __restrict__ tile_group,
-                            int n_rb, int n_cc, int n_leaves, int n_stage_total, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
-                            unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned m = 0u;
-    if (idx < n_rb * n_cc) {
-        const int rb = idx / n_cc, cc = idx % n_cc;
-        for (int s = 0; s < STAGES_PER_CHUNK; ++s) {
-            int gst = cc * STAGES_PER_CHUNK + s;
-            if (gst >= n_stage_total) break;
-            bool on = false;
-            int gprev = -1;
-            for (int ct = 0; ct < STAGE_TILES; ++ct) {
-                int g = tile_group[gst * STAGE_TILES + ct];
-                if (g == gprev) continue;
-                gprev = g;
-                const uint8_t sv = sched[(size_t) rb * n_leaves + g];
-                on = on || (sv & 1) || ((sv & 2) && col_stage_needed(LBsq[(size_t) rb * n_leaves + g], u_stage[gst]));
+// one lane per (row block, chunk, stage): the 32 stages of a (row block, chunk) pair are the 32 lanes of a half wave, the mask is
+// their ballot (one thread per pair walking its 32 stages was a chain of 128 dependent loads: 0.30 + 0.37 ms per pair at 1M)
+__global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __restrict__ sched, const int* __restrict__ tile_group,
+                                                   int n_rb, int n_cc, int n_leaves, int n_stage_total, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
+                                                   unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
+    static_assert(STAGES_PER_CHUNK == 32, "a half wave per (row block, chunk) pair");
+    const long long n_pairs = (long long) n_rb * n_cc;
+    const int s = threadIdx.x & 31;
+    unsigned long long count = 0ull;
+    // (the two half waves of a wave hold consecutive pairs; the upper one may leave the loop one round earlier -- the ballot then
+    // simply lacks its lanes, and the count is taken from lane 0)
+    for (long long idx = ((long long) blockIdx.x * blockDim.x + threadIdx.x) >> 5; idx < n_pairs; idx += ((long long) gridDim.x * blockDim.x) >> 5) {
+        bool on = false;
+        {
+            const int rb = (int) (idx / n_cc), cc = (int) (idx % n_cc);
+            const int gst = cc * STAGES_PER_CHUNK + s;
+            if (gst < n_stage_total) {
+                int gprev = -1;
+#pragma unroll
+                for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                    const int g = tile_group[gst * STAGE_TILES + ct];
+                    if (g == gprev) continue;
+                    gprev = g;
+                    const uint8_t sv = sched[(size_t) rb * n_leaves + g];
+                    on = on || (sv & 1) || ((sv & 2) && col_stage_needed(LBsq[(size_t) rb * n_leaves + g], u_stage[gst]));
+                }
             }
-            if (on) m |= 1u << s;
         }
-        mask[idx] = m;
+        const unsigned long long bal = __ballot(on);
+        if (s == 0) mask[idx] = (unsigned) (bal >> (threadIdx.x & 32));
+        count += (unsigned long long) __popcll(bal);
     }
-    unsigned c = __popc(m);
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&stats->stages[pass], (unsigned long long) c);
+    // one atomic per workgroup (a wave each was half a million same-address atomics)
+    __shared__ unsigned long long cnt_s[4];
+    if ((threadIdx.x & 63) == 0) cnt_s[threadIdx.x >> 6] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long c = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+        if (c) atomicAdd(&stats->stages[pass], c);
+    }
 }
 
 // Self-check of the filter bound (LGR_MATCH_CHECK=1, test sizes only): for sampled queries and every computed group,
