@@ -335,14 +335,16 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         hipStream_t s2 = ctx->aux->stream;
         LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
         LGR_HIP(ctx, hipStreamWaitEvent(s2, ctx->aux_ev, 0));
-        gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, s2>>>(d_b, B.perm, mb_pad, sortedB);
-        if (sortedA) gather_rows_kernel<<<cdiv((long long) ma_pad * 33, 256), 256, 0, s2>>>(d_a, A.perm, ma_pad, sortedA);
-        if (boxes) {
+        if (boxes) {   // first (the bounds wait for them), reading the rows through the placement
             const float* basis = P->basis;   // V [33][33], mu [33] (match_cluster)
             LGR_HIP(ctx, hipMemsetAsync(rmax2, 0, 4, s2));
-            box_kernel<<<n_rb, 256, 0, s2>>>(sortedA, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
-            box_kernel<<<n_leaves, 256, 0, s2>>>(sortedB, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
+            box_kernel<<<n_rb, 256, 0, s2>>>(d_a, A.perm, nullptr, n_rb, basis, basis + 33 * 33, 0, boxA, rmax2);
+            box_kernel<<<n_leaves, 256, 0, s2>>>(d_b, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
+            LGR_HIP(ctx, hipEventRecord(ctx->ev[30], s2));
         }
+        // the sorted copies are for the exact rerank (and the f32 ball bounds): nothing before the MFMA passes reads them
+        gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, s2>>>(d_b, B.perm, mb_pad, sortedB);
+        if (sortedA) gather_rows_kernel<<<cdiv((long long) ma_pad * 33, 256), 256, 0, s2>>>(d_a, A.perm, ma_pad, sortedA);
         LGR_HIP(ctx, hipGetLastError());
         LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, s2));
     }
@@ -456,8 +458,13 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     }
     group_max_kernel<<<dim3(n_groups, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, 0, group_start, gmaxB);
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
-    // (sortedA / sortedB / the boxes: forked onto the second stream above) -- from here on this stream may read them
-    LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev, 0));
+    // (sortedA / sortedB / the boxes: forked onto the second stream above; joined where they are first read)
+    bool sorted_joined = false;
+    auto join_sorted = [&]() -> int {
+        if (!sorted_joined) LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev, 0));
+        sorted_joined = true;
+        return LGR_OK;
+    };
 
     // ---- 4. MFMA passes into the two minimum tables (+inf initialised)
     int *rowmin, *colmin = nullptr;
@@ -626,8 +633,12 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             LGR_HIP(cx, hipGetLastError());
             return (int) LGR_OK;
         };
+        if (!f16) LGR_TRY(join_sorted());   // lb_kernel reads sortedA
         LGR_TRY(launch_lb(ctx));
-        if (boxes) box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
+        if (boxes) {
+            LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[30], 0));
+            box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
+        }
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
         auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {
             if (len <= NEAR_LDS_MAX) {
@@ -714,6 +725,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     }
     LGR_HIP(ctx, hipGetLastError());
 
+    LGR_TRY(join_sorted());   // the self-check and the exact rerank read the sorted rows
     if (mo.self_check && sortedA) {
         unsigned* d_worst = (unsigned*) (misc + 192);
         LGR_HIP(ctx, hipMemsetAsync(d_worst, 0, 8, ctx->stream));

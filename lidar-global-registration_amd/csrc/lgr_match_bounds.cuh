@@ -190,7 +190,8 @@ __global__ void cov_reduce(const float* __restrict__ part, int n_blocks, float* 
 }
 // boxes of row segments in the basis (rows of V, y = V (x - mu)); segments: fixed 256-row blocks (starts == nullptr) or
 // [starts[s], starts[s + 1]).  box[s][0..32] = min, [33..65] = max (transposed: box[c][s]); rmax2: largest |x - mu|^2 seen.
-__global__ __launch_bounds__(256) void box_kernel(const float* __restrict__ Xs, const int* __restrict__ perm, const int* __restrict__ starts, int n_seg,
+// X: the rows in their ORIGINAL order, read through perm (position r holds row perm[r]; -1 = padding)
+__global__ __launch_bounds__(256) void box_kernel(const float* __restrict__ X, const int* __restrict__ perm, const int* __restrict__ starts, int n_seg,
                                                   const float* __restrict__ V /* [33][33] */, const float* __restrict__ mu, int transposed,
                                                   float* __restrict__ box, unsigned* __restrict__ rmax2) {
     __shared__ float Vs[33 * 33 + 33];
@@ -205,11 +206,12 @@ __global__ __launch_bounds__(256) void box_kernel(const float* __restrict__ Xs, 
 #pragma unroll
     for (int k = 0; k < 33; ++k) { mn[k] = inf; mx[k] = -inf; }
     for (int r = b + threadIdx.x; r < e; r += 256) {
-        if (perm[r] < 0) continue;
+        const int o = perm[r];
+        if (o < 0) continue;
         float x[33];
         float n2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 33; ++k) { x[k] = Xs[(size_t) r * 33 + k] - Vs[33 * 33 + k]; n2 = __builtin_fmaf(x[k], x[k], n2); }
+        for (int k = 0; k < 33; ++k) { x[k] = X[(size_t) o * 33 + k] - Vs[33 * 33 + k]; n2 = __builtin_fmaf(x[k], x[k], n2); }
         r2 = fmaxf(r2, n2);
 #pragma unroll 3
         for (int k = 0; k < 33; ++k) {
