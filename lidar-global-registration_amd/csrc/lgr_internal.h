@@ -77,7 +77,7 @@ enum {
     WS_RANSAC_T, WS_RANSAC_STATS, WS_RANSAC_PACK, WS_RANSAC_LIST, WS_RANSAC_HIST, WS_RANSAC_MISC, WS_RANSAC_MASK, WS_RANSAC_MASKT,
     WS_PIPE_SURF_S, WS_PIPE_SURF_T, WS_PIPE_FEAT_S, WS_PIPE_FEAT_T, WS_PIPE_IJ, WS_PIPE_JI, WS_PIPE_DIJ, WS_PIPE_DJI,
     WS_PIPE_CORR, WS_PIPE_KNN_S, WS_PIPE_KNN_T, WS_PIPE_FLAGS, WS_PIPE_MISC, WS_PIPE_KIDX_S, WS_PIPE_KIDX_T, WS_PIPE_KPS_S, WS_PIPE_KPS_T,
-    WS_MS_KNN_I, WS_MS_KNN_D, WS_MS_LIST_S, WS_MS_LIST_T, WS_MS_SUB, WS_MS_FEAT_S, WS_MS_FEAT_T, WS_MS_SURF2, WS_MS_RES, WS_PLANE_VISITED, WS_PLANE_CLAIMED, WS_PLANE_OUT, WS_LOCAL_G, WS_SORT_TMP, WS_MATCH_BOX,
+    WS_MS_KNN_I, WS_MS_KNN_D, WS_MS_LIST_S, WS_MS_LIST_T, WS_MS_SUB, WS_MS_FEAT_S, WS_MS_FEAT_T, WS_MS_SURF2, WS_MS_RES, WS_PLANE_VISITED, WS_PLANE_CLAIMED, WS_PLANE_OUT, WS_LOCAL_G, WS_SORT_TMP, WS_MATCH_BOX, WS_RANSAC_GHIST,
     WS_HOST_A, WS_HOST_B, WS_HOST_C, WS_HOST_D, WS_HOST_E, WS_HOST_F,
     WS_COUNT
 };
