@@ -81,6 +81,21 @@ struct KnnList {
     __device__ __forceinline__ int index(int j) const { return id[j * BLOCK + t]; }
 };
 
+// candidates [b, e) of the sorted point array, pushed in ascending position (the order the list's tie rule is defined on).  Four
+// loads are issued before the first push: the query kernels run at ~2.5 waves per SIMD (the k-best lists fill the LDS), so a
+// load per candidate, each waited for, was the kernels' critical path.
+template <int BLOCK>
+__device__ __forceinline__ void lgr_knn_scan(const GridDev& g, int b, int e, float qx, float qy, float qz, KnnList<BLOCK>& L) {
+    for (int t = b; t < e; t += 4) {
+        const int last = e - 1;
+        const float4 p0 = g.pxyz[t], p1 = g.pxyz[min(t + 1, last)], p2 = g.pxyz[min(t + 2, last)], p3 = g.pxyz[min(t + 3, last)];
+        L.push(lgr_dist2(qx, qy, qz, p0.x, p0.y, p0.z), __float_as_int(p0.w));
+        if (t + 1 < e) L.push(lgr_dist2(qx, qy, qz, p1.x, p1.y, p1.z), __float_as_int(p1.w));
+        if (t + 2 < e) L.push(lgr_dist2(qx, qy, qz, p2.x, p2.y, p2.z), __float_as_int(p2.w));
+        if (t + 3 < e) L.push(lgr_dist2(qx, qy, qz, p3.x, p3.y, p3.z), __float_as_int(p3.w));
+    }
+}
+
 // exact k-NN of (qx,qy,qz) in grid g: ring search with the same termination rule as the oracle
 // (after ring s every point closer than s*h has been seen).
 template <int BLOCK>
@@ -99,18 +114,12 @@ __device__ __forceinline__ void lgr_knn_query(const GridDev& g, float qx, float 
                     int x0 = max(c0x - s, 0), x1 = min(c0x + s, g.dx - 1);
                     if (x0 > x1) continue;
                     int b = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-                    for (int t = b; t < e; ++t) {
-                        float4 p = g.pxyz[t];
-                        L.push(lgr_dist2(qx, qy, qz, p.x, p.y, p.z), __float_as_int(p.w));
-                    }
+                    lgr_knn_scan(g, b, e, qx, qy, qz, L);
                 } else {
                     for (int x = c0x - s; x <= c0x + s; x += 2 * s) {   // the two end cells of an interior row
                         if (x < 0 || x >= g.dx) continue;
                         int b = g.cell_start[row + x], e = g.cell_start[row + x + 1];
-                        for (int t = b; t < e; ++t) {
-                            float4 p = g.pxyz[t];
-                            L.push(lgr_dist2(qx, qy, qz, p.x, p.y, p.z), __float_as_int(p.w));
-                        }
+                        lgr_knn_scan(g, b, e, qx, qy, qz, L);
                     }
                 }
             }
