@@ -207,12 +207,14 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
 // counts[h] = {inliers (4-norm rule, src/metric.cpp:141), support (3-norm rule, src/metric.cpp:111)}
 constexpr int CB = 64;        // hypotheses per workgroup
 constexpr int CCH = 2048;     // correspondences per workgroup
+// Two correspondences per pass on packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: IEEE, elementwise -- every element sees exactly the
+// scalar expressions, no fused multiply-add); the chunk sits in LDS as one array per coordinate so that a pair is one 8-byte read.
 __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts, const int* __restrict__ list, int nh,
                                                     const float4* __restrict__ P0, const float4* __restrict__ P1,
                                                     const float* __restrict__ sstar, int c, int2* __restrict__ counts,
                                                     unsigned* __restrict__ maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */) {
-    __shared__ float4 s0[CB], s1[CB];
-    __shared__ float st[CB];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(8))) float sx[CB], sy[CB], sz[CB], tx[CB], ty[CB], tz[CB], st[CB];
     int h = blockIdx.x * CB + threadIdx.x;
     bool act = h < nh;
     float T[16];
@@ -227,21 +229,33 @@ __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts,
     for (int base = c0; base < c1; base += CB) {
         __syncthreads();
         int i = base + threadIdx.x;
-        if (i < c1) { s0[threadIdx.x] = P0[i]; s1[threadIdx.x] = P1[i]; st[threadIdx.x] = sstar[i]; }
+        {
+            // (lanes past the end stage a pair that can never be an inlier: threshold 0)
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            float ss = 0.f;
+            if (i < c1) { a = P0[i]; b = P1[i]; ss = sstar[i]; }
+            sx[threadIdx.x] = a.x; sy[threadIdx.x] = a.y; sz[threadIdx.x] = a.z;
+            tx[threadIdx.x] = b.x; ty[threadIdx.x] = b.y; tz[threadIdx.x] = b.z; st[threadIdx.x] = ss;
+        }
         __syncthreads();
         int nj = min(CB, c1 - base);
         unsigned long long bits = 0ull;
-        for (int j = 0; j < nj; ++j) {
-            float4 a = s0[j], b = s1[j];
-            float ss = st[j];
-            LGR_APPLY(T, a.x, a.y, a.z, ox, oy, oz)
-            float dx = ox - b.x, dy = oy - b.y, dz = oz - b.z;
-            float d4 = (dx * dx + dz * dz) + (dy * dy + 0.f);   // Eigen 4-vector squaredNorm reduction
-            float d3 = (dx * dx + dy * dy) + dz * dz;           // 3-vector block norm
-            const bool in = d4 < ss;
-            ninl += in ? 1 : 0;
-            nsup += d3 < ss ? 1 : 0;
-            bits |= (unsigned long long) (in ? 1 : 0) << j;
+        for (int j = 0; j < nj; j += 2) {
+            const v2f ax = *reinterpret_cast<const v2f*>(&sx[j]), ay = *reinterpret_cast<const v2f*>(&sy[j]), az = *reinterpret_cast<const v2f*>(&sz[j]);
+            const v2f bx = *reinterpret_cast<const v2f*>(&tx[j]), by = *reinterpret_cast<const v2f*>(&ty[j]), bz = *reinterpret_cast<const v2f*>(&tz[j]);
+            const v2f ss = *reinterpret_cast<const v2f*>(&st[j]);
+            // LGR_APPLY, elementwise: ((c0*x + c1*y) + c2*z) + c3
+            const v2f ox = ((T[0] * ax + T[4] * ay) + T[8] * az) + T[12];
+            const v2f oy = ((T[1] * ax + T[5] * ay) + T[9] * az) + T[13];
+            const v2f oz = ((T[2] * ax + T[6] * ay) + T[10] * az) + T[14];
+            const v2f dx = ox - bx, dy = oy - by, dz = oz - bz;
+            const v2f xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            const v2f d4 = (xx + zz) + (yy + 0.f);   // Eigen 4-vector squaredNorm reduction
+            const v2f d3 = (xx + yy) + zz;           // 3-vector block norm
+            const bool in0 = d4.x < ss.x, in1 = d4.y < ss.y;   // (a staged filler pair has ss = 0: never an inlier)
+            ninl += (in0 ? 1 : 0) + (in1 ? 1 : 0);
+            nsup += (d3.x < ss.x ? 1 : 0) + (d3.y < ss.y ? 1 : 0);
+            bits |= ((unsigned long long) (in0 ? 1 : 0) | ((unsigned long long) (in1 ? 2 : 0))) << j;
         }
         // inlier bits of this hypothesis for the correspondences [base, base + 64): word-major, so the lanes (consecutive
         // hypotheses) store consecutive words; phase 2 walks the set bits instead of testing every correspondence again
