@@ -276,7 +276,9 @@ extern "C" int lgr_knn_dev(lgr_ctx* ctx, const float* d_q, int nq, const float* 
     if (nq == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     GridDev g;
-    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, 4.f, &g));
+    // cell size for about 0.35 k points per cell, at least 4 (the 40-NN tables of the cluster filter at 1M points: 4 / 8 / 12 / 16 / 24
+    // points per cell -> 58.5 / 58.3 / 56.8 / 56.8 / 57.3 ms per pair with `matching: cluster`; the lists do not depend on it)
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, std::max(4.f, 0.35f * (float) k), &g));
     size_t sm = (size_t) k * KNN_BLOCK * 8;
     if (d_q == d_pts && nq == n) {
         if (g.n > 0) knn_kernel<0><<<cdiv(g.n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 1);
