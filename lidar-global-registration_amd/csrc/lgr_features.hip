@@ -159,6 +159,38 @@ __device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, f
     return true;
 }
 
+// The same for TWO pairs at once: every operation is elementwise on 2-vectors (v_pk_mul_f32 / v_pk_add_f32 where the hardware has a
+// packed form -- IEEE, no fused multiply-add --, component by component for the square roots, divisions, selects and the atan2), so
+// each component sees exactly the scalar sequence above.  A pair that the scalar function skips has ok = false (its other
+// outputs are then meaningless: a division by zero may have produced inf / NaN).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f dot3e2(v2f ax, v2f ay, v2f az, v2f bx, v2f by, v2f bz) { return (ax * bx + az * bz) + ay * by; }
+__device__ __forceinline__ v2f sel2(bool c0, bool c1, v2f a, v2f b) { return v2f{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+__device__ __forceinline__ void pair_features2(v2f p1x, v2f p1y, v2f p1z, v2f n1x, v2f n1y, v2f n1z, v2f p2x, v2f p2y, v2f p2z, v2f n2x, v2f n2y, v2f n2z,
+                                               v2f& f1, v2f& f2, v2f& f3, bool& ok0, bool& ok1) {
+    v2f dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    const v2f f4s = dot3e2(dx, dy, dz, dx, dy, dz);
+    const v2f f4 = v2f{__builtin_sqrtf(f4s.x), __builtin_sqrtf(f4s.y)};
+    ok0 = f4.x != 0.0f; ok1 = f4.y != 0.0f;
+    const v2f angle1 = dot3e2(n1x, n1y, n1z, dx, dy, dz) / f4;
+    const v2f angle2 = dot3e2(n2x, n2y, n2z, dx, dy, dz) / f4;
+    const v2f a1 = v2f{fabsf(angle1.x), fabsf(angle1.y)}, a2 = v2f{fabsf(angle2.x), fabsf(angle2.y)};
+    const bool s0 = a1.x <= 1.0f && a2.x <= 1.0f && a1.x < a2.x, s1 = a1.y <= 1.0f && a2.y <= 1.0f && a1.y < a2.y;
+    const v2f ux = sel2(s0, s1, n2x, n1x), uy = sel2(s0, s1, n2y, n1y), uz = sel2(s0, s1, n2z, n1z);
+    const v2f mx = sel2(s0, s1, n1x, n2x), my = sel2(s0, s1, n1y, n2y), mz = sel2(s0, s1, n1z, n2z);
+    dx = sel2(s0, s1, -dx, dx); dy = sel2(s0, s1, -dy, dy); dz = sel2(s0, s1, -dz, dz);
+    f3 = sel2(s0, s1, -angle2, angle1);
+    v2f vx = dy * uz - dz * uy, vy = dz * ux - dx * uz, vz = dx * uy - dy * ux;
+    const v2f vn2 = dot3e2(vx, vy, vz, vx, vy, vz);
+    const v2f v_norm = v2f{__builtin_sqrtf(vn2.x), __builtin_sqrtf(vn2.y)};
+    ok0 = ok0 && v_norm.x != 0.0f; ok1 = ok1 && v_norm.y != 0.0f;
+    vx = vx / v_norm; vy = vy / v_norm; vz = vz / v_norm;
+    const v2f wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
+    f2 = dot3e2(vx, vy, vz, mx, my, mz);
+    const v2f yy = dot3e2(wx, wy, wz, mx, my, mz), xx = dot3e2(ux, uy, uz, mx, my, mz);
+    f1 = v2f{lgr_atan2f(yy.x, xx.x), lgr_atan2f(yy.y, xx.y)};
+}
+
 __device__ __forceinline__ int bin11(double t) {
     double v = floor(11 * t);
     if (!(v == v)) return 0;
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uin
 // order free (the canonical value of a bin is the sequential float sum of `count` copies of the increment), so any
 // enumeration that meets every (point, neighbour) pair exactly once gives the oracle's rows bit for bit.
 constexpr int ST = 16;          // surface points per wave
-constexpr int SQ = 128;         // pair queue entries: (tile point << 8) | candidate slot
+constexpr int SQ = 256;         // pair queue entries: (tile point << 8) | candidate slot
 constexpr int SHP = 36;         // histogram pitch (33 bins + pad)
 
 __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, const int* __restrict__ order, float* __restrict__ spfh /* [n][HP], sorted positions */) {
@@ -255,17 +287,29 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
     const float d_pi = 1.0f / (2.0f * 3.14159274101257324f);   // 1.0f / (2.0f * static_cast<float>(M_PI))
     const double MPI = 3.14159265358979323846;
     int qh = 0, qt = 0;
-    auto process = [&](int nb) {   // the first nb queued pairs, one per lane
-        if (l < nb) {
-            const unsigned e = queue[(qh + l) & (SQ - 1)];
-            const int i = (int) (e >> 8), sl = (int) (e & 255u);
-            const float4 P = tp[i], N = tn[i], Q = cp[sl], M = cn[sl];
-            float f1, f2, f3;
-            if (pair_features(P.x, P.y, P.z, N.x, N.y, N.z, Q.x, Q.y, Q.z, M.x, M.y, M.z, f1, f2, f3)) {
-                const int b1 = bin11(((double) f1 + MPI) * (double) d_pi);
-                const int b2 = 11 + bin11(((double) f2 + 1.0) * 0.5);
-                const int b3 = 22 + bin11(((double) f3 + 1.0) * 0.5);
-                int* h = &hist[l & 1][i][0];
+    auto process = [&](int nb) {   // the first nb (<= 128) queued pairs, two per lane: entries l and 64 + l
+        const bool h0 = l < nb, h1 = 64 + l < nb;
+        if (h0) {   // (every lane with a second pair also has a first one)
+            const unsigned e0 = queue[(qh + l) & (SQ - 1)], e1 = h1 ? queue[(qh + 64 + l) & (SQ - 1)] : e0;
+            const int i0 = (int) (e0 >> 8), i1 = (int) (e1 >> 8);
+            const float4 P0 = tp[i0], N0 = tn[i0], Q0 = cp[e0 & 255u], M0 = cn[e0 & 255u];
+            const float4 P1 = tp[i1], N1 = tn[i1], Q1 = cp[e1 & 255u], M1 = cn[e1 & 255u];
+            v2f f1, f2, f3;
+            bool ok0, ok1;
+            pair_features2(v2f{P0.x, P1.x}, v2f{P0.y, P1.y}, v2f{P0.z, P1.z}, v2f{N0.x, N1.x}, v2f{N0.y, N1.y}, v2f{N0.z, N1.z},
+                           v2f{Q0.x, Q1.x}, v2f{Q0.y, Q1.y}, v2f{Q0.z, Q1.z}, v2f{M0.x, M1.x}, v2f{M0.y, M1.y}, v2f{M0.z, M1.z}, f1, f2, f3, ok0, ok1);
+            if (ok0) {
+                const int b1 = bin11(((double) f1.x + MPI) * (double) d_pi);
+                const int b2 = 11 + bin11(((double) f2.x + 1.0) * 0.5);
+                const int b3 = 22 + bin11(((double) f3.x + 1.0) * 0.5);
+                int* h = &hist[l & 1][i0][0];
+                atomicAdd(h + b1, 1); atomicAdd(h + b2, 1); atomicAdd(h + b3, 1);
+            }
+            if (h1 && ok1) {
+                const int b1 = bin11(((double) f1.y + MPI) * (double) d_pi);
+                const int b2 = 11 + bin11(((double) f2.y + 1.0) * 0.5);
+                const int b3 = 22 + bin11(((double) f3.y + 1.0) * 0.5);
+                int* h = &hist[l & 1][i1][0];
                 atomicAdd(h + b1, 1); atomicAdd(h + b2, 1); atomicAdd(h + b3, 1);
             }
         }
@@ -307,9 +351,9 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
                     queue[(qt + rank) & (SQ - 1)] = (unsigned short) ((i << 8) | l);
                 }
                 qt += __popcll(em);
-                if (qt - qh >= 64) {
+                if (qt - qh >= 128) {
                     __syncthreads();
-                    process(64);
+                    process(128);
                 }
             }
             __syncthreads();
