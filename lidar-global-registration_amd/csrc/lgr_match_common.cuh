@@ -29,11 +29,11 @@ constexpr int MAXLEAF = KCL * SUBMAX;
 #endif
 constexpr int KM_SAMPLE = LGR_KM_SAMPLE;    // sample rows per side
 #ifndef LGR_KM_ITERS
-#define LGR_KM_ITERS 16   // Lloyd iterations, first / second level (6 / 4 -> 10 / 8 -> 16 / 8: 81.7 -> 80.2 -> 79.5 ms per 1M pair; tighter leaves)
+#define LGR_KM_ITERS 12   // Lloyd iterations, first / second level (round 1: 6 / 4 -> 10 / 8 -> 16 / 8: 81.7 -> 80.2 -> 79.5 ms per 1M pair, tighter leaves; with the exact integer sums of round 2 the 1M sample reaches its fixed point by 10 / 6 -- same tile fraction as 16 / 8 -- and every step is ~30-60 us of exposed launch latency)
 #endif
 constexpr int KM_ITERS = LGR_KM_ITERS;
 #ifndef LGR_KM2_ITERS
-#define LGR_KM2_ITERS 8
+#define LGR_KM2_ITERS 6
 #endif
 constexpr int KM2_ITERS = LGR_KM2_ITERS;
 #ifndef LGR_MM_OCC
