@@ -54,6 +54,11 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: check sampled queries of the GPU's 1M x 1M matches against the CPU oracle (parity_sample in the JSON line)")
     ap.add_argument("--verify-queries", type=int, default=4096)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: still form a (one-rank) process group on --backend and run the path's all-gather / barrier / all-reduce "
+                         "through it, i.e. execute the RCCL calls of the N > 1 path on a one-GPU box")
+    ap.add_argument("--single-context", action="store_true",
+                    help="lgr_ctx_options.helper_contexts = 0: no helper host threads / streams (for hosts with fewer than 3 cores per rank)")
     ap.add_argument("--match-opt", action="append", default=[], metavar="FIELD=VALUE",
                     help="lgr_match_options override for ablations / profiles (e.g. coarse_rejection=0); never changes results")
     return ap.parse_args()
@@ -74,19 +79,30 @@ def fan_out(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def _rendezvous_defaults(world):
+    """MASTER_ADDR always; for a one-rank group formed without a launcher (--force-collective) also a free port and the rank variables"""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+
+
 def dry_run(args, world, rank):
     """Ranks + the one collective of the path, no GPU: every rank packs a record that only it can produce, the records are
     all-gathered (gloo), and rank 0 checks that it holds one from each of the `--gpus` ranks."""
     import torch
     import torch.distributed as dist
     from lgr_amd import distributed
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_pg = world > 1 or args.force_collective
+    if use_pg:
+        _rendezvous_defaults(world)
         dist.init_process_group("gloo")
     rec = distributed.pack_record(rank, np.eye(4, dtype=np.float32).reshape(16) * (rank + 1), 1, 2**31 - 1 - rank, 1000 + rank, 0.0, 0.0)
     t0 = time.perf_counter()
     for _ in range(max(1, args.steps)):
-        allr = distributed.gather_records(torch.from_numpy(rec.view(np.int32).copy())[None], world)
+        allr = distributed.gather_records(torch.from_numpy(rec.view(np.int32).copy())[None], world, force=use_pg)
     elapsed = time.perf_counter() - t0
     got = [distributed.unpack_record(r) for r in np.ascontiguousarray(allr.numpy()).view(np.float32)]
     ok = [g["pair_id"] for g in got] == list(range(world)) and all(g["iterations"] == 2**31 - 1 - i for i, g in enumerate(got))
@@ -94,8 +110,9 @@ def dry_run(args, world, rank):
         print(json.dumps({"metric": "scan-pair registrations/sec", "value": None, "unit": "registrations/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
-                          "dry_run": True, "ranks_seen": [g["pair_id"] for g in got], "records_ok": bool(ok)}), flush=True)
-    if world > 1:
+                          "dry_run": True, "ranks_seen": [g["pair_id"] for g in got], "records_ok": bool(ok),
+                          "collective": {"process_group": bool(use_pg), "backend": "gloo" if use_pg else None}}), flush=True)
+    if use_pg:
         dist.destroy_process_group()
     if not ok:
         raise SystemExit(3)
@@ -257,8 +274,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the product and has no CPU fallback")
     if args.backend == "gloo":
         local = local % torch.cuda.device_count()      # rehearsal: several ranks may share one card
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_pg = world > 1 or args.force_collective      # a process group exists: every collective of the path really runs
+    if use_pg:
+        _rendezvous_defaults(world)                  # (--force-collective without a launcher: a one-rank group of our own)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -266,6 +284,8 @@ def main():
     torch.cuda.set_device(local)
     from lgr_amd import capi, synthetic, distributed
     ctx = capi.Context(local)
+    if args.single_context:
+        ctx.set_options(helper_contexts=0)
     if args.match_opt:
         ctx.set_match_options(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.match_opt)})
 
@@ -280,11 +300,15 @@ def main():
         res = ctx.align(src, tgt, params)
         rec = distributed.pack_record(rank, res.transformation, res.converged, res.iterations, res.n_inliers, res.time_cs, res.time_te)
         record.copy_(torch.from_numpy(rec.view(np.int32))[None])
-        distributed.gather_records(record, world)     # the single collective of the path (RCCL all-gather when N > 1)
+        gathered = distributed.gather_records(record, world, force=use_pg)     # the single collective of the path (RCCL all-gather when N > 1)
+        coll["all_gathers"] += int(use_pg)
+        coll["records_seen"] = int(gathered.shape[0])
         return res
 
+    coll = {"all_gathers": 0, "records_seen": 0}
+
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -304,7 +328,7 @@ def main():
         stage_ms.append(list(res.stage_ms)[:7])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -359,6 +383,10 @@ def main():
                          "rerank": mstats, "algorithmic_flop_per_launch": alg_flop, "directions_per_launch": n_dir},
             "stage_ms": dict(zip(["downsample", "normals", "fpfh", "match", "filter", "ransac", "refit"],
                                  [float(x) for x in np.mean(np.array(stage_ms), 0)])),
+            "collective": {"process_group": bool(use_pg), "backend": args.backend if use_pg else None, "all_gathers_executed": coll["all_gathers"],
+                           "records_per_gather": coll["records_seen"], "barrier_and_allreduce_max": bool(use_pg)},
+            "host": {"threads_per_rank": ctx.host_threads(), "usable_cores": _usable_cores(), "ranks_on_host": world,
+                     "usable_cores_per_rank": _usable_cores() / max(1, world), "helper_contexts": int(not args.single_context)},
             "result": {"converged": int(res.converged), "iterations": int(res.iterations), "n_correspondences": int(res.n_correspondences),
                        "n_inliers": int(res.n_inliers), "max_abs_err_vs_gt": err},
         }
@@ -381,7 +409,7 @@ def main():
                     "seconds_per_pair_estimate": total, "stage_seconds": {k: float(v) for k, v in t.items()},
                 }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

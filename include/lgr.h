@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define LGR_VERSION 1
+/* ABI revision.  2 (round 3): lgr_match_last_* take the context, lgr_ctx_options / lgr_ctx_host_threads added; lgr_params grew in
+ * revision 1 -> 2 as well (use_bfmatcher, has_guess, match_search_radius, guess).  A host built against another revision must not
+ * call in: check lgr_version() == LGR_VERSION once after loading (lgr_amd/capi.py and host/lgr_compat.hpp do). */
+#define LGR_VERSION 2
 
 enum {
     LGR_OK = 0,
@@ -56,10 +59,10 @@ typedef struct {
     int32_t normal_nr_points;    /* 30 */
     float   edge_thr_coef;       /* 0.95 */
     float   distance_thr;
-    float   feature_radius;      /* > 0: single scale (multi-scale is SURVEY 8f "next") */
+    float   feature_radius;      /* > 0: single scale; <= 0 = unset: multi-scale (include/matching.h:176-262) */
     float   scale_factor;        /* 2.0 */
     float   confidence;          /* 0.999 */
-    int32_t bf_block_size;       /* 10000 */
+    int32_t bf_block_size;       /* ALIGNMENT_BLOCK_SIZE (lgr_default_params: 10000); every shipped YAML sets 200000 (data/test.yaml:12) */
     int32_t cluster_k;           /* 40 */
     int32_t randomness;          /* 1 (only 1, as data/test.yaml:14 says) */
     int32_t n_samples;           /* 3 */
@@ -99,6 +102,17 @@ typedef struct {
 
 typedef struct lgr_ctx lgr_ctx;
 
+/* How a context uses the HOST and the device queue (never what it returns).  Independent pieces of the path -- the two clouds'
+ * feature stages, the two sides / directions of the matcher, the match filter's per-cloud tables -- run side by side on up to two
+ * internal contexts, each with a stream of its own and ONE persistent helper host thread (started on first use, parked on a
+ * condition variable between calls).  helper_contexts = 0 turns that off: every piece runs on the context's own stream from the
+ * calling thread (no extra threads, no extra streams; the internal contexts remain as workspaces only) -- for hosts that give a
+ * rank fewer cores than 3, at the price of the overlap (about +20 % per 1M-point pair). */
+typedef struct {
+    int32_t helper_contexts;  /* 1 (default) / 0 */
+    int32_t reserved[7];
+} lgr_ctx_options;
+
 /* How the brute-force matcher runs (NEVER what it returns: every setting gives the same matches and distance bits).  The
  * defaults are the production schedule; the other values exist so that tests can drive every path at small sizes and so that
  * profiles can switch single mechanisms off.  Held by the context: lgr_ctx_set_match_options. */
@@ -137,6 +151,12 @@ int  lgr_ctx_get_match_options(lgr_ctx* ctx, lgr_match_options* opt);
  * HBM budget against when it pushes many pairs of different sizes through one context (src/main.cpp:384-407 loops pairs in
  * one process) */
 int  lgr_ctx_workspace_bytes(lgr_ctx* ctx, uint64_t* bytes);
+void lgr_ctx_default_options(lgr_ctx_options* opt);
+/* opt == NULL restores the defaults.  Waits for the context's queued work; call it between alignments, not during one. */
+int  lgr_ctx_set_options(lgr_ctx* ctx, const lgr_ctx_options* opt);
+int  lgr_ctx_get_options(lgr_ctx* ctx, lgr_ctx_options* opt);
+/* host threads this context drives the device from: 1 (the caller's) + the helper threads it has started so far (at most 2) */
+int  lgr_ctx_host_threads(lgr_ctx* ctx, int* n);
 
 /* ---- building block under every grid / voxel / placement step (the reference has no counterpart: its containers are hash maps and
  *      kd-trees): stable LSD radix sort of (key, 32-bit value) pairs on the context's stream, out of place (in != out, input kept).
@@ -210,29 +230,28 @@ int lgr_match_local(lgr_ctx*, const float* query_pts, int mq, const float* train
 int lgr_match_local_dev(lgr_ctx*, const float* d_query_pts, int mq, const float* d_train_pts, int mt, const float* d_q33, const float* d_t33,
                         const float guess16[16] /* host */, float match_search_radius, int32_t* d_idx, float* d_dist);
 
-/* diagnostics of the last match call: [items_ab, dense_ab, items_ba, dense_ba, sub_cols, rg_rows] and the duration of
+/* diagnostics of the context's last match call (stand-alone or inside lgr_align*), kept in the context:
+ * [items_ab, dense_ab, items_ba, dense_ba, sub_cols, rg_rows] and the duration of
  * its MFMA filter kernel (hipEvents on the ctx stream) -- what bench.py's roofline object is computed from */
-int lgr_match_last_stats(unsigned* out6);
+int lgr_match_last_stats(lgr_ctx*, unsigned* out6);
 int lgr_match_last_kernel_ms(lgr_ctx*, float* ms);
 /* fraction of the (256-row block x 128-column stage) tiles the MFMA passes of the last match call computed; the exact
  * bound-based skipping leaves the rest out.  1.0 = dense. */
-int lgr_match_last_work(double* executed_fraction);
-/* coarse rejection inside the MFMA filter kernel (rotated format only; env LGR_MATCH_COARSE=0 turns it off): 32 x 32 tiles
+int lgr_match_last_work(lgr_ctx*, double* executed_fraction);
+/* coarse rejection inside the MFMA filter kernel (rotated format only; lgr_match_options.coarse_rejection = 0 turns it off): 32 x 32 tiles
  * tested after their first two MFMA steps in the last match call, and tiles abandoned there. */
-int lgr_match_last_coarse(double* out2);
-/* exact rerank (f16 operand formats; env LGR_MATCH_REFILTER=0 turns it off): (query, train row) pairs the MFMA re-filter of
+int lgr_match_last_coarse(lgr_ctx*, double* out2);
+/* exact rerank (f16 operand formats; lgr_match_options.rerank_refilter = 0 turns it off): (query, train row) pairs the MFMA re-filter of
  * the candidate groups passed on to the exact distance in the last match call, query->train and train->query direction; a
  * count above the pair buffer (8 per candidate group) means that direction fell back to the exact scan of whole groups. */
-int lgr_match_last_pairs(unsigned* out2);
+int lgr_match_last_pairs(lgr_ctx*, unsigned* out2);
 /* MFMA operand format of the last match call: 1 = two-term f16 splits on v_mfma_f32_32x32x16_f16, K = 112; 2 = the same on
- * 30 Helmert coordinates, K = 96 (chosen when every 11-bin block of all rows has the same sum, as FPFH rows do; env
- * LGR_MATCH_ROT=0/1 forces it off/on); 0 = f32 operands on v_mfma_f32_32x32x2_f32 (env LGR_MATCH_F16=0).  Results do not
- * depend on it. */
-int lgr_match_last_format(int* f16);
-/* self-check of the matcher's filter bound (env LGR_MATCH_CHECK=1, test sizes): worst |filtered - exact| / eps over
+ * 30 Helmert coordinates, K = 96 (chosen when every 11-bin block of all rows has the same sum, as FPFH rows do); 0 = f32
+ * operands on v_mfma_f32_32x32x2_f32 (lgr_match_options.operand_format selects one explicitly).  Results do not depend on it. */
+int lgr_match_last_format(lgr_ctx*, int* f16);
+/* self-check of the matcher's filter bound (lgr_match_options.self_check = 1, test sizes): worst |filtered - exact| / eps over
  * sampled table entries of the last match call, rows then columns; -1 = not run.  Must be <= 1. */
-int lgr_match_last_check(double* out2);
-
+int lgr_match_last_check(lgr_ctx*, double* out2);
 /* ---- src/common.cpp:531-547 calculateSmoothedDensities(pcd, k) / :202-208 calculatePointCloudDensity ---- */
 int lgr_smoothed_densities(lgr_ctx*, const float* pts, int n, int k, float* out);
 int lgr_smoothed_densities_dev(lgr_ctx*, const float* d_pts, int n, int k, float* d_out);

@@ -412,6 +412,10 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     LGR_CHECK(ctx, p->randomness == 1, LGR_ERR_UNSUPPORTED);        // data/test.yaml:14 "currently only 1 is supported"
     LGR_CHECK(ctx, p->feature_nr_points > 0 && p->normal_nr_points >= 1 && p->normal_nr_points <= 64 && p->bf_block_size > 0 && p->scale_factor > 1.f,
               LGR_ERR_INVALID_ARG);
+    // checked before any stage runs (this entry point builds the filter tables itself, so lgr_filter_dev's checks do not cover it):
+    // the cluster filter keeps at most 64 spatial neighbours per point (filter_flags<64>)
+    LGR_CHECK(ctx, p->matching_id == LGR_MATCH_LR || p->matching_id == LGR_MATCH_ONE_SIDED || p->matching_id == LGR_MATCH_CLUSTER, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, p->matching_id != LGR_MATCH_CLUSTER || (p->cluster_k >= 1 && p->cluster_k <= 64), LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     *n_out = 0;
     // include/matching.h:172,230-231: radius quantised to a power of scale_factor; voxel from feature_nr_points
@@ -466,17 +470,20 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     FilterTables ftab;
     LGR_TRY(filter_tables_alloc(ctx, p->matching_id, ns, nt, p->cluster_k, &ftab));
     LGR_TRY(lgr_ctx_aux2(ctx));
-    LGR_HIP(ctx, hipEventRecord(ctx->aux2_ev, ctx->stream));
-    LGR_HIP(ctx, hipStreamWaitEvent(ctx->aux2->stream, ctx->aux2_ev, 0));
-    int rc_tab = LGR_OK;
-    std::thread tables_worker([&]() {
-        lgr_ctx* cx = ctx->aux2;
-        if (hipSetDevice(cx->device) != hipSuccess) { rc_tab = LGR_ERR_HIP; return; }
-        rc_tab = filter_cloud_tables(cx, kclouds[0], ns, p->cluster_k, ftab.thr_s, ftab.knn_s);
-        if (rc_tab == LGR_OK) rc_tab = filter_cloud_tables(cx, kclouds[1], nt, p->cluster_k, ftab.thr_t, ftab.knn_t);
-        if (rc_tab == LGR_OK && hipStreamSynchronize(cx->stream) != hipSuccess) rc_tab = LGR_ERR_HIP;
-    });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{tables_worker};   // every exit path waits for the worker
+    auto cloud_tables = [&](lgr_ctx* cx) -> int {
+        LGR_TRY(filter_cloud_tables(cx, kclouds[0], ns, p->cluster_k, ftab.thr_s, ftab.knn_s));
+        return filter_cloud_tables(cx, kclouds[1], nt, p->cluster_k, ftab.thr_t, ftab.knn_t);
+    };
+    lgr_helper_guard tables_guard{ctx->aux2, false};   // every exit path waits for the helper (which always drains its stream)
+    if (ctx->opt.helper_contexts) {
+        LGR_HIP(ctx, hipEventRecord(ctx->aux2_ev, ctx->stream));
+        LGR_HIP(ctx, hipStreamWaitEvent(ctx->aux2->stream, ctx->aux2_ev, 0));
+        LGR_TRY(lgr_helper_post(ctx, ctx->aux2, lgr_aux_job(ctx->aux2, cloud_tables)));
+        tables_guard.armed = true;
+    } else {
+        const int rc = cloud_tables(ctx->aux2);        // same stream, this thread
+        if (rc != LGR_OK) { ctx->err = ctx->aux2->err; return rc; }
+    }
     if (multiscale) {
         LGR_TRY(ms_match_tables(ctx, clouds, sizes, kclouds, ksizes, p, ij, dij, ji, dji, ms));
     } else {
@@ -527,10 +534,11 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
     LGR_TRY(match_dispatch(ctx, p, kclouds[0], feat[0], ns, kclouds[1], feat[1], nt, p->matching_id != LGR_MATCH_ONE_SIDED, ij, dij, ji, dji));
     }
     tick(ctx, 5);
-    tables_worker.join();
-    (void) hipSetDevice(ctx->device);
-    if (rc_tab != LGR_OK) { ctx->err = ctx->aux2->err; return rc_tab; }
-    LGR_CHECK(ctx, p->matching_id == LGR_MATCH_LR || p->matching_id == LGR_MATCH_ONE_SIDED || p->matching_id == LGR_MATCH_CLUSTER, LGR_ERR_INVALID_ARG);
+    if (tables_guard.armed) {
+        const int rc_tab = tables_guard.wait();
+        (void) hipSetDevice(ctx->device);
+        if (rc_tab != LGR_OK) { ctx->err = ctx->aux2->err; return rc_tab; }
+    }
     LGR_TRY(filter_core(ctx, p->matching_id, ns, ij, dij, ji, dji, p->distance_thr, p->cluster_k, ftab, d_out, n_out));
     if (iss && *n_out) finalize_kernel<<<cdiv(*n_out, 256), 256, 0, ctx->stream>>>(d_out, *n_out, kidx[0], kidx[1]);
     tick(ctx, 6);

@@ -70,28 +70,90 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
     return LGR_OK;
 }
 
-int lgr_ctx_aux(lgr_ctx* ctx) {
-    if (ctx->aux) return LGR_OK;
-    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, LGR_STREAM_OWN, &ctx->aux) == LGR_OK, LGR_ERR_HIP);
-    LGR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
+// internal contexts: own non-blocking stream + helper thread (opt.helper_contexts), or the parent's stream (workspace only)
+static int make_internal(lgr_ctx* ctx, lgr_ctx** out, hipEvent_t* ev) {
+    if (*out) return LGR_OK;
+    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, ctx->opt.helper_contexts ? LGR_STREAM_OWN : (void*) ctx->stream, out) == LGR_OK, LGR_ERR_HIP);
+    (*out)->opt = ctx->opt;
+    (*out)->mopt = ctx->mopt;
+    if (!*ev) LGR_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return LGR_OK;
+}
+int lgr_ctx_aux(lgr_ctx* ctx) { return make_internal(ctx, &ctx->aux, &ctx->aux_ev); }
+int lgr_ctx_aux2(lgr_ctx* ctx) { return make_internal(ctx, &ctx->aux2, &ctx->aux2_ev); }
+
+static void helper_main(lgr_helper* h, int device) {
+    (void) hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(h->mu);
+    for (;;) {
+        h->cv.wait(lk, [h] { return h->has_job || h->quit; });
+        if (h->quit) return;
+        std::function<int()> job = std::move(h->job);
+        h->has_job = false;
+        lk.unlock();
+        int rc;
+        try { rc = job(); } catch (...) { rc = LGR_ERR_HIP; }   // nothing may unwind out of a helper thread
+        lk.lock();
+        h->rc = rc;
+        h->busy = false;
+        h->cv.notify_all();
+    }
+}
+
+int lgr_helper_post(lgr_ctx* owner, lgr_ctx* aux, std::function<int()> job) {
+    if (!aux->helper) aux->helper = new (std::nothrow) lgr_helper();
+    lgr_helper* h = aux->helper;
+    LGR_CHECK(owner, h != nullptr, LGR_ERR_OOM);
+    if (!h->started) {
+        try { h->th = std::thread(helper_main, h, aux->device); }
+        catch (...) { return lgr_fail(owner, LGR_ERR_HIP, "could not start the helper host thread (std::system_error)", __FILE__, __LINE__); }
+        h->started = true;
+    }
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (h->busy) return lgr_fail(owner, LGR_ERR_INVALID_ARG, "helper context busy (a context is not re-entrant)", __FILE__, __LINE__);
+        h->job = std::move(job);
+        h->has_job = true;
+        h->busy = true;
+    }
+    h->cv.notify_all();
     return LGR_OK;
 }
 
-int lgr_ctx_aux2(lgr_ctx* ctx) {
-    if (ctx->aux2) return LGR_OK;
-    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, LGR_STREAM_OWN, &ctx->aux2) == LGR_OK, LGR_ERR_HIP);
-    LGR_HIP(ctx, hipEventCreateWithFlags(&ctx->aux2_ev, hipEventDisableTiming));
-    return LGR_OK;
+int lgr_helper_wait(lgr_ctx* aux) {
+    lgr_helper* h = aux->helper;
+    if (!h) return LGR_OK;
+    std::unique_lock<std::mutex> lk(h->mu);
+    h->cv.wait(lk, [h] { return !h->busy; });
+    return h->rc;
+}
+
+static void helper_stop(lgr_ctx* c) {
+    lgr_helper* h = c->helper;
+    if (!h) return;
+    if (h->started) {
+        { std::lock_guard<std::mutex> lk(h->mu); h->quit = true; }
+        h->cv.notify_all();
+        if (h->th.joinable()) h->th.join();
+    }
+    delete h;
+    c->helper = nullptr;
+}
+
+static void drop_internal(lgr_ctx* ctx) {
+    if (ctx->match_prep) lgr_match_prepare_cancel(ctx);
+    if (ctx->aux) { (void) lgr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
+    if (ctx->aux2) { (void) lgr_ctx_destroy(ctx->aux2); ctx->aux2 = nullptr; }
 }
 
 extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     if (!ctx) return LGR_OK;
     (void) hipSetDevice(ctx->device);
+    helper_stop(ctx);
     (void) hipStreamSynchronize(ctx->stream);
     if (ctx->match_prep && ctx->match_prep_free) { ctx->match_prep_free(ctx->match_prep); ctx->match_prep = nullptr; }
-    if (ctx->aux) { (void) lgr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
+    drop_internal(ctx);
     if (ctx->aux_ev) { (void) hipEventDestroy(ctx->aux_ev); ctx->aux_ev = nullptr; }
-    if (ctx->aux2) { (void) lgr_ctx_destroy(ctx->aux2); ctx->aux2 = nullptr; }
     if (ctx->aux2_ev) { (void) hipEventDestroy(ctx->aux2_ev); ctx->aux2_ev = nullptr; }
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i].p) (void) hipFree(ctx->ws[i].p);
@@ -99,6 +161,45 @@ extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     for (int i = 0; i < 32; ++i) (void) hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
+    return LGR_OK;
+}
+
+extern "C" void lgr_ctx_default_options(lgr_ctx_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->helper_contexts = 1;
+}
+
+extern "C" int lgr_ctx_set_options(lgr_ctx* ctx, const lgr_ctx_options* opt) {
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    lgr_ctx_options o;
+    lgr_ctx_default_options(&o);
+    if (opt) o = *opt;
+    LGR_CHECK(ctx, o.helper_contexts == 0 || o.helper_contexts == 1, LGR_ERR_INVALID_ARG);
+    if (o.helper_contexts != ctx->opt.helper_contexts) {
+        // the internal contexts are bound to a stream when they are created: drop them (workspaces included), they come back on
+        // first use with the stream the new setting asks for
+        LGR_HIP(ctx, hipSetDevice(ctx->device));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        drop_internal(ctx);
+    }
+    ctx->opt = o;
+    return LGR_OK;
+}
+
+extern "C" int lgr_ctx_get_options(lgr_ctx* ctx, lgr_ctx_options* opt) {
+    if (!ctx || !opt) return LGR_ERR_INVALID_ARG;
+    *opt = ctx->opt;
+    return LGR_OK;
+}
+
+static int helper_threads(const lgr_ctx* c) {
+    if (!c) return 0;
+    return ((c->helper && c->helper->started) ? 1 : 0) + helper_threads(c->aux) + helper_threads(c->aux2);
+}
+extern "C" int lgr_ctx_host_threads(lgr_ctx* ctx, int* n) {
+    if (!ctx || !n) return LGR_ERR_INVALID_ARG;
+    *n = 1 + helper_threads(ctx->aux) + helper_threads(ctx->aux2);
     return LGR_OK;
 }
 
@@ -125,10 +226,17 @@ extern "C" void lgr_match_default_options(lgr_match_options* o) {
 
 extern "C" int lgr_ctx_set_match_options(lgr_ctx* ctx, const lgr_match_options* opt) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    if (!opt) { lgr_match_default_options(&ctx->mopt); return LGR_OK; }
+    if (!opt) {
+        lgr_match_default_options(&ctx->mopt);
+        if (ctx->aux) ctx->aux->mopt = ctx->mopt;
+        if (ctx->aux2) ctx->aux2->mopt = ctx->mopt;
+        return LGR_OK;
+    }
     LGR_CHECK(ctx, opt->prune >= -1 && opt->prune <= 1 && opt->leaves >= 0 && opt->leaves <= 64 && opt->near >= 0 &&
                    opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2, LGR_ERR_INVALID_ARG);
     ctx->mopt = *opt;
+    if (ctx->aux) ctx->aux->mopt = *opt;
+    if (ctx->aux2) ctx->aux2->mopt = *opt;
     return LGR_OK;
 }
 

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -16,6 +19,21 @@
 struct lgr_buf {
     void* p = nullptr;
     size_t cap = 0;
+};
+
+// statistics of a context's last match call (bench / diagnostics: lgr_match_last_*): candidate (query, group) items and
+// dense-fallback queries per direction, group counts, the column stages the MFMA passes executed out of all (row block, stage) pairs
+struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; double coarse_tested, coarse_rejected; unsigned pairs_ab, pairs_ba; };
+
+// The one persistent helper host thread of an internal context (lgr_ctx::aux / aux2): started on first use, parked on a condition
+// variable between jobs, joined when the context is destroyed.  One job at a time: post, then wait.
+struct lgr_helper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, busy = false, quit = false, started = false;
+    int rc = 0;
 };
 
 // Per-thread/GPU context: stream, error string, named workspace buffers (grown on demand, reused across calls).
@@ -32,7 +50,7 @@ struct lgr_ctx {
     int n_cu = 256;
     int mfma_timed = 0;
     lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, {0, 0, 0, 0, 0}};   // lgr_match_default_options
-    bool corr_trusted = false;
+    bool corr_trusted = false;                  // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
     void* match_prep = nullptr;                 // the matcher's clustering / prepared query side (lgr_match.hip: MatchPrep)
     void (*match_prep_free)(void*) = nullptr;
     lgr_ctx* aux = nullptr;      // second context (own stream + workspace, same device): the target cloud's feature stages run on it
@@ -40,7 +58,11 @@ struct lgr_ctx {
     hipEvent_t aux_ev = nullptr;
     lgr_ctx* aux2 = nullptr;     // third context: the match filter's per-cloud tables (densities, cluster k-NN lists) are computed on it
                                  // while the matcher runs on this one (lgr_correspondences_dev)
-    hipEvent_t aux2_ev = nullptr;   // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
+    hipEvent_t aux2_ev = nullptr;
+    lgr_ctx_options opt{1, {0, 0, 0, 0, 0, 0, 0}};   // lgr_ctx_default_options
+    lgr_helper* helper = nullptr;               // of an internal context: the host thread that drives it (opt.helper_contexts)
+    lgr_match_stats mstats{};                   // lgr_match_last_*: the last match call of THIS context
+    double mcheck[2] = {-1, -1};
 };
 
 int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line);
@@ -120,21 +142,47 @@ int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
 // What it buys: the host read-backs (counts, extents) and short launches of one piece hide behind the other piece's kernels.
 int lgr_ctx_aux(lgr_ctx* ctx);   // makes sure ctx->aux exists
 int lgr_ctx_aux2(lgr_ctx* ctx);  // makes sure ctx->aux2 exists
+// post `job` to the helper thread of the internal context `aux` (started on first use; a thread that cannot be started is an error
+// code, never an exception across the C ABI); lgr_helper_wait blocks until it has run and returns its status.  Every post must be
+// followed by exactly one wait -- also on the caller's error paths (lgr_helper_guard).
+int lgr_helper_post(lgr_ctx* owner, lgr_ctx* aux, std::function<int()> job);
+int lgr_helper_wait(lgr_ctx* aux);
+struct lgr_helper_guard {   // waits for a posted job on every exit path of the scope
+    lgr_ctx* aux = nullptr;
+    bool armed = false;
+    int wait() { armed = false; return lgr_helper_wait(aux); }
+    ~lgr_helper_guard() { if (armed) (void) lgr_helper_wait(aux); }
+};
+// a job for an internal context: run f(aux), then ALWAYS drain the aux stream (also when f failed: kernels it had already enqueued may
+// still be writing caller-visible buffers, and the caller is about to return an error and let go of them)
+template <class F>
+static inline std::function<int()> lgr_aux_job(lgr_ctx* aux, F&& f) {
+    return [aux, &f]() -> int {
+        int rc = hipSetDevice(aux->device) == hipSuccess ? f(aux) : (int) LGR_ERR_HIP;
+        const hipError_t e = hipStreamSynchronize(aux->stream);
+        if (rc == LGR_OK && e != hipSuccess) rc = lgr_fail(aux, LGR_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
+        return rc;
+    };
+}
 template <class FA, class FB>
 static inline int lgr_run_pair(lgr_ctx* ctx, FA&& fa, FB&& fb) {
     LGR_TRY(lgr_ctx_aux(ctx));
+    lgr_ctx* ax = ctx->aux;
+    if (!ctx->opt.helper_contexts) {   // one host thread, one stream (ax->stream == ctx->stream): the second context is a second workspace
+        LGR_TRY(fa(ctx));
+        const int rc = fb(ax);
+        if (rc != LGR_OK) ctx->err = ax->err;
+        return rc;
+    }
     LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
-    LGR_HIP(ctx, hipStreamWaitEvent(ctx->aux->stream, ctx->aux_ev, 0));
-    int rc_b = LGR_OK;
-    std::thread worker([&]() {
-        if (hipSetDevice(ctx->aux->device) != hipSuccess) { rc_b = LGR_ERR_HIP; return; }
-        rc_b = fb(ctx->aux);
-        if (rc_b == LGR_OK && hipStreamSynchronize(ctx->aux->stream) != hipSuccess) rc_b = LGR_ERR_HIP;
-    });
+    LGR_HIP(ctx, hipStreamWaitEvent(ax->stream, ctx->aux_ev, 0));
+    lgr_helper_guard g{ax, false};
+    LGR_TRY(lgr_helper_post(ctx, ax, lgr_aux_job(ax, fb)));
+    g.armed = true;
     const int rc_a = fa(ctx);
-    worker.join();
+    const int rc_b = g.wait();
     (void) hipSetDevice(ctx->device);
-    if (rc_b != LGR_OK) { ctx->err = ctx->aux->err; return rc_b; }
+    if (rc_b != LGR_OK) { ctx->err = ax->err; return rc_b; }
     return rc_a;
 }
 

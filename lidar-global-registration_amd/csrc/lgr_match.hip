@@ -34,47 +34,44 @@
 #include "lgr_match_bounds.cuh"
 #include "lgr_match_rerank.cuh"
 
-// statistics of the last match call (bench/diagnostics): candidate (query, group) items and dense-fallback queries
-// per direction, group counts, and the column stages the MFMA passes executed out of all (row block, stage) pairs
-struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; double coarse_tested, coarse_rejected; unsigned pairs_ab, pairs_ba; };
-// diagnostics of the calling thread's last match call (one context per host thread)
-static thread_local lgr_match_stats g_last_stats;
-static thread_local double g_last_check[2] = {-1, -1};
-extern "C" int lgr_match_last_stats(unsigned* out6) {
-    out6[0] = g_last_stats.items_ab; out6[1] = g_last_stats.dense_ab; out6[2] = g_last_stats.items_ba;
-    out6[3] = g_last_stats.dense_ba; out6[4] = (unsigned) g_last_stats.sub_cols; out6[5] = (unsigned) g_last_stats.rg_rows;
+// diagnostics of a context's last match call (lgr_match_stats / mcheck live in the context: two contexts driven from one host thread
+// keep separate figures, and the helper thread of the second rerank direction writes into the same object as the caller)
+extern "C" int lgr_match_last_stats(lgr_ctx* ctx, unsigned* out6) {
+    if (!ctx || !out6) return LGR_ERR_INVALID_ARG;
+    const lgr_match_stats& s = ctx->mstats;
+    out6[0] = s.items_ab; out6[1] = s.dense_ab; out6[2] = s.items_ba;
+    out6[3] = s.dense_ba; out6[4] = (unsigned) s.sub_cols; out6[5] = (unsigned) s.rg_rows;
     return LGR_OK;
 }
 // fraction of the (row block x column stage) tiles of the last match call that the MFMA passes computed (1 = dense)
-extern "C" int lgr_match_last_work(double* executed_fraction) {
-    if (!executed_fraction) return LGR_ERR_INVALID_ARG;
-    *executed_fraction = g_last_stats.stages_all > 0 ? g_last_stats.stages_done / g_last_stats.stages_all : 1.0;
+extern "C" int lgr_match_last_work(lgr_ctx* ctx, double* executed_fraction) {
+    if (!ctx || !executed_fraction) return LGR_ERR_INVALID_ARG;
+    *executed_fraction = ctx->mstats.stages_all > 0 ? ctx->mstats.stages_done / ctx->mstats.stages_all : 1.0;
     return LGR_OK;
 }
-
-// MFMA operand format of the last match call: 1 = f16-split operands on v_mfma_f32_32x32x16_f16 (224 FLOP per pair),
-// 0 = f32 operands on v_mfma_f32_32x32x2_f32 (68 FLOP per pair)
-extern "C" int lgr_match_last_pairs(unsigned* out2) {
-    if (!out2) return LGR_ERR_INVALID_ARG;
-    out2[0] = g_last_stats.pairs_ab; out2[1] = g_last_stats.pairs_ba;
+extern "C" int lgr_match_last_pairs(lgr_ctx* ctx, unsigned* out2) {
+    if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = ctx->mstats.pairs_ab; out2[1] = ctx->mstats.pairs_ba;
     return LGR_OK;
 }
-extern "C" int lgr_match_last_coarse(double* out2) {
-    if (!out2) return LGR_ERR_INVALID_ARG;
-    out2[0] = g_last_stats.coarse_tested; out2[1] = g_last_stats.coarse_rejected;
+extern "C" int lgr_match_last_coarse(lgr_ctx* ctx, double* out2) {
+    if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = ctx->mstats.coarse_tested; out2[1] = ctx->mstats.coarse_rejected;
     return LGR_OK;
 }
-extern "C" int lgr_match_last_format(int* f16) {
-    if (!f16) return LGR_ERR_INVALID_ARG;
-    *f16 = g_last_stats.f16;
+// MFMA operand format of the last match call: 2 / 1 = f16-split operands on v_mfma_f32_32x32x16_f16 (rotated: 192, plain: 224 FLOP per
+// pair), 0 = f32 operands on v_mfma_f32_32x32x2_f32 (68 FLOP per pair)
+extern "C" int lgr_match_last_format(lgr_ctx* ctx, int* f16) {
+    if (!ctx || !f16) return LGR_ERR_INVALID_ARG;
+    *f16 = ctx->mstats.f16;
     return LGR_OK;
 }
 
 // lgr_match_options.self_check (tests): worst |filtered - exact| / eps over the sampled table entries of the last call, per direction
 // (rows, columns); -1 when the check did not run.  A proven bound: must be <= 1.
-extern "C" int lgr_match_last_check(double* out2) {
-    if (!out2) return LGR_ERR_INVALID_ARG;
-    out2[0] = g_last_check[0]; out2[1] = g_last_check[1];
+extern "C" int lgr_match_last_check(lgr_ctx* ctx, double* out2) {
+    if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = ctx->mcheck[0]; out2[1] = ctx->mcheck[1];
     return LGR_OK;
 }
 
@@ -282,6 +279,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     bool both = d_ba_idx != nullptr && mb > 0;
     if (d_ba_idx) LGR_CHECK(ctx, d_ba_dist != nullptr, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
+    lgr_match_stats& g_last_stats = ctx->mstats;
+    double* const g_last_check = ctx->mcheck;
     memset(&g_last_stats, 0, sizeof g_last_stats);
     g_last_check[0] = g_last_check[1] = -1;
     ctx->mfma_timed = 0;
@@ -749,7 +748,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // ---- 5. exact rerank
     // (the MFMA re-filter of the rerank items needs the f16 operand formats and the padded train copies)
     RefilterArgs ra{(const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, (f16 && mo.rerank_refilter) ? KS : 0, A.blkcl, mo.pair_cap};
-    lgr_match_stats* st = &g_last_stats;   // (thread_local: the second host thread writes through this pointer)
+    lgr_match_stats* st = &g_last_stats;   // (in the context: the helper thread of the other direction writes its own fields)
     auto rerank_ab = [&](lgr_ctx* cx) {
         return run_rerank<true>(cx, ex, comp_rows, (const float*) rowmin, n_groups, 0, group_start, d_a, A, nAp, nullptr, gmaxB, nullptr, d_b, sortedB, B, block, bestA,
                                 d_ab_idx, d_ab_dist, &st->items_ab, &st->dense_ab, force_dense, ra, &st->pairs_ab);

@@ -133,6 +133,9 @@ inline int& device_ordinal() { static int d = 0; return d; }
 inline void set_device(int d) { device_ordinal() = d; }
 inline lgr_ctx* context() {
     static thread_local lgr_ctx* ctx = nullptr;
+    // a liblgr_hip.so of another ABI revision would read lgr_params with another layout (include/lgr.h LGR_VERSION)
+    if (!ctx && lgr_version() != LGR_VERSION)
+        throw std::runtime_error("lgr: liblgr_hip.so has ABI revision " + std::to_string(lgr_version()) + ", this header is revision " + std::to_string(LGR_VERSION));
     if (!ctx && lgr_ctx_create(device_ordinal(), LGR_STREAM_OWN, &ctx) != LGR_OK)
         throw std::runtime_error("lgr: no MI355X device / context creation failed (there is no CPU fallback)");
     return ctx;

@@ -61,6 +61,11 @@ class MatchOptions(C.Structure):
                 ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
+class CtxOptions(C.Structure):
+    """lgr_ctx_options (include/lgr.h): how the context uses host threads and streams, never what it returns."""
+    _fields_ = [("helper_contexts", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
 FORMAT_AUTO, FORMAT_F32, FORMAT_F16, FORMAT_F16R = -1, 0, 1, 2
 
 
@@ -76,9 +81,13 @@ def load():
     return C.CDLL(LIB_PATH)
 
 
+ABI_VERSION = 2      # LGR_VERSION of the include/lgr.h these structures mirror
+
 _lib = load()
 _lib.lgr_last_error.restype = C.c_char_p
 _lib.lgr_last_error.argtypes = [C.c_void_p]
+if _lib.lgr_version() != ABI_VERSION:     # a stale liblgr_hip.so would read lgr_params / call lgr_match_last_* with another layout
+    raise ImportError(f"{LIB_PATH} has ABI revision {_lib.lgr_version()}, this binding needs {ABI_VERSION}: rebuild it (make -C {_CSRC})")
 
 
 def lib():
@@ -158,6 +167,22 @@ class Context:
         self.check(_lib.lgr_ctx_get_match_options(self.h, C.byref(o)))
         return o
 
+    def set_options(self, **kw):
+        """lgr_ctx_options: defaults + overrides (helper_contexts=0: one host thread, one stream); returns the options now in force"""
+        o = CtxOptions()
+        _lib.lgr_ctx_default_options(C.byref(o))
+        for k, v in kw.items():
+            assert hasattr(o, k), k
+            setattr(o, k, int(v))
+        self.check(_lib.lgr_ctx_set_options(self.h, C.byref(o)))
+        return o
+
+    def host_threads(self):
+        """1 + the helper host threads this context has started (at most 2)"""
+        n = C.c_int(0)
+        self.check(_lib.lgr_ctx_host_threads(self.h, C.byref(n)))
+        return n.value
+
     def workspace_bytes(self):
         out = C.c_uint64(0)
         self.check(_lib.lgr_ctx_workspace_bytes(self.h, C.byref(out)))
@@ -233,38 +258,38 @@ class Context:
 
     def match_stats(self):
         out = (C.c_uint * 6)()
-        _lib.lgr_match_last_stats(out)
+        self.check(_lib.lgr_match_last_stats(self.h, out))
         return dict(items_ab=out[0], dense_ab=out[1], items_ba=out[2], dense_ba=out[3], sub_cols=out[4], rg_rows=out[5])
 
     def match_work(self):
         """fraction of the (row block x column stage) tiles the MFMA passes of the last match call computed"""
         f = C.c_double(1.0)
-        self.check(_lib.lgr_match_last_work(C.byref(f)))
+        self.check(_lib.lgr_match_last_work(self.h, C.byref(f)))
         return f.value
 
     def match_pairs(self):
         """(query->train, train->query) pairs the MFMA re-filter of the rerank handed to the exact distance in the last match call"""
         out = (C.c_uint * 2)()
-        self.check(_lib.lgr_match_last_pairs(out))
+        self.check(_lib.lgr_match_last_pairs(self.h, out))
         return out[0], out[1]
 
     def match_coarse(self):
         """(tiles tested, tiles abandoned) by the coarse rejection inside the MFMA filter kernel in the last match call"""
         out = (C.c_double * 2)()
-        self.check(_lib.lgr_match_last_coarse(out))
+        self.check(_lib.lgr_match_last_coarse(self.h, out))
         return out[0], out[1]
 
     def match_format(self):
         """'f16' (split operands on the f16 MFMA, K = 112), 'f16r' (the same on 30 rotated coordinates, K = 96) or 'f32'
         for the last match call"""
         v = C.c_int(0)
-        self.check(_lib.lgr_match_last_format(C.byref(v)))
+        self.check(_lib.lgr_match_last_format(self.h, C.byref(v)))
         return {0: "f32", 1: "f16", 2: "f16r"}[v.value]
 
     def match_check(self):
-        """(rows, cols) worst |filtered - exact| / eps of the last match call run with LGR_MATCH_CHECK=1, or -1"""
+        """(rows, cols) worst |filtered - exact| / eps of the last match call run under set_match_options(self_check=1), or -1"""
         out = (C.c_double * 2)()
-        self.check(_lib.lgr_match_last_check(out))
+        self.check(_lib.lgr_match_last_check(self.h, out))
         return out[0], out[1]
 
     def match_kernel_ms(self):

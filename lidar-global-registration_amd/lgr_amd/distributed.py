@@ -40,12 +40,14 @@ def unpack_record(rec):
                 n_inliers=int(words[_I_INL]), time_cs=float(rec[_F_TCS]), time_te=float(rec[_F_TTE]), pair_id=int(words[_I_PAIR]))
 
 
-def gather_records(local_records, world, device=None):
+def gather_records(local_records, world, device=None, force=False):
     """local_records: [k, RECORD_FLOATS] tensor of 4-byte words (int32 views of the records; k equal on all ranks, pad with pair_id = -1).
-    Returns the [world * k, RECORD_FLOATS] tensor of all ranks' records on every rank (one all_gather)."""
+    Returns the [world * k, RECORD_FLOATS] tensor of all ranks' records on every rank (one all_gather).  world == 1 needs no exchange;
+    force=True still issues the collective on the (one-rank) process group -- bench.py --force-collective, which runs the RCCL code
+    of the N > 1 path on a one-GPU box."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local_records
     out = [torch.empty_like(local_records) for _ in range(world)]
     dist.all_gather(out, local_records)

@@ -1,5 +1,10 @@
 """The BASELINE.json configs that are not the bench line, as -m gpu tests ("configs untested"):
 
+  configs[0]  the reference's YAML-default profile as ONE flow (data/test.yaml:3-37): PLY files -> loadPointClouds preprocessing
+              (src/common.cpp:429-470) -> automatic distance_thr / iss_radius (:257-333) -> keypoint iss, multi-scale descriptors
+              (include/matching.h:176-262), matching cluster (:480-551), RANSAC with the uniformity metric, 1e6 iterations ->
+              transformations.csv / correspondences CSV; every stage and the result bit-equal to the oracle on the same files;
+
   configs[2]  scan pairs of different sizes sharded over ranks, pushed through ONE context per rank (src/main.cpp:384-407 loops
               pairs in one process): records equal the single-pair runs in fresh contexts, whatever ran before in the workspace;
   configs[3]  5M-point pair end to end (properties + sampled matcher parity vs the oracle + workspace budget) and the RANSAC
@@ -25,6 +30,67 @@ def to_orc_corr(oracle, corr):
     out["query"] = corr["index_query"]; out["match"] = corr["index_match"]
     out["distance"] = corr["distance"]; out["threshold"] = corr["threshold"]
     return out
+
+
+# ------------------------------------------------------------------------------------------------------ configs[0]
+@pytest.mark.parametrize("n_raw", [100_000, 1_000_000])     # 1e6 raw points leave ~1.2e5 per cloud after the loader's voxel grid (config 1's M ~ 1e5)
+def test_config0_default_profile(lgr, oracle, tmp_path, n_raw):
+    from lgr_amd import capi, formats, profile, synthetic
+    pair = synthetic.make_pair(n_raw, seed=566)
+    paths = {}
+    for side in ("src", "tgt"):       # xyz-only scans, as the kizhi / WHU-TLS files are: pointCloudHasNormals == false
+        paths[side] = str(tmp_path / ("scan_%s.ply" % side))
+        formats.write_ply(paths[side], pair[side], binary=True, with_normals=False)
+    # -- loadPointClouds on the device vs the oracle, from the files
+    ld = profile.load_pair(lgr, paths["src"], paths["tgt"], vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
+    assert ld["normals_available"] is False
+    host, dens_o = {}, {}
+    for side in ("src", "tgt"):
+        np.testing.assert_array_equal(bits(ld["raw_" + side][:, :3]), bits(pair[side][:, :3]))
+        want, voxel = oracle.preprocess(ld["raw_" + side], vp=pair["vp_" + side], normals_available=False)
+        host[side] = ld[side].cpu().numpy()
+        assert np.float32(voxel) == np.float32(ld["voxel_" + side])
+        np.testing.assert_array_equal(bits(host[side]), bits(want))
+        dens_o[side] = oracle.cloud_density(want)
+        assert np.float32(dens_o[side]) == np.float32(ld["density_" + side])
+        assert (0.08 if n_raw > 500_000 else 0.008) * n_raw < len(want) < 0.2 * n_raw
+    # -- the YAML-default parameters (nothing but source / target set): automatic thresholds from the two densities
+    kw = dict(vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
+    p_g = profile.default_profile(capi, ld["density_src"], ld["density_tgt"], **kw)
+    p_o = profile.default_profile(oracle, dens_o["src"], dens_o["tgt"], rng_mode=oracle.RNG_PHILOX, **kw)
+    assert (p_g.keypoint_id, p_g.matching_id, p_g.metric_id, p_g.score_id, p_g.max_iterations, p_g.bf_block_size, p_g.cluster_k) == (1, 2, 1, 2, 1000000, 200000, 40)
+    assert p_g.feature_radius <= 0 and np.float32(p_g.distance_thr) == np.float32(4) * max(np.float32(dens_o["src"]), np.float32(dens_o["tgt"]))
+    assert np.float32(p_g.iss_radius_src) == np.float32(2) * np.float32(dens_o["src"])
+    # -- alignPointClouds: correspondences and the 4x4 bit-equal
+    ores, ocorr, _ = oracle.align(host["src"], host["tgt"], p_o)
+    corr = lgr.correspondences(ld["src"], ld["tgt"], p_g).cpu().numpy().view(capi.CORR_DTYPE).reshape(-1)
+    assert len(corr) == len(ocorr) > (400 if n_raw > 500_000 else 100)
+    np.testing.assert_array_equal(corr["index_query"], ocorr["query"])
+    np.testing.assert_array_equal(corr["index_match"], ocorr["match"])
+    np.testing.assert_array_equal(bits(corr["distance"]), bits(ocorr["distance"]))
+    np.testing.assert_array_equal(bits(corr["threshold"]), bits(ocorr["threshold"]))
+    res = lgr.align(ld["src"], ld["tgt"], p_g)
+    assert (res.n_correspondences, res.iterations, res.n_inliers, res.converged, res.best_iteration) == \
+           (len(ocorr), ores.iterations, ores.n_inliers, ores.converged, ores.best_iteration)
+    np.testing.assert_array_equal(bits(res.matrix()), bits(ores.matrix()))
+    assert np.float32(res.metric) == np.float32(ores.metric)
+    if n_raw > 500_000:               # at ~1.2e5 points per cloud the default profile registers the pair
+        T = res.matrix().astype(np.float64)
+        ang = np.degrees(np.arccos(np.clip((np.trace(pair["T_gt"][:3, :3].T @ T[:3, :3]) - 1) / 2, -1, 1)))
+        assert res.converged == 1 and ang < 1.0 and np.linalg.norm(T[:3, 3] - pair["T_gt"][:3, 3]) < 0.1
+    # -- the two CSV side effects of alignPointClouds (src/alignment.cpp:78,87,103-108), written and re-read
+    tcsv, ccsv = str(tmp_path / "transformations.csv"), str(tmp_path / "correspondences.csv")
+    formats.save_transformation(tcsv, "scan_src_scan_tgt", res.matrix())
+    formats.save_transformation(tcsv, "oracle", ores.matrix())
+    back = formats.get_transformation(tcsv, "scan_src_scan_tgt")
+    assert np.abs(back - res.matrix()).max() <= 1e-5 * max(1.0, np.abs(res.matrix()).max())      # 6 significant digits (ostream << float)
+    lines = open(tcsv).read().splitlines()
+    assert lines[0] == formats.TRANSFORMATION_HEADER and lines[1].split(",", 1)[1] == lines[2].split(",", 1)[1]
+    formats.save_correspondences(ccsv, host["src"], host["tgt"], corr)
+    rb = formats.read_correspondences(ccsv)
+    np.testing.assert_array_equal(rb["index_query"], corr["index_query"])
+    np.testing.assert_array_equal(rb["index_match"], corr["index_match"])
+    assert np.allclose(rb["distance"], corr["distance"], rtol=1e-5) and np.allclose(rb["threshold"], corr["threshold"], rtol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------------------ configs[2]

@@ -53,3 +53,65 @@ def test_same_buffers_new_contents_and_standalone_matcher_after_pipeline(lgr):
     for x, y in zip(r2, r2f):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     assert not np.array_equal(r1[0], r2[0])
+
+
+def test_single_context_mode_is_identical_and_starts_no_threads():
+    """lgr_ctx_options.helper_contexts = 0: every piece on the caller's stream from the caller's thread -- same
+    results bit for bit in every matching mode, host_threads() stays 1; the default mode starts its (at most two) persistent helper
+    threads once and keeps that number over repeated calls."""
+    import torch
+    from lgr_amd import capi, synthetic
+    pair = synthetic.make_pair(30000, seed=11)
+    src, tgt = torch.from_numpy(pair["src"]).cuda(), torch.from_numpy(pair["tgt"]).cuda()
+    multi, single = capi.Context(0), capi.Context(0)
+    try:
+        assert single.set_options(helper_contexts=0).helper_contexts == 0
+        assert multi.host_threads() == 1 and single.host_threads() == 1
+        for kw in (dict(matching_id=0), dict(matching_id=2), dict(matching_id=1),
+                   dict(matching_id=2, keypoint_id=capi.KEYPOINT_ISS, iss_radius_src=0.08, iss_radius_tgt=0.08, feature_radius=0.0)):
+            p = _params(capi, **kw)
+            a = multi.align(src, tgt, p)
+            b = single.align(src, tgt, p)
+            assert np.array_equal(a.matrix().view(np.uint32), b.matrix().view(np.uint32)), kw
+            assert (a.n_correspondences, a.n_inliers, a.iterations, a.converged) == (b.n_correspondences, b.n_inliers, b.iterations, b.converged)
+            ca = multi.correspondences(src, tgt, p).cpu().numpy()
+            cb = single.correspondences(src, tgt, p).cpu().numpy()
+            assert np.array_equal(ca, cb)
+        assert single.host_threads() == 1
+        assert 2 <= multi.host_threads() <= 3
+        n = multi.host_threads()
+        for _ in range(3):
+            multi.align(src, tgt, _params(capi))
+        assert multi.host_threads() == n                 # persistent: no thread per call
+        # switching an existing context over and back: internal contexts are rebuilt, results unchanged
+        want = multi.align(src, tgt, _params(capi)).matrix()
+        multi.set_options(helper_contexts=0)
+        assert multi.host_threads() == 1
+        assert np.array_equal(multi.align(src, tgt, _params(capi)).matrix().view(np.uint32), want.view(np.uint32))
+        multi.set_options()
+        assert np.array_equal(multi.align(src, tgt, _params(capi)).matrix().view(np.uint32), want.view(np.uint32))
+    finally:
+        multi.close(); single.close()
+
+
+def test_match_statistics_belong_to_the_context():
+    """lgr_match_last_* (they were thread_local): two contexts driven from ONE host thread keep separate figures."""
+    import torch
+    from lgr_amd import capi
+    rng = np.random.default_rng(1)
+    a = torch.from_numpy(np.abs(rng.normal(size=(9000, 33))).astype(np.float32)).cuda()
+    b = torch.from_numpy(np.abs(rng.normal(size=(7000, 33))).astype(np.float32)).cuda()
+    c1, c2 = capi.Context(0), capi.Context(0)
+    try:
+        c1.set_match_options(prune=1, leaves=4, operand_format=capi.FORMAT_F16)
+        c2.set_match_options(prune=0, operand_format=capi.FORMAT_F32)
+        r1 = [t.cpu().numpy() for t in c1.match_bf2(a, b)]
+        r2 = [t.cpu().numpy() for t in c2.match_bf2(a, b)]
+        c1.sync(); c2.sync()
+        assert c1.match_format() == "f16" and c2.match_format() == "f32"       # c1's figures survived c2's call on the same thread
+        assert c1.match_work() < 1.0 and c2.match_work() == 1.0
+        assert c1.match_stats()["sub_cols"] != 0 and c1.match_stats() != c2.match_stats()
+        for x, y in zip(r1, r2):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    finally:
+        c1.close(); c2.close()

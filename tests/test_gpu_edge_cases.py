@@ -116,6 +116,20 @@ def test_invalid_arguments_return_status_not_crash(lgr, pair):
     assert lib.lgr_align_dev(lgr.h, ps, src.shape[0], pt, tgt.shape[0], C.byref(bad), C.byref(res)) == ERR_UNSUPPORTED
     bad = base_params(capi, pair); bad.alignment_id = 2                                                        # "teaser": alignTeaser throws in the reference
     assert lib.lgr_align_dev(lgr.h, ps, src.shape[0], pt, tgt.shape[0], C.byref(bad), C.byref(res)) == ERR_UNSUPPORTED
+    # the pipeline entry points build the filter tables themselves -- cluster_k outside what the cluster filter keeps
+    # (1 .. 64 spatial neighbours) and unknown matching ids are refused BEFORE any stage runs, not after a full pipeline run
+    import time
+    for field, value in (("cluster_k", 65), ("cluster_k", 0), ("cluster_k", -3), ("matching_id", 7)):
+        bad = base_params(capi, pair); bad.matching_id = capi.MATCH_CLUSTER
+        setattr(bad, field, value)
+        n = C.c_int(-1)
+        out = lgr.empty((src.shape[0], 4), src.dtype)
+        t0 = time.perf_counter()
+        assert lib.lgr_align_dev(lgr.h, ps, src.shape[0], pt, tgt.shape[0], C.byref(bad), C.byref(res)) == ERR_INVALID_ARG, (field, value)
+        assert lib.lgr_correspondences_dev(lgr.h, ps, src.shape[0], pt, tgt.shape[0], C.byref(bad), C.c_void_p(out.data_ptr()), C.byref(n)) == ERR_INVALID_ARG
+        assert time.perf_counter() - t0 < 0.05          # no stage ran
+    okc = base_params(capi, pair); okc.matching_id = capi.MATCH_LR; okc.cluster_k = 65     # cluster_k is not read by the other filters (the reference ignores it too)
+    assert lib.lgr_align_dev(lgr.h, ps, src.shape[0], pt, tgt.shape[0], C.byref(okc), C.byref(res)) == 0
     # the context stays usable after errors
     ok = lgr.align(src, tgt, p)
     assert ok.n_correspondences > 0

@@ -113,6 +113,20 @@ def test_match_1m_refilter_on_off_identical(lgr, st, matches):
         np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_match_1m_prune_off_identical(lgr, st, matches):
+    """the dense schedule (prune = 0: every 32 x 32 tile computed, no bounds, no masks, no coarse rejection) vs the
+    production schedule on the pair's REAL FPFH rows: all four tables bit-equal for ALL 2 M queries."""
+    lgr.set_match_options(prune=0)
+    try:
+        dense = [x.cpu().numpy() for x in lgr.match_bf2(st["src"]["feat"], st["tgt"]["feat"], BLOCK)]
+        lgr.sync()
+        assert lgr.match_work() == 1.0
+    finally:
+        lgr.set_match_options()
+    for a, b in zip(matches["h"], dense):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 @pytest.fixture(scope="module")
 def corr(lgr, st, matches):
     from lgr_amd import capi
@@ -160,3 +174,34 @@ def test_ransac_1m_full_and_pipeline(lgr, st, corr, oracle):
     full = lgr.align(st["src"]["cloud"], st["tgt"]["cloud"], p_g)
     np.testing.assert_array_equal(bits(full.matrix()), bits(res.matrix()))
     assert (full.iterations, full.n_inliers, full.n_correspondences) == (res.iterations, res.n_inliers, len(corr))
+
+
+def test_cluster_1m_full(lgr, st, matches, oracle):
+    """SURVEY 8(d)'s second run of config 2 -- `matching: cluster`, the YAML default (include/matching.h:480-551) -- at
+    BASELINE size: the cluster filter in full (two 40-NN tables of 1M points, both directional consistency distances) and the whole
+    RANSAC + refit on its ~3e5 correspondences vs the oracle; then the one-call pipeline == the staged chain."""
+    from lgr_amd import capi
+    pair = st["pair"]
+    ab_i, ab_d, ba_i, ba_d = matches["t"]
+    got = lgr.filter(capi.MATCH_CLUSTER, st["src"]["cloud"], st["tgt"]["cloud"], ab_i, ab_d, ba_i, ba_d, 0.1, 40)
+    h = matches["h"]
+    want = oracle.filter_matches(oracle.MATCH_CLUSTER, pair["src"], pair["tgt"], h[0], h[1], h[2], h[3], 0.1, 40)
+    assert len(got) == len(want) > 100_000
+    np.testing.assert_array_equal(got["index_query"], want["query"])
+    np.testing.assert_array_equal(got["index_match"], want["match"])
+    np.testing.assert_array_equal(bits(got["distance"]), bits(want["distance"]))
+    np.testing.assert_array_equal(bits(got["threshold"]), bits(want["threshold"]))
+    p_g = _params(capi, pair)
+    p_g.matching_id = capi.MATCH_CLUSTER
+    res, mask = lgr.ransac(st["src"]["cloud"], st["tgt"]["cloud"], got, p_g)
+    p_o = _params(oracle, pair, rng_mode=oracle.RNG_PHILOX)
+    p_o.matching_id = oracle.MATCH_CLUSTER
+    ores, omask = oracle.ransac(pair["src"], pair["tgt"], want, p_o)
+    assert (res.iterations, res.n_inliers, res.best_iteration, res.converged, res.num_rejections) == \
+           (ores.iterations, ores.n_inliers, ores.best_iteration, ores.converged, ores.num_rejections)
+    np.testing.assert_array_equal(mask, omask)
+    np.testing.assert_array_equal(bits(res.matrix()), bits(ores.matrix()))
+    assert np.float32(res.metric) == np.float32(ores.metric)
+    full = lgr.align(st["src"]["cloud"], st["tgt"]["cloud"], p_g)
+    np.testing.assert_array_equal(bits(full.matrix()), bits(res.matrix()))
+    assert (full.iterations, full.n_inliers, full.n_correspondences) == (res.iterations, res.n_inliers, len(got))

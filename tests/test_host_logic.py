@@ -118,3 +118,12 @@ def test_bench_gpus_2_forms_two_ranks():
 def test_bench_rejects_world_size_mismatch():
     r, out = _run_bench("--gpus", "1", "--dry-run", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and not out
+
+
+def test_bench_force_collective_one_rank_group():
+    """--force-collective: a one-rank process group is formed without a launcher and the record all-gather goes through it (gloo here;
+    the -m gpu twin in tests/test_gpu_bench_ranks.py runs the same code on RCCL)."""
+    r, out = _run_bench("--gpus", "1", "--dry-run", "--force-collective", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1 and out[0]["n_gpus"] == 1 and out[0]["ranks_seen"] == [0] and out[0]["records_ok"] is True
+    assert out[0]["collective"] == {"process_group": True, "backend": "gloo"}

@@ -24,30 +24,27 @@ def main():
     ap.add_argument("--matching", default="cluster", choices=["lr", "one_sided", "cluster"])
     ap.add_argument("--alignment", default="ransac", choices=["ransac", "gror"])
     ap.add_argument("--feature-radius", type=float, default=0.0, help="<= 0: multi-scale (the reference's behaviour when unset)")
-    ap.add_argument("--distance-thr", type=float, default=0.0, help="<= 0: 2 x the coarser of the two voxel sizes")
+    ap.add_argument("--distance-thr", type=float, default=0.0, help="<= 0: automatic, 4 x the larger cloud density (src/common.cpp:267)")
     ap.add_argument("--iterations", type=int, default=1000000)
     ap.add_argument("--out", default=None, help="transformations.csv to append to")
     a = ap.parse_args()
 
     import numpy as np
-    import torch
-    from lgr_amd import capi, formats
+    from lgr_amd import capi, formats, profile
     ctx = capi.Context(0)
-    clouds, voxels = [], []
-    for path in (a.source, a.target):
-        pts, fields = formats.read_ply(path)
-        t = time.perf_counter()
-        out, voxel = ctx.preprocess(torch.from_numpy(pts).cuda(), normals_available=formats.has_normals(fields))
-        ctx.sync()
-        print(f"{os.path.basename(path)}: {len(pts)} points -> {out.shape[0]} after preprocessing (voxel {voxel:.4g}, {1e3 * (time.perf_counter() - t):.1f} ms)")
-        clouds.append(out.clone()); voxels.append(voxel)
-    thr = a.distance_thr if a.distance_thr > 0 else 2.0 * max(voxels)
-    p = capi.default_params(
-        keypoint_id=capi.KEYPOINT_ISS if a.keypoint == "iss" else capi.KEYPOINT_ANY,
-        iss_radius_src=2.0 * voxels[0], iss_radius_tgt=2.0 * voxels[1],              # "automatic ISS radius": 2 x density (src/common.cpp:328)
-        metric_id={"correspondences": 0, "uniformity": 1, "closest_plane": 2, "combination": 3}[a.metric],
-        matching_id={"lr": 0, "one_sided": 1, "cluster": 2}[a.matching], alignment_id=1 if a.alignment == "gror" else 0,
-        feature_radius=a.feature_radius, distance_thr=thr, bf_block_size=200000, max_iterations=a.iterations)
+    t = time.perf_counter()
+    ld = profile.load_pair(ctx, a.source, a.target)        # loadPointClouds: duplicates, 2 x density voxel grid, normals
+    ctx.sync()
+    for side, path in (("src", a.source), ("tgt", a.target)):
+        print(f"{os.path.basename(path)}: {len(ld['raw_' + side])} points -> {ld[side].shape[0]} after preprocessing "
+              f"(voxel {ld['voxel_' + side]:.4g}, density {ld['density_' + side]:.4g})")
+    print(f"loaded in {1e3 * (time.perf_counter() - t):.1f} ms")
+    clouds = [ld["src"], ld["tgt"]]
+    # getParametersFromConfig with the keys left out: distance_thr = 4 x max density, iss_radius = 2 x density (src/common.cpp:266-271,325-333)
+    p = profile.default_profile(capi, ld["density_src"], ld["density_tgt"], keypoint=a.keypoint, metric=a.metric, matching=a.matching,
+                                alignment=a.alignment, feature_radius=a.feature_radius if a.feature_radius > 0 else None,
+                                distance_thr=a.distance_thr if a.distance_thr > 0 else None, iterations=a.iterations,
+                                normals_available=ld["normals_available"])
     t = time.perf_counter()
     res = ctx.align(clouds[0], clouds[1], p)
     dt = time.perf_counter() - t
