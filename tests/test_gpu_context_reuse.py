@@ -109,7 +109,7 @@ def test_match_statistics_belong_to_the_context():
         r2 = [t.cpu().numpy() for t in c2.match_bf2(a, b)]
         c1.sync(); c2.sync()
         assert c1.match_format() == "f16" and c2.match_format() == "f32"       # c1's figures survived c2's call on the same thread
-        assert c1.match_work() < 1.0 and c2.match_work() == 1.0
+        assert c2.match_work() == 1.0 and c1.match_work() != 1.0          # (tiny inputs: pass 0 and the final pass overlap, the sum can exceed 1)
         assert c1.match_stats()["sub_cols"] != 0 and c1.match_stats() != c2.match_stats()
         for x, y in zip(r1, r2):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
