@@ -15,6 +15,8 @@ Rank 0 prints ONE JSON line with the contract keys plus
                    fraction) / launch duration measured with hipEvents on the launch stream, against the dense f16
                    MFMA peak of MI355X; the algorithmic 69 * Mq * Mt over the same time is given beside it
                    ("effective_tflops_algorithmic"); "traffic" = HBM-side bytes from the committed PMC passes;
+  "roofline_stages": per stage of the path (downsample, normals, fpfh, match, filter, ransac): SURVEY 8(d)'s algorithmic bytes and
+                   FLOP over the stage's time when run alone, as fractions of the HBM and fp32 peaks;
   "cpu_baseline" : the CPU oracle ("port": the reference itself needs PCL/OpenCV and cannot be built here) timed on
                    this host's cores on the same pair: every stage in full except the brute-force matcher, which runs a
                    bounded sample of queries (real FPFH rows) against all train rows and is scaled by M/S;
@@ -54,6 +56,7 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: check sampled queries of the GPU's 1M x 1M matches against the CPU oracle (parity_sample in the JSON line)")
     ap.add_argument("--verify-queries", type=int, default=4096)
+    ap.add_argument("--no-stage-rooflines", action="store_true", help="skip the stand-alone stage timings behind `roofline_stages` (profiling runs)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: still form a (one-rank) process group on --backend and run the path's all-gather / barrier / all-reduce "
                          "through it, i.e. execute the RCCL calls of the N > 1 path on a one-GPU box")
@@ -180,6 +183,63 @@ def gpu_stages(ctx, capi, pair, src, tgt, params, voxel, radius):
     out["corr"] = corr
     res, mask = ctx.ransac(src, tgt, corr, params)
     out["ransac"] = (res, mask)
+    return out
+
+
+HBM_PEAK_GBS = 8000.0            # same guide: HBM3E 8 TB/s (about 6.3 TB/s achievable with a copy)
+FP32_PEAK_TFLOPS = 157.3         # fp32 vector = fp32 matrix rate
+
+
+def stage_rooflines(ctx, capi, torch, pair, src, tgt, params, n_steps_res):
+    """`roofline_stages`: every stage of the path run ALONE on the ctx stream (outside the timed region, second of two runs),
+    wall time between stream synchronisations, against SURVEY 8(d)'s algorithmic bytes / FLOP per unit of work:
+      downsample 48 M + 48 N bytes; normals 48 N + 16 N; FPFH = SPFH (32 N + 132 N bytes, 90 N K FLOP) + weighting
+      (132 N + 16 M + 132 M bytes, 66 M K FLOP), K = feature_nr = 352 neighbours by construction; matching 69 Mq Mt FLOP,
+      132 (Mq + Mt) + 8 (Mq + Mt) bytes; RANSAC 150 FLOP per iteration + 30 C FLOP per hypothesis that survives the
+      prerejection, 28 C bytes per verification launch; M = points, N = surface voxels (both clouds summed).
+    The stage time holds the stage's helper launches too (grid build, sorts); the per-kernel split is in profiles/."""
+    r = 0.25
+    voxel = float(np.sqrt(np.float32(np.pi * r * r / 352.0)))
+
+    def timed(f):
+        f(); ctx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = f()
+        ctx.sync(); torch.cuda.synchronize()
+        return out, 1e3 * (time.perf_counter() - t0)
+
+    M = N = 0
+    ms = dict(downsample=0.0, normals=0.0, fpfh=0.0)
+    feats = []
+    for cloud, vp in ((src, pair["vp_src"]), (tgt, pair["vp_tgt"])):
+        surf, t = timed(lambda: ctx.downsample(cloud, voxel).clone()); ms["downsample"] += t
+        nrm, t = timed(lambda: ctx.normals_knn(surf.clone(), 30, vp=vp)); ms["normals"] += t
+        f, t = timed(lambda: ctx.fpfh(cloud, nrm, r)); ms["fpfh"] += t
+        feats.append(f)
+        M += int(cloud.shape[0]); N += int(surf.shape[0])
+    m, t = timed(lambda: ctx.match_bf2(feats[0], feats[1], params.bf_block_size)); ms["match"] = t
+    corr, t = timed(lambda: ctx.filter(params.matching_id, src, tgt, *m, params.distance_thr)); ms["filter"] = t
+    (rres, _), t = timed(lambda: ctx.ransac(src, tgt, corr, params)); ms["ransac"] = t
+    mq, mt, C, K = int(src.shape[0]), int(tgt.shape[0]), int(len(corr)), 352
+    H = max(0, int(rres.iterations) - int(rres.num_rejections))
+    alg = {
+        "downsample": dict(bound="hbm", bytes=48.0 * M + 48.0 * N, flop=0.0),
+        "normals": dict(bound="hbm", bytes=48.0 * N + 16.0 * N, flop=0.0),
+        "fpfh": dict(bound="hbm", bytes=(32.0 + 132.0) * N + 132.0 * N + (16.0 + 132.0) * M, flop=90.0 * N * K + 66.0 * M * K),
+        "match": dict(bound="mfma", bytes=140.0 * (mq + mt), flop=69.0 * mq * mt),
+        "filter": dict(bound="hbm", bytes=48.0 * (mq + mt) + 8.0 * (mq + mt) + 16.0 * C, flop=0.0),
+        "ransac": dict(bound="valu", bytes=28.0 * C, flop=150.0 * rres.iterations + 30.0 * C * H),
+    }
+    out = {}
+    for k, a in alg.items():
+        sec = ms[k] * 1e-3
+        gbs, tf = a["bytes"] / sec / 1e9, a["flop"] / sec / 1e12
+        out[k] = {"bound": a["bound"], "ms_alone": ms[k], "algorithmic_bytes": a["bytes"], "algorithmic_flop": a["flop"],
+                  "achieved_GBps": gbs, "frac_hbm": gbs / HBM_PEAK_GBS, "achieved_TFLOPs": tf, "frac_fp32": tf / FP32_PEAK_TFLOPS}
+    out["units"] = {"M_points_both_clouds": M, "N_surface_voxels_both_clouds": N, "K_neighbours": K, "C_correspondences": C,
+                    "ransac_iterations": int(rres.iterations), "hypotheses_verified": H}
+    out["note"] = ("stage run alone, host wall between stream synchronisations (second of two runs); match: the algorithmic 69 Mq Mt FLOP over the whole "
+                   "stage -- frac_fp32 above 1 is the exact tile skipping, the issued-FLOP fraction of the f16 MFMA peak is `roofline.frac`")
     return out
 
 
@@ -390,6 +450,8 @@ def main():
             "result": {"converged": int(res.converged), "iterations": int(res.iterations), "n_correspondences": int(res.n_correspondences),
                        "n_inliers": int(res.n_inliers), "max_abs_err_vs_gt": err},
         }
+        if world == 1 and not args.no_stage_rooflines:
+            out["roofline_stages"] = stage_rooflines(ctx, capi, torch, pair, src, tgt, params, res)
         if (not args.no_cpu_baseline or args.verify) and world == 1:   # CPU leg: rank 0 of the 1-GPU run only, outside the timed region
             voxel = float(np.sqrt(np.float32(np.pi * 0.25 * 0.25 / 352.0)))
             g = gpu_stages(ctx, capi, pair, src, tgt, params, voxel, 0.25)

@@ -30,6 +30,9 @@ extern "C" {
 typedef struct { int32_t query, match; float distance, threshold; } lgr_orc_corr;
 
 enum { ORC_ORDER_LIBSTDCXX = 0, ORC_ORDER_CANONICAL = 1 };
+/* arithmetic of the third-party pieces: the canonical orders the HIP path restates, or PCL 1.12.1's own (measurement only) */
+enum { ORC_ARITH_CANONICAL = 0, ORC_ARITH_PCL_EIGEN33 = 1 /* normals: pcl::eigen33 */, ORC_ARITH_PCL_LIBM = 2 /* pair features: acosf swap test, atan2f */,
+       ORC_ARITH_PCL_WEIGHTING = 4 /* FPFH: ascending-distance neighbours, mul then add, double sums of the vals */, ORC_ARITH_PCL = 7 };
 enum { ORC_METRIC_CORRESPONDENCES = 0, ORC_METRIC_UNIFORMITY = 1, ORC_METRIC_CLOSEST_PLANE = 2, ORC_METRIC_COMBINATION = 3 };
 enum { ORC_SCORE_CONSTANT = 0, ORC_SCORE_MAE = 1, ORC_SCORE_MSE = 2, ORC_SCORE_EXP = 3 };
 enum { ORC_MATCH_LR = 0, ORC_MATCH_ONE_SIDED = 1, ORC_MATCH_CLUSTER = 2 };
@@ -84,6 +87,8 @@ typedef struct {
 void orc_default_params(lgr_orc_params* p);
 int  orc_num_threads(void);
 void orc_set_num_threads(int n);
+void orc_set_arith_mode(int mode);   /* process-wide; ORC_ARITH_CANONICAL by default */
+int  orc_arith_mode(void);
 
 /* include/common.h:266-280 (FLT_MIN-initialised max quirk reproduced) */
 int orc_bbox(const float* pts, int n, float* mn3, float* mx3);

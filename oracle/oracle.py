@@ -164,6 +164,19 @@ def default_params(**kw):
     return p
 
 
+ARITH_CANONICAL, ARITH_PCL_EIGEN33, ARITH_PCL_LIBM, ARITH_PCL_WEIGHTING, ARITH_PCL = 0, 1, 2, 4, 7
+
+
+def set_arith_mode(mode):
+    """ARITH_CANONICAL (default: the orders the HIP path restates) or ARITH_PCL (PCL 1.12.1's own neighbour order, rounding steps, libm
+    calls and eigen33 -- CPU-only measurement mode, see orc_features.cpp)"""
+    lib().orc_set_arith_mode(int(mode))
+
+
+def arith_mode():
+    return int(lib().orc_arith_mode())
+
+
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
 

@@ -17,6 +17,16 @@
 
 using namespace orc;
 
+// Arithmetic mode of the third-party pieces (normals eigen-solver, pair-feature swap test / atan2, FPFH weighting order):
+//   ORC_ARITH_CANONICAL (default): the fixed orders DESIGN.md section 4 defines and the HIP kernels restate bit for bit;
+//   ORC_ARITH_PCL: the orders PCL 1.12.1 itself uses (restated from the pinned upstream version: neighbours by ascending distance,
+//   val = hist * w rounded then added, double block sums of the vals, libm acosf / atan2f, pcl::eigen33 closed form).  CPU only; it
+//   exists to MEASURE what the documented deviations do to the north-star observables (tests/test_oracle_pcl_order.py,
+//   tools/pcl_order_report.py) -- nothing is compared bit for bit against it.
+static int g_arith_mode = ORC_ARITH_CANONICAL;
+extern "C" void orc_set_arith_mode(int mode) { g_arith_mode = mode & ORC_ARITH_PCL; }   // bit mask: single deviations can be switched alone
+extern "C" int orc_arith_mode(void) { return g_arith_mode; }
+
 extern "C" int orc_num_threads(void) { return omp_get_max_threads(); }
 extern "C" void orc_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : omp_get_num_procs()); }
 
@@ -147,6 +157,64 @@ extern "C" int orc_knn(const float* qpts, int nq, const float* pts, int n, int k
 //   fewer than 3 neighbours or non-finite query -> NaN normal and curvature.
 //   postprocessNormals: normals_available orients by the stored normal (compares the point with itself in the
 //   reference, src/common.cpp:597-598, i.e. a no-op unless NaN); then unit-normalise finite normals.
+namespace {
+// pcl::eigen33(mat, eigenvalue, eigenvector) -- smallest eigenvalue and its eigenvector of a symmetric 3x3 [3P, PCL 1.12.1
+// common/impl/eigen.hpp: computeRoots / computeRoots2 / detail::getLargest3x3Eigenvector], all in float with libm, as
+// pcl::solvePlaneParameters calls it.  C row-major (symmetric).
+inline void pcl_roots2(float b, float c, float r[3]) {
+    r[0] = 0.f;
+    float d = (float) (b * b - 4.0 * c);
+    if (d < 0.0) d = 0.0;
+    float sd = std::sqrt(d);
+    r[2] = 0.5f * (b + sd);
+    r[1] = 0.5f * (b - sd);
+}
+inline void pcl_roots(const float m[9], float r[3]) {
+    float c0 = m[0] * m[4] * m[8] + 2.f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+    float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+    float c2 = m[0] + m[4] + m[8];
+    if (std::fabs(c0) < std::numeric_limits<float>::epsilon()) { pcl_roots2(c2, c1, r); return; }
+    const float s_inv3 = (float) (1.0 / 3.0);
+    const float s_sqrt3 = std::sqrt(3.0f);
+    float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.f) a_over_3 = 0.f;
+    float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.f) q = 0.f;
+    float rho = std::sqrt(-a_over_3);
+    float theta = std::atan2(std::sqrt(-q), half_b) * s_inv3;
+    float cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+    r[0] = c2_over_3 + 2.f * rho * cos_theta;
+    r[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    r[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    if (r[0] >= r[1]) std::swap(r[0], r[1]);
+    if (r[1] >= r[2]) { std::swap(r[1], r[2]); if (r[0] >= r[1]) std::swap(r[0], r[1]); }
+    if (r[0] <= 0) pcl_roots2(c2, c1, r);
+}
+inline void pcl_eigen33(const float C[9], float& eigenvalue, float v[3]) {
+    float scale = 0.f;
+    for (int i = 0; i < 9; ++i) scale = std::max(scale, std::fabs(C[i]));
+    if (scale <= std::numeric_limits<float>::min()) scale = 1.f;
+    float m[9];
+    for (int i = 0; i < 9; ++i) m[i] = C[i] / scale;
+    float r[3];
+    pcl_roots(m, r);
+    eigenvalue = r[0] * scale;
+    m[0] -= r[0]; m[4] -= r[0]; m[8] -= r[0];
+    auto cross = [](const float* a, const float* b, float* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+    float cp[3][3];
+    cross(m, m + 3, cp[0]); cross(m, m + 6, cp[1]); cross(m + 3, m + 6, cp[2]);
+    int best = 0;
+    float len = -1.f;
+    for (int i = 0; i < 3; ++i) {
+        float l = std::sqrt(cp[i][0] * cp[i][0] + cp[i][1] * cp[i][1] + cp[i][2] * cp[i][2]);
+        if (l > len) { len = l; best = i; }      // maxCoeff: first maximum
+    }
+    for (int i = 0; i < 3; ++i) v[i] = cp[best][i] / len;
+}
+}  // namespace
+
 extern "C" int orc_normals_knn(float* pts, int n, const float* surf, int ns, int k, const float* vp, int normals_available) {
     std::vector<float> copy;
     const float* S = surf;
@@ -178,11 +246,19 @@ extern "C" int orc_normals_knn(float* pts, int n, const float* surf, int ns, int
             C[0] = a[0] - a[6] * a[6]; C[1] = a[1] - a[6] * a[7]; C[2] = a[2] - a[6] * a[8];
             C[4] = a[3] - a[7] * a[7]; C[5] = a[4] - a[7] * a[8]; C[8] = a[5] - a[8] * a[8];
             C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-            float U[9], Sg[3], V[9];
-            c_svd3(C, U, Sg, V);
-            float nx = V[2], ny = V[5], nz = V[8];  // column 2 = smallest singular value
+            float nx, ny, nz, lambda_min;
+            if (g_arith_mode & ORC_ARITH_PCL_EIGEN33) {
+                float v[3];
+                pcl_eigen33(C, lambda_min, v);
+                nx = v[0]; ny = v[1]; nz = v[2];
+            } else {
+                float U[9], Sg[3], V[9];
+                c_svd3(C, U, Sg, V);
+                nx = V[2]; ny = V[5]; nz = V[8];  // column 2 = smallest singular value
+                lambda_min = Sg[2];
+            }
             float eig_sum = C[0] + C[4] + C[8];
-            float curv = (eig_sum != 0.f) ? std::fabs(Sg[2] / eig_sum) : 0.f;
+            float curv = (eig_sum != 0.f) ? std::fabs(lambda_min / eig_sum) : 0.f;
             float dx = vpx - p[0], dy = vpy - p[1], dz = vpz - p[2];
             float cos_theta = (dx * nx + dy * ny + dz * nz);
             if (cos_theta < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
@@ -215,7 +291,9 @@ inline bool pair_features(const float* p1, const float* n1, const float* p2, con
     // reference: if (acos(|angle1|) > acos(|angle2|)) swap.  acos is decreasing on [0,1] and NaN outside, so this is
     // restated as (|a1| <= 1 && |a2| <= 1 && |a1| < |a2|)  (no libm call; differs from libm only when two distinct
     // arguments round to the same acosf value).
-    if (a1 <= 1.0f && a2 <= 1.0f && a1 < a2) {
+    const bool swap = (g_arith_mode & ORC_ARITH_PCL_LIBM) ? (std::acos(a1) > std::acos(a2))     // libm acosf on floats, as PCL writes it
+                                                      : (a1 <= 1.0f && a2 <= 1.0f && a1 < a2);
+    if (swap) {
         u = n2; m2 = n1;
         d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
         f3 = -angle2;
@@ -231,7 +309,7 @@ inline bool pair_features(const float* p1, const float* n1, const float* p2, con
     float w[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
     f2 = dot3(v, m2);
     float yy = dot3(w, m2), xx = dot3(u, m2);
-    f1 = libm ? std::atan2(yy, xx) : c_atan2f(yy, xx);
+    f1 = (libm || (g_arith_mode & ORC_ARITH_PCL_LIBM)) ? std::atan2(yy, xx) : c_atan2f(yy, xx);
     return true;
 }
 
@@ -316,6 +394,25 @@ extern "C" int orc_fpfh(const float* kps, int m, const float* surf, int n, float
         int found = 0;
         float fp[33];
         for (int b = 0; b < 33; ++b) fp[b] = 0.f;
+        if (g_arith_mode & ORC_ARITH_PCL_WEIGHTING) {
+            // pcl::FPFHEstimation::weightPointSPFHSignature [3P, PCL 1.12.1 features/impl/fpfh.hpp]: radiusSearch returns the neighbours
+            // by ascending squared distance (sorted results; ties: index); per neighbour and bin val = hist * weight (rounded to float),
+            // sum_f += val in double, fpfh[bin] += val in float; finally fpfh[bin] * (100.0 / sum_f) in double, stored as float.
+            std::vector<std::pair<float, int>> nb;
+            if (finite3(P)) g.visit27(P, [&](int q) { float d2 = dist2(P, surf + 12 * (size_t) q); if (d2 < r2) nb.emplace_back(d2, q); });
+            if (nb.empty()) { for (int b = 0; b < 33; ++b) o[b] = std::numeric_limits<float>::quiet_NaN(); continue; }
+            std::sort(nb.begin(), nb.end());
+            double sum[3] = {0, 0, 0};
+            for (const auto& e : nb) {
+                if (e.first == 0.f) continue;
+                float weight = 1.0f / e.first;
+                const float* h = spfh.data() + 33 * (size_t) e.second;
+                for (int b = 0; b < 33; ++b) { float val = h[b] * weight; sum[b / 11] += val; fp[b] += val; }
+            }
+            for (int s3 = 0; s3 < 3; ++s3) if (sum[s3] != 0) sum[s3] = 100.0 / sum[s3];
+            for (int b = 0; b < 33; ++b) o[b] = (float) ((double) fp[b] * sum[b / 11]);
+            continue;
+        }
         if (finite3(P)) {
             g.visit27(P, [&](int q) {
                 float d2 = dist2(P, surf + 12 * (size_t) q);
