@@ -283,3 +283,15 @@ extern "C" void lgr_default_params(lgr_params* p) {
     p->use_bfmatcher = 1;                // ALIGNMENT_USE_BFMATCHER include/common.h:41
     for (int i = 0; i < 4; ++i) p->guess[5 * i] = 1.f;
 }
+
+// Diagnostics (tools/exp_concurrent_stages.py; not part of include/lgr.h): device pointer and capacity of a named pipeline buffer of the
+// context's workspace, as the last lgr_correspondences* / lgr_align* call left it.
+extern "C" int lgr_debug_ws(lgr_ctx* ctx, const char* name, void** p, size_t* cap) {
+    if (!ctx || !name || !p || !cap) return LGR_ERR_INVALID_ARG;
+    static const struct { const char* n; int slot; } T[] = {
+        {"surf_s", WS_PIPE_SURF_S}, {"surf_t", WS_PIPE_SURF_T}, {"feat_s", WS_PIPE_FEAT_S}, {"feat_t", WS_PIPE_FEAT_T}, {"ij", WS_PIPE_IJ}, {"ji", WS_PIPE_JI},
+        {"dij", WS_PIPE_DIJ}, {"dji", WS_PIPE_DJI}, {"corr", WS_PIPE_CORR}, {"thr", WS_PIPE_MISC}, {"knn_s", WS_PIPE_KNN_S}, {"knn_t", WS_PIPE_KNN_T}};
+    for (const auto& e : T)
+        if (!strcmp(e.n, name)) { *p = ctx->ws[e.slot].p; *cap = ctx->ws[e.slot].cap; return LGR_OK; }
+    return LGR_ERR_INVALID_ARG;
+}

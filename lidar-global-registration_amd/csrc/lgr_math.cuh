@@ -118,10 +118,12 @@ __device__ __forceinline__ void lgr_svd3(const float* A, float* U, float* S, flo
 #pragma unroll
     for (int j = 0; j < 3; ++j) sg[j] = __builtin_sqrtf((W[0][j] * W[0][j] + W[1][j] * W[1][j]) + W[2][j] * W[2][j]);
     // column order by descending sigma; ties keep the lower column first (same selection network as the oracle)
+    // (sg is read through selects, never through a variable index: a dynamically indexed local array lives in scratch memory)
+    auto sgv = [&](int o) { return (o == 0) ? sg[0] : ((o == 1) ? sg[1] : sg[2]); };
     int o0 = 0, o1 = 1, o2 = 2;
-    if (sg[o1] > sg[o0]) { int t = o0; o0 = o1; o1 = t; }
-    if (sg[o2] > sg[o0]) { int t = o0; o0 = o2; o2 = t; }
-    if (sg[o2] > sg[o1]) { int t = o1; o1 = o2; o2 = t; }
+    if (sgv(o1) > sgv(o0)) { int t = o0; o0 = o1; o1 = t; }
+    if (sgv(o2) > sgv(o0)) { int t = o0; o0 = o2; o2 = t; }
+    if (sgv(o2) > sgv(o1)) { int t = o1; o1 = o2; o2 = t; }
     const int ord[3] = {o0, o1, o2};
     float Uc[3][3];
 #pragma unroll

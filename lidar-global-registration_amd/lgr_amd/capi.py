@@ -120,12 +120,15 @@ def _ptr(t):
 
 
 class Context:
-    """One lgr_ctx bound to a torch device + (by default) torch's current stream on it."""
+    """One lgr_ctx bound to a torch device + (by default) torch's current stream on it.  stream=-1 (LGR_STREAM_OWN): the context
+    creates a non-blocking stream of its own -- torch's stream does not wait for it, so device outputs of the *_dev wrappers below
+    must be consumed after ctx.sync() (the wrappers that read results back through torch do that themselves: _join)."""
 
     def __init__(self, device=0, stream=None):
         import torch
         self.torch = torch
         self.device = int(device)
+        self.foreign_stream = stream is not None and stream != torch.cuda.current_stream(self.device).cuda_stream
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         h = C.c_void_p()
@@ -151,6 +154,11 @@ class Context:
 
     def sync(self):
         self.check(_lib.lgr_ctx_sync(self.h))
+
+    def _join(self):
+        """before torch reads a buffer the library wrote: nothing to do on torch's own stream, a stream sync otherwise"""
+        if self.foreign_stream:
+            self.sync()
 
     def set_match_options(self, **kw):
         """defaults + overrides (no arguments: back to the defaults); returns the options now in force"""
@@ -387,6 +395,7 @@ class Context:
         self.check(_lib.lgr_filter_dev(self.h, int(matching_id), _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0],
                                        _ptr(ij), _ptr(dij), _ptr(ji), _ptr(dji), C.c_float(distance_thr), int(cluster_k),
                                        _ptr(out), C.byref(n)))
+        self._join()
         return out[: n.value].cpu().numpy().view(CORR_DTYPE).reshape(-1)
 
     def correspondences(self, src, tgt, params):
@@ -420,6 +429,7 @@ class Context:
         ni, rm, me = C.c_int(0), C.c_float(0), C.c_float(0)
         self.check(_lib.lgr_evaluate_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), c, T16,
                                          int(metric_id), int(score_id), _ptr(mask), C.byref(ni), C.byref(rm), C.byref(me)))
+        self._join()
         return mask[:c].cpu().numpy(), ni.value, rm.value, me.value
 
     def choose_best_hypothesis(self, src, tgt, corr, tns):
@@ -452,6 +462,7 @@ class Context:
         ninl = self.empty((n,), torch.int32); met = self.empty((n,), torch.float32)
         self.check(_lib.lgr_ransac_replay_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), corr.shape[0],
                                               C.byref(params), _ptr(triples), n, _ptr(ok), _ptr(Ts), _ptr(ninl), _ptr(met)))
+        self._join()
         return ok.cpu().numpy(), Ts.cpu().numpy(), ninl.cpu().numpy(), met.cpu().numpy()
 
     def ransac(self, src, tgt, corr, params):
@@ -461,6 +472,7 @@ class Context:
         mask = self.empty((max(c, 1),), self.torch.uint8)
         self.check(_lib.lgr_ransac_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), c,
                                        C.byref(params), C.byref(res), _ptr(mask)))
+        self._join()
         return res, mask[:c].cpu().numpy()
 
     def gror(self, src, tgt, corr, resolution, k_optimal=800):
@@ -470,6 +482,7 @@ class Context:
         mask = self.empty((max(c, 1),), self.torch.uint8)
         self.check(_lib.lgr_gror_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), c,
                                      C.c_float(resolution), int(k_optimal), C.byref(res), _ptr(mask)))
+        self._join()
         return res, mask[:c].cpu().numpy()
 
     def gror_node_degree(self, src, tgt, corr, resolution):
@@ -477,6 +490,7 @@ class Context:
         c = corr.shape[0]
         deg = self.empty((max(c, 1),), self.torch.int32)
         self.check(_lib.lgr_gror_node_degree_dev(self.h, _ptr(src), _ptr(tgt), _ptr(corr), c, C.c_float(resolution), _ptr(deg)))
+        self._join()
         return deg[:c].cpu().numpy()
 
     def refit(self, src, tgt, corr, mask=None):
