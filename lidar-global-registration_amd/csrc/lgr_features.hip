@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NB) void normals_kernel(GridDev g, const float* __r
     int* si = (int*) (smem + (size_t) k * NB);
     int i = blockIdx.x * NB + threadIdx.x;
     if (by_grid == 1) {
+        i = lgr_xcd_tile(blockIdx.x, cdiv_dev(g.n, NB)) * NB + threadIdx.x;   // grid order, one contiguous range per XCD (lgr_grid.cuh)
         if (i >= g.n) return;
         i = __float_as_int(g.pxyz[i].w);
     } else if (i >= n) return;
@@ -268,8 +269,10 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
     const int l = threadIdx.x;
     int pos = -1, cell = -1;   // sorted position / cell of tile point l (lanes 0..15)
     float x = 0.f, y = 0.f, z = 0.f;
+    const int tile = lgr_xcd_tile(blockIdx.x, cdiv_dev(g.n, ST));   // one contiguous range of the sorted order per XCD (lgr_grid.cuh)
+    if (tile * ST >= g.n) return;
     if (l < ST) {
-        const int rnk = blockIdx.x * ST + l;
+        const int rnk = tile * ST + l;
         if (rnk < g.n) {
             pos = order ? order[rnk] : rnk;
             const float4 P = g.pxyz[pos];
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
     for (int q = l; q < ST * HP; q += 64) {
         const int i = q / HP, b = q % HP;
         const int ps = __float_as_int(tp[i].w);
-        if (blockIdx.x * ST + i >= g.n) continue;
+        if (tile * ST + i >= g.n) continue;
         float v = 0.f;
         if (b < 33) {
             const int cnt = hist[0][i][b] + hist[1][i][b];
@@ -452,7 +455,9 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
     __shared__ float4 ring[FRING];
     __shared__ float fpl[FT * FP_PITCH];
     const int l = threadIdx.x, i = l & 15, k = l >> 4;
-    const int r = blockIdx.x * FT + i;
+    const int tile = lgr_xcd_tile(blockIdx.x, cdiv_dev(m, FT));   // one contiguous range of the (cell, Morton) order per XCD (lgr_grid.cuh)
+    if (tile * FT >= m) return;
+    const int r = tile * FT + i;
     const float nanv = __uint_as_float(0x7fc00000u);
     int kp = -1;
     float x = nanv, y = nanv, z = nanv;
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
     __syncthreads();
     if (l < 3 * FT) {
         const int kq = l / 3, blk = l % 3;
-        const int rr = blockIdx.x * FT + kq;
+        const int rr = tile * FT + kq;
         if (rr < m) {
             const bool any = ((fm >> kq) | (fm >> (kq + 16)) | (fm >> (kq + 32)) | (fm >> (kq + 48))) & 1ull;
             float* o = out + (size_t) order[rr] * 33 + 11 * blk;
@@ -758,7 +763,7 @@ extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const floa
     size_t sm = (size_t) k * NB * 8;
     const float vx = vp3 ? vp3[0] : 0.f, vy = vp3 ? vp3[1] : 0.f, vz = vp3 ? vp3[2] : 0.f;
     if (!d_surf) {
-        if (g.n > 0) normals_kernel<<<cdiv(g.n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 1);
+        if (g.n > 0) normals_kernel<<<lgr_xcd_grid(cdiv(g.n, NB)), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 1);
         if (g.n < n) normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 2);   // non-finite points: NaN normals
     } else {
         normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 0);
@@ -812,11 +817,11 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     if (g.n > 0) {
         fine_keys<<<cdiv(g.n, 256), 256, 0, ctx->stream>>>(g, reinterpret_cast<const float*>(g.pxyz), 4, g.n, sb, keys, vals);
         LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) g.n, 0, key_bits));
-        spfh_tile_kernel<<<cdiv(g.n, ST), 64, 0, ctx->stream>>>(g, r2, vals2, spfh);
+        spfh_tile_kernel<<<lgr_xcd_grid(cdiv(g.n, ST)), 64, 0, ctx->stream>>>(g, r2, vals2, spfh);
     }
     fine_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, 12, m, sb, keys, vals);
     LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) m, 0, key_bits));
-    fpfh_mfma_kernel<<<cdiv(m, FT), 64, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
+    fpfh_mfma_kernel<<<lgr_xcd_grid(cdiv(m, FT)), 64, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }

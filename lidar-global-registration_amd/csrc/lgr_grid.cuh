@@ -6,6 +6,15 @@
 #pragma once
 #include "lgr_internal.h"
 
+// XCD-aware tile order for kernels whose workgroups walk the (cell, Morton)-sorted points: the hardware places workgroup b on XCD
+// b % 8 (speed only -- any order gives the same results), so with the identity mapping the eight neighbours b .. b+7 of the sorted order
+// pull the same candidate cells into eight different L2s.  lgr_xcd_tile hands XCD x the contiguous tile range [x * per, (x + 1) * per):
+// consecutive tiles of the sorted order run back to back on ONE L2.  Launch lgr_xcd_grid(n_tiles) workgroups; a tile >= n_tiles has
+// nothing to do.
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ int lgr_xcd_grid(int n_tiles) { return ((n_tiles + 7) >> 3) << 3; }
+__device__ __forceinline__ int lgr_xcd_tile(int b, int n_tiles) { return (b & 7) * ((n_tiles + 7) >> 3) + (b >> 3); }
+
 __device__ __forceinline__ int lgr_cellc(float v, float o, float h) { return (int) floorf((v - o) / h); }
 
 __device__ __forceinline__ float lgr_dist2(float ax, float ay, float az, float bx, float by, float bz) {

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(GridDev g, const float* 
     int* si = (int*) (smem + (size_t) k * KNN_BLOCK);
     int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
     if (by_grid == 1) {
+        i = lgr_xcd_tile(blockIdx.x, cdiv_dev(g.n, KNN_BLOCK)) * KNN_BLOCK + threadIdx.x;   // grid order, one contiguous range per XCD
         if (i >= g.n) return;
         i = __float_as_int(g.pxyz[i].w);
     } else if (i >= nq) return;
@@ -281,7 +282,7 @@ extern "C" int lgr_knn_dev(lgr_ctx* ctx, const float* d_q, int nq, const float* 
     LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, std::max(4.f, 0.35f * (float) k), &g));
     size_t sm = (size_t) k * KNN_BLOCK * 8;
     if (d_q == d_pts && nq == n) {
-        if (g.n > 0) knn_kernel<0><<<cdiv(g.n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 1);
+        if (g.n > 0) knn_kernel<0><<<lgr_xcd_grid(cdiv(g.n, KNN_BLOCK)), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 1);
         if (g.n < nq) knn_kernel<0><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 2);
     } else {
         knn_kernel<0><<<cdiv(nq, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, 0);
@@ -301,7 +302,7 @@ extern "C" int lgr_smoothed_densities_dev(lgr_ctx* ctx, const float* d_pts, int 
     LGR_TRY(lgr_ws_t(ctx, WS_DENS_A, (size_t) n, &dk));
     LGR_TRY(lgr_ws_t(ctx, WS_DENS_B, (size_t) n, &nn1));
     size_t sm = (size_t) k * KNN_BLOCK * 8;
-    if (g.n > 0) knn_kernel<1><<<cdiv(g.n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_pts, n, k, nn1, dk, 1);
+    if (g.n > 0) knn_kernel<1><<<lgr_xcd_grid(cdiv(g.n, KNN_BLOCK)), KNN_BLOCK, sm, ctx->stream>>>(g, d_pts, n, k, nn1, dk, 1);
     if (g.n < n) knn_kernel<1><<<cdiv(n, KNN_BLOCK), KNN_BLOCK, sm, ctx->stream>>>(g, d_pts, n, k, nn1, dk, 2);
     density_min<<<cdiv(n, 256), 256, 0, ctx->stream>>>(dk, nn1, n, d_out);
     LGR_HIP(ctx, hipGetLastError());

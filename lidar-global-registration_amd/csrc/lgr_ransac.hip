@@ -167,11 +167,23 @@ __global__ void hypotheses_kernel(const float* __restrict__ src, const float* __
 __device__ __forceinline__ float next_up(float x) { return __uint_as_float(__float_as_uint(x) + 1u); }
 __device__ __forceinline__ float next_down(float x) { return __uint_as_float(__float_as_uint(x) - 1u); }
 
+// PP (count_kernel's operand): one 64-byte record per TWO correspondences, {sx sy sz | qx qy qz | s* | band slope} as 2-vectors, padded
+// with never-inlier fillers to a multiple of 64 correspondences; pstats = bit patterns of max |source coordinate|, max |target
+// coordinate|, max finite s* (float max through integer atomics: all values >= 0).
+constexpr int CP_FLOATS = 16;
 __global__ void pack_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
                             float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                            float4* __restrict__ P0, float4* __restrict__ P1, float* __restrict__ sstar) {
+                            float4* __restrict__ P0, float4* __restrict__ P1, float* __restrict__ sstar,
+                            float* __restrict__ PP, unsigned* __restrict__ pstats, int cpad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
+    if (i >= c) {
+        if (PP && i < cpad) {
+            float* r = PP + (size_t) (i >> 1) * CP_FLOATS + (i & 1);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) r[2 * f] = 0.f;   // s* = 0: d2 < 0 never holds
+        }
+        return;
+    }
     lgr_corr cr = corr[i];
     P3 s = ldp(src, cr.index_query), t = ldp(tgt, cr.index_match);
     float thr = cr.threshold;
@@ -194,6 +206,18 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
         ss = g;
     }
     sstar[i] = ss;
+    if (PP) {
+        float* r = PP + (size_t) (i >> 1) * CP_FLOATS + (i & 1);
+        r[0] = s.x; r[2] = s.y; r[4] = s.z; r[6] = t.x; r[8] = t.y; r[10] = t.z; r[12] = ss;
+        // slope of the decision band of count_kernel's fused evaluation: 28 sqrt(s*), rounded up (inf for an infinite threshold)
+        r[14] = (ss < 3.4028234663852886e38f) ? next_up(28.f * __builtin_sqrtf(ss)) * 1.000001f : __uint_as_float(0x7f800000u);
+        const float sm = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fabsf(s.z)), qm = fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fabsf(t.z));
+        // NaN coordinates: the integer max of the bit pattern keeps them (a NaN pattern is above every finite one) -> the band becomes NaN
+        // -> every chunk takes the exact path
+        atomicMax(&pstats[0], __float_as_uint(sm));
+        atomicMax(&pstats[1], __float_as_uint(qm));
+        if (ss < 3.4028234663852886e38f) atomicMax(&pstats[2], __float_as_uint(ss));
+    }
 }
 
 // T (column-major) applied as Eigen's Matrix4f * Vector4f on SSE: ((c0*x + c1*y) + c2*z) + c3
@@ -205,18 +229,28 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
 // ---------------------------------------------------------------------------------------------------- phase 1
 // lane = hypothesis (T in registers), loop over a chunk of correspondences broadcast from LDS.
 // counts[h] = {inliers (4-norm rule, src/metric.cpp:141), support (3-norm rule, src/metric.cpp:111)}
-constexpr int CB = 64;        // hypotheses per workgroup
-constexpr int CCH = 2048;     // correspondences per workgroup
-// Two correspondences per pass on packed fp32 math (v_pk_mul_f32 / v_pk_add_f32: IEEE, elementwise -- every element sees exactly the
-// scalar expressions, no fused multiply-add); the chunk sits in LDS as one array per coordinate so that a pair is one 8-byte read.
+constexpr int CB = 64;        // hypotheses per workgroup (one wave)
+constexpr int CCH = 2048;     // correspondences per workgroup (fewer when there are few hypotheses: cch of count_kernel)
+// The O(H x C) verification.  Round 3: per (hypothesis, correspondence) pair the reference's expressions (LGR_APPLY, the Eigen
+// 4-vector and 3-vector norms: ~25 unfused multiply / add instructions per pair) are evaluated only where they can decide something.
+// A FUSED evaluation -- e_k = fma(c_k0, x, fma(c_k1, y, fma(c_k2, z, c_k3 - q_k))), d2~ = fma(e_z, e_z, fma(e_y, e_y, e_x e_x)): 15 packed
+// instructions per two correspondences -- differs from both reference values by at most
+//     err(x) = 7u x + 3.5 eta sqrt(x) + 3 eta^2,   eta = 12u (max_k sum_j |c_kj| * max|s| + max_k |c_k3| + max|q|),  u = 2^-24
+// (4 roundings per component in either order, 3 in either sum of squares), so the sign of d2~ - s* IS the
+// reference's decision whenever |d2~ - s*| > 8 err(s*) + 16 eta^2.  Per correspondence the kernel keeps the sign bit (one v_alignbit);
+// a pair of correspondences for which ANY lane of the wave comes within that band (hypotheses that survive the prerejection are good
+// enough that ~1e-3 of the pairs do: ~10 % of the iterations) is re-evaluated on the spot with the reference's own expressions, for
+// the inlier (4-norm) and the support (3-norm) rule.  The correspondences are wave-uniform: they arrive through scalar loads
+// (s_load_dwordx16 per pair record), not through LDS.
+typedef float v2f_c __attribute__((ext_vector_type(2)));
+struct CPair { v2f_c sx, sy, sz, qx, qy, qz, ss, rs; };
+static_assert(sizeof(CPair) == CP_FLOATS * 4, "pack_kernel writes this layout");
+
 __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts, const int* __restrict__ list, int nh,
-                                                    const float4* __restrict__ P0, const float4* __restrict__ P1,
-                                                    const float* __restrict__ sstar, int c, int2* __restrict__ counts,
-                                                    unsigned* __restrict__ maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(8))) float sx[CB], sy[CB], sz[CB], tx[CB], ty[CB], tz[CB], st[CB];
-    int h = blockIdx.x * CB + threadIdx.x;
-    bool act = h < nh;
+                                                    const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* __restrict__ counts,
+                                                    unsigned* __restrict__ maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */, int cch) {
+    const int h = blockIdx.x * CB + threadIdx.x;
+    const bool act = h < nh;
     float T[16];
     {
         const float4* tp = reinterpret_cast<const float4*>(Ts + (size_t) (act ? list[h] : 0) * 16);
@@ -224,44 +258,63 @@ __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts,
         T[0] = a.x; T[1] = a.y; T[2] = a.z; T[3] = a.w; T[4] = b.x; T[5] = b.y; T[6] = b.z; T[7] = b.w;
         T[8] = cc.x; T[9] = cc.y; T[10] = cc.z; T[11] = cc.w; T[12] = d.x; T[13] = d.y; T[14] = d.z; T[15] = d.w;
     }
+    // decision band of this hypothesis (see above); anything non-finite -> kh = +inf: every pair is evaluated with the reference's expressions
+    const float smax = __uint_as_float(pstats[0]), qmax = __uint_as_float(pstats[1]), ssmax = __uint_as_float(pstats[2]);
+    const float rowl1 = fmaxf(fmaxf(fabsf(T[0]) + fabsf(T[4]) + fabsf(T[8]), fabsf(T[1]) + fabsf(T[5]) + fabsf(T[9])), fabsf(T[2]) + fabsf(T[6]) + fabsf(T[10]));
+    const float Ah = rowl1 * smax + fmaxf(fmaxf(fabsf(T[12]), fabsf(T[13])), fabsf(T[14])) + qmax;
+    float eta = 7.152557373046875e-7f * Ah;                                  // 12 u
+    float kh = (3.814697265625e-6f * ssmax + 56.f * eta * eta) * 1.0001f;    // 64 u s*max + 56 eta^2 >= 56 u s* + 40 eta^2
+    if (!(kh < 3.4028234663852886e38f) || !(eta < 3.4028234663852886e38f)) { kh = __uint_as_float(0x7f800000u); eta = 0.f; }
+    const float neg_eta = -eta;
     int ninl = 0, nsup = 0;
-    int c0 = blockIdx.y * CCH, c1 = min(c, c0 + CCH);
-    for (int base = c0; base < c1; base += CB) {
-        __syncthreads();
-        int i = base + threadIdx.x;
-        {
-            // (lanes past the end stage a pair that can never be an inlier: threshold 0)
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            float ss = 0.f;
-            if (i < c1) { a = P0[i]; b = P1[i]; ss = sstar[i]; }
-            sx[threadIdx.x] = a.x; sy[threadIdx.x] = a.y; sz[threadIdx.x] = a.z;
-            tx[threadIdx.x] = b.x; ty[threadIdx.x] = b.y; tz[threadIdx.x] = b.z; st[threadIdx.x] = ss;
+    const int c0 = blockIdx.y * cch, c1 = min(c, c0 + cch);
+    for (int base = c0; base < c1; base += 64) {
+        const CPair* __restrict__ pp = PP + (base >> 1);   // wave-uniform: scalar loads
+        unsigned w[2], sd[2] = {0u, 0u};                   // inlier bits; support bits that differ from them (borderline pairs only)
+        CPair nxt = pp[0], nxt2 = pp[1];                   // two pair records are in flight while the current one is evaluated
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            unsigned bits = 0u;
+#pragma unroll 4
+            for (int jj = 0; jj < 16; ++jj) {
+                const CPair p = nxt;
+                nxt = nxt2;
+                nxt2 = pp[min(half * 16 + jj + 2, 31)];
+                v2f_c ex = T[12] - p.qx, ey = T[13] - p.qy, ez = T[14] - p.qz;
+                ex = __builtin_elementwise_fma(v2f_c{T[8], T[8]}, p.sz, ex); ey = __builtin_elementwise_fma(v2f_c{T[9], T[9]}, p.sz, ey); ez = __builtin_elementwise_fma(v2f_c{T[10], T[10]}, p.sz, ez);
+                ex = __builtin_elementwise_fma(v2f_c{T[4], T[4]}, p.sy, ex); ey = __builtin_elementwise_fma(v2f_c{T[5], T[5]}, p.sy, ey); ez = __builtin_elementwise_fma(v2f_c{T[6], T[6]}, p.sy, ez);
+                ex = __builtin_elementwise_fma(v2f_c{T[0], T[0]}, p.sx, ex); ey = __builtin_elementwise_fma(v2f_c{T[1], T[1]}, p.sx, ey); ez = __builtin_elementwise_fma(v2f_c{T[2], T[2]}, p.sx, ez);
+                v2f_c d2 = ex * ex;
+                d2 = __builtin_elementwise_fma(ey, ey, d2);
+                d2 = __builtin_elementwise_fma(ez, ez, d2);
+                const v2f_c u = d2 - p.ss;
+                // sign bit of u = "d2~ < s*" (u = -0 cannot occur: x - x is +0); correspondence 2 jj (+1) ends up at bit 31 - 2 jj (- 1)
+                bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(u.x), 31);
+                bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(u.y), 31);
+                const float t0 = __builtin_fmaf(neg_eta, p.rs.x, fabsf(u.x)), t1 = __builtin_fmaf(neg_eta, p.rs.y, fabsf(u.y));
+                if (__any(!(t0 > kh) || !(t1 > kh))) {   // wave-uniform; NaN -> taken
+                    const v2f_c ox = ((T[0] * p.sx + T[4] * p.sy) + T[8] * p.sz) + T[12];     // LGR_APPLY, elementwise
+                    const v2f_c oy = ((T[1] * p.sx + T[5] * p.sy) + T[9] * p.sz) + T[13];
+                    const v2f_c oz = ((T[2] * p.sx + T[6] * p.sy) + T[10] * p.sz) + T[14];
+                    const v2f_c dx = ox - p.qx, dy = oy - p.qy, dz = oz - p.qz;
+                    const v2f_c xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                    const v2f_c d4 = (xx + zz) + (yy + 0.f);   // Eigen 4-vector squaredNorm reduction
+                    const v2f_c d3 = (xx + yy) + zz;           // 3-vector block norm
+                    const unsigned in0 = d4.x < p.ss.x ? 1u : 0u, in1 = d4.y < p.ss.y ? 1u : 0u;
+                    const unsigned s0 = d3.x < p.ss.x ? 1u : 0u, s1 = d3.y < p.ss.y ? 1u : 0u;
+                    bits = (bits & ~3u) | (in0 << 1) | in1;
+                    sd[half] |= ((in0 ^ s0) | ((in1 ^ s1) << 1)) << (2 * jj);
+                }
+            }
+            w[half] = __builtin_bitreverse32(bits);
         }
-        __syncthreads();
-        int nj = min(CB, c1 - base);
-        unsigned long long bits = 0ull;
-        for (int j = 0; j < nj; j += 2) {
-            const v2f ax = *reinterpret_cast<const v2f*>(&sx[j]), ay = *reinterpret_cast<const v2f*>(&sy[j]), az = *reinterpret_cast<const v2f*>(&sz[j]);
-            const v2f bx = *reinterpret_cast<const v2f*>(&tx[j]), by = *reinterpret_cast<const v2f*>(&ty[j]), bz = *reinterpret_cast<const v2f*>(&tz[j]);
-            const v2f ss = *reinterpret_cast<const v2f*>(&st[j]);
-            // LGR_APPLY, elementwise: ((c0*x + c1*y) + c2*z) + c3
-            const v2f ox = ((T[0] * ax + T[4] * ay) + T[8] * az) + T[12];
-            const v2f oy = ((T[1] * ax + T[5] * ay) + T[9] * az) + T[13];
-            const v2f oz = ((T[2] * ax + T[6] * ay) + T[10] * az) + T[14];
-            const v2f dx = ox - bx, dy = oy - by, dz = oz - bz;
-            const v2f xx = dx * dx, yy = dy * dy, zz = dz * dz;
-            const v2f d4 = (xx + zz) + (yy + 0.f);   // Eigen 4-vector squaredNorm reduction
-            const v2f d3 = (xx + yy) + zz;           // 3-vector block norm
-            const bool in0 = d4.x < ss.x, in1 = d4.y < ss.y;   // (a staged filler pair has ss = 0: never an inlier)
-            ninl += (in0 ? 1 : 0) + (in1 ? 1 : 0);
-            nsup += (d3.x < ss.x ? 1 : 0) + (d3.y < ss.y ? 1 : 0);
-            bits |= ((unsigned long long) (in0 ? 1 : 0) | ((unsigned long long) (in1 ? 2 : 0))) << j;
-        }
+        ninl += __popc(w[0]) + __popc(w[1]);
+        nsup += __popc(w[0] ^ sd[0]) + __popc(w[1] ^ sd[1]);
         // inlier bits of this hypothesis for the correspondences [base, base + 64): word-major, so the lanes (consecutive
         // hypotheses) store consecutive words; phase 2 walks the set bits instead of testing every correspondence again
         if (maskT && act) {
-            maskT[(size_t) (base >> 5) * nh + h] = (unsigned) bits;
-            if (base + 32 < c) maskT[(size_t) ((base >> 5) + 1) * nh + h] = (unsigned) (bits >> 32);
+            maskT[(size_t) (base >> 5) * nh + h] = w[0];
+            if (base + 32 < c) maskT[(size_t) ((base >> 5) + 1) * nh + h] = w[1];
         }
     }
     if (act) { atomicAdd(&counts[h].x, ninl); atomicAdd(&counts[h].y, nsup); }
@@ -652,7 +705,7 @@ int est_from_support(int count, int c, float confidence, int nr_samples) {
     return static_cast<int>(std::min((double) INT_MAX, iterations));
 }
 
-struct Packed { float4* P0; float4* P1; float* sstar; };
+struct Packed { float4* P0; float4* P1; float* sstar; const CPair* PP; const unsigned* pstats; };
 
 __global__ void corr_range_kernel(const lgr_corr* __restrict__ corr, int c, int ns, int nt, int* __restrict__ bad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -685,11 +738,17 @@ int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, c
     float bb[12];
     LGR_TRY(lgr_bbox_host(ctx, d_src, ns, bb));   // UniformityMetricEstimator::setSourceCloud (src/metric.cpp:167-170)
     float4* P;
-    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_PACK, (size_t) c * 2 + (size_t) (c + 3) / 4 + 4, &P));
+    const int cpad = (c + 63) & ~63;
+    const size_t n4 = (size_t) c * 2 + (size_t) (c + 3) / 4 + 4;                     // P0, P1, sstar
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_PACK, n4 + (size_t) cpad * 2 + 8, &P));           // + PP (32 bytes per correspondence) + pstats
     out->P0 = P; out->P1 = P + c; out->sstar = (float*) (P + 2 * (size_t) c);
+    float* PP = (float*) (P + n4);
+    unsigned* pstats = (unsigned*) (P + n4 + (size_t) cpad * 2);
+    out->PP = (const CPair*) PP; out->pstats = pstats;
+    LGR_HIP(ctx, hipMemsetAsync(pstats, 0, 16, ctx->stream));
     if (c > 0)
-        pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bb[6], bb[7], bb[8], bb[9], bb[10], bb[11],
-                                                           out->P0, out->P1, out->sstar);
+        pack_kernel<<<cdiv(cpad, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bb[6], bb[7], bb[8], bb[9], bb[10], bb[11],
+                                                              out->P0, out->P1, out->sstar, PP, pstats, cpad);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
@@ -906,13 +965,15 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     *n_ok = nh; *n_cand = 0;
     if (nh == 0) return LGR_OK;
     LGR_HIP(ctx, hipMemsetAsync(b.counts, 0, (size_t) nh * 8, ctx->stream));
-    dim3 g(cdiv(nh, CB), cdiv(c, CCH));
+    // few hypotheses (the first round, the lr filter): shorter correspondence chunks, so that the launch still has a few thousand waves
+    const int cch = ((long long) cdiv(nh, CB) * cdiv(c, CCH) >= 4096) ? CCH : (((long long) cdiv(nh, CB) * cdiv(c, 512) >= 4096) ? 512 : 128);
+    dim3 g(cdiv(nh, CB), cdiv(c, cch));
     // inlier bit masks for phase 2 (uniformity / correspondence-count metrics need the inlier set only); skipped when they
     // would not fit 2 GB (then phase 2 tests every correspondence again)
     unsigned* maskT = nullptr;
     const size_t mask_words = (size_t) ((c + 31) >> 5) * nh;
     if (!plane && p->metric_id == LGR_METRIC_UNIFORMITY && mask_words * 4 <= ((size_t) 2 << 30)) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASKT, mask_words, &maskT));
-    count_kernel<<<g, CB, 0, ctx->stream>>>(b.Ts, b.list, nh, pk.P0, pk.P1, pk.sstar, c, b.counts, maskT);
+    count_kernel<<<g, CB, 0, ctx->stream>>>(b.Ts, b.list, nh, pk.PP, pk.pstats, c, b.counts, maskT, cch);
     int* pl_cnt = nullptr;
     float* pl_cp = nullptr;
     if (plane) {
@@ -1142,7 +1203,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
         Packed pp;
         float4* P;
         LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_LIST, (size_t) 3 * std::max(np, 1) + 4, &P));
-        pp.P0 = P; pp.P1 = P + std::max(np, 1); pp.sstar = nullptr;
+        pp.P0 = P; pp.P1 = P + std::max(np, 1); pp.sstar = nullptr; pp.PP = nullptr; pp.pstats = nullptr;
         int2* d_pairs = (int2*) (P + 2 * (size_t) std::max(np, 1));
         if (np) {
             LGR_HIP(ctx, hipMemcpyAsync(d_pairs, plane_pairs.data(), (size_t) np * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1203,8 +1264,8 @@ extern "C" int lgr_refit_svd_dev(lgr_ctx* ctx, const float* d_src, const float* 
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     float4* P;
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_PACK, (size_t) c * 2 + (size_t) (c + 3) / 4 + 4, &P));
-    Packed pk{P, P + c, (float*) (P + 2 * (size_t) c)};
-    if (c > 0) pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, pk.P0, pk.P1, pk.sstar);
+    Packed pk{P, P + c, (float*) (P + 2 * (size_t) c), nullptr, nullptr};
+    if (c > 0) pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, pk.P0, pk.P1, pk.sstar, nullptr, nullptr, c);
     float* dT;
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &dT));
     LGR_TRY(refit_launch(ctx, pk, c, d_mask, dT));
