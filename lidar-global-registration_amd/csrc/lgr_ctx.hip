@@ -79,6 +79,13 @@ static int make_internal(lgr_ctx* ctx, lgr_ctx** out, hipEvent_t* ev) {
     if (!*ev) LGR_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return LGR_OK;
 }
+int lgr_ctx_stream3(lgr_ctx* ctx, hipStream_t* out) {
+    if (!ctx->ev3) LGR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev3, hipEventDisableTiming));
+    if (!ctx->opt.helper_contexts) { *out = ctx->stream; return LGR_OK; }
+    if (!ctx->stream3) LGR_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    *out = ctx->stream3;
+    return LGR_OK;
+}
 int lgr_ctx_aux(lgr_ctx* ctx) { return make_internal(ctx, &ctx->aux, &ctx->aux_ev); }
 int lgr_ctx_aux2(lgr_ctx* ctx) { return make_internal(ctx, &ctx->aux2, &ctx->aux2_ev); }
 
@@ -154,6 +161,8 @@ extern "C" int lgr_ctx_destroy(lgr_ctx* ctx) {
     if (ctx->match_prep && ctx->match_prep_free) { ctx->match_prep_free(ctx->match_prep); ctx->match_prep = nullptr; }
     drop_internal(ctx);
     if (ctx->aux_ev) { (void) hipEventDestroy(ctx->aux_ev); ctx->aux_ev = nullptr; }
+    if (ctx->stream3) { (void) hipStreamSynchronize(ctx->stream3); (void) hipStreamDestroy(ctx->stream3); ctx->stream3 = nullptr; }
+    if (ctx->ev3) { (void) hipEventDestroy(ctx->ev3); ctx->ev3 = nullptr; }
     if (ctx->aux2_ev) { (void) hipEventDestroy(ctx->aux2_ev); ctx->aux2_ev = nullptr; }
     for (int i = 0; i < WS_COUNT; ++i)
         if (ctx->ws[i].p) (void) hipFree(ctx->ws[i].p);

@@ -59,6 +59,8 @@ struct lgr_ctx {
     lgr_ctx* aux2 = nullptr;     // third context: the match filter's per-cloud tables (densities, cluster k-NN lists) are computed on it
                                  // while the matcher runs on this one (lgr_correspondences_dev)
     hipEvent_t aux2_ev = nullptr;
+    hipStream_t stream3 = nullptr;  // matcher: the column operands are packed on it while the bounds of pass 0 are computed on `stream` (lgr_ctx_stream3)
+    hipEvent_t ev3 = nullptr;
     lgr_ctx_options opt{1, {0, 0, 0, 0, 0, 0, 0}};   // lgr_ctx_default_options
     lgr_helper* helper = nullptr;               // of an internal context: the host thread that drives it (opt.helper_contexts)
     lgr_match_stats mstats{};                   // lgr_match_last_*: the last match call of THIS context
@@ -142,6 +144,7 @@ int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
 // What it buys: the host read-backs (counts, extents) and short launches of one piece hide behind the other piece's kernels.
 int lgr_ctx_aux(lgr_ctx* ctx);   // makes sure ctx->aux exists
 int lgr_ctx_aux2(lgr_ctx* ctx);  // makes sure ctx->aux2 exists
+int lgr_ctx_stream3(lgr_ctx* ctx, hipStream_t* out);   // a third stream (ctx->stream itself when opt.helper_contexts == 0)
 // post `job` to the helper thread of the internal context `aux` (started on first use; a thread that cannot be started is an error
 // code, never an exception across the C ABI); lgr_helper_wait blocks until it has run and returns its status.  Every post must be
 // followed by exactly one wait -- also on the caller's error paths (lgr_helper_guard).

@@ -407,6 +407,20 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ROWMIN, a_op_bytes + 256, &Aop));
     const size_t b_op_bytes = KCL * bset_stride * frag_bytes;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_COLMIN, b_op_bytes + 256, &Bop));
+    // The column (train-side) operands -- 16 sets, 3 GB at 1M rows, the longest piece of the set-up -- are packed on a third stream:
+    // nothing before the first MFMA pass reads them (the bounds of pass 0 need the ROW operands, the packed leaf centres and the
+    // boxes), so that chain runs beside the packing instead of behind it.  sB is joined in launch_mfma.
+    // (It starts BEHIND the row operands' packing: side by side the two packing kernels share the HBM write bandwidth and the row
+    // operands, which the bounds wait for, take as long as the 3 GB of column sets.)
+    hipStream_t sB = ctx->stream;
+    if (f16) LGR_TRY(lgr_ctx_stream3(ctx, &sB));
+    auto fork_b = [&]() -> int {
+        if (sB != ctx->stream) {
+            LGR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
+            LGR_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev3, 0));
+        }
+        return LGR_OK;
+    };
     if (!f16) {
         pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, (float*) Aop, nAp, d_max + 2);
         pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, (float*) Bop, nBp, d_max + 2);
@@ -418,10 +432,12 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     } else {
         if (rot) {
             pack16_kernel<true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
-            pack16_kernel<true><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
+            LGR_TRY(fork_b());
+            pack16_kernel<true><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
         } else {
             pack16_kernel<false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
-            pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
+            LGR_TRY(fork_b());
+            pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
         }
     }
     const int n_rg = cdiv(ma_pad, rg_rows);
@@ -455,8 +471,21 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_HIP(ctx, hipMemcpyAsync(group_start, h_group_start.data(), h_group_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    group_max_kernel<<<dim3(n_groups, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, 0, group_start, gmaxB);
+    if (sB != ctx->stream) {   // (group_start was uploaded on the main stream just above)
+        LGR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
+        LGR_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev3, 0));
+    }
+    group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
+    bool b_joined = sB == ctx->stream;
+    auto join_b = [&]() -> int {   // everything that reads the column operands, their norms or maxima comes after this
+        if (!b_joined) {
+            LGR_HIP(ctx, hipEventRecord(ctx->ev3, sB));
+            LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev3, 0));
+        }
+        b_joined = true;
+        return LGR_OK;
+    };
     // (sortedA / sortedB / the boxes: forked onto the second stream above; joined where they are first read)
     bool sorted_joined = false;
     auto join_sorted = [&]() -> int {
@@ -498,6 +527,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         items_emit_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(iflags, ipos, item_rb, n_ir, ccx, ilist, xcd_start);
         LGR_HIP(ctx, hipMemsetAsync(xcd_ctr, 0, 32, ctx->stream));
         LGR_CHECK(ctx, ctx->mfma_timed < 8, LGR_ERR_INVALID_ARG);
+        LGR_TRY(join_b());
         (void) hipEventRecord(ctx->ev[9 + 2 * ctx->mfma_timed], ctx->stream);
 #define LGR_MFMA_ARGS bset_stride, c_scale, out_scale, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin, n_cc, item_rb, ilist, xcd_start, xcd_ctr, ca
         if (f16 && rot && ca.u_rb) {
@@ -575,7 +605,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned long long* coarse_cnt = (unsigned long long*) (pb + o_ccnt);
         CoarseArgs ca_on{};
         if (coarse) {
-            group_max_kernel<<<dim3(n_stage_total, KCL), 256, 0, ctx->stream>>>(nBp, mb_pad, STAGE_COLS, nullptr, smaxB);
+            group_max_kernel<<<dim3(n_stage_total, KCL), 256, 0, sB>>>(nBp, mb_pad, STAGE_COLS, nullptr, smaxB);   // (behind the packing, on its stream)
             LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 16, ctx->stream));
             const double c_quad = 9.5367477e-6 * (double) ex.quad * 1.00001;            // eps (group_eps)
             const double d11 = std::ldexp(1.0, -11) * (1.0 + std::ldexp(1.0, -9));      // delta: 2^-11 (x^2 + y^2) + 2^-10 x y
@@ -670,7 +700,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                                                                                             colstage && pass == n_beta ? 1 : 0, done, sched);
             }
             mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage, mask, mstats);
-            init_tables_kernel<<<n_rb, BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
+            init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             CoarseArgs ca = ca_on;
             if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.n_ct_total = tb; }

@@ -191,13 +191,17 @@ __global__ void cov_reduce(const float* __restrict__ part, int n_blocks, float* 
 // boxes of row segments in the basis (rows of V, y = V (x - mu)); segments: fixed 256-row blocks (starts == nullptr) or
 // [starts[s], starts[s + 1]).  box[s][0..32] = min, [33..65] = max (transposed: box[c][s]); rmax2: largest |x - mu|^2 seen.
 // X: the rows in their ORIGINAL order, read through perm (position r holds row perm[r]; -1 = padding)
-__global__ __launch_bounds__(256) void box_kernel(const float* __restrict__ X, const int* __restrict__ perm, const int* __restrict__ starts, int n_seg,
+__global__ __launch_bounds__(256, 4) void box_kernel(const float* __restrict__ X, const int* __restrict__ perm, const int* __restrict__ starts, int n_seg,
                                                   const float* __restrict__ V /* [33][33] */, const float* __restrict__ mu, int transposed,
                                                   float* __restrict__ box, unsigned* __restrict__ rmax2) {
-    __shared__ float Vs[33 * 33 + 33];
+    // basis rows padded to 36 floats: a row is nine 16-byte LDS reads (every lane reads the same address: broadcasts); the loops below
+    // are fully unrolled so that x / mn / mx stay in registers (a variable index puts them in scratch: 1.4 + 0.6 ms per step at 1M,
+    // on the critical path of the pass-0 bounds)
+    __shared__ __attribute__((aligned(16))) float Vs[33 * 36];
+    __shared__ float mus[33];
     __shared__ float red[4][66];
-    for (int i = threadIdx.x; i < 33 * 33; i += 256) Vs[i] = V[i];
-    if (threadIdx.x < 33) Vs[33 * 33 + threadIdx.x] = mu[threadIdx.x];
+    for (int i = threadIdx.x; i < 33 * 36; i += 256) { const int k = i / 36, j = i % 36; Vs[i] = j < 33 ? V[k * 33 + j] : 0.f; }
+    if (threadIdx.x < 33) mus[threadIdx.x] = mu[threadIdx.x];
     __syncthreads();
     const int seg = blockIdx.x;
     const int b = starts ? starts[seg] : seg * BLOCK_ROWS, e = starts ? starts[seg + 1] : (seg + 1) * BLOCK_ROWS;
@@ -208,16 +212,23 @@ __global__ __launch_bounds__(256) void box_kernel(const float* __restrict__ X, c
     for (int r = b + threadIdx.x; r < e; r += 256) {
         const int o = perm[r];
         if (o < 0) continue;
+        asm volatile("" ::: "memory");   // the basis is loop invariant: without this its 300 LDS reads are hoisted out of the row loop into 1200 registers
         float x[33];
         float n2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 33; ++k) { x[k] = X[(size_t) o * 33 + k] - Vs[33 * 33 + k]; n2 = __builtin_fmaf(x[k], x[k], n2); }
+        for (int k = 0; k < 33; ++k) { x[k] = X[(size_t) o * 33 + k] - mus[k]; n2 = __builtin_fmaf(x[k], x[k], n2); }
         r2 = fmaxf(r2, n2);
-#pragma unroll 3
+#pragma unroll
         for (int k = 0; k < 33; ++k) {
+            const float4* vr = reinterpret_cast<const float4*>(&Vs[k * 36]);
             float y = 0.f;
 #pragma unroll
-            for (int j = 0; j < 33; ++j) y = __builtin_fmaf(Vs[k * 33 + j], x[j], y);
+            for (int j4 = 0; j4 < 8; ++j4) {
+                const float4 v = vr[j4];
+                y = __builtin_fmaf(v.x, x[4 * j4], y); y = __builtin_fmaf(v.y, x[4 * j4 + 1], y);
+                y = __builtin_fmaf(v.z, x[4 * j4 + 2], y); y = __builtin_fmaf(v.w, x[4 * j4 + 3], y);
+            }
+            y = __builtin_fmaf(Vs[k * 36 + 32], x[32], y);
             mn[k] = fminf(mn[k], y); mx[k] = fmaxf(mx[k], y);
         }
     }
