@@ -220,6 +220,10 @@ struct lgr_plane_dev {
 int lgr_plane_setup(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, uint64_t seed, lgr_plane_dev* out);
 // hypothesis h in [0, nh): transform d_Ts + 16 * off, Philox counter = counter_base + off, off = d_list ? d_list[h] : h.
 // d_rmse / d_pairs (+ d_n_pairs) optional; pairs = (source index, nearest target index) of the inliers, unordered.
+// Gate (RANSAC batches): best_prev = best metric of the earlier batches, record_prev = their record inlier count (INT_MAX when the plane
+// counts are not the records), d_factor (optional) = per-hypothesis factor of the metric (combination: the correspondence metric);
+// a hypothesis whose upper bounds fall below both is abandoned -- it can be neither the best nor a record.  0 / INT_MAX / NULL: no gate.
 int lgr_plane_eval(lgr_ctx* ctx, const lgr_plane_dev& pd, const float* d_Ts, const int* d_list, int nh, unsigned counter_base, int score_id,
-                   int* d_cnt, float* d_metric, float* d_rmse, int2* d_pairs, int* d_n_pairs);
+                   int* d_cnt, float* d_metric, float* d_rmse, int2* d_pairs, int* d_n_pairs, float best_prev = 0.f, int record_prev = 0x7fffffff,
+                   const float* d_factor = nullptr);
 

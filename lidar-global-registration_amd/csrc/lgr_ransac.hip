@@ -947,7 +947,8 @@ static int batch_buffers(lgr_ctx* ctx, int nb, BatchBuffers* b) {
 // runs one batch.  h_counts: [0] n_ok, [1] n_cand (hypotheses with >= MIN_NR_INLIERS inliers)
 static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c, const Packed& pk,
                      const lgr_params* p, uint64_t seed, int first, int nb, const int32_t* d_triples, BatchBuffers& b,
-                     int* n_ok, int* n_cand, const lgr_plane_dev* plane = nullptr, int min_inliers = MIN_NR_INLIERS) {
+                     int* n_ok, int* n_cand, const lgr_plane_dev* plane = nullptr, int min_inliers = MIN_NR_INLIERS,
+                     float best_prev = 0.f, int record_prev = 0) {
     hypotheses_kernel<<<cdiv(nb, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, first, nb, d_triples,
                                                               p->edge_thr_coef, b.Ts, b.ok);
     size_t tb = 0;
@@ -982,7 +983,9 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     }
     if (plane && p->metric_id == LGR_METRIC_CLOSEST_PLANE) {
         // every hypothesis that passed the prerejection is evaluated on its sparse subset; its plane inliers are "the inliers"
-        LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list, nh, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr));
+        // (gate: a hypothesis that can reach neither the best metric nor the record inlier count of the earlier batches is abandoned)
+        LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list, nh, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr,
+                               best_prev, record_prev, nullptr));   // (record_prev == 0: no record yet, nothing is abandoned)
         plane_counts_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(pl_cnt, nh, b.counts);
     }
     flag_ge_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.counts, nh, min_inliers, b.flags2);
@@ -999,7 +1002,8 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
         plane_pick_kernel<<<cdiv(nh, 256), 256, 0, ctx->stream>>>(b.flags2, b.pos2, nh, pl_cnt, pl_cp, b.metric, b.ninl);
     } else if (plane) {   // combination: correspondences metric with the constant score (include/metric.h:191-192) x plane metric
         LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, LGR_METRIC_CORRESPONDENCES, LGR_SCORE_CONSTANT, b.metric, b.ninl, nullptr, nullptr));
-        LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list2, nh2, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr));
+        LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list2, nh2, (unsigned) first, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr,
+                               best_prev, 0x7fffffff, b.metric));   // (records are correspondence counts here: only the metric gates)
         plane_mul_kernel<<<cdiv(nh2, 256), 256, 0, ctx->stream>>>(b.metric, pl_cp, nh2);
     } else {
         LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr, maskT, b.hpos, nh));
@@ -1143,7 +1147,8 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
         else if (final_metric > 0.f && p->metric_id == LGR_METRIC_CORRESPONDENCES)
             min_inliers = std::max(min_inliers, (int) std::floor((double) final_metric * (double) c / 1.001) - 1);
         LGR_HIP(ctx, hipMemsetAsync(b.st, 0, sizeof(BatchStats) * n_batches, ctx->stream));
-        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand, plane_metric ? &plane : nullptr, min_inliers));
+        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand, plane_metric ? &plane : nullptr, min_inliers,
+                          final_metric, largest));
         if (ransac_debug) fprintf(stderr, "[lgr] ransac round at %d: %d iterations (%d batches), %d pass the prerejection, %d scored (gate %d inliers), best metric %.4f, largest %d, bound %d\n",
                                   done, nb, n_batches, n_ok, n_cand, min_inliers, final_metric, largest, bound);
         BatchStats* hs;
