@@ -153,6 +153,15 @@ __device__ __forceinline__ void lgr_visit27(const GridDev& g, float qx, float qy
             if (x0 > x1) continue;
             size_t c = ((size_t) z * g.dy + y) * g.dx;
             int b = g.cell_start[c + x0], e = g.cell_start[c + x1 + 1];   // three x-cells are contiguous
-            for (int t = b; t < e; ++t) f(t, g.pxyz[t]);
+            // four loads in flight before the first callback (a load per candidate, each waited for, is a dependent round trip per
+            // candidate: the closest-plane metric went from 38 to 16 ms per alignment with this, round 3); same visiting order
+            for (int t = b; t < e; t += 4) {
+                const int last = e - 1;
+                const float4 q0 = g.pxyz[t], q1 = g.pxyz[min(t + 1, last)], q2 = g.pxyz[min(t + 2, last)], q3 = g.pxyz[min(t + 3, last)];
+                f(t, q0);
+                if (t + 1 < e) f(t + 1, q1);
+                if (t + 2 < e) f(t + 2, q2);
+                if (t + 3 < e) f(t + 3, q3);
+            }
         }
 }
