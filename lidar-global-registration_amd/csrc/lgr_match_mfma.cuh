@@ -79,6 +79,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
     if (COLDIR) {
         for (int i = tid; i < CHUNK_COLS; i += NTHR) cmin_s[i] = IINF;   // every flush leaves the array at +inf again
     }
+    const unsigned cmin_lane_base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) int*) &cmin_s[lane & 31];
     int cur_cc = -1, col_tile0 = 0, n_coltiles = 0;
     unsigned full = 0u;
     unsigned tend[STAGE_TILES] = {0u, 0u, 0u, 0u};
@@ -199,17 +200,26 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     int cm = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
                     for (int g = 2; g < 16; g += 2) cm = min(min(cm, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
-                    // fold the two lane halves (rows 4*half + ...) with the VALU lane swap of gfx950
-                    auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
-                    int other = (int) (half ? sw[0] : sw[1]);
-                    cm = min(cm, other);
-                    // both halves hold the folded minimum: all 64 lanes issue the LDS atomic (no exec-mask branch in
-                    // the MFMA block; the two lanes of a column hit the same word with the same value)
+                    // The two lane halves (rows 4 * half + ...) hold partial minima of the same 32 columns.  Round 3: they are NOT folded in
+                    // the VALU any more (v_permlane32_swap + select + min = 3 vector instructions per tile on the unit that bounds this
+                    // kernel): both halves issue the LDS atomic on the same word and the LDS unit, which has slack, merges them.
                     // (inline asm: behind a compiler-visible LDS atomic hipcc waits vmcnt(0), i.e. for the LDS-DMA of the
                     // next stage, in the middle of the current one; the s_waitcnt lgkmcnt(0) before the column flush's
-                    // barrier retires these)
-                    const unsigned lds_addr = (unsigned) (uintptr_t) (__attribute__((address_space(3))) int*) &cmin_s[(st * STAGE_TILES + ct) * TILE + (lane & 31)];
-                    asm volatile("ds_min_i32 %0, %1" : : "v"(lds_addr), "v"(cm));
+                    // barrier retires these.)  The address is a per-lane base + a compile-time tile offset + a per-stage scalar.
+#ifdef LGR_MM_FOLD   // A/B switch (tools/exp_env.sh): the round-2 epilogue folded the halves with v_permlane32_swap before the atomic
+                    {
+                        auto sw = __builtin_amdgcn_permlane32_swap((unsigned) cm, (unsigned) cm, false, false);
+                        cm = min(cm, (int) (half ? sw[0] : sw[1]));
+                    }
+#endif
+                    const unsigned lds_addr = cmin_lane_base + (unsigned) (st * STAGE_TILES * TILE * 4);   // (st is wave uniform: one add per stage)
+                    static_assert(STAGE_TILES == 4 && TILE == 32, "the tile offsets below are literal");
+                    switch (ct) {   // ct is a literal after unrolling: the tile's 128-byte offset rides in the instruction
+                        case 0: asm volatile("ds_min_i32 %0, %1" : : "v"(lds_addr), "v"(cm)); break;
+                        case 1: asm volatile("ds_min_i32 %0, %1 offset:128" : : "v"(lds_addr), "v"(cm)); break;
+                        case 2: asm volatile("ds_min_i32 %0, %1 offset:256" : : "v"(lds_addr), "v"(cm)); break;
+                        default: asm volatile("ds_min_i32 %0, %1 offset:384" : : "v"(lds_addr), "v"(cm)); break;
+                    }
                 }
             };
             auto tile_ends_group = [&](int st, int ct) {

@@ -14,7 +14,8 @@ except ImportError:  # pragma: no cover
     _torch = None
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-LIB_PATH = os.path.join(_CSRC, "liblgr_hip.so")
+# LGR_HIP_LIB: another build of the same sources (A/B experiments of tools/: e.g. a library built with `make EXP=-D...`); never a fallback
+LIB_PATH = os.environ.get("LGR_HIP_LIB") or os.path.join(_CSRC, "liblgr_hip.so")
 
 MATCH_LR, MATCH_ONE_SIDED, MATCH_CLUSTER = 0, 1, 2
 METRIC_CORRESPONDENCES, METRIC_UNIFORMITY, METRIC_CLOSEST_PLANE, METRIC_COMBINATION = 0, 1, 2, 3
