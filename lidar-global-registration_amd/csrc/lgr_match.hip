@@ -407,6 +407,47 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ROWMIN, a_op_bytes + 256, &Aop));
     const size_t b_op_bytes = KCL * bset_stride * frag_bytes;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_COLMIN, b_op_bytes + 256, &Bop));
+    const int n_rg = cdiv(ma_pad, rg_rows);
+    // column groups of the row-minimum table: a leaf, cut into pieces of at most GROUP_COLS columns (k-means leaves of
+    // near-duplicate descriptors can hold tens of thousands of rows; the exact rerank scans a whole group per item)
+    std::vector<int> h_group_start, h_tiles(2 * (size_t) tb);   // [tile] -> group, [tb + tile] -> leaf
+    int group_cols = GROUP_COLS;   // larger pieces for very large inputs: keep the table [groups][ma_pad] under ~24 GB
+    while (group_cols < 65536 && ((size_t) mb_pad / group_cols + n_leaves) * (size_t) ma_pad * 4 > ((size_t) 24 << 30)) group_cols *= 2;
+    for (int l = 0; l < n_leaves; ++l)
+        for (int s0 = B.h_leaf_start[l]; s0 < B.h_leaf_start[l + 1]; s0 += group_cols) {
+            int s1 = std::min(B.h_leaf_start[l + 1], s0 + group_cols), g = (int) h_group_start.size();
+            h_group_start.push_back(s0);
+            for (int t = s0 / TILE; t < s1 / TILE; ++t) { h_tiles[t] = g; h_tiles[tb + t] = l; }
+        }
+    const int n_groups = (int) h_group_start.size();
+    g_last_stats.sub_cols = n_groups;
+    h_group_start.push_back(mb_pad);
+    float *gmaxB, *gmaxA;
+    int *cl_of_rg, *tile_group, *tile_leaf, *group_start;
+    int *group_leaf, *leaf_g0;   // [n_groups]: leaf of a group; [n_leaves + 1]: first group of a leaf (the skipping schedule's tables)
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_B, (size_t) KCL * n_groups + 2 * (size_t) n_rg + 2 * (size_t) tb + 2 * (size_t) n_groups + n_leaves + 72, &gmaxB));
+    gmaxA = gmaxB + (size_t) KCL * n_groups;
+    cl_of_rg = (int*) (gmaxA + n_rg);
+    tile_group = cl_of_rg + n_rg;
+    tile_leaf = tile_group + tb;
+    group_start = tile_leaf + tb;
+    group_leaf = group_start + n_groups + 1;
+    leaf_g0 = group_leaf + n_groups;
+    {
+        // every small host-built table of the call goes up HERE, before the operand packing is enqueued: the one host wait they need
+        // (the staging vectors go out of scope) then falls on the short placement kernels, not behind the packing
+        std::vector<int> h(n_rg), hgl(n_groups), hl(n_leaves + 1, n_groups);
+        for (int g = 0; g < n_rg; ++g) h[g] = A.h_blkcl[(size_t) g * (rg_rows / BLOCK_ROWS)];
+        for (int g = 0; g < n_groups; ++g) hgl[g] = h_tiles[tb + h_group_start[g] / TILE];
+        for (int g = n_groups - 1; g >= 0; --g) hl[hgl[g]] = g;                       // first group of every leaf that has one
+        for (int l = n_leaves - 1; l >= 0; --l) hl[l] = std::min(hl[l], hl[l + 1]);   // empty leaves: g0 == g1
+        LGR_HIP(ctx, hipMemcpyAsync(cl_of_rg, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(tile_group, h_tiles.data(), h_tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(group_start, h_group_start.data(), h_group_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(group_leaf, hgl.data(), hgl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipMemcpyAsync(leaf_g0, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // The column (train-side) operands -- 16 sets, 3 GB at 1M rows, the longest piece of the set-up -- are packed on a third stream:
     // nothing before the first MFMA pass reads them (the bounds of pass 0 need the ROW operands, the packed leaf centres and the
     // boxes), so that chain runs beside the packing instead of behind it.  sB is joined in launch_mfma.
@@ -440,41 +481,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
         }
     }
-    const int n_rg = cdiv(ma_pad, rg_rows);
-    // column groups of the row-minimum table: a leaf, cut into pieces of at most GROUP_COLS columns (k-means leaves of
-    // near-duplicate descriptors can hold tens of thousands of rows; the exact rerank scans a whole group per item)
-    std::vector<int> h_group_start, h_tiles(2 * (size_t) tb);   // [tile] -> group, [tb + tile] -> leaf
-    int group_cols = GROUP_COLS;   // larger pieces for very large inputs: keep the table [groups][ma_pad] under ~24 GB
-    while (group_cols < 65536 && ((size_t) mb_pad / group_cols + n_leaves) * (size_t) ma_pad * 4 > ((size_t) 24 << 30)) group_cols *= 2;
-    for (int l = 0; l < n_leaves; ++l)
-        for (int s0 = B.h_leaf_start[l]; s0 < B.h_leaf_start[l + 1]; s0 += group_cols) {
-            int s1 = std::min(B.h_leaf_start[l + 1], s0 + group_cols), g = (int) h_group_start.size();
-            h_group_start.push_back(s0);
-            for (int t = s0 / TILE; t < s1 / TILE; ++t) { h_tiles[t] = g; h_tiles[tb + t] = l; }
-        }
-    const int n_groups = (int) h_group_start.size();
-    g_last_stats.sub_cols = n_groups;
-    h_group_start.push_back(mb_pad);
-    float *gmaxB, *gmaxA;
-    int *cl_of_rg, *tile_group, *tile_leaf, *group_start;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_BEST_B, (size_t) KCL * n_groups + 2 * (size_t) n_rg + 2 * (size_t) tb + n_groups + 65, &gmaxB));
-    gmaxA = gmaxB + (size_t) KCL * n_groups;
-    cl_of_rg = (int*) (gmaxA + n_rg);
-    tile_group = cl_of_rg + n_rg;
-    tile_leaf = tile_group + tb;
-    group_start = tile_leaf + tb;
-    {
-        std::vector<int> h(n_rg);
-        for (int g = 0; g < n_rg; ++g) h[g] = A.h_blkcl[(size_t) g * (rg_rows / BLOCK_ROWS)];
-        LGR_HIP(ctx, hipMemcpyAsync(cl_of_rg, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        LGR_HIP(ctx, hipMemcpyAsync(tile_group, h_tiles.data(), h_tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        LGR_HIP(ctx, hipMemcpyAsync(group_start, h_group_start.data(), h_group_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    if (sB != ctx->stream) {   // (group_start was uploaded on the main stream just above)
-        LGR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
-        LGR_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev3, 0));
-    }
     group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
     bool b_joined = sB == ctx->stream;
@@ -501,7 +507,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     if (both) colmin = rowmin + (size_t) n_groups * ma_pad;
     unsigned long long* bestA = (unsigned long long*) (rowmin + tab_floats + (tab_floats & 1));
     unsigned long long* bestB = bestA + ma;
-    fill_u64<<<cdiv(ma + mb, 256), 256, 0, ctx->stream>>>(bestA, ma + mb, ~0ull);
+    fill_u64<<<cdiv(ma + mb, 256), 256, 0, sB>>>(bestA, ma + mb, ~0ull);   // (the exact rerank's tables: joined with the column operands)
     // dense mode: +inf everywhere; skipping mode: init_tables_kernel covers what each pass computes (LGR_MATCH_POISON=1, tests: the
     // rest is filled with 0 -- the most harmful value a stale entry could have -- to show that nothing reads it)
     if (!prune) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
@@ -582,8 +588,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
-        const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg), o_gl = pcarve((size_t) n_groups * 4);
-        const size_t o_lg = pcarve((size_t) (n_leaves + 1) * 4);
+        const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(16);
         const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
         const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
@@ -619,18 +624,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         }
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
-        int* group_leaf = (int*) (pb + o_gl);
-        int* leaf_g0 = (int*) (pb + o_lg);
         LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, o_cr - o_done, ctx->stream));   // done, sched, masks, bounds, stats
-        {
-            std::vector<int> h(n_groups), hl(n_leaves + 1, n_groups);
-            for (int g = 0; g < n_groups; ++g) h[g] = h_tiles[tb + h_group_start[g] / TILE];
-            for (int g = n_groups - 1; g >= 0; --g) hl[h[g]] = g;                     // first group of every leaf that has one
-            for (int l = n_leaves - 1; l >= 0; --l) hl[l] = std::min(hl[l], hl[l + 1]);   // empty leaves: g0 == g1
-            LGR_HIP(ctx, hipMemcpyAsync(group_leaf, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            LGR_HIP(ctx, hipMemcpyAsync(leaf_g0, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
         auto build_comp = [&]() {
             comp_rows_kernel<<<cdiv((long long) n_rb * n_groups, 256), 256, 0, ctx->stream>>>(done, sched, group_leaf, n_rb, n_leaves, n_groups, comp_r);
             if (both) comp_cols_kernel<<<cdiv((long long) n_leaves * n_rg, 256), 256, 0, ctx->stream>>>(done, sched, n_rb, n_leaves, n_rg, rg_rows / BLOCK_ROWS, comp_c);

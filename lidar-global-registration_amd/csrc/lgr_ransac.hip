@@ -631,10 +631,16 @@ __global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ P
             stage(i0);
             if (l < 6) {
                 const int m = min(RCH, c - i0);
-                for (int i = 0; i < m; ++i) {
-                    if (!sm[i]) continue;
-                    acc += sp[i * 8 + l];
-                    ++n;
+                if (!mask) {   // (every caller compacts first: no per-element branch, so the LDS reads run ahead of the dependent adds)
+#pragma unroll 8
+                    for (int i = 0; i < m; ++i) acc += sp[i * 8 + l];
+                    n += m;
+                } else {
+                    for (int i = 0; i < m; ++i) {
+                        if (!sm[i]) continue;
+                        acc += sp[i * 8 + l];
+                        ++n;
+                    }
                 }
             }
         }
@@ -649,9 +655,14 @@ __global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ P
             if (l < 9) {
                 if (i0 == 0) { ca = cen[a]; cb = cen[3 + b]; }
                 const int m = min(RCH, c - i0);
-                for (int i = 0; i < m; ++i) {
-                    if (!sm[i]) continue;
-                    acc += (sp[i * 8 + a] - ca) * (sp[i * 8 + 3 + b] - cb);
+                if (!mask) {
+#pragma unroll 8
+                    for (int i = 0; i < m; ++i) acc += (sp[i * 8 + a] - ca) * (sp[i * 8 + 3 + b] - cb);
+                } else {
+                    for (int i = 0; i < m; ++i) {
+                        if (!sm[i]) continue;
+                        acc += (sp[i * 8 + a] - ca) * (sp[i * 8 + 3 + b] - cb);
+                    }
                 }
             }
         }
