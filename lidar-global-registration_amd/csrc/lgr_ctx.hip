@@ -56,9 +56,15 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return LGR_ERR_NO_DEVICE;
     lgr_ctx* c = new lgr_ctx();
     c->device = device;
-    if (stream != LGR_STREAM_OWN) { c->stream = (hipStream_t) stream; c->own_stream = false; }
+    if (stream != LGR_STREAM_OWN && stream != LGR_STREAM_OWN_LOW) { c->stream = (hipStream_t) stream; c->own_stream = false; }
     else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LGR_ERR_HIP; }
+        // LGR_STREAM_OWN_LOW (the internal helper contexts): lowest stream priority, so that the caller's stream -- which carries the
+        // chains of short dependent launches (clustering, bounds, masks) -- gets compute units first when both have work queued
+        int lo = 0, hi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const hipError_t e = stream == LGR_STREAM_OWN_LOW ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, lo)
+                                                          : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return LGR_ERR_HIP; }
         c->own_stream = true;
     }
     for (int i = 0; i < 32; ++i)
@@ -73,7 +79,7 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
 // internal contexts: own non-blocking stream + helper thread (opt.helper_contexts), or the parent's stream (workspace only)
 static int make_internal(lgr_ctx* ctx, lgr_ctx** out, hipEvent_t* ev) {
     if (*out) return LGR_OK;
-    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, ctx->opt.helper_contexts ? LGR_STREAM_OWN : (void*) ctx->stream, out) == LGR_OK, LGR_ERR_HIP);
+    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, ctx->opt.helper_contexts ? LGR_STREAM_OWN_LOW : (void*) ctx->stream, out) == LGR_OK, LGR_ERR_HIP);
     (*out)->opt = ctx->opt;
     (*out)->mopt = ctx->mopt;
     if (!*ev) LGR_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableTiming));

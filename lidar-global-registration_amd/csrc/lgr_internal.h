@@ -15,6 +15,7 @@
 #include "../../include/lgr.h"
 
 #define LGR_WAVE 64
+#define LGR_STREAM_OWN_LOW ((void*) (intptr_t) -2)   // internal: an own non-blocking stream of the lowest priority (helper contexts)
 
 struct lgr_buf {
     void* p = nullptr;
