@@ -54,8 +54,9 @@ def main():
                     g("SQ_WAVES"), 100 * g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), 100 * g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
                     100 * g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 100 * g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES")))
             if g("SQ_BUSY_CU_CYCLES") and g("SQ_WAVE_CYCLES"):
-                # SQ_BUSY_CU_CYCLES: quad-cycles a CU had waves; waves resident per SIMD = wave quad-cycles / (4 SIMDs x busy quad-cycles)
-                lines.append("  derived: %.2f waves resident per SIMD while the CU is busy" % (g("SQ_WAVE_CYCLES") / (4.0 * g("SQ_BUSY_CU_CYCLES"))))
+                # SQ_WAVE_CYCLES counts quad-cycles per wave, SQ_BUSY_CU_CYCLES cycles per CU: waves per SIMD = 4 x wave quad-cycles / (4 SIMDs x
+                # busy cycles).  (Calibrated on match_mfma, which is resident with exactly 4 waves per SIMD: ratio 3.99.)
+                lines.append("  derived: %.2f waves resident per SIMD while the CU is busy" % (g("SQ_WAVE_CYCLES") / g("SQ_BUSY_CU_CYCLES")))
             if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
                 lines.append("  derived: per wave %.0f VALU + %.0f SALU + %.0f LDS + %.0f VMEM-read instructions; LDS bank-conflict cycles / LDS active %.1f %%" % (
                     g("SQ_INSTS_VALU") / g("SQ_WAVES"), g("SQ_INSTS_SALU") / g("SQ_WAVES"), g("SQ_INSTS_LDS") / g("SQ_WAVES"), g("SQ_INSTS_VMEM_RD") / g("SQ_WAVES"),
