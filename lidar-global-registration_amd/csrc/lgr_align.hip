@@ -107,9 +107,7 @@ static int filter_tables_alloc(lgr_ctx* ctx, int matching_id, int ns, int nt, in
 static int filter_cloud_tables(lgr_ctx* cx, const float* pts, int n, int cluster_k, float* thr, int32_t* knn) {
     LGR_TRY(lgr_smoothed_densities_dev(cx, pts, n, 2, thr));   // calculateSmoothedDensities(kps) (include/matching.h:396-397 etc.)
     if (knn) {
-        float* d2;
-        LGR_TRY(lgr_ws_t(cx, WS_DENS_C, (size_t) n * cluster_k, &d2));
-        LGR_TRY(lgr_knn_dev(cx, pts, n, pts, n, cluster_k, knn, d2));
+        LGR_TRY(lgr_knn_lists(cx, pts, n, pts, n, cluster_k, knn, nullptr));   // (membership tests only: no distance table)
     }
     return LGR_OK;
 }

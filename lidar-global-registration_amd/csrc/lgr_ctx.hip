@@ -79,7 +79,9 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
 // internal contexts: own non-blocking stream + helper thread (opt.helper_contexts), or the parent's stream (workspace only)
 static int make_internal(lgr_ctx* ctx, lgr_ctx** out, hipEvent_t* ev) {
     if (*out) return LGR_OK;
-    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, ctx->opt.helper_contexts ? LGR_STREAM_OWN_LOW : (void*) ctx->stream, out) == LGR_OK, LGR_ERR_HIP);
+    // (LGR_STREAM_OWN_LOW was measured for the helpers: -0.1 ms under `lr`, but the cluster filter's second 40-NN table then slides from the
+    // feature phase under pass 0 of the matcher and costs it 2 ms: plain priority)
+    LGR_CHECK(ctx, lgr_ctx_create(ctx->device, ctx->opt.helper_contexts ? LGR_STREAM_OWN : (void*) ctx->stream, out) == LGR_OK, LGR_ERR_HIP);
     (*out)->opt = ctx->opt;
     (*out)->mopt = ctx->mopt;
     if (!*ev) LGR_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableTiming));

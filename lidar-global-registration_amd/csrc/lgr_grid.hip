@@ -148,22 +148,36 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(GridDev g, const float* 
     float* sd = smem;
     int* si = (int*) (smem + (size_t) k * KNN_BLOCK);
     int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+    bool active = true;
     if (by_grid == 1) {
         i = lgr_xcd_tile(blockIdx.x, cdiv_dev(g.n, KNN_BLOCK)) * KNN_BLOCK + threadIdx.x;   // grid order, one contiguous range per XCD
-        if (i >= g.n) return;
-        i = __float_as_int(g.pxyz[i].w);
-    } else if (i >= nq) return;
-    float x = q[(size_t) i * 12], y = q[(size_t) i * 12 + 1], z = q[(size_t) i * 12 + 2];
-    if (by_grid == 2 && lgr_finite3(x, y, z)) return;   // done by the grid-ordered launch
+        active = i < g.n;
+        i = active ? __float_as_int(g.pxyz[i].w) : 0;
+    } else if (i >= nq) { active = false; i = 0; }
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (active) { x = q[(size_t) i * 12]; y = q[(size_t) i * 12 + 1]; z = q[(size_t) i * 12 + 2]; }
+    if (by_grid == 2 && lgr_finite3(x, y, z)) active = false;   // done by the grid-ordered launch
     KnnList<KNN_BLOCK> L;
     L.init(sd, si, k, threadIdx.x);
-    if (lgr_finite3(x, y, z) && g.n > 0) lgr_knn_query(g, x, y, z, L);
+    if (active && lgr_finite3(x, y, z) && g.n > 0) lgr_knn_query(g, x, y, z, L);
     if (MODE == 0) {
-        for (int j = 0; j < k; ++j) {
-            idx[(size_t) i * k + j] = j < L.count ? L.index(j) : -1;
-            d2[(size_t) i * k + j] = j < L.count ? L.dist(j) : INFINITY;
+        // The lists leave through the workgroup: a wave takes one query's row at a time and its lanes write the k entries of that row --
+        // one contiguous k * 4-byte segment per store instruction.  (A thread writing its own row touched 64 cache lines with 4 bytes each
+        // per instruction, 2 k instructions per wave: the two 40-NN tables of the cluster filter are 320 MB of such stores per cloud.)
+        // (each wave writes its own 64 queries: row ids and counts travel through v_readlane, no extra LDS -- one more KB would cost the
+        // k = 40 launch its fourth workgroup per CU -- and no workgroup barrier)
+        const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+        const int my_row = active ? i : -1, my_cnt = L.count;
+        for (int r = 0; r < 64; ++r) {
+            const int row = __builtin_amdgcn_readlane(my_row, r);
+            if (row < 0) continue;
+            const int cnt = __builtin_amdgcn_readlane(my_cnt, r);
+            for (int j = lane; j < k; j += 64) {
+                idx[(size_t) row * k + j] = j < cnt ? si[j * KNN_BLOCK + wbase + r] : -1;
+                if (d2) d2[(size_t) row * k + j] = j < cnt ? sd[j * KNN_BLOCK + wbase + r] : INFINITY;
+            }
         }
-    } else {
+    } else if (active) {
         d2[i] = L.count >= k ? __builtin_sqrtf(L.dist(k - 1)) : __uint_as_float(0x7fc00000u);
         idx[i] = L.count >= 2 ? L.index(1) : i;
     }
@@ -273,7 +287,13 @@ int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, flo
 
 extern "C" int lgr_knn_dev(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, int n, int k, int32_t* d_idx, float* d_d2) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    LGR_CHECK(ctx, nq >= 0 && n >= 0 && k >= 1 && k <= 128 && (d_q || nq == 0) && (d_pts || n == 0) && d_idx && d_d2, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, d_d2 != nullptr, LGR_ERR_INVALID_ARG);
+    return lgr_knn_lists(ctx, d_q, nq, d_pts, n, k, d_idx, d_d2);
+}
+
+// d_d2 == nullptr: the index lists alone (the cluster filter tests membership only)
+int lgr_knn_lists(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, int n, int k, int32_t* d_idx, float* d_d2) {
+    LGR_CHECK(ctx, nq >= 0 && n >= 0 && k >= 1 && k <= 128 && (d_q || nq == 0) && (d_pts || n == 0) && d_idx, LGR_ERR_INVALID_ARG);
     if (nq == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     GridDev g;

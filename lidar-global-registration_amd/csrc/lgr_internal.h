@@ -137,6 +137,8 @@ int lgr_grid_build(lgr_ctx* ctx, int slot_base, const float* d_pts, int n, float
 // both bounding boxes of a cloud: out12 (host) = true min3, true max3 (finite points only; +-inf when empty),
 // reference-quirk min3, max3 (include/common.h:266-280)
 int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
+// lgr_knn_dev with an optional distance table (d_d2 == nullptr: index lists only)
+int lgr_knn_lists(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, int n, int k, int32_t* d_idx, float* d_d2);
 
 // Two independent pieces of host-driven GPU work side by side: fa(ctx) on this context, fb(ctx->aux) on the second context (own
 // stream and workspace, same device; created on first use) from a second host thread.  Everything enqueued on ctx->stream before
