@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "lgr_grid.cuh"
+#include "lgr_knn_wave.cuh"
 #include "lgr_math.cuh"
 
 namespace {
@@ -73,6 +74,42 @@ __global__ void voxel_accumulate(const float* __restrict__ pts, const unsigned l
 // ------------------------------------------------------------------------------------------------ normals
 constexpr int NB = 128;
 
+// covariance of the neighbours (in list order), its smallest eigenvector, orientation and curvature: the tail of the per-point work
+template <class IndexOf>
+__device__ __forceinline__ void normals_finish(float* __restrict__ p, float px, float py, float pz, int count, IndexOf&& index_of,
+                                               const float* __restrict__ surf, float vpx, float vpy, float vpz) {
+    const float nanv = __uint_as_float(0x7fc00000u);
+    if (count < 3) { p[4] = nanv; p[5] = nanv; p[6] = nanv; p[9] = nanv; return; }
+    const float* K = surf + (size_t) index_of(0) * 12;
+    float Kx = K[0], Ky = K[1], Kz = K[2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f;
+    for (int j = 0; j < count; ++j) {
+        const float* q = surf + (size_t) index_of(j) * 12;
+        float x = q[0] - Kx, y = q[1] - Ky, z = q[2] - Kz;
+        a0 += x * x; a1 += x * y; a2 += x * z; a3 += y * y; a4 += y * z; a5 += z * z;
+        a6 += x; a7 += y; a8 += z;
+    }
+    float fn = (float) count;
+    a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
+    float C[9];
+    C[0] = a0 - a6 * a6; C[1] = a1 - a6 * a7; C[2] = a2 - a6 * a8;
+    C[4] = a3 - a7 * a7; C[5] = a4 - a7 * a8; C[8] = a5 - a8 * a8;
+    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+    float U[9], Sg[3], V[9];
+    lgr_svd3(C, U, Sg, V);
+    float nx = V[2], ny = V[5], nz = V[8];
+    float eig_sum = C[0] + C[4] + C[8];
+    float curv = (eig_sum != 0.f) ? fabsf(Sg[2] / eig_sum) : 0.f;
+    float dx = vpx - px, dy = vpy - py, dz = vpz - pz;
+    float cos_theta = (dx * nx + dy * ny + dz * nz);
+    if (cos_theta < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+    if (lgr_finite3(nx, ny, nz)) {
+        float norm = __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+        nx /= norm; ny /= norm; nz /= norm;
+    }
+    p[4] = nx; p[5] = ny; p[6] = nz; p[9] = curv;
+}
+
 // pcl::NormalEstimationOMP (k-NN) + flipNormalTowardsViewpoint + postprocessNormals; see oracle orc_normals_knn.
 // by_grid: the queries are the surface points themselves; thread t takes the point at sorted position t of the grid, so a
 // wave's 64 queries sit in one or two cells and walk the same rings (coherent loops and loads); points that are not in the
@@ -94,36 +131,49 @@ __global__ __launch_bounds__(NB) void normals_kernel(GridDev g, const float* __r
     KnnList<NB> L;
     L.init(sd, si, k, threadIdx.x);
     if (lgr_finite3(px, py, pz) && g.n > 0) lgr_knn_query(g, px, py, pz, L);
-    const float nanv = __uint_as_float(0x7fc00000u);
-    if (L.count < 3) { p[4] = nanv; p[5] = nanv; p[6] = nanv; p[9] = nanv; return; }
-    const float* K = surf + (size_t) L.index(0) * 12;
-    float Kx = K[0], Ky = K[1], Kz = K[2];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f;
-    for (int j = 0; j < L.count; ++j) {
-        const float* q = surf + (size_t) L.index(j) * 12;
-        float x = q[0] - Kx, y = q[1] - Ky, z = q[2] - Kz;
-        a0 += x * x; a1 += x * y; a2 += x * z; a3 += y * y; a4 += y * z; a5 += z * z;
-        a6 += x; a7 += y; a8 += z;
+    normals_finish(p, px, py, pz, L.count, [&](int j) { return L.index(j); }, surf, vpx, vpy, vpz);
+}
+
+// The same with the wave-per-query search (lgr_knn_wave.cuh) for the grid-ordered launch: a wave finds the neighbours of its 64
+// points one point at a time (64 lanes = 64 candidates), leaves the sorted index lists in LDS ([k][64] per wave), and then goes back
+// to one point per lane for the covariance and its eigenvector.
+constexpr int NW_WAVES = 4;
+template <int KPL>
+__global__ __launch_bounds__(64 * NW_WAVES) void normals_wave_kernel(GridDev g, const float* __restrict__ surf, float* __restrict__ pts, int k,
+                                                                      float vpx, float vpy, float vpz, float r2_init) {
+    extern __shared__ int slist[];   // [NW_WAVES][k][64]
+    __shared__ unsigned long long sbuf[NW_WAVES][WaveKnn<KPL>::BUF];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n_tiles = cdiv_dev(g.n, 64 * NW_WAVES);
+    const int tile = lgr_xcd_tile(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    const int t = (tile * NW_WAVES + wv) * 64 + lane;
+    int* list = slist + (size_t) wv * k * 64;
+    int qi = -1;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (t < g.n) {
+        const float4 q = g.pxyz[t];
+        qi = __float_as_int(q.w); px = q.x; py = q.y; pz = q.z;
     }
-    float fn = (float) L.count;
-    a0 /= fn; a1 /= fn; a2 /= fn; a3 /= fn; a4 /= fn; a5 /= fn; a6 /= fn; a7 /= fn; a8 /= fn;
-    float C[9];
-    C[0] = a0 - a6 * a6; C[1] = a1 - a6 * a7; C[2] = a2 - a6 * a8;
-    C[4] = a3 - a7 * a7; C[5] = a4 - a7 * a8; C[8] = a5 - a8 * a8;
-    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-    float U[9], Sg[3], V[9];
-    lgr_svd3(C, U, Sg, V);
-    float nx = V[2], ny = V[5], nz = V[8];
-    float eig_sum = C[0] + C[4] + C[8];
-    float curv = (eig_sum != 0.f) ? fabsf(Sg[2] / eig_sum) : 0.f;
-    float dx = vpx - px, dy = vpy - py, dz = vpz - pz;
-    float cos_theta = (dx * nx + dy * ny + dz * nz);
-    if (cos_theta < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
-    if (lgr_finite3(nx, ny, nz)) {
-        float norm = __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
-        nx /= norm; ny /= norm; nz /= norm;
+    float guess = r2_init;
+    int count = 0;
+    WaveKnn<KPL> W;
+    const int nloc = min(64, g.n - (tile * NW_WAVES + wv) * 64);
+    for (int l = 0; l < nloc; ++l) {
+        const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(px), l));
+        const float y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(py), l));
+        const float z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pz), l));
+        lgr_wave_knn<KPL>(g, x, y, z, k, guess, sbuf[wv], W);   // (grid points are finite)
+        const int mk = min(W.m, k);
+#pragma unroll
+        for (int j = 0; j < KPL; ++j)
+            if (W.rank[j] < mk) list[W.rank[j] * 64 + l] = (int) (unsigned) W.key[j];
+        if (lane == l) count = mk;
     }
-    p[4] = nx; p[5] = ny; p[6] = nz; p[9] = curv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (qi < 0) return;
+    normals_finish(pts + (size_t) qi * 12, px, py, pz, count, [&](int j) { return list[j * 64 + lane]; }, surf, vpx, vpy, vpz);
 }
 
 // ------------------------------------------------------------------------------------------------ FPFH
@@ -762,7 +812,18 @@ extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const floa
     LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, S, ns, 0.f, 6.f, &g));
     size_t sm = (size_t) k * NB * 8;
     const float vx = vp3 ? vp3[0] : 0.f, vy = vp3 ? vp3[1] : 0.f, vz = vp3 ? vp3[2] : 0.f;
-    if (!d_surf) {
+    static const bool heap = getenv("LGR_KNN_HEAP") != nullptr;
+    if (!d_surf && k >= 16 && !heap) {
+        // (below k = 16 the per-thread heaps win: a wave per query leaves most of its lanes without a candidate)
+        const float r2i = g.h * g.h * 1.25f * (float) k / (3.14159265f * 6.f);
+        const int grid = lgr_xcd_grid(cdiv(g.n, 64 * NW_WAVES));
+        const size_t sml = (size_t) NW_WAVES * k * 64 * sizeof(int);
+        if (g.n > 0) {
+            if (k <= 40) normals_wave_kernel<1><<<grid, 64 * NW_WAVES, sml, ctx->stream>>>(g, S, d_pts, k, vx, vy, vz, r2i);
+            else normals_wave_kernel<2><<<grid, 64 * NW_WAVES, sml, ctx->stream>>>(g, S, d_pts, k, vx, vy, vz, r2i);
+        }
+        if (g.n < n) normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 2);   // non-finite points: NaN normals
+    } else if (!d_surf) {
         if (g.n > 0) normals_kernel<<<lgr_xcd_grid(cdiv(g.n, NB)), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 1);
         if (g.n < n) normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 2);   // non-finite points: NaN normals
     } else {

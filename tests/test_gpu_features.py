@@ -86,7 +86,62 @@ def test_knn_ties_on_grid(lgr, oracle):
     np.testing.assert_array_equal(gi.cpu().numpy(), oi)
 
 
-@pytest.mark.parametrize("k", [2, 8])
+@pytest.mark.parametrize("k", [5, 40, 64, 100, 128])
+def test_knn_self_queries(lgr, oracle, pair, k):
+    """queries = the cloud itself (grid-ordered launch), all three buffer widths of the wave search (k <= 40, <= 96, <= 128)"""
+    p = pair["src"][:20000]
+    oi, od = oracle.knn(p, p, k)
+    t = cuda(p)
+    gi, gd = lgr.knn(t, t, k)
+    lgr.sync()
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits(gd.cpu().numpy()), bits(od))
+
+
+def test_knn_degenerate_clouds(lgr, oracle):
+    """what the threshold search of the wave k-NN has to survive: hundreds of identical points (no radius separates k of them from
+    the rest: only the index part of the key does), equal distances on a lattice, clusters of very different density, fewer points
+    than k, non-finite points among queries and cloud"""
+    from lgr_amd.synthetic import make_points
+    rng = np.random.default_rng(5)
+    blob = np.repeat(np.array([[0.25, -0.5, 1.0]], np.float32), 700, 0)                       # 700 copies of one point
+    blob2 = np.repeat(np.array([[0.26, -0.5, 1.0]], np.float32), 90, 0)
+    lattice = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(2), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.5
+    dense = (rng.normal(size=(3000, 3)) * 1e-3 + np.array([5.0, 5.0, 0.0])).astype(np.float32)
+    sparse = (rng.uniform(-40, 40, size=(400, 3))).astype(np.float32)
+    xyz = np.concatenate([blob, lattice, dense, blob2, sparse])
+    xyz = xyz[rng.permutation(len(xyz))]
+    p = make_points(xyz)
+    p[17, 0] = np.nan
+    p[400, 2] = np.inf
+    for k in (1, 7, 40, 64, 128):
+        oi, od = oracle.knn(p, p, k)
+        t = cuda(p)
+        gi, gd = lgr.knn(t, t, k)
+        lgr.sync()
+        np.testing.assert_array_equal(gi.cpu().numpy(), oi, err_msg=f"k={k}")
+        np.testing.assert_array_equal(bits(gd.cpu().numpy()), bits(od), err_msg=f"k={k}")
+    # other queries than the cloud, in an order that jumps between the clusters
+    q = make_points(np.concatenate([sparse[:50] + 0.01, blob[:3], dense[:40], lattice[:30] + 0.25]).astype(np.float32)[rng.permutation(123)])
+    oi, od = oracle.knn(q, p, 40)
+    gi, gd = lgr.knn(cuda(q), cuda(p), 40)
+    lgr.sync()
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits(gd.cpu().numpy()), bits(od))
+    # fewer points than k: the lists end with -1 / +inf
+    small = make_points(rng.normal(size=(9, 3)).astype(np.float32))
+    oi, od = oracle.knn(small, small, 40)
+    gi, gd = lgr.knn(cuda(small), cuda(small), 40)
+    lgr.sync()
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits(gd.cpu().numpy()), bits(od))
+    for k in (2, 5, 24):
+        want = oracle.smoothed_densities(p, k)
+        got = lgr.smoothed_densities(cuda(p), k).cpu().numpy()
+        np.testing.assert_array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("k", [2, 8, 20])
 def test_smoothed_densities(lgr, oracle, pair, k):
     want = oracle.smoothed_densities(pair["src"], k)
     got = lgr.smoothed_densities(cuda(pair["src"]), k).cpu().numpy()
