@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * NW_WAVES) void normals_wave_kernel(GridDev g, 
                                                                       float vpx, float vpy, float vpz, float r2_init) {
     extern __shared__ int slist[];   // [NW_WAVES][k][64]
     __shared__ unsigned long long sbuf[NW_WAVES][WaveKnn<KPL>::BUF];
+    __shared__ int srow[NW_WAVES][128];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n_tiles = cdiv_dev(g.n, 64 * NW_WAVES);
     const int tile = lgr_xcd_tile(blockIdx.x, n_tiles);
@@ -157,19 +158,13 @@ __global__ __launch_bounds__(64 * NW_WAVES) void normals_wave_kernel(GridDev g, 
     }
     float guess = r2_init;
     int count = 0;
-    WaveKnn<KPL> W;
-    const int nloc = min(64, g.n - (tile * NW_WAVES + wv) * 64);
-    for (int l = 0; l < nloc; ++l) {
-        const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(px), l));
-        const float y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(py), l));
-        const float z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pz), l));
-        lgr_wave_knn<KPL>(g, x, y, z, k, guess, sbuf[wv], W);   // (grid points are finite)
+    lgr_wave_knn_tile<KPL>(g, qi >= 0, px, py, pz, k, guess, sbuf[wv], srow[wv], [&](int l, const WaveKnn<KPL>& W) {   // (grid points are finite)
         const int mk = min(W.m, k);
 #pragma unroll
         for (int j = 0; j < KPL; ++j)
             if (W.rank[j] < mk) list[W.rank[j] * 64 + l] = (int) (unsigned) W.key[j];
         if (lane == l) count = mk;
-    }
+    });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (qi < 0) return;
@@ -807,15 +802,18 @@ extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const floa
         S = snap; ns = n;
     }
     GridDev g;
-    // cell size for about 6 points per cell (measured at 1M, k = 30: 2 / 3 / 4 / 6 / 8 / 12 / 16 points per cell -> 6.2 / 5.3 / 4.8 / 4.1 / 4.0 /
-    // 4.1 / 4.0 ms for the two clouds' normals, the later stages slowing down slightly from 8 on; the neighbours do not depend on it)
-    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, S, ns, 0.f, 6.f, &g));
+    // cell size: about 6 points per cell for the per-thread heaps (measured at 1M, k = 30: 2 / 3 / 4 / 6 / 8 / 12 / 16 points per cell -> 6.2 / 5.3 /
+    // 4.8 / 4.1 / 4.0 / 4.1 / 4.0 ms for the two clouds' normals, the later stages slowing down slightly from 8 on), about 10 for the wave
+    // search (6 / 8 / 10 / 12 / 14 -> normals stage 1.87 / 1.61 / 1.56 / 1.63 / 1.64 ms; more queries share a cell's candidate set, at more
+    // candidates per scan).  The neighbours do not depend on it.
+    const bool wave = !d_surf && k >= 16;
+    const float ppc = wave ? 10.f : 6.f;
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, S, ns, 0.f, ppc, &g));
     size_t sm = (size_t) k * NB * 8;
     const float vx = vp3 ? vp3[0] : 0.f, vy = vp3 ? vp3[1] : 0.f, vz = vp3 ? vp3[2] : 0.f;
-    static const bool heap = getenv("LGR_KNN_HEAP") != nullptr;
-    if (!d_surf && k >= 16 && !heap) {
+    if (wave) {
         // (below k = 16 the per-thread heaps win: a wave per query leaves most of its lanes without a candidate)
-        const float r2i = g.h * g.h * 1.25f * (float) k / (3.14159265f * 6.f);
+        const float r2i = g.h * g.h * 1.25f * (float) k / (3.14159265f * ppc);
         const int grid = lgr_xcd_grid(cdiv(g.n, 64 * NW_WAVES));
         const size_t sml = (size_t) NW_WAVES * k * 64 * sizeof(int);
         if (g.n > 0) {

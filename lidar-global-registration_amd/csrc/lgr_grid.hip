@@ -188,31 +188,50 @@ __global__ __launch_bounds__(KNN_BLOCK) void knn_kernel(GridDev g, const float* 
 // other, carrying the k-th distance of one as the first guess of the next.  by_grid as above.
 constexpr int WK_WAVES = 4, WK_Q = 32;
 template <int MODE, int KPL>
+__device__ __forceinline__ void knn_wave_emit(const WaveKnn<KPL>& W, int m, int i, int k, int32_t* __restrict__ idx, float* __restrict__ d2) {
+    const int lane = threadIdx.x & 63;
+    if (MODE == 0) {
+        const int mk = min(m, k);
+#pragma unroll
+        for (int j = 0; j < KPL; ++j)
+            if (m > 0 && W.rank[j] < mk) {
+                idx[(size_t) i * k + W.rank[j]] = (int) (unsigned) W.key[j];
+                if (d2) d2[(size_t) i * k + W.rank[j]] = wk_key_d2(W.key[j]);
+            }
+        for (int j = mk + lane; j < k; j += 64) {
+            idx[(size_t) i * k + j] = -1;
+            if (d2) d2[(size_t) i * k + j] = INFINITY;
+        }
+    } else {
+        if (m >= k) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) if (W.rank[j] == k - 1) d2[i] = __builtin_sqrtf(wk_key_d2(W.key[j]));
+        } else if (lane == 0) d2[i] = __uint_as_float(0x7fc00000u);
+        if (m >= 2) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) if (W.rank[j] == 1) idx[i] = (int) (unsigned) W.key[j];
+        } else if (lane == 0) idx[i] = i;
+    }
+}
+
+// by_grid 0 / 2: queries in the order given, one after the other (lgr_wave_knn)
+template <int MODE, int KPL>
 __global__ __launch_bounds__(64 * WK_WAVES) void knn_wave_kernel(GridDev g, const float* __restrict__ q, int nq, int k,
                                                                   int32_t* __restrict__ idx, float* __restrict__ d2, int by_grid, float r2_init) {
     __shared__ unsigned long long sbuf[WK_WAVES][WaveKnn<KPL>::BUF];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int total = by_grid == 1 ? g.n : nq;
-    const int n_tiles = cdiv_dev(total, WK_WAVES * WK_Q);
-    const int tile = by_grid == 1 ? lgr_xcd_tile(blockIdx.x, n_tiles) : (int) blockIdx.x;
-    if (tile >= n_tiles) return;
-    const int t0 = (tile * WK_WAVES + wv) * WK_Q;
+    const int t0 = (blockIdx.x * WK_WAVES + wv) * WK_Q;
     // the wave's queries: lane l holds query t0 + l
     int qi = -1;
     float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (lane < WK_Q && t0 + lane < total) {
-        if (by_grid == 1) {
-            const float4 p = g.pxyz[t0 + lane];
-            qi = __float_as_int(p.w); qx = p.x; qy = p.y; qz = p.z;
-        } else {
-            qi = t0 + lane;
-            qx = q[(size_t) qi * 12]; qy = q[(size_t) qi * 12 + 1]; qz = q[(size_t) qi * 12 + 2];
-            if (by_grid == 2 && lgr_finite3(qx, qy, qz)) qi = -1;   // done by the grid-ordered launch
-        }
+    if (lane < WK_Q && t0 + lane < nq) {
+        qi = t0 + lane;
+        qx = q[(size_t) qi * 12]; qy = q[(size_t) qi * 12 + 1]; qz = q[(size_t) qi * 12 + 2];
+        if (by_grid == 2 && lgr_finite3(qx, qy, qz)) qi = -1;   // done by the grid-ordered launch
     }
     float guess = r2_init;
     WaveKnn<KPL> W;
-    const int nloc = min(WK_Q, total - t0);
+    const int nloc = min(WK_Q, nq - t0);
     for (int l = 0; l < nloc; ++l) {
         const int i = __builtin_amdgcn_readlane(qi, l);
         if (i < 0) continue;
@@ -221,30 +240,30 @@ __global__ __launch_bounds__(64 * WK_WAVES) void knn_wave_kernel(GridDev g, cons
         const float z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qz), l));
         W.m = 0;
         if (lgr_finite3(x, y, z) && g.n > 0) lgr_wave_knn<KPL>(g, x, y, z, k, guess, sbuf[wv], W);
-        const int m = W.m;
-        if (MODE == 0) {
-            const int mk = min(m, k);
-#pragma unroll
-            for (int j = 0; j < KPL; ++j)
-                if (m > 0 && W.rank[j] < mk) {
-                    idx[(size_t) i * k + W.rank[j]] = (int) (unsigned) W.key[j];
-                    if (d2) d2[(size_t) i * k + W.rank[j]] = wk_key_d2(W.key[j]);
-                }
-            for (int j = mk + lane; j < k; j += 64) {
-                idx[(size_t) i * k + j] = -1;
-                if (d2) d2[(size_t) i * k + j] = INFINITY;
-            }
-        } else {
-            if (m >= k) {
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) if (W.rank[j] == k - 1) d2[i] = __builtin_sqrtf(wk_key_d2(W.key[j]));
-            } else if (lane == 0) d2[i] = __uint_as_float(0x7fc00000u);
-            if (m >= 2) {
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) if (W.rank[j] == 1) idx[i] = (int) (unsigned) W.key[j];
-            } else if (lane == 0) idx[i] = i;
-        }
+        knn_wave_emit<MODE, KPL>(W, W.m, i, k, idx, d2);
     }
+}
+
+// by_grid 1: the grid's own points in sorted order, 64 per wave, cell by cell (lgr_wave_knn_tile)
+template <int MODE, int KPL>
+__global__ __launch_bounds__(64 * WK_WAVES) void knn_tile_kernel(GridDev g, int k, int32_t* __restrict__ idx, float* __restrict__ d2, float r2_init) {
+    __shared__ unsigned long long sbuf[WK_WAVES][WaveKnn<KPL>::BUF];
+    __shared__ int srow[WK_WAVES][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n_tiles = cdiv_dev(g.n, WK_WAVES * 64);
+    const int tile = lgr_xcd_tile(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    const int t = (tile * WK_WAVES + wv) * 64 + lane;
+    int qi = -1;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (t < g.n) {
+        const float4 p = g.pxyz[t];
+        qi = __float_as_int(p.w); px = p.x; py = p.y; pz = p.z;
+    }
+    float guess = r2_init;
+    lgr_wave_knn_tile<KPL>(g, qi >= 0, px, py, pz, k, guess, sbuf[wv], srow[wv], [&](int l, const WaveKnn<KPL>& W) {
+        knn_wave_emit<MODE, KPL>(W, W.m, __builtin_amdgcn_readlane(qi, l), k, idx, d2);
+    });
 }
 
 // first threshold of a wave's first query: the radius that holds 1.25 k points at `ppc` points per cell of a surface
@@ -252,14 +271,21 @@ static float wk_r2_init(const GridDev& g, int k, float ppc) { return g.h * g.h *
 
 template <int MODE>
 static void knn_wave_launch(lgr_ctx* ctx, const GridDev& g, const float* d_q, int nq, int k, int32_t* d_idx, float* d_d2, int by_grid, float ppc) {
-    const int total = by_grid == 1 ? g.n : nq;
-    if (total <= 0) return;
-    const int n_tiles = cdiv(total, WK_WAVES * WK_Q);
-    const int grid = by_grid == 1 ? lgr_xcd_grid(n_tiles) : n_tiles;
     const float r2i = wk_r2_init(g, k, ppc);
-    if (k <= 40) knn_wave_kernel<MODE, 1><<<grid, 64 * WK_WAVES, 0, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, by_grid, r2i);
-    else if (k <= 96) knn_wave_kernel<MODE, 2><<<grid, 64 * WK_WAVES, 0, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, by_grid, r2i);
-    else knn_wave_kernel<MODE, 4><<<grid, 64 * WK_WAVES, 0, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, by_grid, r2i);
+    const int T = 64 * WK_WAVES;
+    if (by_grid == 1) {
+        if (g.n <= 0) return;
+        const int grid = lgr_xcd_grid(cdiv(g.n, WK_WAVES * 64));
+        if (k <= 40) knn_tile_kernel<MODE, 1><<<grid, T, 0, ctx->stream>>>(g, k, d_idx, d_d2, r2i);
+        else if (k <= 96) knn_tile_kernel<MODE, 2><<<grid, T, 0, ctx->stream>>>(g, k, d_idx, d_d2, r2i);
+        else knn_tile_kernel<MODE, 4><<<grid, T, 0, ctx->stream>>>(g, k, d_idx, d_d2, r2i);
+        return;
+    }
+    if (nq <= 0) return;
+    const int grid = cdiv(nq, WK_WAVES * WK_Q);
+    if (k <= 40) knn_wave_kernel<MODE, 1><<<grid, T, 0, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, by_grid, r2i);
+    else if (k <= 96) knn_wave_kernel<MODE, 2><<<grid, T, 0, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, by_grid, r2i);
+    else knn_wave_kernel<MODE, 4><<<grid, T, 0, ctx->stream>>>(g, d_q, nq, k, d_idx, d_d2, by_grid, r2i);
 }
 
 __global__ void density_min(const float* __restrict__ dk, const int32_t* __restrict__ nn1, int n, float* __restrict__ out) {
@@ -376,14 +402,13 @@ int lgr_knn_lists(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, in
     if (nq == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     GridDev g;
-    // cell size for about 0.35 k points per cell, at least 4 (the 40-NN tables of the cluster filter at 1M points: 4 / 8 / 12 / 16 / 24
-    // points per cell -> 58.5 / 58.3 / 56.8 / 56.8 / 57.3 ms per pair with `matching: cluster`; the lists do not depend on it)
-    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, std::max(4.f, 0.35f * (float) k), &g));
+    // cell size for about 0.35 k points per cell, at least 4 (the 40-NN tables of the cluster filter at 1M points, wave search: 5 / 8 / 14
+    // points per cell -> 45.5 / 45.0 / 44.9 ms per pair with `matching: cluster`; the lists do not depend on it)
+    const float ppc = std::max(4.f, 0.35f * (float) k);
+    LGR_TRY(lgr_grid_build(ctx, WS_GRID_A, d_pts, n, 0.f, ppc, &g));
     size_t sm = (size_t) k * KNN_BLOCK * 8;
     // below k = 16 the per-thread heaps win (k = 2: 0.16 against 0.96 ms at 1M): a wave per query leaves most lanes without a candidate
-    static const bool heap_env = getenv("LGR_KNN_HEAP") != nullptr;
-    const bool heap = heap_env || k < 16;
-    const float ppc = std::max(4.f, 0.35f * (float) k);
+    const bool heap = k < 16;
     if (!heap) {
         if (d_q == d_pts && nq == n) {
             knn_wave_launch<0>(ctx, g, d_q, nq, k, d_idx, d_d2, 1, ppc);
@@ -412,8 +437,7 @@ extern "C" int lgr_smoothed_densities_dev(lgr_ctx* ctx, const float* d_pts, int 
     LGR_TRY(lgr_ws_t(ctx, WS_DENS_A, (size_t) n, &dk));
     LGR_TRY(lgr_ws_t(ctx, WS_DENS_B, (size_t) n, &nn1));
     size_t sm = (size_t) k * KNN_BLOCK * 8;
-    static const bool heap_env = getenv("LGR_KNN_HEAP") != nullptr;
-    const bool heap = heap_env || k < 16;
+    const bool heap = k < 16;
     if (!heap) {
         knn_wave_launch<1>(ctx, g, d_pts, n, k, nn1, dk, 1, 4.f);
         if (g.n < n) knn_wave_launch<1>(ctx, g, d_pts, n, k, nn1, dk, 2, 4.f);

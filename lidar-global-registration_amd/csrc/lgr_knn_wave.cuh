@@ -21,6 +21,9 @@
 #pragma once
 #include "lgr_grid.cuh"
 
+#ifndef WK_GUESS
+#define WK_GUESS 1.25f
+#endif
 template <int KPL>
 struct WaveKnn {
     static constexpr int CAP = 64 * KPL;
@@ -114,23 +117,28 @@ __device__ __forceinline__ int wk_scan(const GridDev& g, float qx, float qy, flo
     return m;
 }
 
-// The whole wave answers ONE query (qx, qy, qz wave-uniform and finite, g.n > 0).  r2_guess: in = first threshold to try
-// (any positive value; only the number of scans depends on it), out = the guess for the wave's next query.
-// buf: this wave's WaveKnn<KPL>::BUF entries of LDS.
-template <int KPL>
-__device__ __forceinline__ void lgr_wave_knn(const GridDev& g, float qx, float qy, float qz, int k, float& r2_guess,
-                                             unsigned long long* __restrict__ buf, WaveKnn<KPL>& W) {
+// Threshold search over a scan functor (scan(kthr) = number of points with key <= kthr among the functor's candidates, the first
+// CAP of them in buf).  kmax: the largest threshold the candidate set is COMPLETE for (ALL = every grid point is a candidate).
+// Returns false when fewer than k points have a key <= kmax (the caller needs a larger candidate set); otherwise W holds the
+// ranked survivors.  r2_guess: in = first threshold to try (any positive value; only the number of scans depends on it),
+// out = the guess for the wave's next query.  all_fit: the whole grid fits the buffer (then one scan with ALL does it).
+template <int KPL, class Scan>
+__device__ __forceinline__ bool wk_search(Scan&& scan, unsigned long long kmax, bool all_fit, float r2_floor, int k, float& r2_guess,
+                                          unsigned long long* __restrict__ buf, WaveKnn<KPL>& W) {
     constexpr int CAP = WaveKnn<KPL>::CAP;
     const int lane = threadIdx.x & 63;
     const unsigned long long ALL = ~0ull;
     unsigned long long lo = 0ull, hi = ALL;      // count(lo) < k (or lo = 0: nothing known), count(hi) > CAP (or hi = ALL: nothing known)
     bool lo_known = false, hi_known = false;
-    unsigned long long kthr = g.n <= CAP ? ALL : (((unsigned long long) __float_as_uint(r2_guess) << 32) | 0xffffffffull);
+    unsigned long long kthr = ((unsigned long long) __float_as_uint(r2_guess) << 32) | 0xffffffffull;
+    if (kthr > kmax) kthr = kmax;
+    if (all_fit && kmax == ALL) kthr = ALL;
     int m = 0;
     for (int iter = 0;; ++iter) {
         __builtin_amdgcn_wave_barrier();
-        m = wk_scan<CAP>(g, qx, qy, qz, kthr, buf);
+        m = scan(kthr);
         if (m <= CAP && (m >= k || kthr == ALL)) break;
+        if (m < k && kthr == kmax) return false;
         const float r2 = wk_key_d2(kthr);
         unsigned long long next;
         if (m < k) {
@@ -138,8 +146,9 @@ __device__ __forceinline__ void lgr_wave_knn(const GridDev& g, float qx, float q
             // the count grows like r2 on a surface: aim at 1.25 k, at least +30 %, at most x 4 per step
             float f = m > 0 ? 1.25f * (float) k / (float) m : 4.f;
             f = fminf(fmaxf(f, 1.3f), 4.f);
-            const float nr2 = fmaxf(r2 * f, g.h * g.h * 1e-6f);
+            const float nr2 = fmaxf(r2 * f, r2_floor);
             next = nr2 < 3.0e38f ? (((unsigned long long) __float_as_uint(nr2) << 32) | 0xffffffffull) : ALL;
+            if (next > kmax) next = kmax;
         } else {
             hi = kthr; hi_known = true;
             float f = 1.25f * (float) k / (float) m;
@@ -152,7 +161,7 @@ __device__ __forceinline__ void lgr_wave_knn(const GridDev& g, float qx, float q
         const bool inside = (!lo_known || next > lo) && (!hi_known || next < hi);
         if (!inside || iter >= 5) {
             if (lo_known && hi_known) next = lo + ((hi - lo) >> 1);
-            else if (!inside) next = lo_known ? ALL : 0ull;   // (cannot happen: growing from lo without hi, shrinking from hi without lo)
+            else if (!inside) next = lo_known ? kmax : 0ull;   // (cannot happen: growing from lo without hi, shrinking from hi without lo)
         }
         kthr = next;
     }
@@ -182,7 +191,150 @@ __device__ __forceinline__ void lgr_wave_knn(const GridDev& g, float qx, float q
         if (hit) dk = __uint_as_float(__builtin_amdgcn_readlane((int) (W.key[j] >> 32), __builtin_ctzll(hit)));
     }
     if (m >= k && dk > 0.f) {
-        const float target = fminf(1.25f * (float) k, 0.5f * (float) (k + CAP));
+        const float target = fminf(WK_GUESS * (float) k, 0.5f * (float) (k + CAP));
         r2_guess = dk * (target / (float) k);
+    }
+    return true;
+}
+
+// The whole wave answers ONE query (qx, qy, qz wave-uniform and finite, g.n > 0) from its own box of cells.
+// buf: this wave's WaveKnn<KPL>::BUF entries of LDS.
+template <int KPL>
+__device__ __forceinline__ void lgr_wave_knn(const GridDev& g, float qx, float qy, float qz, int k, float& r2_guess,
+                                             unsigned long long* __restrict__ buf, WaveKnn<KPL>& W) {
+    constexpr int CAP = WaveKnn<KPL>::CAP;
+    (void) wk_search<KPL>([&](unsigned long long kthr) { return wk_scan<CAP>(g, qx, qy, qz, kthr, buf); }, ~0ull, g.n <= CAP, g.h * g.h * 1e-6f,
+                          k, r2_guess, buf, W);
+}
+
+// ---- 64 queries per wave, the queries of one cell sharing one candidate set.
+// The queries of a grid cell see nearly the same neighbourhood, and most of a single query's instructions above are set-up (cell
+// ranges with their divisions, row addresses, the dependent loads of the cell table and then of the candidates).  So: lane l holds
+// query l; the wave takes the queries cell by cell; for a cell it loads the points of the (2 s + 1)^3 cells around it ONCE into
+// registers (lane = candidate, up to WK_NBATCH batches of 64; the rows' runs are flattened, so every lane holds a candidate), and each
+// query of the cell then runs its threshold search on those registers -- a scan is a distance, a compare and a ballot per batch, and a
+// second scan (threshold moved) costs no memory access.  A query may only use thresholds up to its SAFE radius: the distance to
+// the nearest face of the box that has cells behind it -- every point closer than that is among the candidates; if k points
+// are not found below it (or the box holds more than 64 WK_NBATCH points) the query falls back to lgr_wave_knn with its own box.
+constexpr int WK_NBATCH = 8, WK_SMAX = 3;
+
+// emit(l, W): called wave-uniformly once per valid query l (lane index), W = its ranked survivors (W.m = 0 is never passed)
+// rowtab: 128 ints of LDS per wave.  valid / px / py / pz: this lane's query (finite when valid).  g.n > 0.
+template <int KPL, class Emit>
+__device__ __forceinline__ void lgr_wave_knn_tile(const GridDev& g, bool valid, float px, float py, float pz, int k, float& guess,
+                                                  unsigned long long* __restrict__ buf, int* __restrict__ rowtab, Emit&& emit) {
+    constexpr int CAP = WaveKnn<KPL>::CAP;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long ALL = ~0ull;
+    const float INF = __uint_as_float(0x7f800000u);
+    int cx = 0, cy = 0, cz = 0;
+    if (valid) {
+        cx = min(max(lgr_cellc(px, g.ox, g.h), 0), g.dx - 1);
+        cy = min(max(lgr_cellc(py, g.oy, g.h), 0), g.dy - 1);
+        cz = min(max(lgr_cellc(pz, g.oz, g.h), 0), g.dz - 1);
+    }
+    const bool all_fit = g.n <= CAP;
+    const float r2_floor = g.h * g.h * 1e-6f;
+    unsigned long long rem = __ballot(valid);
+    WaveKnn<KPL> W;
+    while (rem) {
+        const int l0 = __builtin_ctzll(rem);
+        const int gx = __builtin_amdgcn_readlane(cx, l0), gy = __builtin_amdgcn_readlane(cy, l0), gz = __builtin_amdgcn_readlane(cz, l0);
+        const unsigned long long grp = __ballot(valid && cx == gx && cy == gy && cz == gz) & rem;
+        rem &= ~grp;
+        // the box: s cells each way, s from the current guess (a query on the cell's border reaches s h beyond it)
+        int s = (int) ceilf(__builtin_sqrtf(guess) * 1.05f / g.h);
+        s = __builtin_amdgcn_readfirstlane(min(max(s, 1), WK_SMAX));
+        const int x0 = max(gx - s, 0), x1 = min(gx + s, g.dx - 1), y0 = max(gy - s, 0), y1 = min(gy + s, g.dy - 1);
+        const int z0 = max(gz - s, 0), z1 = min(gz + s, g.dz - 1);
+        const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;   // <= 49
+        int b = 0, e = 0;
+        if (lane < nrows) {
+            const int z = z0 + lane / ny, y = y0 + lane % ny;
+            const size_t row = ((size_t) z * g.dy + y) * g.dx;
+            b = g.cell_start[row + x0];
+            e = g.cell_start[row + x1 + 1];
+        }
+        const int len = e - b;
+        int inc = len;   // inclusive scan over the rows
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        const int T = __builtin_amdgcn_readlane(inc, 63);
+        const bool fast = T <= 64 * WK_NBATCH;
+        float4 p[WK_NBATCH];
+        float rs2 = 0.f;
+        if (fast) {
+            __builtin_amdgcn_wave_barrier();
+            rowtab[lane] = lane < nrows ? inc - len : 0x7fffffff;   // first flat position of row `lane`
+            rowtab[64 + lane] = b - (inc - len);                     // sorted position = flat position + this
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int bi = 0; bi < WK_NBATCH; ++bi) {
+                p[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bi * 64 < T) {
+                    const int f = bi * 64 + lane;
+                    int r = 0;   // the last row that starts at or before f (empty rows share their successor's start)
+#pragma unroll
+                    for (int st = 32; st > 0; st >>= 1) if (rowtab[r + st] <= f) r += st;
+                    if (f < T) p[bi] = g.pxyz[f + rowtab[64 + r]];
+                }
+            }
+            // this lane's query: how far it can see inside the box.  A point outside the box on the low x side has cell <= x0 - 1, i.e.
+            // floor((v - ox) / h) < x0, so v < ox + x0 h (1 + a few ulp): below L = ox + x0 h + margin; likewise above U on the high side.
+            // (rounding of v - ox, of the division and of ox + x0 h: < 4.1 ulp of |ox| + dx h; the margin is eight times that)
+            const float mgx = 2e-6f * (fabsf(g.ox) + (float) g.dx * g.h), mgy = 2e-6f * (fabsf(g.oy) + (float) g.dy * g.h);
+            const float mgz = 2e-6f * (fabsf(g.oz) + (float) g.dz * g.h);
+            float rs = INF;
+            if (x0 > 0) rs = fminf(rs, px - (g.ox + (float) x0 * g.h + mgx));
+            if (x1 < g.dx - 1) rs = fminf(rs, (g.ox + (float) (x1 + 1) * g.h - mgx) - px);
+            if (y0 > 0) rs = fminf(rs, py - (g.oy + (float) y0 * g.h + mgy));
+            if (y1 < g.dy - 1) rs = fminf(rs, (g.oy + (float) (y1 + 1) * g.h - mgy) - py);
+            if (z0 > 0) rs = fminf(rs, pz - (g.oz + (float) z0 * g.h + mgz));
+            if (z1 < g.dz - 1) rs = fminf(rs, (g.oz + (float) (z1 + 1) * g.h - mgz) - pz);
+            rs = fmaxf(rs, 0.f) * 0.9999f;   // computed d2 <= r2  =>  true |dx| <= sqrt(r2) (1 + 4 ulp)
+            rs2 = rs * rs;
+        }
+        // (the queries that need their own box wait until the cell's candidates are dead: the two paths then share the registers)
+        unsigned long long todo = fast ? grp : 0ull, own = fast ? 0ull : grp;
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const float qx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(px), l));
+            const float qy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(py), l));
+            const float qz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pz), l));
+            const float r2max = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rs2), l));
+            const unsigned long long kmax = r2max < 3.0e38f ? (((unsigned long long) __float_as_uint(r2max) << 32) | 0xffffffffull) : ALL;
+            const bool ok = wk_search<KPL>([&](unsigned long long kthr) {
+                int m = 0;
+#pragma unroll
+                for (int bi = 0; bi < WK_NBATCH; ++bi)
+                    if (bi * 64 < T) {
+                        const unsigned long long key = wk_key(lgr_dist2(qx, qy, qz, p[bi].x, p[bi].y, p[bi].z), __float_as_int(p[bi].w));
+                        const bool keep = bi * 64 + lane < T && key <= kthr;
+                        const unsigned long long mask = __ballot(keep);
+                        if (mask) {
+                            const int pos = m + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
+                            if (keep && pos < CAP) buf[pos] = key;
+                            m += __popcll(mask);
+                        }
+                    }
+                return m;
+            }, kmax, all_fit, r2_floor, k, guess, buf, W);
+            if (ok) emit(l, W);
+            else own |= 1ull << l;
+        }
+        while (own) {
+            const int l = __builtin_ctzll(own);
+            own &= own - 1ull;
+            const float qx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(px), l));
+            const float qy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(py), l));
+            const float qz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pz), l));
+            lgr_wave_knn<KPL>(g, qx, qy, qz, k, guess, buf, W);
+            emit(l, W);
+        }
     }
 }
