@@ -11,11 +11,11 @@ namespace {
 //    The column operand set is chosen per row block: Bp + blkcl[rb] * bset_stride.
 //    stage_mask[rb][chunk] (optional) selects the stages to compute: bound-based skipping, section 3b.
 //    Row minima are flushed per column group (tile_group[tile], a leaf of the train side) with an integer atomicMin
-//    on the float bits; column minima per row group with a read-modify-write (one owner per entry).  Both tables must
+//    on the float bits; column minima per row group likewise (no-return atomics; one owner per entry).  Both tables must
 //    be initialised to +inf bits, so several masked passes accumulate into the same tables.
 //    CO = true (rotated format, launches that have upper bounds: CoarseArgs): per row block a coarse sweep over the active
 //    stages (two of the six K steps per tile, tested against the stage threshold, survivors recorded in bit masks; coarse
-//    fragments only, staged through a ring of four LDS slots three stages ahead) and then the recorded tiles in full,
+//    fragments only, staged through a ring of six LDS slots, two pairs of stages ahead, two stages per barrier) and then the recorded tiles in full,
 //    outside the per-stage barriers, on B fragments read straight from memory.
 #ifdef EXP_PROF
 __device__ unsigned long long g_prof[16];
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
     // ONE __shared__ object: with a second one beside the LDS-DMA staging array hipcc waits vmcnt(0) before the first
     // ds_read of every stage, i.e. for the DMA of the NEXT stage it has just issued (cdna_hip_programming.md, projection GEMM
     // item 4a) -- the staging then never overlaps the stage's own MFMA chains
-    constexpr int CO_FRAGS = STAGE_TILES * 2 * 64, CO_NB = 4, CO_D = 3;   // coarse kernel: ring slot (fragments), slots, prefetch distance
-    static_assert(CO_D == 3 && CO_NB == CO_D + 1, "the counted waits below are written for three stages in flight");
+    constexpr int CO_FRAGS = STAGE_TILES * 2 * 64, CO_NB = 6, CO_D = 4;   // coarse kernel: ring slot (fragments), slots, stages in flight
+    static_assert(CO_D == 4 && CO_NB == CO_D + 2, "the counted waits below are written for two pairs of stages in flight");
     constexpr int BS_BYTES = CO ? CO_NB * CO_FRAGS * (int) sizeof(frag) : 2 * STAGE_FRAGS * (int) sizeof(frag);
     __shared__ __attribute__((aligned(16))) unsigned char smem[BS_BYTES + CHUNK_COLS * 4 + (CHUNK_COLS / TILE) * 4 + 16];
     frag (*Bs)[STAGE_FRAGS] = reinterpret_cast<frag (*)[STAGE_FRAGS]>(smem);
@@ -138,22 +138,6 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
             // coarse-rejection thresholds of the 128 column tiles of this (row block, chunk) for this wave's 32 rows: tile q = 4 stage + ct
             // sits in lane q & 63 of t_lane[q >> 6] (bit pattern of a float >= 0, scaled like the accumulator; +inf = keep everything)
             int t_lane[2] = {IINF, IINF};
-            if (use_coarse) {
-                const float ur = ca.u_rt[rb * (BLOCK_ROWS / TILE) + wave];   // this wave's 32 rows
-                const float x = ca.xmax[rb / rg_blocks];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int q = lane + 64 * r;
-                    const int gst = min(cc * STAGES_PER_CHUNK + (q >> 2), ca.n_stage_total - 1);
-                    const int gct = min(col_tile0 + q, ca.n_ct_total - 1);
-                    const float us = ca.u_stage ? __uint_as_float(ca.u_ct[gct]) : 0.f;
-                    const float y = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
-                    const float s = x + y;
-                    float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (x * y) + ca.lin * s + ca.abs);
-                    t = (t * 1.0001f) * c_scale;
-                    t_lane[r] = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
-                }
-            }
             unsigned kept[STAGE_TILES] = {0u, 0u, 0u, 0u};   // coarse sweep: bit st of kept[ct] = tile ct of stage st goes on (wave uniform)
             int rmin[16];   // float bit patterns, see the epilogue note
 #pragma unroll
@@ -171,10 +155,12 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
             };
             // first active stage of this row block (barrier first: every wave is past the previous row block's LDS reads)
             int st = __builtin_ctz(mask);
-            __syncthreads();
+            const unsigned sweep_mask = mask;
+            // (a raw barrier: the A fragments just requested stay in flight while the first stage is requested)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
             if (!COARSE) {
                 stage_dma(st, 0);
-                __syncthreads();   // waits for the DMA (vmcnt(0)) and makes the stage visible
+                __syncthreads();   // waits for the A fragments and the DMA (vmcnt(0)) and makes the stage visible
             }
             PROF_T(t_v1);
             PROF_ADD(0, t_v0, t_v1);
@@ -317,10 +303,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
 #pragma unroll
                         for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
                         const int t_st = __builtin_amdgcn_readlane(t_sel, (st * STAGE_TILES + ct) & 63);
-                        const bool keep = __ballot(m <= t_st) != 0ull;
-                        n_tested += 1u;
-                        if (keep) kept[ct] |= 1u << st;
-                        else n_rejected += 1u;
+                        if (__ballot(m <= t_st) != 0ull) kept[ct] |= 1u << st;   // (the tested / rejected counts are taken from the masks after the sweep)
                     }
                     return;
                 }
@@ -342,9 +325,9 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                 // Coarse sweep over the active stages.  Only the two coarse fragments of each tile are staged (8 x 1 KB pieces
                 // per stage, one LDS-DMA instruction per wave) into a ring of CO_NB slots, CO_D stages ahead: a stage of the
                 // sweep is too short (eight MFMAs per wave) to cover the latency of a DMA issued one stage earlier.  Per
-                // stage: counted vmcnt (this wave's piece of the stage has landed; newer ones stay in flight), raw barrier
-                // (everybody's pieces have landed, everybody is done with the previous stage), issue the DMA CO_D stages
-                // ahead into the slot the previous stage used, compute.  (__syncthreads() would drain the DMA queue.)
+                // PAIR of stages: counted vmcnt (this wave's pieces of the pair have landed; newer ones stay in flight), raw barrier
+                // (everybody's pieces have landed, everybody is done with the previous pair), issue the DMAs of the pair after
+                // the next into the slots the previous pair used, compute both.  (__syncthreads() would drain the DMA queue.)
                 static_assert(WAVES == 2 * STAGE_TILES, "one coarse piece per wave");
                 unsigned to_issue = mask, to_do = mask;
                 int issued = 0, done_ = 0;
@@ -356,21 +339,45 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     __builtin_amdgcn_global_load_lds((const void*) (src + lane * 16), (__attribute__((address_space(3))) void*) dst, 16, 0, 0);
                     ++issued;
                 };
-                // (the thresholds come from ordinary loads: have them in registers before the first DMA is issued -- behind a
-                // DMA in flight hipcc waits for such a load with vmcnt(0), which would drain the ring it has just filled)
-                asm volatile("" : : "v"(t_lane[0]), "v"(t_lane[1]) : "memory");
                 while (issued < CO_D && to_issue) dma_coarse();
+                // The thresholds come from ordinary loads, issued HERE, behind the first DMAs: hipcc waits for them with vmcnt(0), i.e. for
+                // the A fragments, the DMAs and these loads together -- one memory round trip per visit.  (Round 2 had them in registers
+                // before the first DMA, behind the visit's full barrier: two round trips in a row, 15 % of the launch by the in-kernel timers.)
+                if (use_coarse) {
+                    const float ur = ca.u_rt[rb * (BLOCK_ROWS / TILE) + wave];   // this wave's 32 rows
+                    const float x = ca.xmax[rb / rg_blocks];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int q = lane + 64 * r;
+                        const int gst = min(cc * STAGES_PER_CHUNK + (q >> 2), ca.n_stage_total - 1);
+                        const int gct = min(col_tile0 + q, ca.n_ct_total - 1);
+                        const float us = ca.u_stage ? __uint_as_float(ca.u_ct[gct]) : 0.f;
+                        const float y = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
+                        const float s = x + y;
+                        float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (x * y) + ca.lin * s + ca.abs);
+                        t = (t * 1.0001f) * c_scale;
+                        t_lane[r] = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
+                    }
+                }
+                asm volatile("" : : "v"(t_lane[0]), "v"(t_lane[1]) : "memory");
+                // Two stages per barrier (round 3): a stage of the sweep is eight MFMAs per wave, and at one raw barrier per stage the waves
+                // spent as long waiting for the slowest of the eight as computing (a stage visit took 1.9 k cycles against ~1 k of issue).
                 while (to_do) {
                     st = __builtin_ctz(to_do);
                     to_do &= to_do - 1u;
-                    const int newer = issued - done_ - 1;   // DMAs issued after this stage's
+                    int st2 = -1;
+                    if (to_do) { st2 = __builtin_ctz(to_do); to_do &= to_do - 1u; }
+                    const int n_now = st2 >= 0 ? 2 : 1;
+                    const int newer = issued - done_ - n_now;   // DMAs issued after this pair's
                     if (newer >= 2) asm volatile("s_waitcnt vmcnt(2)" : : : "memory");
                     else if (newer == 1) asm volatile("s_waitcnt vmcnt(1)" : : : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
                     __builtin_amdgcn_s_barrier();
+                    if (to_issue) dma_coarse();   // into the two slots the previous pair used
                     if (to_issue) dma_coarse();
                     compute(st, done_ % CO_NB, -1);
-                    ++done_;
+                    if (st2 >= 0) compute(st2, (done_ + 1) % CO_NB, -1);
+                    done_ += n_now;
                 }
             }
             mask &= mask - 1u;   // st is taken
@@ -389,6 +396,8 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                 st = nxt;
             }
             if (COARSE) {
+                n_tested += (unsigned) (STAGE_TILES * __builtin_popcount(sweep_mask));
+                n_rejected += (unsigned) (STAGE_TILES * __builtin_popcount(sweep_mask) - __builtin_popcount(kept[0]) - __builtin_popcount(kept[1]) - __builtin_popcount(kept[2]) - __builtin_popcount(kept[3]));
                 // the recorded tiles, in column order: the whole chain on B fragments read straight from memory (the stage
                 // image has the same order there as in LDS), the usual epilogue, row minima flushed when the group changes
                 PROF_T(t_k0);
@@ -431,19 +440,14 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
         int ncols = n_coltiles * TILE;
         int* dst = colmin + (size_t) rg * mb_pad + col_tile0 * TILE;
         constexpr int NCM = CHUNK_COLS / NTHR;   // 8 columns per thread: all loads in flight before the merge
-        int cur[NCM], old[NCM];
+        // (atomics without return: nobody waits for the table's old values -- a read-modify-write cost one exposed memory round trip per item)
 #pragma unroll
         for (int j = 0; j < NCM; ++j) {
             int i = tid + NTHR * j;
-            cur[j] = i < ncols ? cmin_s[i] : IINF;
-            old[j] = cur[j] != IINF ? dst[i] : IINF;
-        }
-#pragma unroll
-        for (int j = 0; j < NCM; ++j) {
-            int i = tid + NTHR * j;
-            if (cur[j] != IINF) {
-                int v = F16 ? __float_as_int(__int_as_float(cur[j]) * out_scale) : cur[j];
-                if (v < old[j]) dst[i] = v;
+            const int cur = i < ncols ? cmin_s[i] : IINF;
+            if (cur != IINF) {
+                const int v = F16 ? __float_as_int(__int_as_float(cur) * out_scale) : cur;
+                atomicMin(&dst[i], v);
                 cmin_s[i] = IINF;
             }
         }
