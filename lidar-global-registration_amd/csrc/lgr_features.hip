@@ -869,18 +869,23 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     const int sb = std::max(0, std::min(2, (32 - cell_bits) / 3));
     const int key_bits = std::min(32, cell_bits + 3 * sb);
     const int mx = std::max(m, g.n);
-    unsigned *keys, *keys2;
-    int *vals, *vals2;
-    LGR_TRY(lgr_ws_t(ctx, WS_KP_ORDER, (size_t) mx * 4 + 16, &keys));
+    // Both processing orders are sorted BEFORE the SPFH kernel: the weighting kernel then follows it directly in the stream.  (With the key
+    // points' sort between the two, its short launches starved behind the OTHER cloud's SPFH kernel -- 2 ms for a 13 us scatter -- and the
+    // two clouds' big kernels ran strictly one after the other; now the latency-bound weighting of one cloud shares the device with the
+    // VALU-bound SPFH of the other.)
+    unsigned *keys, *keys2, *kkeys, *kkeys2;
+    int *vals, *vals2, *kvals, *kvals2;
+    LGR_TRY(lgr_ws_t(ctx, WS_KP_ORDER, (size_t) mx * 8 + 16, &keys));
     keys2 = keys + mx; vals = (int*) (keys2 + mx); vals2 = vals + mx;
+    kkeys = (unsigned*) (vals2 + mx); kkeys2 = kkeys + mx; kvals = (int*) (kkeys2 + mx); kvals2 = kvals + mx;
+    fine_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, 12, m, sb, kkeys, kvals);
+    LGR_TRY(lgr_sort_pairs_u32(ctx, kkeys, kkeys2, kvals, kvals2, (size_t) m, 0, key_bits));
     if (g.n > 0) {
         fine_keys<<<cdiv(g.n, 256), 256, 0, ctx->stream>>>(g, reinterpret_cast<const float*>(g.pxyz), 4, g.n, sb, keys, vals);
         LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) g.n, 0, key_bits));
         spfh_tile_kernel<<<lgr_xcd_grid(cdiv(g.n, ST)), 64, 0, ctx->stream>>>(g, r2, vals2, spfh);
     }
-    fine_keys<<<cdiv(m, 256), 256, 0, ctx->stream>>>(g, d_kps, 12, m, sb, keys, vals);
-    LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) m, 0, key_bits));
-    fpfh_mfma_kernel<<<lgr_xcd_grid(cdiv(m, FT)), 64, 0, ctx->stream>>>(g, d_kps, vals2, m, r2, spfh, d_out);
+    fpfh_mfma_kernel<<<lgr_xcd_grid(cdiv(m, FT)), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
