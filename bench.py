@@ -377,7 +377,7 @@ def main():
         res = step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, stage_ms, work, coarse = [], [], [], []
+    kernel_ms, stage_ms, work, coarse, shell = [], [], [], [], []
     for _ in range(args.steps):
         res = step()
         kernel_ms.append(ctx.match_kernel_ms())
@@ -385,6 +385,7 @@ def main():
         mstats["refilter_pairs_ab"], mstats["refilter_pairs_ba"] = ctx.match_pairs()
         work.append(ctx.match_work())
         coarse.append(ctx.match_coarse())
+        shell.append(ctx.match_shell())
         stage_ms.append(list(res.stage_ms)[:7])
     barrier()
     elapsed = time.perf_counter() - t0
@@ -410,7 +411,9 @@ def main():
         peak = MFMA_F32_PEAK_TFLOPS if fmt == "f32" else MFMA_F16_PEAK_TFLOPS
         # tiles the kernel abandons after their first two MFMA steps (coarse rejection, rotated format) issue 64 of the 192 FLOP
         c_tested, c_abandoned = [float(x) for x in np.mean(np.array(coarse), 0)]
-        issued = flop_per_pair * m * m * executed - (c_abandoned * 1024.0 * (192.0 - 64.0) if fmt == "f16r" else 0.0)
+        # ... and tiles the shell test leaves out of a swept stage issue none
+        c_skipped = float(np.mean(shell))
+        issued = flop_per_pair * m * m * executed - ((c_abandoned * (192.0 - 64.0) + c_skipped * 192.0) * 1024.0 if fmt == "f16r" else 0.0)
         achieved = issued / (k_ms * 1e-3) / 1e12
         effective = alg_flop / (k_ms * 1e-3) / 1e12
         # HBM-side bytes of the same kernel (both launches of one step) from the committed PMC passes (tools/pmc_bench.sh:
@@ -438,7 +441,7 @@ def main():
                          "operand_format": {"f16": "f16 two-term splits, f32 accumulate, K = 112 (224 MFMA FLOP/pair)",
                                             "f16r": "f16 two-term splits of 30 Helmert coordinates, f32 accumulate, K = 96 (192 MFMA FLOP/pair)",
                                             "f32": "f32 (68 MFMA FLOP/pair)"}[fmt],
-                         "kernel_ms": k_ms, "executed_tile_fraction": executed, "coarse_tiles_tested": c_tested, "coarse_tiles_abandoned": c_abandoned,
+                         "kernel_ms": k_ms, "executed_tile_fraction": executed, "coarse_tiles_tested": c_tested, "coarse_tiles_abandoned": c_abandoned, "shell_tiles_skipped": c_skipped,
                          "mfma_flop_issued": issued, "effective_tflops_algorithmic": effective,
                          "rerank": mstats, "algorithmic_flop_per_launch": alg_flop, "directions_per_launch": n_dir},
             "stage_ms": dict(zip(["downsample", "normals", "fpfh", "match", "filter", "ransac", "refit"],

@@ -119,7 +119,7 @@ typedef struct {
 typedef struct {
     int32_t prune;            /* exact bound-based tile skipping: -1 auto (on from 65536 x 65536 pairs), 0 off (dense), 1 on */
     int32_t leaves;           /* second-level k-means leaves per cluster: 0 auto (about 1024 rows per leaf), else 1 .. 64 */
-    int32_t near;             /* pass-0 width: nearest leaves per row block / row blocks per leaf; 0 = default (28) */
+    int32_t near;             /* pass-0 width: nearest leaves per row block / row blocks per leaf; 0 = default (40) */
     int32_t operand_format;   /* -1 auto (f16 two-term splits, rotated to 30 coordinates when the rows allow it), 0 f32, 1 f16, 2 f16 rotated */
     int32_t box_bounds;       /* bounding-box lower bounds beside the ball bounds: 1 PCA basis (default), 2 raw coordinates, 0 off */
     int32_t column_stage;     /* per-stage column criterion in the final schedule: 1 (default) / 0 */
@@ -128,7 +128,8 @@ typedef struct {
     int32_t pair_cap;         /* pairs per rerank item the re-filter may emit before falling back to the group scan: -1 default (8) */
     int32_t poison_tables;    /* diagnostics: fill never-computed minimum-table entries with 0 (nothing may read them) */
     int32_t self_check;       /* diagnostics: device check of the proven filter bound on sampled queries (lgr_match_last_check) */
-    int32_t reserved[5];
+    int32_t shell_bound;      /* radial shell bound per (row block, column stage) in the passes that have upper bounds: 1 (default) / 0 */
+    int32_t reserved[4];
 } lgr_match_options;
 
 /* ---- context ---- */
@@ -241,6 +242,9 @@ int lgr_match_last_work(lgr_ctx*, double* executed_fraction);
 /* coarse rejection inside the MFMA filter kernel (rotated format only; lgr_match_options.coarse_rejection = 0 turns it off): 32 x 32 tiles
  * tested after their first two MFMA steps in the last match call, and tiles abandoned there. */
 int lgr_match_last_coarse(lgr_ctx*, double* out2);
+/* shell test inside the same sweep (lgr_match_options.shell_bound): 32 x 32 tiles of the swept stages a wave left out before any MFMA step,
+ * because the radial shells of its rows and of the tile's columns about their cluster centre are farther apart than every upper bound */
+int lgr_match_last_shell(lgr_ctx*, double* tiles_skipped);
 /* exact rerank (f16 operand formats; lgr_match_options.rerank_refilter = 0 turns it off): (query, train row) pairs the MFMA re-filter of
  * the candidate groups passed on to the exact distance in the last match call, query->train and train->query direction; a
  * count above the pair buffer (8 per candidate group) means that direction fell back to the exact scan of whole groups. */

@@ -54,6 +54,11 @@ extern "C" int lgr_match_last_pairs(lgr_ctx* ctx, unsigned* out2) {
     out2[0] = ctx->mstats.pairs_ab; out2[1] = ctx->mstats.pairs_ba;
     return LGR_OK;
 }
+extern "C" int lgr_match_last_shell(lgr_ctx* ctx, double* tiles_skipped) {
+    if (!ctx || !tiles_skipped) return LGR_ERR_INVALID_ARG;
+    *tiles_skipped = ctx->mstats.shell_skipped;
+    return LGR_OK;
+}
 extern "C" int lgr_match_last_coarse(lgr_ctx* ctx, double* out2) {
     if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
     out2[0] = ctx->mstats.coarse_tested; out2[1] = ctx->mstats.coarse_rejected;
@@ -589,7 +594,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_stats = pcarve(sizeof(MaskStats));
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
-        const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(16);
+        const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
+        const size_t o_smin = pcarve((size_t) KCL * n_stage_total * 4), o_rsh = pcarve((size_t) 2 * n_rb * 4);
+        const size_t o_rts = pcarve((size_t) ta * 8), o_cts = pcarve((size_t) KCL * tb * 8);
         const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
         const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
@@ -611,7 +618,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         CoarseArgs ca_on{};
         if (coarse) {
             group_max_kernel<<<dim3(n_stage_total, KCL), 256, 0, sB>>>(nBp, mb_pad, STAGE_COLS, nullptr, smaxB);   // (behind the packing, on its stream)
-            LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 16, ctx->stream));
+            group_min_kernel<<<dim3(n_stage_total, KCL), 256, 0, sB>>>(nBp, mb_pad, STAGE_COLS, (float*) (pb + o_smin));
+            LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 32, ctx->stream));
             const double c_quad = 9.5367477e-6 * (double) ex.quad * 1.00001;            // eps (group_eps)
             const double d11 = std::ldexp(1.0, -11) * (1.0 + std::ldexp(1.0, -9));      // delta: 2^-11 (x^2 + y^2) + 2^-10 x y
             ca_on.xmax = gmaxA; ca_on.ymax = smaxB; ca_on.n_stage_total = n_stage_total;
@@ -622,6 +630,22 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             ca_on.cnt = coarse_cnt;
             chk_uq_rows = u_rt; chk_uq_cols = both ? u_ct : nullptr;
         }
+        // shell bound of the masked passes that have upper bounds (with the coarse rejection: the same "an entry may miss what lies above
+        // the U^2 of its row and column" contract, and the same upper-bound tables)
+        ShellArgs shell{};
+        if (coarse && mo.shell_bound != 0) {
+            float* rsh = (float*) (pb + o_rsh);
+            group_min_kernel<<<dim3(n_rb, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, BLOCK_ROWS, rsh);
+            group_max_kernel<<<dim3(n_rb, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, BLOCK_ROWS, nullptr, rsh + n_rb);
+            shell.rminA = rsh; shell.rmaxA = rsh + n_rb; shell.sminB = (float*) (pb + o_smin); shell.smaxB = smaxB;
+            shell.blkcl = A.blkcl; shell.u_rb = u_rb; shell.cols = both ? 1 : 0;
+            // ... and per 32-row / 32-column tile for the test inside the coarse sweep
+            tile_shell_kernel<<<cdiv(ta, 256), 256, 0, ctx->stream>>>(nAp, ma_pad, 1, (float2*) (pb + o_rts));
+            tile_shell_kernel<<<cdiv((long long) KCL * tb, 256), 256, 0, sB>>>(nBp, mb_pad, KCL, (float2*) (pb + o_cts));
+            ca_on.rt_shell = (const float2*) (pb + o_rts); ca_on.ct_shell = (const float2*) (pb + o_cts);
+        }
+        ShellArgs shell0 = shell;   // pass 0: the stages of overlapping shells only
+        shell0.u_rb = nullptr;
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
         LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, o_cr - o_done, ctx->stream));   // done, sched, masks, bounds, stats
@@ -691,9 +715,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves,
-                                                                                            colstage && pass == n_beta ? 1 : 0, done, sched);
+                                                                                            colstage && pass == n_beta ? 1 : 0, pass == 1 && shell0.rminA ? 1 : 0, done, sched);
             }
-            mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage, mask, mstats);
+            if (pass == 0 && shell0.rminA) LGR_TRY(join_b());   // (the stage shells come from the column norms, written by the packing)
+            mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
+                                                                                                         pass > 0 ? shell : shell0, mask, mstats);
             init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             CoarseArgs ca = ca_on;
@@ -705,11 +731,12 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_TRY(lgr_pinned(ctx, 256, (void**) &hs));
         LGR_HIP(ctx, hipMemcpyAsync(hs, mstats, sizeof(MaskStats), hipMemcpyDeviceToHost, ctx->stream));
         unsigned long long* h_cc = (unsigned long long*) ((char*) hs + 128);
-        h_cc[0] = h_cc[1] = 0ull;
-        if (coarse) LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+        h_cc[0] = h_cc[1] = h_cc[2] = 0ull;
+        if (coarse) LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 24, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         g_last_stats.coarse_tested = (double) h_cc[0];
         g_last_stats.coarse_rejected = (double) h_cc[1];
+        g_last_stats.shell_skipped = (double) h_cc[2];
         g_last_stats.stages_done = 0;
         for (int k = 0; k <= n_beta; ++k) g_last_stats.stages_done += (double) hs->stages[k];
         if (env_int("LGR_MATCH_DEBUG", 0)) {

@@ -40,9 +40,9 @@ constexpr int KM2_ITERS = LGR_KM2_ITERS;
 #define LGR_MM_OCC 4          // waves per SIMD of match_mfma (2: 256 VGPRs, one workgroup per CU; 4: 128 VGPRs, two)
 #endif
 #ifndef LGR_NEAR_T
-#define LGR_NEAR_T 28
+#define LGR_NEAR_T 40
 #endif
-constexpr int NEAR_T = LGR_NEAR_T;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured at 1M: 16 / 24 / 32 / 48 / 64 -> 75.5 / 73.1 / 72.2 / 73.7 / 76.4 ms per pair in round 1; with the per-tile coarse thresholds of round 2 the final pass is cheaper per tile: 16 / 20 / 24 / 28 / 32 -> 40.4 / 39.8 / 39.4 / 39.45 / 39.8-40.1)
+constexpr int NEAR_T = LGR_NEAR_T;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured at 1M: 16 / 24 / 32 / 48 / 64 -> 75.5 / 73.1 / 72.2 / 73.7 / 76.4 ms per pair in round 1; with the per-tile coarse thresholds of round 2 the final pass is cheaper per tile: 16 / 20 / 24 / 28 / 32 -> 40.4 / 39.8 / 39.4 / 39.45 / 39.8-40.1; round 3, pass 0 takes only the stages of overlapping shells of those leaves and is three times cheaper per leaf: 28 / 36 / 48 / 64 -> 30.7-31.2 / 29.9-30.5 / 30.0-30.6 / 30.6)
 #ifndef LGR_PRUNE_BETAS
 #define LGR_PRUNE_BETAS 1.0f   // intermediate thresholds (e.g. 0.5f, 1.0f) were measured: no gain over one final pass
 #endif
@@ -92,7 +92,10 @@ struct CoarseArgs {
     const float* ymax;          // [KCL][column stages] max |b'| per set (group_max_kernel over 128-column windows)
     int n_stage_total;
     float quad, cross, lin, abs;   // T = max(U) (1 + 1e-5) + quad (x + y)^2 + cross x y + lin (x + y) + abs
-    unsigned long long* cnt;    // [2]: tiles tested, tiles abandoned (or nullptr)
+    unsigned long long* cnt;    // [3]: tiles tested, tiles abandoned, tiles skipped by the shell test before any MFMA (or nullptr)
+    // radial shells [min |x - c|, max |x - c|] of the 32-row / 32-column tiles (shell test per wave and tile; nullptr: off)
+    const float2* rt_shell;     // [row tiles] about the row block's own centre
+    const float2* ct_shell;     // [KCL][column tiles] about every centre
 };
 
 // proven bound of |filtered - d2| for a pair whose operands have |a'| <= x and |b'| <= y: evaluated in float,

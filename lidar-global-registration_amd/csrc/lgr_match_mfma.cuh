@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
     constexpr bool F16 = FMT != FMT_F32;
     static_assert(!CO || FMT == FMT_F16R, "the rotated K order puts a coarse d2~ into the first two steps (pack16_kernel)");
     constexpr bool COARSE = CO, use_coarse = CO;
-    unsigned n_tested = 0u, n_rejected = 0u;   // wave-uniform tile counts
+    unsigned n_tested = 0u, n_rejected = 0u, n_skipped = 0u;   // wave-uniform tile counts
     typedef typename OpFmt<FMT>::frag frag;
     constexpr int KS = OpFmt<FMT>::KS;
     constexpr int STAGE_FRAGS = STAGE_TILES * KS * 64;
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
             // coarse-rejection thresholds of the 128 column tiles of this (row block, chunk) for this wave's 32 rows: tile q = 4 stage + ct
             // sits in lane q & 63 of t_lane[q >> 6] (bit pattern of a float >= 0, scaled like the accumulator; +inf = keep everything)
             int t_lane[2] = {IINF, IINF};
+            unsigned long long skipm[2] = {0ull, 0ull};   // shell test: bit q & 63 of skipm[q >> 6] = this wave leaves tile q out (wave uniform)
             unsigned kept[STAGE_TILES] = {0u, 0u, 0u, 0u};   // coarse sweep: bit st of kept[ct] = tile ct of stage st goes on (wave uniform)
             int rmin[16];   // float bit patterns, see the epilogue note
 #pragma unroll
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
             };
             // first active stage of this row block (barrier first: every wave is past the previous row block's LDS reads)
             int st = __builtin_ctz(mask);
-            const unsigned sweep_mask = mask;
+            const unsigned sweep_mask = mask, skipped_before = n_skipped;
             // (a raw barrier: the A fragments just requested stay in flight while the first stage is requested)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
             if (!COARSE) {
@@ -287,6 +288,24 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     // barrier for a wave that happens to hold the few full tiles.
                     const int t_sel = st < 16 ? t_lane[0] : t_lane[1];   // (st is wave uniform)
                     const frag* cs = reinterpret_cast<const frag*>(smem) + buf * CO_FRAGS + lane;   // ring slot `buf`: [tile][2 steps][64]
+                    const unsigned sk4 = (unsigned) ((st < 16 ? skipm[0] : skipm[1]) >> ((st * STAGE_TILES) & 63)) & 0xfu;   // tiles the shell test leaves out
+                    if (sk4) {
+                        n_skipped += (unsigned) __builtin_popcount(sk4);
+                        if (sk4 == 0xfu) return;
+#pragma unroll
+                        for (int ct = 0; ct < STAGE_TILES; ++ct) {
+                            if ((sk4 >> ct) & 1u) continue;
+                            const frag c0 = cs[ct * 128], c1 = cs[ct * 128 + 64];
+                            f32x16 acc = mfma_step(a[0], c0, nav);
+                            acc = mfma_step(a[1], c1, acc);
+                            int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
+#pragma unroll
+                            for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
+                            const int t_st = __builtin_amdgcn_readlane(t_sel, (st * STAGE_TILES + ct) & 63);
+                            if (__ballot(m <= t_st) != 0ull) kept[ct] |= 1u << st;
+                        }
+                        return;
+                    }
                     b[0] = cs[0];
                     b[1] = cs[64];
 #pragma unroll
@@ -352,9 +371,24 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                         const int gst = min(cc * STAGES_PER_CHUNK + (q >> 2), ca.n_stage_total - 1);
                         const int gct = min(col_tile0 + q, ca.n_ct_total - 1);
                         const float us = ca.u_stage ? __uint_as_float(ca.u_ct[gct]) : 0.f;
-                        const float y = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
-                        const float s = x + y;
-                        float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (x * y) + ca.lin * s + ca.abs);
+                        float xt = x, yt = ca.ymax[(size_t) blkcl[rb] * ca.n_stage_total + gst];
+                        // Shell test (round 3): rows and columns are sorted by their distance to the cluster centre inside their leaves, so
+                        // this wave's 32 rows and the 32 columns of tile q are thin radial shells about the centre both are packed against;
+                        // |a - b| >= | |a - c| - |b - c| |, so when the gap of the two shells exceeds the upper bounds of all its rows and
+                        // columns the tile holds no nearest neighbour and no tie: not even its coarse steps are issued.  The shells' outer
+                        // radii are also the tile's own max |a'| and max |b'|: the error term of the coarse threshold is stated in those
+                        // (it was the row group's and the stage's maxima: (x + y)^2 up to 2.5 times larger, and one tile in six went on).
+                        if (ca.rt_shell) {
+                            const float2 sa = ca.rt_shell[rb * (BLOCK_ROWS / TILE) + wave];
+                            const float2 sb = ca.ct_shell[(size_t) blkcl[rb] * ca.n_ct_total + gct];
+                            const float gap = fmaxf(sb.x - sa.y, sa.x - sb.y) - 4e-6f * (sa.y + sb.y);   // (norms: 33-term float sums, 2e-6 on a radius)
+                            const float U = fmaxf(fmaxf(ur, us), 0.f);
+                            const bool skip = gap > 0.f && gap * gap * (0.99999f * 0.99999f * 0.99999f) > U * 1.00001f + 1e-12f;
+                            skipm[r] = __ballot(skip);
+                            xt = fminf(xt, sa.y); yt = fminf(yt, sb.y);
+                        }
+                        const float s = xt + yt;
+                        float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (xt * yt) + ca.lin * s + ca.abs);
                         t = (t * 1.0001f) * c_scale;
                         t_lane[r] = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
                     }
@@ -396,8 +430,12 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                 st = nxt;
             }
             if (COARSE) {
-                n_tested += (unsigned) (STAGE_TILES * __builtin_popcount(sweep_mask));
-                n_rejected += (unsigned) (STAGE_TILES * __builtin_popcount(sweep_mask) - __builtin_popcount(kept[0]) - __builtin_popcount(kept[1]) - __builtin_popcount(kept[2]) - __builtin_popcount(kept[3]));
+                // (n_skipped so far counts every visit of this wave; the difference to its value before the sweep is this visit's)
+                {
+                    const unsigned swept = (unsigned) (STAGE_TILES * __builtin_popcount(sweep_mask)), sk_now = n_skipped - skipped_before;
+                    n_tested += swept - sk_now;
+                    n_rejected += swept - sk_now - (unsigned) (__builtin_popcount(kept[0]) + __builtin_popcount(kept[1]) + __builtin_popcount(kept[2]) + __builtin_popcount(kept[3]));
+                }
                 // the recorded tiles, in column order: the whole chain on B fragments read straight from memory (the stage
                 // image has the same order there as in LDS), the usual epilogue, row minima flushed when the group changes
                 PROF_T(t_k0);
@@ -458,6 +496,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
     if (use_coarse && ca.cnt && lane == 0) {
         if (n_tested) atomicAdd(&ca.cnt[0], (unsigned long long) n_tested);
         if (n_rejected) atomicAdd(&ca.cnt[1], (unsigned long long) n_rejected);
+        if (n_skipped) atomicAdd(&ca.cnt[2], (unsigned long long) n_skipped);
     }
     PROF_T(t_wg1);
     PROF_ADD(4, t_wg0, t_wg1);

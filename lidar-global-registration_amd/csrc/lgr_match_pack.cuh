@@ -182,4 +182,45 @@ __global__ void group_max_kernel(const float* __restrict__ nrm, int n_pad, int g
 }
 
 
+// per-window minima of sqrt(norm) (finite entries only; +inf when the window has none): out[set][g], fixed windows of `group` positions,
+// rounded down.  With group_max_kernel this gives the radial shell [min |x - c|, max |x - c|] of a row block / a column stage about a
+// cluster centre c (mask_kernel's shell bound).
+__global__ void group_min_kernel(const float* __restrict__ nrm, int n_pad, int group, float* __restrict__ out) {
+    int g = blockIdx.x, set = blockIdx.y, n_groups = gridDim.x;
+    float m = __uint_as_float(0x7f800000u);
+    int p0 = g * group, p1 = min(n_pad, (g + 1) * group);
+    for (int pos = p0 + threadIdx.x; pos < p1; pos += blockDim.x) {
+        float v = nrm[(size_t) set * n_pad + pos];
+        if (v < FLT_BIG) m = fminf(m, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int) (blockDim.x >> 6); ++w) m = fminf(m, sh[w]);
+        out[(size_t) set * n_groups + g] = m < FLT_BIG ? sqrtf(m) * 0.9999998f : m;   // rounded down
+    }
+}
+
+
+// radial shell of every 32-position tile: out[set][tile] = (min, max) of sqrt(norm) over the finite entries (min rounded down, max up;
+// an empty tile: (+inf, 0)).  One thread per (set, tile).
+__global__ void tile_shell_kernel(const float* __restrict__ nrm, int n_pad, int n_sets, float2* __restrict__ out) {
+    const int n_tiles = n_pad / TILE;
+    const long long id = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long) n_sets * n_tiles) return;
+    const int set = (int) (id / n_tiles), tile = (int) (id % n_tiles);
+    const float4* src = reinterpret_cast<const float4*>(nrm + (size_t) set * n_pad + (size_t) tile * TILE);
+    float mn = __uint_as_float(0x7f800000u), mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < TILE / 4; ++j) {
+        const float4 v = src[j];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (e[k] < FLT_BIG) { mn = fminf(mn, e[k]); mx = fmaxf(mx, e[k]); }
+    }
+    out[id] = make_float2(mn < FLT_BIG ? sqrtf(mn) * 0.9999998f : mn, sqrtf(mx) * 1.0000002f);
+}
+
 }  // namespace

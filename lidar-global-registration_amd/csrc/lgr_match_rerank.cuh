@@ -129,13 +129,18 @@ __device__ __forceinline__ int comp_list(const CompView& c, int i0, int n_i, int
     __syncthreads();
     return cnt_s;
 }
+// tile states (section 3b).  sched: 1 = the whole (row block, leaf) tile, 2 = column-partial (final pass), SCHED_NOT_P0 = without the stages
+// pass 0 already took.  done: 1 = computed, DONE_SHELL = pass 0 computed the stages of overlapping shells only (mask_kernel).
+constexpr uint8_t SCHED_NOT_P0 = 4, DONE_SHELL = 8;
 __global__ void comp_rows_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched, const int* __restrict__ group_leaf,
                                  int n_rb, int n_leaves, int n_groups, uint8_t* __restrict__ comp_r) {
     size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t) n_rb * n_groups) return;
     int rb = (int) (idx / n_groups), g = (int) (idx % n_groups);
     size_t t = (size_t) rb * n_leaves + group_leaf[g];
-    comp_r[idx] = (done[t] | sched[t]) & 1;   // bit 1 (column-partial, see sched_kernel) leaves the row entries incomplete: not for the row scans
+    // bit 1 (column-partial, see sched_kernel) leaves the row entries incomplete: not for the row scans; DONE_SHELL (pass 0 took the stages
+    // of overlapping shells only) leaves minima over real pairs in them: good upper bounds, and everything they miss lies above them
+    comp_r[idx] = (((done[t] | sched[t]) & 1) || (done[t] & DONE_SHELL)) ? 1 : 0;
 }
 __global__ void comp_cols_kernel(const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched, int n_rb, int n_leaves, int n_rg,
                                  int rg_blocks, uint8_t* __restrict__ comp_c) {
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* 
     const int rg = rb / rg_blocks, rb_lo = rg * rg_blocks, rb_hi = min(n_rb, rb_lo + rg_blocks);
     for (int l = l0 + tid; l < l1; l += BLOCK_ROWS) {
         const uint8_t sv = sched[(size_t) rb * n_leaves + l];
-        uint8_t f = (sv & 1) ? 1 : 0;   // rows of the block: whole-leaf tiles only
+        uint8_t f = ((sv & 1) && !(sv & SCHED_NOT_P0)) ? 1 : 0;   // rows of the block: whole-leaf tiles only; not again when pass 0 has minima in them
         if (sv && colmin) {
             bool first = true;
             for (int r = rb_lo; r < rb_hi; ++r) {
@@ -251,27 +256,45 @@ struct MaskStats { unsigned long long stages[8]; };
 // block's ROWS do not need the leaf, some of its COLUMNS may: mask_kernel then takes just the 128-column stages whose own
 // columns ask for it (LB^2 <= the stage's largest U^2) instead of the whole leaf because of its worst column.
 __device__ __forceinline__ bool col_stage_needed(float lbsq, unsigned ustage_bits) { return lbsq <= __uint_as_float(ustage_bits) * LB_GROW + 1e-12f; }
+// prev_shell: the pass just finished was pass 0 with the shell selection -- its tiles are DONE_SHELL, not done, and a later pass that
+// needs such a tile takes the rest of it (SCHED_NOT_P0)
 __global__ void sched_kernel(int both, float beta_sq, const float* __restrict__ LBsq, const float* __restrict__ u_rb,
-                             const unsigned* __restrict__ u_leaf, int n_rb, int n_leaves, int col_partial, uint8_t* __restrict__ done, uint8_t* __restrict__ sched) {
+                             const unsigned* __restrict__ u_leaf, int n_rb, int n_leaves, int col_partial, int prev_shell,
+                             uint8_t* __restrict__ done, uint8_t* __restrict__ sched) {
     const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t) n_rb * n_leaves) return;
     const int rb = (int) (idx / n_leaves), g = (int) (idx % n_leaves);
-    uint8_t d = done[idx] | sched[idx];
+    uint8_t d = done[idx];
+    if (sched[idx]) d |= prev_shell ? DONE_SHELL : 1;
     done[idx] = d;
     uint8_t s = 0;
-    if (!d) {
+    if (!(d & 1)) {
         float lb = LBsq[idx], urb = u_rb[rb];
         bool need = urb >= 0.f && lb <= beta_sq * (urb * LB_GROW + 1e-12f);
         s = need ? 1 : 0;
         if (both && !need) { float ug = __uint_as_float(u_leaf[g]); if (lb <= beta_sq * (ug * LB_GROW + 1e-12f)) s = col_partial ? 2 : 1; }
+        if (s && (d & DONE_SHELL)) s |= SCHED_NOT_P0;
     }
     sched[idx] = s;
 }
 // one lane per (row block, chunk, stage): the 32 stages of a (row block, chunk) pair are the 32 lanes of a half wave, the mask is
 // their ballot (one thread per pair walking its 32 stages was a chain of 128 dependent loads: 0.30 + 0.37 ms per pair at 1M)
+// Shell bound (round 3, passes with upper bounds): rows and columns are sorted inside their leaves by their distance to the cluster
+// centre (assign_kernel's key), so a row block and a column stage are thin radial shells [r0, r1] about the centre c of the row block's
+// cluster -- the centre both are packed against, whose squared distances are the norms nA / nB[set].  By the reverse triangle inequality
+// every pair has |a - b| >= | |a - c| - |b - c| | >= gap(shells): a stage of a scheduled leaf whose shell gap exceeds the upper bounds of
+// the block's rows AND of the stage's columns holds no nearest neighbour and no tie of either, and is dropped.  (The radii of a cluster's
+// rows spread over several times a typical nearest-neighbour distance: tools/exp_radial_bound.py.)
+struct ShellArgs {
+    const float *rminA, *rmaxA;   // [row blocks] shell of the block's valid rows about its own centre (min rounded down, max up)
+    const float *sminB, *smaxB;   // [KCL][column stages] shell of the stage's columns about every centre
+    const int* blkcl;             // [row blocks]
+    const float* u_rb;            // [row blocks] largest U^2 of the block's rows (< 0: none); nullptr in pass 0 (no bounds yet)
+    int cols;                     // 0: row direction only; 1: u_stage holds the stages' largest column U^2
+};
 __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __restrict__ sched, const int* __restrict__ tile_group,
                                                    int n_rb, int n_cc, int n_leaves, int n_stage_total, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
-                                                   unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
+                                                   ShellArgs sh, unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
     static_assert(STAGES_PER_CHUNK == 32, "a half wave per (row block, chunk) pair");
     const long long n_pairs = (long long) n_rb * n_cc;
     const int s = threadIdx.x & 31;
@@ -284,6 +307,15 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
             const int rb = (int) (idx / n_cc), cc = (int) (idx % n_cc);
             const int gst = cc * STAGES_PER_CHUNK + s;
             if (gst < n_stage_total) {
+                // shell gap of (row block, stage) about the centre of the block's cluster (the norms are 33-term float sums: 2e-6 relative on
+                // a radius; the shells are widened by 4e-6 of their radii); > 0: no pair of the two is closer than that
+                float gap = 0.f;
+                if (sh.rminA) {
+                    const int c = sh.blkcl[rb];
+                    const float b0 = sh.sminB[(size_t) c * n_stage_total + gst], b1 = sh.smaxB[(size_t) c * n_stage_total + gst];
+                    gap = fmaxf(b0 - sh.rmaxA[rb], sh.rminA[rb] - b1) - 4e-6f * (sh.rmaxA[rb] + b1);
+                }
+                const bool overlap = !(gap > 0.f);   // what pass 0 takes of a scheduled leaf when the shells are known
                 int gprev = -1;
 #pragma unroll
                 for (int ct = 0; ct < STAGE_TILES; ++ct) {
@@ -291,7 +323,17 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
                     if (g == gprev) continue;
                     gprev = g;
                     const uint8_t sv = sched[(size_t) rb * n_leaves + g];
-                    on = on || (sv & 1) || ((sv & 2) && col_stage_needed(LBsq[(size_t) rb * n_leaves + g], u_stage[gst]));
+                    bool want = (sv & 1) || ((sv & 2) && col_stage_needed(LBsq[(size_t) rb * n_leaves + g], u_stage[gst]));
+                    if (sh.rminA && !sh.u_rb) want = want && overlap;     // pass 0: a heuristic selection, it only looks for good upper bounds
+                    if (sv & SCHED_NOT_P0) want = want && !overlap;       // ... and a later pass does not repeat it
+                    on = on || want;
+                }
+                if (on && sh.u_rb && gap > 0.f && gap < FLT_BIG) {
+                    const float lb = gap * gap * (LB_SHRINK * LB_SHRINK * LB_SHRINK);
+                    const float urb = sh.u_rb[rb];
+                    const bool rows_need = urb >= 0.f && lb <= urb * LB_GROW + 1e-12f;
+                    const bool cols_need = sh.cols != 0 && col_stage_needed(lb, u_stage[gst]);
+                    on = rows_need || cols_need;
                 }
             }
         }
@@ -357,7 +399,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                     const size_t t = (size_t) (j / BLOCK_ROWS) * n_leaves + gl;
                     const uint8_t sv = done[t] | sched[t];
                     const bool c = (sv & 1) || ((sv & 2) && u_stage && col_stage_needed(LBsq[t], u_stage[gst]));   // mask_kernel's rule
-                    on = on || c;
+                    on = on || c || (sv & DONE_SHELL);   // (pass 0's shell selection may have reached the column: not guaranteed)
                     if (gl == my_leaf) sure = c;
                 }
                 if (!on) continue;

@@ -59,7 +59,7 @@ class MatchOptions(C.Structure):
     """lgr_match_options (include/lgr.h): how the matcher runs, never what it returns."""
     _fields_ = [("prune", C.c_int32), ("leaves", C.c_int32), ("near", C.c_int32), ("operand_format", C.c_int32), ("box_bounds", C.c_int32),
                 ("column_stage", C.c_int32), ("coarse_rejection", C.c_int32), ("rerank_refilter", C.c_int32), ("pair_cap", C.c_int32),
-                ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("shell_bound", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class CtxOptions(C.Structure):
@@ -287,6 +287,12 @@ class Context:
         out = (C.c_double * 2)()
         self.check(_lib.lgr_match_last_coarse(self.h, out))
         return out[0], out[1]
+
+    def match_shell(self):
+        """tiles of the swept stages the shell test left out before any MFMA step in the last match call"""
+        out = C.c_double()
+        self.check(_lib.lgr_match_last_shell(self.h, C.byref(out)))
+        return out.value
 
     def match_format(self):
         """'f16' (split operands on the f16 MFMA, K = 112), 'f16r' (the same on 30 rotated coordinates, K = 96) or 'f32'

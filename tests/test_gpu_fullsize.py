@@ -71,6 +71,15 @@ def test_matcher_1m_coarse_rejection_is_invisible(lgr, opts):
         np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
     print(f"1M coarse rejection: {abandoned:.0f} of {tested:.0f} final-pass tiles abandoned, work {lgr.match_work():.3f}, "
           f"bound ratios {r_rows:.3g} / {r_cols:.3g}")
+    # ... and the same without the shell bound (pass 0 over whole leaves, no stage / tile left out for its shell gap)
+    opts(poison_tables=1, self_check=1, shell_bound=0)
+    noshell = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 200000)]
+    lgr.sync()
+    assert lgr.match_shell() == 0.0
+    r_rows, r_cols = lgr.match_check()
+    assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
+    for x, y in zip(on, noshell):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
 
 
 def test_downsample_1m_sorted_weights_idempotent(lgr, pair1m):

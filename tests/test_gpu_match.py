@@ -238,6 +238,49 @@ def test_coarse_rejection(lgr, oracle, matcher_mode):
     print(f"coarse rejection [{matcher_mode}]: {abandoned:.0f} of {tested:.0f} tiles abandoned")
 
 
+def test_shell_bound(lgr, oracle, matcher_mode):
+    """Rows and columns lie in radial shells about their cluster centre (they are sorted by that radius inside their leaves), and
+    |a - b| >= | |a - c| - |b - c| |.  Pass 0 takes only the stages whose shell overlaps the row block's, the later passes drop stages
+    -- and, inside the sweep, single tiles -- whose shell gap exceeds every upper bound (lgr_match_options.shell_bound).  None of
+    that may show: same matches and distance bits as the oracle and as the run with the shell bound off, both directions and the
+    single-direction entry point, with the device self-check of the filter bound in force; and on clustered rows with a spread of
+    radii it really does leave tiles out."""
+    import torch
+    if matcher_mode not in ("prune_sub4", "prune_sub64"):
+        pytest.skip("needs the skipping passes (upper bounds) and the default schedule")
+    rng = np.random.default_rng(99)
+    centres = fpfh_like(rng, 24)
+    def cloud(m):
+        # clusters whose members sit at very different distances from their centre: wide radial spread, close neighbours
+        x = centres[rng.integers(0, 24, m)].astype(np.float64).reshape(m, 3, 11)
+        x = np.abs(x + rng.normal(0, 1.0, x.shape) * rng.uniform(0.2, 6.0, (m, 1, 1))) + 1e-3
+        return (100.0 * x / x.sum(2, keepdims=True)).reshape(m, 33).astype(np.float32)
+    a = np.concatenate([cloud(9000), fpfh_like(rng, 3000)]); b = np.concatenate([fpfh_like(rng, 4000), cloud(11000)])
+    a[17] = b[40]; a[18] = b[40]                                   # exact ties across the two sets
+    opts(lgr, self_check=1)
+    run_both(lgr, oracle, a, b, 4000)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    on = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
+    lgr.sync()
+    assert lgr.match_format() == "f16r"
+    skipped, work_on = lgr.match_shell(), lgr.match_work()
+    r_rows, r_cols = lgr.match_check()
+    assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
+    one = [t.cpu().numpy() for t in lgr.match_bf(ta, tb, 4000)]
+    opts(lgr, self_check=1, shell_bound=0)
+    off = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
+    lgr.sync()
+    assert lgr.match_shell() == 0.0
+    work_off = lgr.match_work()
+    r_rows, r_cols = lgr.match_check()
+    assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
+    for x, y in zip(on, off):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    np.testing.assert_array_equal(one[0], on[0]); np.testing.assert_array_equal(one[1].view(np.uint32), on[1].view(np.uint32))
+    assert skipped > 0 and work_on <= work_off, (skipped, work_on, work_off)
+    print(f"shell bound [{matcher_mode}]: {skipped:.0f} tiles left out inside the sweep, stages computed {work_on:.4f} (off: {work_off:.4f})")
+
+
 def test_rerank_refilter(lgr, oracle, matcher_mode):
     """The exact rerank re-filters each candidate group with the MFMA operands and takes the exact distance only for the
     (query, train row) pairs under the query's threshold.  Same result as scanning the whole groups and as the oracle, in
