@@ -361,8 +361,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     F16Scale sc{1.f, 1.f, {1.f, 1.f, 1.f}};
     bool rot = false;
     float *nAp, *nBp;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_NORMS, (size_t) ma_pad + (size_t) KCL * mb_pad + 64, &nAp));
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_NORMS, (size_t) ma_pad + (size_t) KCL * mb_pad + 2 * ((size_t) ta + (size_t) KCL * tb) + 64, &nAp));
     nBp = nAp + ma_pad;
+    // radial shells of the 32-row / 32-column tiles about the centres they are packed against (written by the f16 packing kernels)
+    float2* const shellA = (float2*) (nBp + (size_t) KCL * mb_pad);
+    float2* const shellB = shellA + ta;
     unsigned* d_max = (unsigned*) (misc + 128);   // [2]: norm overflow flag of the f32 packing (the f16 statistics come from assign_kernel)
     LGR_HIP(ctx, hipMemsetAsync(d_max, 0, 12, ctx->stream));
     bool force_dense = false;
@@ -477,13 +480,13 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         force_dense = h_ovf[0] != 0u;
     } else {
         if (rot) {
-            pack16_kernel<true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
+            pack16_kernel<true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
             LGR_TRY(fork_b());
-            pack16_kernel<true><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
+            pack16_kernel<true><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, shellB);
         } else {
-            pack16_kernel<false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp);
+            pack16_kernel<false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
             LGR_TRY(fork_b());
-            pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp);
+            pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, shellB);
         }
     }
     group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
@@ -595,8 +598,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
-        const size_t o_smin = pcarve((size_t) KCL * n_stage_total * 4), o_rsh = pcarve((size_t) 2 * n_rb * 4);
-        const size_t o_rts = pcarve((size_t) ta * 8), o_cts = pcarve((size_t) KCL * tb * 8);
+        const size_t o_ssh = pcarve((size_t) KCL * n_stage_total * 8), o_rsh = pcarve((size_t) n_rb * 8);
         const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
         const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
@@ -617,8 +619,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned long long* coarse_cnt = (unsigned long long*) (pb + o_ccnt);
         CoarseArgs ca_on{};
         if (coarse) {
-            group_max_kernel<<<dim3(n_stage_total, KCL), 256, 0, sB>>>(nBp, mb_pad, STAGE_COLS, nullptr, smaxB);   // (behind the packing, on its stream)
-            group_min_kernel<<<dim3(n_stage_total, KCL), 256, 0, sB>>>(nBp, mb_pad, STAGE_COLS, (float*) (pb + o_smin));
+            // stage shells and stage maxima from the tiles' shells (behind the packing, on its stream)
+            shell_reduce_kernel<<<cdiv((long long) KCL * n_stage_total, 256), 256, 0, sB>>>(shellB, KCL, tb, STAGE_TILES, (float2*) (pb + o_ssh), smaxB);
             LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 32, ctx->stream));
             const double c_quad = 9.5367477e-6 * (double) ex.quad * 1.00001;            // eps (group_eps)
             const double d11 = std::ldexp(1.0, -11) * (1.0 + std::ldexp(1.0, -9));      // delta: 2^-11 (x^2 + y^2) + 2^-10 x y
@@ -634,15 +636,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         // the U^2 of its row and column" contract, and the same upper-bound tables)
         ShellArgs shell{};
         if (coarse && mo.shell_bound != 0) {
-            float* rsh = (float*) (pb + o_rsh);
-            group_min_kernel<<<dim3(n_rb, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, BLOCK_ROWS, rsh);
-            group_max_kernel<<<dim3(n_rb, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, BLOCK_ROWS, nullptr, rsh + n_rb);
-            shell.rminA = rsh; shell.rmaxA = rsh + n_rb; shell.sminB = (float*) (pb + o_smin); shell.smaxB = smaxB;
+            shell_reduce_kernel<<<cdiv(n_rb, 256), 256, 0, ctx->stream>>>(shellA, 1, ta, BLOCK_ROWS / TILE, (float2*) (pb + o_rsh), nullptr);
+            shell.rshA = (const float2*) (pb + o_rsh); shell.sshB = (const float2*) (pb + o_ssh);
             shell.blkcl = A.blkcl; shell.u_rb = u_rb; shell.cols = both ? 1 : 0;
-            // ... and per 32-row / 32-column tile for the test inside the coarse sweep
-            tile_shell_kernel<<<cdiv(ta, 256), 256, 0, ctx->stream>>>(nAp, ma_pad, 1, (float2*) (pb + o_rts));
-            tile_shell_kernel<<<cdiv((long long) KCL * tb, 256), 256, 0, sB>>>(nBp, mb_pad, KCL, (float2*) (pb + o_cts));
-            ca_on.rt_shell = (const float2*) (pb + o_rts); ca_on.ct_shell = (const float2*) (pb + o_cts);
+            ca_on.rt_shell = shellA; ca_on.ct_shell = shellB;   // ... and per tile for the test inside the coarse sweep
         }
         ShellArgs shell0 = shell;   // pass 0: the stages of overlapping shells only
         shell0.u_rb = nullptr;
@@ -668,11 +665,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 f16x8* Cop = (f16x8*) (pb + o_cop);
                 centre_perm_kernel<<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(n_leaves, n_cpad, cperm);
                 if (rot) {
-                    pack16_kernel<true><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC);
+                    pack16_kernel<true><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
                     lb_mfma_kernel<OpFmt<FMT_F16R>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
                                                                                              B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
                 } else {
-                    pack16_kernel<false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC);
+                    pack16_kernel<false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
                     lb_mfma_kernel<OpFmt<FMT_F16>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
                                                                                             B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
                 }
@@ -715,9 +712,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves,
-                                                                                            colstage && pass == n_beta ? 1 : 0, pass == 1 && shell0.rminA ? 1 : 0, done, sched);
+                                                                                            colstage && pass == n_beta ? 1 : 0, pass == 1 && shell0.rshA ? 1 : 0, done, sched);
             }
-            if (pass == 0 && shell0.rminA) LGR_TRY(join_b());   // (the stage shells come from the column norms, written by the packing)
+            if (pass == 0 && shell0.rshA) LGR_TRY(join_b());   // (the stage shells come from the column norms, written by the packing)
             mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
                                                                                                          pass > 0 ? shell : shell0, mask, mstats);
             init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,

@@ -63,7 +63,7 @@ __device__ __forceinline__ void helmert11(const float* __restrict__ x, float* __
 template <bool ROT>
 __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X, const int* __restrict__ perm, int n_pad, int role,
                               const float* __restrict__ cen, const int* __restrict__ blkcl, F16Scale sc,
-                              _Float16* __restrict__ P, float* __restrict__ nrm) {
+                              _Float16* __restrict__ P, float* __restrict__ nrm, float2* __restrict__ shell /* [sets][n_pad / 32] or nullptr */) {
     int pos = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = pos < n_pad;
     if (!in_range) pos = n_pad - 1;           // (nothing is stored for these lanes)
@@ -87,6 +87,16 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X
         n2 = __uint_as_float(0x7f800000u);
     }
     if (in_range) nrm[(size_t) set * n_pad + pos] = n2;   // |x'|^2 in all 33 coordinates: the magnitude the error bounds are stated in
+    if (shell) {
+        // radial shell of the 32-position tile about this centre: (min, max) of |x'| over its finite rows (min rounded down, max up; an
+        // empty tile: (+inf, 0)) -- the 32 rows of a tile are the 32 lanes of a half wave (shell bound, lgr_match_rerank.cuh / match_mfma)
+        const bool fin = in_range && n2 < FLT_BIG;
+        float mn = fin ? n2 : __uint_as_float(0x7f800000u), mx = fin ? n2 : 0.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+        if (in_range && (pos & 31) == 0)
+            shell[(size_t) set * (n_pad / TILE) + (pos >> 5)] = make_float2(mn < FLT_BIG ? sqrtf(mn) * 0.9999998f : mn, sqrtf(mx) * 1.0000002f);
+    }
     float y[30], u0, u1, u2;
     if (ROT) { helmert11(v, y, &u0); helmert11(v + 11, y + 10, &u1); helmert11(v + 22, y + 20, &u2); }
     if (!in_range) continue;
@@ -182,45 +192,20 @@ __global__ void group_max_kernel(const float* __restrict__ nrm, int n_pad, int g
 }
 
 
-// per-window minima of sqrt(norm) (finite entries only; +inf when the window has none): out[set][g], fixed windows of `group` positions,
-// rounded down.  With group_max_kernel this gives the radial shell [min |x - c|, max |x - c|] of a row block / a column stage about a
-// cluster centre c (mask_kernel's shell bound).
-__global__ void group_min_kernel(const float* __restrict__ nrm, int n_pad, int group, float* __restrict__ out) {
-    int g = blockIdx.x, set = blockIdx.y, n_groups = gridDim.x;
-    float m = __uint_as_float(0x7f800000u);
-    int p0 = g * group, p1 = min(n_pad, (g + 1) * group);
-    for (int pos = p0 + threadIdx.x; pos < p1; pos += blockDim.x) {
-        float v = nrm[(size_t) set * n_pad + pos];
-        if (v < FLT_BIG) m = fminf(m, v);
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
-    __shared__ float sh[4];
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int) (blockDim.x >> 6); ++w) m = fminf(m, sh[w]);
-        out[(size_t) set * n_groups + g] = m < FLT_BIG ? sqrtf(m) * 0.9999998f : m;   // rounded down
-    }
-}
-
-
-// radial shell of every 32-position tile: out[set][tile] = (min, max) of sqrt(norm) over the finite entries (min rounded down, max up;
-// an empty tile: (+inf, 0)).  One thread per (set, tile).
-__global__ void tile_shell_kernel(const float* __restrict__ nrm, int n_pad, int n_sets, float2* __restrict__ out) {
-    const int n_tiles = n_pad / TILE;
+// shells of windows of `group` consecutive tiles from the tiles' shells (pack16_kernel): out[set][g] = (min of the minima, max of the maxima);
+// out_max (optional) = the maxima alone (the stage maxima of the coarse thresholds)
+__global__ void shell_reduce_kernel(const float2* __restrict__ tile_shell, int n_sets, int n_tiles, int group, float2* __restrict__ out, float* __restrict__ out_max) {
+    const int n_groups = (n_tiles + group - 1) / group;
     const long long id = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (long long) n_sets * n_tiles) return;
-    const int set = (int) (id / n_tiles), tile = (int) (id % n_tiles);
-    const float4* src = reinterpret_cast<const float4*>(nrm + (size_t) set * n_pad + (size_t) tile * TILE);
+    if (id >= (long long) n_sets * n_groups) return;
+    const int set = (int) (id / n_groups), g = (int) (id % n_groups);
     float mn = __uint_as_float(0x7f800000u), mx = 0.f;
-#pragma unroll
-    for (int j = 0; j < TILE / 4; ++j) {
-        const float4 v = src[j];
-        const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (e[k] < FLT_BIG) { mn = fminf(mn, e[k]); mx = fmaxf(mx, e[k]); }
+    for (int t = g * group; t < min(n_tiles, (g + 1) * group); ++t) {
+        const float2 v = tile_shell[(size_t) set * n_tiles + t];
+        mn = fminf(mn, v.x); mx = fmaxf(mx, v.y);
     }
-    out[id] = make_float2(mn < FLT_BIG ? sqrtf(mn) * 0.9999998f : mn, sqrtf(mx) * 1.0000002f);
+    out[id] = make_float2(mn, mx);
+    if (out_max) out_max[id] = mx;
 }
 
 }  // namespace

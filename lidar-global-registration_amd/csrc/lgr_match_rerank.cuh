@@ -286,8 +286,8 @@ __global__ void sched_kernel(int both, float beta_sq, const float* __restrict__ 
 // the block's rows AND of the stage's columns holds no nearest neighbour and no tie of either, and is dropped.  (The radii of a cluster's
 // rows spread over several times a typical nearest-neighbour distance: tools/exp_radial_bound.py.)
 struct ShellArgs {
-    const float *rminA, *rmaxA;   // [row blocks] shell of the block's valid rows about its own centre (min rounded down, max up)
-    const float *sminB, *smaxB;   // [KCL][column stages] shell of the stage's columns about every centre
+    const float2* rshA;           // [row blocks] shell (min, max |a - c|) of the block's valid rows about its own centre (min rounded down, max up)
+    const float2* sshB;           // [KCL][column stages] shell of the stage's columns about every centre
     const int* blkcl;             // [row blocks]
     const float* u_rb;            // [row blocks] largest U^2 of the block's rows (< 0: none); nullptr in pass 0 (no bounds yet)
     int cols;                     // 0: row direction only; 1: u_stage holds the stages' largest column U^2
@@ -310,10 +310,9 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
                 // shell gap of (row block, stage) about the centre of the block's cluster (the norms are 33-term float sums: 2e-6 relative on
                 // a radius; the shells are widened by 4e-6 of their radii); > 0: no pair of the two is closer than that
                 float gap = 0.f;
-                if (sh.rminA) {
-                    const int c = sh.blkcl[rb];
-                    const float b0 = sh.sminB[(size_t) c * n_stage_total + gst], b1 = sh.smaxB[(size_t) c * n_stage_total + gst];
-                    gap = fmaxf(b0 - sh.rmaxA[rb], sh.rminA[rb] - b1) - 4e-6f * (sh.rmaxA[rb] + b1);
+                if (sh.rshA) {
+                    const float2 sa = sh.rshA[rb], sb = sh.sshB[(size_t) sh.blkcl[rb] * n_stage_total + gst];
+                    gap = fmaxf(sb.x - sa.y, sa.x - sb.y) - 4e-6f * (sa.y + sb.y);
                 }
                 const bool overlap = !(gap > 0.f);   // what pass 0 takes of a scheduled leaf when the shells are known
                 int gprev = -1;
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
                     gprev = g;
                     const uint8_t sv = sched[(size_t) rb * n_leaves + g];
                     bool want = (sv & 1) || ((sv & 2) && col_stage_needed(LBsq[(size_t) rb * n_leaves + g], u_stage[gst]));
-                    if (sh.rminA && !sh.u_rb) want = want && overlap;     // pass 0: a heuristic selection, it only looks for good upper bounds
+                    if (sh.rshA && !sh.u_rb) want = want && overlap;     // pass 0: a heuristic selection, it only looks for good upper bounds
                     if (sv & SCHED_NOT_P0) want = want && !overlap;       // ... and a later pass does not repeat it
                     on = on || want;
                 }
