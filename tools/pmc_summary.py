@@ -11,7 +11,7 @@ import json
 import re
 import sys
 
-KERNELS = ["normals_kernel", "normals_wave_kernel", "knn_wave_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_kernel", "match_mfma", "knn_kernel", "metric_kernel", "plane_kernel",
+KERNELS = ["normals_kernel", "normals_wave_kernel", "knn_wave_kernel", "knn_tile_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_kernel", "match_mfma", "knn_kernel", "metric_kernel", "plane_kernel",
            "assign_kernel", "pack16_kernel", "rerank_refilter", "init_tables_kernel", "voxel_accumulate", "filter_flags"]
 
 
