@@ -29,10 +29,11 @@
 extern "C" {
 #endif
 
-/* ABI revision.  2 (round 3): lgr_match_last_* take the context, lgr_ctx_options / lgr_ctx_host_threads added; lgr_params grew in
- * revision 1 -> 2 as well (use_bfmatcher, has_guess, match_search_radius, guess).  A host built against another revision must not
+/* ABI revision.  3 (round 3): lgr_match_options.shell_bound (one of the reserved words: a host that zeroes them would switch the shell
+ * bound off), lgr_match_last_shell added.  2 (round 3): lgr_match_last_* take the context, lgr_ctx_options / lgr_ctx_host_threads added;
+ * lgr_params grew in revision 1 -> 2 as well (use_bfmatcher, has_guess, match_search_radius, guess).  A host built against another revision must not
  * call in: check lgr_version() == LGR_VERSION once after loading (lgr_amd/capi.py and host/lgr_compat.hpp do). */
-#define LGR_VERSION 2
+#define LGR_VERSION 3
 
 enum {
     LGR_OK = 0,

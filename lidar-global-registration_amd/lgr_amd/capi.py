@@ -82,7 +82,7 @@ def load():
     return C.CDLL(LIB_PATH)
 
 
-ABI_VERSION = 2      # LGR_VERSION of the include/lgr.h these structures mirror
+ABI_VERSION = 3      # LGR_VERSION of the include/lgr.h these structures mirror
 
 _lib = load()
 _lib.lgr_last_error.restype = C.c_char_p
