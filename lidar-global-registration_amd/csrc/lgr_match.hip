@@ -7,7 +7,9 @@
 //
 // Structure (DESIGN.md "matcher"):
 //   1. cluster      : 16 k-means centres of the descriptors (Lloyd on a sample, on the device); every row is assigned
-//                     to its nearest centre and both sets are sorted by (cluster, distance to centre).
+//                     to its nearest centre and both sets are sorted by (cluster, leaf, distance to the cluster centre) -- the
+//                     last key makes every 32 / 128 / 256-row piece of a leaf a thin radial shell about that centre, which
+//                     the skipping passes use as a second lower bound (| |a - c| - |b - c| | <= |a - b|: mask_kernel, match_mfma).
 //   2. pack         : MFMA operands, K = 34: A' = [-2(a - c_p), 1] for a in cluster p, and one column set per cluster,
 //                     B'(p) = [b - c_p, |b - c_p|^2].  Distances are translation invariant, so for a row of cluster p
 //                     S = A'.B'(p) = |b - c_p|^2 - 2 (a - c_p).(b - c_p) = d2 - |a - c_p|^2 -- and its rounding error
@@ -15,7 +17,8 @@
 //                     (FPFH data is full of near-duplicate "flat surface" rows far from the global mean).
 //   3. match_mfma   : the brute-force contraction on v_mfma_f32_32x32x2_f32 with a fused epilogue that keeps only
 //                     min_b d2~ per (row, column group) and min_a d2~ per (column, row group), d2~ = S + |a'|^2.
-//                     FILTER only.
+//                     FILTER only.  (f16 formats, the default: two-term f16 splits of the operands on v_mfma_f32_32x32x16_f16,
+//                     K = 96 or 112, under the same kind of proven bound; bound-based tile skipping in masked passes: section 3b.)
 //   4. rerank_*     : per query, a group is a candidate when its lower bound (value - proven error) does not exceed
 //                     the smallest upper bound; candidate groups are rescanned with the exact canonical distance and
 //                     a packed 64-bit atomicMin applies the reference's tie rules (order independent).
