@@ -539,7 +539,37 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
         const int cz = c / (g.dx * g.dy), cy = (c / g.dx) % g.dy, cx = c % g.dx;
         int head = 0, tail = 0;   // ring positions (monotone; entry e lives at e & (FRING - 1))
         auto consume = [&](int n_groups) {
-            for (int gq = 0; gq < n_groups; ++gq, head += 4) {
+            int gq = 0;
+            // Four groups (16 candidates) per round, their twelve SPFH loads in flight together: one group per round left the MFMAs waiting for
+            // a dependent L2 round trip each time (PMC: 17 % of the wave cycles active, 49 % parked).  Same products in the same order: the
+            // groups' MFMAs follow each other in candidate order; a group nobody uses is left out as before.
+            for (; gq + 4 <= n_groups; gq += 4, head += 16) {
+                float w[4], b0[4], b1[4], b2[4];
+                bool used[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 e = ring[(head + 4 * u + k) & (FRING - 1)];
+                    const float d2 = lgr_dist2(x, y, z, e.x, e.y, e.z);
+                    const bool in = active && d2 < r2;
+                    found = found || in;
+                    const bool use = in && d2 != 0.f;
+                    used[u] = __ballot(use) != 0ull;   // (wave uniform)
+                    w[u] = 0.f; b0[u] = 0.f; b1[u] = 0.f; b2[u] = 0.f;
+                    if (used[u]) {
+                        w[u] = use ? 1.0f / d2 : 0.f;
+                        const float* h = hbase + (size_t) __float_as_int(e.w) * HP;
+                        b0[u] = h[0]; b1[u] = h[16]; b2[u] = h[32];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!used[u]) continue;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], b0[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], b1[u], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], b2[u], acc2, 0, 0, 0);
+                }
+            }
+            for (; gq < n_groups; ++gq, head += 4) {
                 const float4 e = ring[(head + k) & (FRING - 1)];
                 const float d2 = lgr_dist2(x, y, z, e.x, e.y, e.z);
                 const bool in = active && d2 < r2;
