@@ -601,6 +601,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
+        const size_t o_urow = pcarve((size_t) ma_pad * 4);
         const size_t o_ssh = pcarve((size_t) KCL * n_stage_total * 8), o_rsh = pcarve((size_t) n_rb * 8);
         const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
         const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
@@ -611,6 +612,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned* mask = (unsigned*) (pb + o_mask);
         float* u_rb = (float*) (pb + o_urb);
         float* u_rt = (float*) (pb + o_urt);
+        float* u_row = (float*) (pb + o_urow);   // every row's own upper bound (the sweep's per-row thresholds)
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
         unsigned* u_stage = (unsigned*) (pb + o_ust);
@@ -633,7 +635,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             ca_on.lin = (float) (2.0 * (double) ex.lin * 1.00001 + 1e-30);
             ca_on.abs = (float) (((double) ex.abs * 1.00001 + 2.0 * (double) sc.a_norm[0] * std::ldexp(1.0, -25) * (double) sc.inv_s2) * 1.000001 + 1e-12);
             ca_on.cnt = coarse_cnt;
-            chk_uq_rows = u_rt; chk_uq_cols = both ? u_ct : nullptr;
+            chk_uq_rows = u_row; chk_uq_cols = both ? u_ct : nullptr;
         }
         // shell bound of the masked passes that have upper bounds (with the coarse rejection: the same "an entry may miss what lies above
         // the U^2 of its row and column" contract, and the same upper-bound tables)
@@ -706,7 +708,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         for (int pass = 0; pass <= n_beta; ++pass) {
             if (pass > 0) {
                 build_comp();
-                row_u_kernel<<<n_rb, BLOCK_ROWS, (size_t) (n_groups + 8) * 4, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, comp_rows, u_rb, u_rt);
+                row_u_kernel<<<n_rb, BLOCK_ROWS, (size_t) (n_groups + 8) * 4, ctx->stream>>>((const float*) rowmin, n_groups, ma_pad, A.perm, nAp, A.blkcl, gmaxB, ex, comp_rows, u_rb, u_rt, coarse ? u_row : nullptr);
                 if (both) {
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
                     LGR_HIP(ctx, hipMemsetAsync(u_stage, 0, (size_t) n_stage_total * 4, ctx->stream));
@@ -723,7 +725,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             CoarseArgs ca = ca_on;
-            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.n_ct_total = tb; }
+            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.n_ct_total = tb; }
             LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans

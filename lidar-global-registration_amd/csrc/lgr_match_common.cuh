@@ -85,6 +85,7 @@ struct F16Scale { float s_mul; float inv_s2; float a_norm[3]; };   // 2^s, 2^-2s
 struct CoarseArgs {
     const float* u_rb;          // [row blocks] or nullptr: no coarse rejection in this launch
     const float* u_rt;          // [row tiles]: largest U^2 of the 32 rows of a tile (the row side of a wave's threshold)
+    const float* u_row;         // [rows] U^2 of every row (< 0: padding), or nullptr: the sweep then tests with the tile's u_rt for all rows
     const unsigned* u_stage;    // [column stages] float bits, or nullptr (row direction only)
     const unsigned* u_ct;       // [column tiles] float bits: largest U^2 of the 32 columns of a tile (with u_stage)
     int n_ct_total;

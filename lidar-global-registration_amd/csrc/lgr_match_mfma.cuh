@@ -138,6 +138,12 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
             // coarse-rejection thresholds of the 128 column tiles of this (row block, chunk) for this wave's 32 rows: tile q = 4 stage + ct
             // sits in lane q & 63 of t_lane[q >> 6] (bit pattern of a float >= 0, scaled like the accumulator; +inf = keep everything)
             int t_lane[2] = {IINF, IINF};
+            // Round 3: the sweep's product is TRANSPOSED (columns x rows), so a lane holds one ROW of the wave's tile (row lane & 31, 16 of
+            // the tile's 32 columns) and compares its smallest coarse value with a threshold made of ITS OWN row's upper bound and the
+            // tile's column bound: thr = max(U_row, U_cols(tile)) (1 + 1e-5) + error term.  With the tile's largest row bound for every row
+            // (round 2) one loose row of the 32 kept a tile alive for all of them: 15 % of the tested tiles went on.
+            float e_lane[2] = {0.f, 0.f};   // error term of tile q (scaled like the accumulator), same lanes as t_lane
+            float trow = 0.f;               // this lane's row: U_row (1 + 1e-5) 1.0001 c_scale
             unsigned long long skipm[2] = {0ull, 0ull};   // shell test: bit q & 63 of skipm[q >> 6] = this wave leaves tile q out (wave uniform)
             unsigned kept[STAGE_TILES] = {0u, 0u, 0u, 0u};   // coarse sweep: bit st of kept[ct] = tile ct of stage st goes on (wave uniform)
             int rmin[16];   // float bit patterns, see the epilogue note
@@ -287,6 +293,13 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     // outside the per-stage barriers -- every wave does the same work per stage, so nobody waits at the
                     // barrier for a wave that happens to hold the few full tiles.
                     const int t_sel = st < 16 ? t_lane[0] : t_lane[1];   // (st is wave uniform)
+                    const float e_sel = st < 16 ? e_lane[0] : e_lane[1];
+                    // threshold of this lane's row against tile q: max(row part + error term, column part + error term), as a bit pattern
+                    auto lane_thr = [&](int q) -> int {
+                        const int tc = __builtin_amdgcn_readlane(t_sel, q & 63);
+                        const float te = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_sel), q & 63));
+                        return max(__float_as_int(trow + te), tc);   // (both >= +0: integer order is float order; IINF = keep everything)
+                    };
                     const frag* cs = reinterpret_cast<const frag*>(smem) + buf * CO_FRAGS + lane;   // ring slot `buf`: [tile][2 steps][64]
                     const unsigned sk4 = (unsigned) ((st < 16 ? skipm[0] : skipm[1]) >> ((st * STAGE_TILES) & 63)) & 0xfu;   // tiles the shell test leaves out
                     if (sk4) {
@@ -296,13 +309,12 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                         for (int ct = 0; ct < STAGE_TILES; ++ct) {
                             if ((sk4 >> ct) & 1u) continue;
                             const frag c0 = cs[ct * 128], c1 = cs[ct * 128 + 64];
-                            f32x16 acc = mfma_step(a[0], c0, nav);
-                            acc = mfma_step(a[1], c1, acc);
+                            f32x16 acc = mfma_step(c0, a[0], nav);   // transposed: lane = row
+                            acc = mfma_step(c1, a[1], acc);
                             int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
                             for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
-                            const int t_st = __builtin_amdgcn_readlane(t_sel, (st * STAGE_TILES + ct) & 63);
-                            if (__ballot(m <= t_st) != 0ull) kept[ct] |= 1u << st;
+                            if (__ballot(m <= lane_thr(st * STAGE_TILES + ct)) != 0ull) kept[ct] |= 1u << st;
                         }
                         return;
                     }
@@ -310,8 +322,8 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                     b[1] = cs[64];
 #pragma unroll
                     for (int ct = 0; ct < STAGE_TILES; ++ct) {
-                        f32x16 acc = mfma_step(a[0], b[0], nav);
-                        acc = mfma_step(a[1], b[1], acc);
+                        f32x16 acc = mfma_step(b[0], a[0], nav);   // transposed: lane = row
+                        acc = mfma_step(b[1], a[1], acc);
                         if (ct + 1 < STAGE_TILES) {
                             b[0] = cs[(ct + 1) * 128];
                             b[1] = cs[(ct + 1) * 128 + 64];
@@ -321,8 +333,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                         int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
                         for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
-                        const int t_st = __builtin_amdgcn_readlane(t_sel, (st * STAGE_TILES + ct) & 63);
-                        if (__ballot(m <= t_st) != 0ull) kept[ct] |= 1u << st;   // (the tested / rejected counts are taken from the masks after the sweep)
+                        if (__ballot(m <= lane_thr(st * STAGE_TILES + ct)) != 0ull) kept[ct] |= 1u << st;   // (the tested / rejected counts are taken from the masks after the sweep)
                     }
                     return;
                 }
@@ -364,6 +375,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                 // before the first DMA, behind the visit's full barrier: two round trips in a row, 15 % of the launch by the in-kernel timers.)
                 if (use_coarse) {
                     const float ur = ca.u_rt[rb * (BLOCK_ROWS / TILE) + wave];   // this wave's 32 rows
+                    if (ca.u_row) trow = ((fmaxf(ca.u_row[(size_t) row_tile * TILE + (lane & 31)], 0.f) * 1.00001f) * 1.0001f) * c_scale;
                     const float x = ca.xmax[rb / rg_blocks];
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
@@ -388,12 +400,15 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                             xt = fminf(xt, sa.y); yt = fminf(yt, sb.y);
                         }
                         const float s = xt + yt;
-                        float t = fmaxf(fmaxf(ur, us), 0.f) * 1.00001f + ((ca.quad * s) * s + ca.cross * (xt * yt) + ca.lin * s + ca.abs);
+                        const float et = (ca.quad * s) * s + ca.cross * (xt * yt) + ca.lin * s + ca.abs;
+                        // column side (and, without per-row bounds, the tile's largest row bound) + error term; the row side is added per lane
+                        float t = fmaxf(fmaxf(ca.u_row ? 0.f : ur, us), 0.f) * 1.00001f + et;
                         t = (t * 1.0001f) * c_scale;
                         t_lane[r] = t >= 0.f ? __float_as_int(t) : IINF;   // NaN (never expected): keep everything
+                        e_lane[r] = (et * 1.0001f) * c_scale;
                     }
                 }
-                asm volatile("" : : "v"(t_lane[0]), "v"(t_lane[1]) : "memory");
+                asm volatile("" : : "v"(t_lane[0]), "v"(t_lane[1]), "v"(e_lane[0]), "v"(e_lane[1]), "v"(trow) : "memory");
                 // Two stages per barrier (round 3): a stage of the sweep is eight MFMAs per wave, and at one raw barrier per stage the waves
                 // spent as long waiting for the slowest of the eight as computing (a stage visit took 1.9 k cycles against ~1 k of issue).
                 while (to_do) {

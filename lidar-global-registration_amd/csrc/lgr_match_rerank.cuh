@@ -156,7 +156,8 @@ __global__ void comp_cols_kernel(const uint8_t* __restrict__ done, const uint8_t
 __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restrict__ table, int n_groups, int q_pad, const int* __restrict__ permQ,
                                                             const float* __restrict__ nQ, const int* __restrict__ blkclQ,
                                                             const float* __restrict__ gmax, EpsExtra ex, CompView comp, float* __restrict__ u_rb,
-                                                            float* __restrict__ u_rt /* [row tiles]: the same maximum per 32-row tile */) {
+                                                            float* __restrict__ u_rt /* [row tiles]: the same maximum per 32-row tile */,
+                                                            float* __restrict__ u_row /* [rows]: every row's own bound (-1: padding), or nullptr */) {
     extern __shared__ int list_s[];
     const int i = blockIdx.x * BLOCK_ROWS + threadIdx.x;
     const int n_list = comp_list(comp, blockIdx.x * BLOCK_ROWS, q_pad, n_groups, list_s);
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(BLOCK_ROWS) void row_u_kernel(const float* __restri
             ub = fminf(ub, v + e);
         });
     }
+    if (u_row && i < q_pad) u_row[i] = ub;
     for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
     if ((threadIdx.x & 31) == 0 && i < q_pad) u_rt[i / TILE] = ub;
     ub = fmaxf(ub, __shfl_xor(ub, 32));
@@ -360,7 +362,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                              const float* __restrict__ nQ_sets, const float* __restrict__ gmax, const int* __restrict__ cl_of_group,
                              EpsExtra ex, CompView comp, int stride, const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched,
                              int n_leaves, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
-                             const float* __restrict__ uq_rows /* coarse rejection: u_rt (per 32-row tile), or nullptr */,
+                             const float* __restrict__ uq_rows /* coarse rejection: u_row (per row), or nullptr */,
                              const unsigned* __restrict__ uq_cols /* coarse rejection: u_stage bits, or nullptr */, unsigned* __restrict__ worst) {
     extern __shared__ int list_s[];
     const int i = blockIdx.x * stride;   // sampled padded query position
@@ -425,7 +427,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                 // an entry may exceed the exact minimum (or stay +inf) when that minimum is above the query's own U^2 (u_rb of
                 // its row block / u_stage of its column stage).  Lower side (entry >= minimum over all rows - eps): always.
                 bool upper = best < 1e299;
-                if (ROWDIR && uq_rows) upper = upper && best <= (double) uq_rows[i / TILE];
+                if (ROWDIR && uq_rows) upper = upper && best <= (double) uq_rows[i];
                 if (!ROWDIR && uq_cols) upper = upper && best <= (double) __uint_as_float(uq_cols[i / TILE]);
                 float ratio = 0.f;
                 if (v < FLT_BIG) {
