@@ -586,7 +586,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const float* chk_lb = nullptr;
     const unsigned* chk_ustage = nullptr;
     const float* chk_uq_rows = nullptr;
-    const unsigned* chk_uq_cols = nullptr;
+    const float* chk_uq_cols = nullptr;
     if (!prune) {
         LGR_TRY(launch_mfma(nullptr, CoarseArgs{}));
         g_last_stats.stages_done = g_last_stats.stages_all;
@@ -601,7 +601,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
-        const size_t o_urow = pcarve((size_t) ma_pad * 4);
+        const size_t o_urow = pcarve((size_t) ma_pad * 4), o_ucolv = pcarve((size_t) mb_pad * 4);
         const size_t o_ssh = pcarve((size_t) KCL * n_stage_total * 8), o_rsh = pcarve((size_t) n_rb * 8);
         const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
         const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
@@ -613,6 +613,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         float* u_rb = (float*) (pb + o_urb);
         float* u_rt = (float*) (pb + o_urt);
         float* u_row = (float*) (pb + o_urow);   // every row's own upper bound (the sweep's per-row thresholds)
+        float* u_colv = (float*) (pb + o_ucolv); // ... and every column's (the per-element re-test of the tiles the sweep keeps)
         unsigned* u_leaf = (unsigned*) (pb + o_ul);
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
         unsigned* u_stage = (unsigned*) (pb + o_ust);
@@ -635,7 +636,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             ca_on.lin = (float) (2.0 * (double) ex.lin * 1.00001 + 1e-30);
             ca_on.abs = (float) (((double) ex.abs * 1.00001 + 2.0 * (double) sc.a_norm[0] * std::ldexp(1.0, -25) * (double) sc.inv_s2) * 1.000001 + 1e-12);
             ca_on.cnt = coarse_cnt;
-            chk_uq_rows = u_row; chk_uq_cols = both ? u_ct : nullptr;
+            chk_uq_rows = u_row; chk_uq_cols = both ? u_colv : nullptr;
         }
         // shell bound of the masked passes that have upper bounds (with the coarse rejection: the same "an entry may miss what lies above
         // the U^2 of its row and column" contract, and the same upper-bound tables)
@@ -713,7 +714,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                     LGR_HIP(ctx, hipMemsetAsync(u_leaf, 0, (size_t) MAXLEAF * 4, ctx->stream));
                     LGR_HIP(ctx, hipMemsetAsync(u_stage, 0, (size_t) n_stage_total * 4, ctx->stream));
                     col_u_kernel<<<cdiv(mb_pad, 256), 256, (size_t) (n_rg + 8) * 4, ctx->stream>>>((const float*) colmin, n_rg, mb_pad, B.perm, nBp, gmaxA, cl_of_rg, tile_leaf, ex, comp_cols, u_leaf,
-                                                                                                   (colstage || coarse) ? u_stage : nullptr, coarse ? u_ct : nullptr);
+                                                                                                   (colstage || coarse) ? u_stage : nullptr, coarse ? u_ct : nullptr, coarse ? u_colv : nullptr);
                 }
                 float bsq = betas[pass - 1] * betas[pass - 1];
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves,
@@ -725,7 +726,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             CoarseArgs ca = ca_on;
-            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.n_ct_total = tb; }
+            if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb; }
             LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans

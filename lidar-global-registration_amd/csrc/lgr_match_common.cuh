@@ -88,6 +88,7 @@ struct CoarseArgs {
     const float* u_row;         // [rows] U^2 of every row (< 0: padding), or nullptr: the sweep then tests with the tile's u_rt for all rows
     const unsigned* u_stage;    // [column stages] float bits, or nullptr (row direction only)
     const unsigned* u_ct;       // [column tiles] float bits: largest U^2 of the 32 columns of a tile (with u_stage)
+    const float* u_colv;        // [columns] U^2 of every column (0: padding), or nullptr: tiles the first test keeps are not re-tested per element
     int n_ct_total;
     const float* xmax;          // [row groups] max |a'| (gmaxA)
     const float* ymax;          // [KCL][column stages] max |b'| per set (group_max_kernel over 128-column windows)

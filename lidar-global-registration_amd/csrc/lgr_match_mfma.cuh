@@ -58,11 +58,14 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
     constexpr int CO_FRAGS = STAGE_TILES * 2 * 64, CO_NB = 6, CO_D = 4;   // coarse kernel: ring slot (fragments), slots, stages in flight
     static_assert(CO_D == 4 && CO_NB == CO_D + 2, "the counted waits below are written for two pairs of stages in flight");
     constexpr int BS_BYTES = CO ? CO_NB * CO_FRAGS * (int) sizeof(frag) : 2 * STAGE_FRAGS * (int) sizeof(frag);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BS_BYTES + CHUNK_COLS * 4 + (CHUNK_COLS / TILE) * 4 + 16];
+    // (coarse launch: + the chunk's per-column thresholds as bf16, rounded up -- 8 KB; 72.6 KB per workgroup, two per CU)
+    constexpr int UCOL_BYTES = CO ? CHUNK_COLS * 2 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BS_BYTES + CHUNK_COLS * 4 + (CHUNK_COLS / TILE) * 4 + 16 + UCOL_BYTES];
     frag (*Bs)[STAGE_FRAGS] = reinterpret_cast<frag (*)[STAGE_FRAGS]>(smem);
     int* const cmin_s = reinterpret_cast<int*>(smem + BS_BYTES);
     int* const tg_s = cmin_s + CHUNK_COLS;
     int& item_s = tg_s[CHUNK_COLS / TILE];
+    unsigned short* const ucol_s = reinterpret_cast<unsigned short*>(smem + BS_BYTES + CHUNK_COLS * 4 + (CHUNK_COLS / TILE) * 4 + 16);
 
     // Persistent workgroups over a compacted work list.  An item is (column chunk, item_rb row blocks) with at least
     // one stage to compute.  Hardware places workgroup i on XCD i % 8; the list is partitioned per XCD (XCD x owns the
@@ -104,6 +107,17 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
         // column group (train leaf) of every 32-column tile of this chunk; tend[ct] bit st = tile ct of stage st is
         // the last tile of its group (uniform registers: nothing is loaded between the MFMA chains)
         if (tid < CHUNK_COLS / TILE) tg_s[tid] = tid < n_coltiles ? tile_group[col_tile0 + tid] : -1;
+        if (CO && ca.u_colv) {
+            // per-column row of the thresholds, scaled like the accumulator: U_col (1 + 1e-5) 1.0001 c_scale, as bf16 rounded UP (a larger
+            // threshold only keeps more); the chunk's columns are the same for all the item's row blocks
+            for (int i = tid; i < CHUNK_COLS; i += NTHR) {
+                const int col = col_tile0 * TILE + i;
+                float t = 0.f;
+                if (col < mb_pad) t = ((fmaxf(ca.u_colv[col], 0.f) * 1.00001f) * 1.0001f) * c_scale;
+                const unsigned bits = t >= 0.f ? __float_as_uint(t) : 0x7f800000u;   // (NaN, never expected: keep everything)
+                ucol_s[i] = (unsigned short) (min(bits + 0xffffu, 0x7f800000u) >> 16);
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int ct = 0; ct < STAGE_TILES; ++ct) {
@@ -300,6 +314,26 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                         const float te = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_sel), q & 63));
                         return max(__float_as_int(trow + te), tc);   // (both >= +0: integer order is float order; IINF = keep everything)
                     };
+                    // A tile the lane test keeps is tested again PER ELEMENT when the columns' own bounds are at hand: element (row lane & 31,
+                    // column c) goes on only if its coarse value is at most max(U_row, U_col(c)) (1 + 1e-5) + error term.  (The first test uses
+                    // the largest column bound of the tile for all 32 columns: one loose column kept a tile alive for every row -- 5.8 M of
+                    // 54 M tested tiles went on, 0.7 M would with no column side at all.)  Registers of the transposed product: acc[g] =
+                    // column (g & 3) + 8 (g >> 2) + 4 half of the tile.
+                    auto keep_tile = [&](const f32x16& acc, int q) -> bool {
+                        if (!ca.u_colv) return true;
+                        const float te = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e_sel), q & 63));
+                        const unsigned short* uc = ucol_s + (q << 5) + 4 * half;
+                        bool kp = false;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const uint2 w = *reinterpret_cast<const uint2*>(uc + 8 * gq);   // four bf16 thresholds
+                            const float c0 = __uint_as_float(w.x << 16), c1 = __uint_as_float(w.x & 0xffff0000u);
+                            const float c2 = __uint_as_float(w.y << 16), c3 = __uint_as_float(w.y & 0xffff0000u);
+                            kp = kp || acc[4 * gq] <= fmaxf(trow, c0) + te || acc[4 * gq + 1] <= fmaxf(trow, c1) + te
+                                    || acc[4 * gq + 2] <= fmaxf(trow, c2) + te || acc[4 * gq + 3] <= fmaxf(trow, c3) + te;
+                        }
+                        return __ballot(kp) != 0ull;
+                    };
                     const frag* cs = reinterpret_cast<const frag*>(smem) + buf * CO_FRAGS + lane;   // ring slot `buf`: [tile][2 steps][64]
                     const unsigned sk4 = (unsigned) ((st < 16 ? skipm[0] : skipm[1]) >> ((st * STAGE_TILES) & 63)) & 0xfu;   // tiles the shell test leaves out
                     if (sk4) {
@@ -314,7 +348,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                             int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
                             for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
-                            if (__ballot(m <= lane_thr(st * STAGE_TILES + ct)) != 0ull) kept[ct] |= 1u << st;
+                            if (__ballot(m <= lane_thr(st * STAGE_TILES + ct)) != 0ull && keep_tile(acc, st * STAGE_TILES + ct)) kept[ct] |= 1u << st;
                         }
                         return;
                     }
@@ -333,7 +367,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
                         int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));
 #pragma unroll
                         for (int g = 2; g < 16; g += 2) m = min(min(m, __float_as_int(acc[g])), __float_as_int(acc[g + 1]));
-                        if (__ballot(m <= lane_thr(st * STAGE_TILES + ct)) != 0ull) kept[ct] |= 1u << st;   // (the tested / rejected counts are taken from the masks after the sweep)
+                        if (__ballot(m <= lane_thr(st * STAGE_TILES + ct)) != 0ull && keep_tile(acc, st * STAGE_TILES + ct)) kept[ct] |= 1u << st;   // (the tested / rejected counts are taken from the masks after the sweep)
                     }
                     return;
                 }

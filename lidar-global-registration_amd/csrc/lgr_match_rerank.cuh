@@ -187,7 +187,8 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
                              const float* __restrict__ nT_sets, const float* __restrict__ gmaxA, const int* __restrict__ cl_of_rg,
                              const int* __restrict__ tile_group, EpsExtra ex, CompView comp, unsigned* __restrict__ u_leaf /* float bits, >= 0 */,
                              unsigned* __restrict__ u_stage /* [stages] or nullptr: the same maximum per 128-column stage */,
-                             unsigned* __restrict__ u_ct /* [column tiles] or nullptr: per 32-column tile (plain store: one writer) */) {
+                             unsigned* __restrict__ u_ct /* [column tiles] or nullptr: per 32-column tile (plain store: one writer) */,
+                             float* __restrict__ u_colv /* [columns] or nullptr: every column's own bound (0: padding) */) {
     extern __shared__ int list_s[];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     bool several;
@@ -201,6 +202,7 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
         });
         ub = ub > 0.f ? ub : 0.f;
     }
+    if (u_colv && j < t_pad) u_colv[j] = ub;
     // the 32 columns of a tile share a leaf: one atomic per tile (t_pad is a multiple of the block size, so whole waves get here)
     for (int o = 16; o > 0; o >>= 1) ub = fmaxf(ub, __shfl_xor(ub, o));
     if (u_ct && (threadIdx.x & 31) == 0 && j < t_pad) u_ct[j / TILE] = ub > 0.f ? __float_as_uint(ub) : 0u;
@@ -363,7 +365,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                              EpsExtra ex, CompView comp, int stride, const uint8_t* __restrict__ done, const uint8_t* __restrict__ sched,
                              int n_leaves, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
                              const float* __restrict__ uq_rows /* coarse rejection: u_row (per row), or nullptr */,
-                             const unsigned* __restrict__ uq_cols /* coarse rejection: u_stage bits, or nullptr */, unsigned* __restrict__ worst) {
+                             const float* __restrict__ uq_cols /* coarse rejection: u_colv (per column), or nullptr */, unsigned* __restrict__ worst) {
     extern __shared__ int list_s[];
     const int i = blockIdx.x * stride;   // sampled padded query position
     // the computed groups of the row block (rows) / of the leaf (columns) this query lives in
@@ -428,7 +430,7 @@ __global__ void check_kernel(const float* __restrict__ table, int n_groups, int 
                 // its row block / u_stage of its column stage).  Lower side (entry >= minimum over all rows - eps): always.
                 bool upper = best < 1e299;
                 if (ROWDIR && uq_rows) upper = upper && best <= (double) uq_rows[i];
-                if (!ROWDIR && uq_cols) upper = upper && best <= (double) __uint_as_float(uq_cols[i / TILE]);
+                if (!ROWDIR && uq_cols) upper = upper && best <= (double) uq_cols[i];
                 float ratio = 0.f;
                 if (v < FLT_BIG) {
                     ratio = (float) (fmax(best_all - (double) v, 0.0) / (double) e);
