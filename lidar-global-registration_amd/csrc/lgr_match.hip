@@ -519,7 +519,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     unsigned long long* bestA = (unsigned long long*) (rowmin + tab_floats + (tab_floats & 1));
     unsigned long long* bestB = bestA + ma;
     fill_u64<<<cdiv(ma + mb, 256), 256, 0, sB>>>(bestA, ma + mb, ~0ull);   // (the exact rerank's tables: joined with the column operands)
-    // dense mode: +inf everywhere; skipping mode: init_tables_kernel covers what each pass computes (LGR_MATCH_POISON=1, tests: the
+    // dense mode: +inf everywhere; skipping mode: init_tables_kernel covers what each pass computes (lgr_match_options.poison_tables, tests: the
     // rest is filled with 0 -- the most harmful value a stale entry could have -- to show that nothing reads it)
     if (!prune) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
     else if (mo.poison_tables) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0, tab_floats, ctx->stream));

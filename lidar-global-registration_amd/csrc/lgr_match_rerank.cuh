@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
     }
 }
 
-// Self-check of the filter bound (LGR_MATCH_CHECK=1, test sizes only): for sampled queries and every computed group,
+// Self-check of the filter bound (lgr_match_options.self_check; tests, up to 1M x 1M): for sampled queries and every computed group,
 // |filtered minimum - exact minimum of the squared distance (double)| / eps, maximised through atomicMax on the float
 // bits.  eps is a proven bound, so the ratio must stay <= 1; tests assert it on both operand formats.
 template <bool ROWDIR>
