@@ -774,6 +774,24 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 }
             const double tot = (double) n_rb * mb_pad;
             fprintf(stderr, "[lgr] final pass by criterion: rows only %.4f, columns only %.4f, both %.4f of the tiles\n", by_rows / tot, by_cols / tot, by_both / tot);
+            if (coarse) {
+                // how loose are the tile-level maxima the sweep's shell test uses?  quantiles of the rows' own bounds and of (tile max / tile median)
+                std::vector<float> hu(ma_pad);
+                LGR_HIP(ctx, hipMemcpy(hu.data(), u_row, hu.size() * 4, hipMemcpyDeviceToHost));
+                std::vector<float> all, ratio;
+                for (int t = 0; t < ma_pad / TILE; ++t) {
+                    std::vector<float> v;
+                    for (int r = 0; r < TILE; ++r) if (hu[(size_t) t * TILE + r] > 0.f) v.push_back(hu[(size_t) t * TILE + r]);
+                    if (v.size() < 8) continue;
+                    std::sort(v.begin(), v.end());
+                    ratio.push_back(v.back() / v[v.size() / 2]);
+                    all.insert(all.end(), v.begin(), v.end());
+                }
+                std::sort(all.begin(), all.end()); std::sort(ratio.begin(), ratio.end());
+                auto q = [](const std::vector<float>& v, double f) { return v.empty() ? 0.f : v[(size_t) (f * (v.size() - 1))]; };
+                fprintf(stderr, "[lgr] row bounds U^2: q10 %.3g q50 %.3g q90 %.3g q99 %.3g max %.3g; tile max / tile median: q10 %.2f q50 %.2f q90 %.2f q99 %.2f\n",
+                        q(all, 0.1), q(all, 0.5), q(all, 0.9), q(all, 0.99), q(all, 1.0), q(ratio, 0.1), q(ratio, 0.5), q(ratio, 0.9), q(ratio, 0.99));
+            }
         }
     }
     LGR_HIP(ctx, hipGetLastError());
