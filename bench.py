@@ -53,6 +53,9 @@ def parse():
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rank formation + the record all-gather only (no GPU, no HIP library): proves that --gpus N forms N ranks; used by the CPU tests")
+    ap.add_argument("--pairs", type=int, default=0,
+                    help="with --dry-run: shard this many scan pairs over the ranks through distributed.run_pairs (the job shape of data/tests.yaml: "
+                         "156 pairs over 8 ranks = shards of 20 / 19) and check the gathered records on rank 0")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: check sampled queries of the GPU's 1M x 1M matches against the CPU oracle (parity_sample in the JSON line)")
     ap.add_argument("--verify-queries", type=int, default=4096)
@@ -109,11 +112,22 @@ def dry_run(args, world, rank):
     elapsed = time.perf_counter() - t0
     got = [distributed.unpack_record(r) for r in np.ascontiguousarray(allr.numpy()).view(np.float32)]
     ok = [g["pair_id"] for g in got] == list(range(world)) and all(g["iterations"] == 2**31 - 1 - i for i, g in enumerate(got))
+    shards = None
+    if args.pairs > 0:
+        # the whole job shape: pair p -> rank p mod world, every rank aligns its shard (here: a record only that pair id can produce), ONE
+        # all-gather of the padded shards, records back in pair order on every rank
+        def fake(pid):
+            return distributed.pack_record(pid, np.eye(4, dtype=np.float32).reshape(16) * (pid + 1), pid % 2, 2**31 - 1 - pid, 1000 + pid, 0.0, 0.0)
+        allp = distributed.run_pairs(args.pairs, world, rank, fake)
+        gotp = [distributed.unpack_record(r) for r in allp]
+        ok = ok and [g["pair_id"] for g in gotp] == list(range(args.pairs)) and all(g["iterations"] == 2**31 - 1 - i and g["n_inliers"] == 1000 + i
+                                                                                  and g["T"][0, 0] == i + 1 for i, g in enumerate(gotp))
+        shards = [len(distributed.shard_pairs(args.pairs, world, r)) for r in range(world)]
     if rank == 0:
         print(json.dumps({"metric": "scan-pair registrations/sec", "value": None, "unit": "registrations/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
-                          "dry_run": True, "ranks_seen": [g["pair_id"] for g in got], "records_ok": bool(ok),
+                          "dry_run": True, "ranks_seen": [g["pair_id"] for g in got], "records_ok": bool(ok), "pairs": args.pairs, "shard_sizes": shards,
                           "collective": {"process_group": bool(use_pg), "backend": "gloo" if use_pg else None}}), flush=True)
     if use_pg:
         dist.destroy_process_group()

@@ -95,8 +95,8 @@ __device__ __forceinline__ void normals_finish(float* __restrict__ p, float px, 
     C[0] = a0 - a6 * a6; C[1] = a1 - a6 * a7; C[2] = a2 - a6 * a8;
     C[4] = a3 - a7 * a7; C[5] = a4 - a7 * a8; C[8] = a5 - a8 * a8;
     C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-    float U[9], Sg[3], V[9];
-    lgr_svd3(C, U, Sg, V);
+    float Sg[3], V[9];
+    lgr_svd3<false>(C, nullptr, Sg, V);   // the normal is V's last column: U is never built
     float nx = V[2], ny = V[5], nz = V[8];
     float eig_sum = C[0] + C[4] + C[8];
     float curv = (eig_sum != 0.f) ? fabsf(Sg[2] / eig_sum) : 0.f;

@@ -137,15 +137,15 @@ __global__ void gror_umeyama_kernel(const float4* __restrict__ Sc, const float4*
     __syncthreads();
     if (l == 0) {
         float A[9], U[9], Sg[3], V[9];
-        for (int k = 0; k < 9; ++k) A[k] = sig[k];
+        _Pragma("unroll") for (int k = 0; k < 9; ++k) A[k] = sig[k];
         lgr_svd3(A, U, Sg, V);
         float flip = (lgr_det3(U) * lgr_det3(V) < 0.f) ? -1.f : 1.f;
         float R[9];
-        for (int r = 0; r < 3; ++r)
-            for (int q = 0; q < 3; ++q) R[3 * r + q] = (U[3 * r] * V[3 * q] + U[3 * r + 1] * V[3 * q + 1]) + (U[3 * r + 2] * flip) * V[3 * q + 2];
-        for (int k = 0; k < 16; ++k) Tout[k] = 0.f;
-        for (int r = 0; r < 3; ++r) {
-            for (int q = 0; q < 3; ++q) Tout[4 * q + r] = R[3 * r + q];
+        _Pragma("unroll") for (int r = 0; r < 3; ++r)
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) R[3 * r + q] = (U[3 * r] * V[3 * q] + U[3 * r + 1] * V[3 * q + 1]) + (U[3 * r + 2] * flip) * V[3 * q + 2];
+        _Pragma("unroll") for (int k = 0; k < 16; ++k) Tout[k] = 0.f;
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) Tout[4 * q + r] = R[3 * r + q];
             Tout[12 + r] = mean[3 + r] - ((R[3 * r] * mean[0] + R[3 * r + 1] * mean[1]) + R[3 * r + 2] * mean[2]);
         }
         Tout[15] = 1.f;

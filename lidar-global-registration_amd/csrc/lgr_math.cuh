@@ -82,7 +82,14 @@ __device__ __forceinline__ float lgr_det3(const float* M) {
 
 // One-sided (Hestenes) Jacobi SVD of a row-major 3x3: A = U diag(S) V^T, S descending.  12 fixed sweeps over the
 // column pairs (0,1),(0,2),(1,2); a pair is skipped when gamma^2 <= 1e-14 alpha beta.  Rank-deficient completion:
-// sigma_j <= 1e-5 sigma_0 -> u_j from cross products.
+// sigma_j <= 1e-5 sigma_0 -> u_j from cross products.  Op for op the sequence of c_svd3 (oracle/src/orc_math.h).
+//
+// Shape of the code (round 4): NO lane-divergent control flow and NO memory.  A lane that skips a pair keeps its values through
+// selects (the rotation is computed and discarded); the only branch is wave-uniform (no lane of the wave rotates -> nothing is
+// issued).  The rank-deficient completion computes both alternatives and selects.  Every local array is indexed by compile-time
+// constants only, so nothing is demoted to scratch (tools/isa_hazards.py --gate checks the code object: 0 bytes of scratch in every
+// caller); callers that need only V and S instantiate WANT_U = false and pass U = nullptr.
+template <bool WANT_U = true>
 __device__ __forceinline__ void lgr_svd3(const float* A, float* U, float* S, float* V) {
     float W[3][3], Vm[3][3];
 #pragma unroll
@@ -93,87 +100,72 @@ __device__ __forceinline__ void lgr_svd3(const float* A, float* U, float* S, flo
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
-            float alpha = (W[0][p] * W[0][p] + W[1][p] * W[1][p]) + W[2][p] * W[2][p];
-            float beta = (W[0][q] * W[0][q] + W[1][q] * W[1][q]) + W[2][q] * W[2][q];
-            float gamma = (W[0][p] * W[0][q] + W[1][p] * W[1][q]) + W[2][p] * W[2][q];
-            if (gamma * gamma <= 1e-14f * alpha * beta) continue;
-            float zeta = (beta - alpha) / (2.0f * gamma);
-            float az = fabsf(zeta);
+            const float alpha = (W[0][p] * W[0][p] + W[1][p] * W[1][p]) + W[2][p] * W[2][p];
+            const float beta = (W[0][q] * W[0][q] + W[1][q] * W[1][q]) + W[2][q] * W[2][q];
+            const float gamma = (W[0][p] * W[0][q] + W[1][p] * W[1][q]) + W[2][p] * W[2][q];
+            const bool rot = !(gamma * gamma <= 1e-14f * alpha * beta);
+            if (__builtin_amdgcn_ballot_w64(rot) == 0ull) continue;   // wave-uniform
+            const float zeta = (beta - alpha) / (2.0f * gamma);       // (inf / nan in a lane that does not rotate: discarded below)
+            const float az = fabsf(zeta);
             float t = 1.0f / (az + __builtin_sqrtf(1.0f + zeta * zeta));
-            if (zeta < 0.0f) t = -t;
-            float c = 1.0f / __builtin_sqrtf(1.0f + t * t);
-            float s = c * t;
+            t = (zeta < 0.0f) ? -t : t;
+            const float c = 1.0f / __builtin_sqrtf(1.0f + t * t);
+            const float s = c * t;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float wp = W[i][p], wq = W[i][q];
-                W[i][p] = c * wp - s * wq;
-                W[i][q] = s * wp + c * wq;
-                float vp = Vm[i][p], vq = Vm[i][q];
-                Vm[i][p] = c * vp - s * vq;
-                Vm[i][q] = s * vp + c * vq;
+                const float wp = W[i][p], wq = W[i][q];
+                const float nwp = c * wp - s * wq, nwq = s * wp + c * wq;
+                W[i][p] = rot ? nwp : wp;
+                W[i][q] = rot ? nwq : wq;
+                const float vp = Vm[i][p], vq = Vm[i][q];
+                const float nvp = c * vp - s * vq, nvq = s * vp + c * vq;
+                Vm[i][p] = rot ? nvp : vp;
+                Vm[i][q] = rot ? nvq : vq;
             }
         }
     }
-    float sg[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) sg[j] = __builtin_sqrtf((W[0][j] * W[0][j] + W[1][j] * W[1][j]) + W[2][j] * W[2][j]);
+    const float sg0 = __builtin_sqrtf((W[0][0] * W[0][0] + W[1][0] * W[1][0]) + W[2][0] * W[2][0]);
+    const float sg1 = __builtin_sqrtf((W[0][1] * W[0][1] + W[1][1] * W[1][1]) + W[2][1] * W[2][1]);
+    const float sg2 = __builtin_sqrtf((W[0][2] * W[0][2] + W[1][2] * W[1][2]) + W[2][2] * W[2][2]);
     // column order by descending sigma; ties keep the lower column first (same selection network as the oracle)
-    // (sg is read through selects, never through a variable index: a dynamically indexed local array lives in scratch memory)
-    auto sgv = [&](int o) { return (o == 0) ? sg[0] : ((o == 1) ? sg[1] : sg[2]); };
+    auto sgv = [&](int o) { return (o == 0) ? sg0 : ((o == 1) ? sg1 : sg2); };
     int o0 = 0, o1 = 1, o2 = 2;
     if (sgv(o1) > sgv(o0)) { int t = o0; o0 = o1; o1 = t; }
     if (sgv(o2) > sgv(o0)) { int t = o0; o0 = o2; o2 = t; }
     if (sgv(o2) > sgv(o1)) { int t = o1; o1 = o2; o2 = t; }
-    const int ord[3] = {o0, o1, o2};
-    float Uc[3][3];
+    auto col = [&](const float (&M)[3][3], int i, int o) { return (o == 0) ? M[i][0] : ((o == 1) ? M[i][1] : M[i][2]); };
+    const float s0 = sgv(o0), s1 = sgv(o1), s2 = sgv(o2);
+    S[0] = s0; S[1] = s1; S[2] = s2;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        int o = ord[j];
-        float s0 = (o == 0) ? sg[0] : ((o == 1) ? sg[1] : sg[2]);
-        S[j] = s0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float vv = (o == 0) ? Vm[i][0] : ((o == 1) ? Vm[i][1] : Vm[i][2]);
-            float ww = (o == 0) ? W[i][0] : ((o == 1) ? W[i][1] : W[i][2]);
-            V[3 * i + j] = vv;
-            Uc[j][i] = ww;
-        }
-    }
-    float tiny = 1e-5f * S[0];
-    if (!(S[0] > 0.0f)) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0f : 0.0f;
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) Uc[0][i] = Uc[0][i] / S[0];
-    if (S[1] > tiny) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) Uc[1][i] = Uc[1][i] / S[1];
-    } else {
-        float a0 = fabsf(Uc[0][0]), a1 = fabsf(Uc[0][1]), a2 = fabsf(Uc[0][2]);
+    for (int i = 0; i < 3; ++i) { V[3 * i + 0] = col(Vm, i, o0); V[3 * i + 1] = col(Vm, i, o1); V[3 * i + 2] = col(Vm, i, o2); }
+    if constexpr (WANT_U) {
+        const float tiny = 1e-5f * s0;
+        const bool zero = !(s0 > 0.0f);
+        // u0 = w_o0 / s0
+        const float u00 = col(W, 0, o0) / s0, u01 = col(W, 1, o0) / s0, u02 = col(W, 2, o0) / s0;
+        // u1 = w_o1 / s1, or (rank 1) a unit vector orthogonal to u0: cross with the axis of u0's smallest |component|
+        const float d10 = col(W, 0, o1) / s1, d11 = col(W, 1, o1) / s1, d12 = col(W, 2, o1) / s1;
+        float a0 = fabsf(u00);
+        const float a1 = fabsf(u01), a2 = fabsf(u02);
         int ax = 0;
         if (a1 < a0) { ax = 1; a0 = a1; }
         if (a2 < a0) { ax = 2; }
-        float e0 = ax == 0 ? 1.0f : 0.0f, e1 = ax == 1 ? 1.0f : 0.0f, e2 = ax == 2 ? 1.0f : 0.0f;
-        float cx = Uc[0][1] * e2 - Uc[0][2] * e1;
-        float cy = Uc[0][2] * e0 - Uc[0][0] * e2;
-        float cz = Uc[0][0] * e1 - Uc[0][1] * e0;
-        float nn = __builtin_sqrtf((cx * cx + cy * cy) + cz * cz);
-        Uc[1][0] = cx / nn; Uc[1][1] = cy / nn; Uc[1][2] = cz / nn;
+        const float e0 = ax == 0 ? 1.0f : 0.0f, e1 = ax == 1 ? 1.0f : 0.0f, e2 = ax == 2 ? 1.0f : 0.0f;
+        const float cx = u01 * e2 - u02 * e1;
+        const float cy = u02 * e0 - u00 * e2;
+        const float cz = u00 * e1 - u01 * e0;
+        const float nn = __builtin_sqrtf((cx * cx + cy * cy) + cz * cz);
+        const bool full1 = s1 > tiny;
+        const float u10 = full1 ? d10 : cx / nn, u11 = full1 ? d11 : cy / nn, u12 = full1 ? d12 : cz / nn;
+        // u2 = w_o2 / s2, or u0 x u1
+        const bool full2 = s2 > tiny;
+        const float u20 = full2 ? col(W, 0, o2) / s2 : u01 * u12 - u02 * u11;
+        const float u21 = full2 ? col(W, 1, o2) / s2 : u02 * u10 - u00 * u12;
+        const float u22 = full2 ? col(W, 2, o2) / s2 : u00 * u11 - u01 * u10;
+        U[0] = zero ? 1.0f : u00; U[1] = zero ? 0.0f : u10; U[2] = zero ? 0.0f : u20;
+        U[3] = zero ? 0.0f : u01; U[4] = zero ? 1.0f : u11; U[5] = zero ? 0.0f : u21;
+        U[6] = zero ? 0.0f : u02; U[7] = zero ? 0.0f : u12; U[8] = zero ? 1.0f : u22;
     }
-    if (S[2] > tiny) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) Uc[2][i] = Uc[2][i] / S[2];
-    } else {
-        Uc[2][0] = Uc[0][1] * Uc[1][2] - Uc[0][2] * Uc[1][1];
-        Uc[2][1] = Uc[0][2] * Uc[1][0] - Uc[0][0] * Uc[1][2];
-        Uc[2][2] = Uc[0][0] * Uc[1][1] - Uc[0][1] * Uc[1][0];
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) U[3 * i + j] = Uc[j][i];
 }
 
 // eigenvalues of a symmetric 3x3 in double (a00 a01 a02 a11 a12 a22), ascending: cyclic Jacobi, 10 fixed sweeps.

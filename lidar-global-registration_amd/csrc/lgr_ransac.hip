@@ -44,20 +44,25 @@ __device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned ite
 
 // src/sac_prerejective_omp.cpp:33-77 selectCorrespondences, nr_samples = 3 (control flow kept literally)
 __device__ __forceinline__ void select3(const int r[3], int n_corr, int sample[3]) {
-    for (int i = 0; i < 3; i++) {
-        sample[i] = r[i] % n_corr;
-        for (int j = 0; j < i; j++) {
-            if (sample[i] >= sample[j]) {
-                if (sample[i] < n_corr - 1) { sample[i]++; continue; }
-                else if (sample[j] == 0) { sample[i] = 1; continue; }
-                else { sample[i] = 0; }
-            }
-            int tmp = sample[i];
-            for (int k = i; k > j; k--) sample[k] = sample[k - 1];
-            sample[j] = tmp;
-            break;
+    // The reference's loops (for i < 3: draw, for j < i: bump / wrap / insert-and-break) written out for i = 0, 1, 2 on three scalars:
+    // with run-time indices sample[] lived in scratch memory.  `step` is one pass of the j loop's body at position j for the value x
+    // being placed: returns true for `continue` (x was bumped and stays the candidate for the next j), false for "insert x at j".
+    auto step = [&](int& x, int sj) {
+        if (x >= sj) {
+            if (x < n_corr - 1) { x++; return true; }
+            else if (sj == 0) { x = 1; return true; }
+            else { x = 0; }
         }
-    }
+        return false;
+    };
+    int s0 = r[0] % n_corr, s1, s2;
+    int x = r[1] % n_corr;
+    if (step(x, s0)) { s1 = x; } else { s1 = s0; s0 = x; }
+    x = r[2] % n_corr;
+    if (!step(x, s0)) { s2 = s1; s1 = s0; s0 = x; }
+    else if (step(x, s1)) { s2 = x; }
+    else { s2 = s1; s1 = x; }
+    sample[0] = s0; sample[1] = s1; sample[2] = s2;
 }
 
 __global__ void samples_kernel(unsigned long long seed, int first, int n, int n_corr, int32_t* __restrict__ triples) {
@@ -672,29 +677,31 @@ __global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ P
     if (l == 0) {
         float T[16];
         if (sn == 0) {
+_Pragma("unroll")
             for (int i = 0; i < 16; ++i) T[i] = __uint_as_float(0x7fc00000u);   // 0/0 centroids in the reference
         } else {
             float H[9], U[9], Sg[3], V[9], R[9];
-            for (int i = 0; i < 9; ++i) H[i] = Hs[i];
+            _Pragma("unroll") for (int i = 0; i < 9; ++i) H[i] = Hs[i];
             lgr_svd3(H, U, Sg, V);
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j)
+            _Pragma("unroll") for (int i = 0; i < 3; ++i)
+                _Pragma("unroll") for (int j = 0; j < 3; ++j)
                     R[3 * i + j] = (V[3 * i + 0] * U[3 * j + 0] + V[3 * i + 1] * U[3 * j + 1]) + V[3 * i + 2] * U[3 * j + 2];
             if (lgr_det3(R) < 0.f) {
                 V[2] = -V[2]; V[5] = -V[5]; V[8] = -V[8];
-                for (int i = 0; i < 3; ++i)
-                    for (int j = 0; j < 3; ++j)
+                _Pragma("unroll") for (int i = 0; i < 3; ++i)
+                    _Pragma("unroll") for (int j = 0; j < 3; ++j)
                         R[3 * i + j] = (V[3 * i + 0] * U[3 * j + 0] + V[3 * i + 1] * U[3 * j + 1]) + V[3 * i + 2] * U[3 * j + 2];
             }
             float t[3];
-            for (int i = 0; i < 3; ++i) t[i] = cen[3 + i] - ((R[3 * i + 0] * cen[0] + R[3 * i + 1] * cen[1]) + R[3 * i + 2] * cen[2]);
-            for (int i = 0; i < 16; ++i) T[i] = 0.f;
-            for (int i = 0; i < 3; ++i) {
-                for (int j = 0; j < 3; ++j) T[4 * j + i] = R[3 * i + j];
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) t[i] = cen[3 + i] - ((R[3 * i + 0] * cen[0] + R[3 * i + 1] * cen[1]) + R[3 * i + 2] * cen[2]);
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) T[i] = 0.f;
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) {
+                _Pragma("unroll") for (int j = 0; j < 3; ++j) T[4 * j + i] = R[3 * i + j];
                 T[12 + i] = t[i];
             }
             T[15] = 1.f;
         }
+_Pragma("unroll")
         for (int i = 0; i < 16; ++i) Tout[i] = T[i];
     }
 }

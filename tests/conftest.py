@@ -17,6 +17,20 @@ def pytest_configure(config):
 def oracle():
     import oracle as o
     o.build()
+    # threads the oracle may really use: the affinity mask capped by the cgroup CPU quota (a one-GPU box hands the job 16 of the host's
+    # cores; OpenMP's default of one thread per visible core only oversubscribes them)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        tok = open("/sys/fs/cgroup/cpu.max").read().split()
+        if tok[0] != "max":
+            cores = min(cores, max(1, round(int(tok[0]) / int(tok[1]))))
+    except Exception:
+        pass
+    o.set_num_threads(cores)
     return o
 
 

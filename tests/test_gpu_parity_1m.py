@@ -100,6 +100,23 @@ def test_match_1m_sampled_oracle(st, matches, oracle):
     assert mism == 0
 
 
+def test_match_1m_full_oracle_one_direction(st, matches, oracle):
+    """EVERY src -> tgt query of the 1M pair (1 000 000 queries x 1 000 000 train rows = 1e12 exact distances, about
+    three minutes of oracle time on the box's host cores) against oracle.match_bf_subset -- index and distance bits of the production
+    schedule's table.  (The other direction + this one = tools/full_match_check.py, profiles/r3_full_match_check_1M.json.)"""
+    fs, ft = st["src"]["feat_h"], st["tgt"]["feat_h"]
+    gi, gd = matches["h"][0], matches["h"][1]
+    n = fs.shape[0]
+    bad_i = bad_d = 0
+    for lo in range(0, n, 100_000):
+        sel = np.arange(lo, min(n, lo + 100_000), dtype=np.int32)
+        oi, od = oracle.match_bf_subset(fs, sel, ft, BLOCK)
+        ok = oi >= 0
+        bad_i += int((gi[sel] != oi).sum())
+        bad_d += int((bits(gd[sel])[ok] != bits(od)[ok]).sum())
+    assert (bad_i, bad_d) == (0, 0)
+
+
 def test_match_1m_refilter_on_off_identical(lgr, st, matches):
     """the rerank's MFMA re-filter + pair path (default) vs the whole-group exact scan, at BASELINE size."""
     lgr.set_match_options(rerank_refilter=0)

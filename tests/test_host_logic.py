@@ -115,6 +115,16 @@ def test_bench_gpus_2_forms_two_ranks():
     assert out[0]["n_gpus"] == 2 and out[0]["ranks_seen"] == [0, 1] and out[0]["records_ok"] is True
 
 
+def test_bench_gpus_8_dry_run_shards_156_pairs():
+    """The 8-GPU job shape without hardware (data/tests.yaml = 156 pairs, src/main.cpp:384-407): `bench.py --gpus 8 --dry-run --pairs 156`
+    forms 8 gloo ranks, every rank runs its shard of distributed.run_pairs (uneven: 20 / 19 pairs), one all-gather of the padded shards, and rank 0
+    holds all 156 records in pair order."""
+    r, out = _run_bench("--gpus", "8", "--dry-run", "--pairs", "156", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1 and out[0]["n_gpus"] == 8 and out[0]["ranks_seen"] == list(range(8)) and out[0]["records_ok"] is True
+    assert out[0]["pairs"] == 156 and out[0]["shard_sizes"] == [20, 20, 20, 20, 19, 19, 19, 19]
+
+
 def test_bench_rejects_world_size_mismatch():
     r, out = _run_bench("--gpus", "1", "--dry-run", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and not out
