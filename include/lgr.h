@@ -18,7 +18,8 @@
  *     path and download.  *_dev entry points take DEVICE pointers (HIP), enqueue on the context stream and are
  *     asynchronous unless stated; outputs are caller-allocated device buffers.
  *   - one lgr_ctx per host thread / GPU.  A ctx owns its workspace (grown on demand, never inside a timed launch
- *     once warmed up).
+ *     once warmed up) and is not re-entrant.  Several contexts on ONE device are allowed, but by default they take turns call
+ *     by call (lgr_ctx_options.concurrent_contexts): results are then bit-identical to a serial run by construction.
  *   - the HIP extension is mandatory: there is no CPU fallback anywhere behind this ABI.
  */
 #ifndef LGR_H
@@ -110,8 +111,15 @@ typedef struct lgr_ctx lgr_ctx;
  * calling thread (no extra threads, no extra streams; the internal contexts remain as workspaces only) -- for hosts that give a
  * rank fewer cores than 3, at the price of the overlap (about +20 % per 1M-point pair). */
 typedef struct {
-    int32_t helper_contexts;  /* 1 (default) / 0 */
-    int32_t reserved[7];
+    int32_t helper_contexts;      /* 1 (default) / 0 */
+    int32_t concurrent_contexts;  /* 0 (default): the contexts of one device take turns call by call -- the device never executes two
+                                   * contexts' work side by side (a context's own helper streams are not affected).  1: this context does
+                                   * not wait its turn.  Several pairs in flight per GPU bought +5 % throughput at best (DESIGN.md section
+                                   * 10), and in round 3 the builder's MI355X boxes returned normals that differed at rounding level
+                                   * (1-500 ulp) between runs when 2-3 contexts worked at once; round 4 could not reproduce that -- not even
+                                   * with the round-3 binary -- on the unit it was given (DESIGN.md section 10 has the full record), so the
+                                   * cause is not established and the default stays exclusive.  One process per GPU is unaffected. */
+    int32_t reserved[6];
 } lgr_ctx_options;
 
 /* How the brute-force matcher runs (NEVER what it returns: every setting gives the same matches and distance bits).  The

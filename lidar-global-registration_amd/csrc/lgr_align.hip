@@ -124,6 +124,7 @@ static int filter_core(lgr_ctx* ctx, int matching_id, int ns, const int32_t* d_i
 extern "C" int lgr_filter_dev(lgr_ctx* ctx, int matching_id, const float* d_src, int ns, const float* d_tgt, int nt,
                               const int32_t* d_ij_idx, const float* d_ij_dist, const int32_t* d_ji_idx, const float* d_ji_dist,
                               float distance_thr, int cluster_k, lgr_corr* d_out, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && d_ij_idx && d_ij_dist && d_out && n_out && ns > 1 && nt > 1, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, matching_id == LGR_MATCH_LR || matching_id == LGR_MATCH_ONE_SIDED || matching_id == LGR_MATCH_CLUSTER, LGR_ERR_INVALID_ARG);
@@ -410,6 +411,7 @@ __global__ void finalize_kernel(lgr_corr* __restrict__ corr, int n, const int32_
 
 extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params* p,
                                        lgr_corr* d_out, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_src || ns == 0) && (d_tgt || nt == 0) && p && n_out && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
     if (ns < 2 || nt < 2) { *n_out = 0; return LGR_OK; }   // nothing to match (the reference ends with an empty correspondence list)
@@ -556,6 +558,7 @@ extern "C" int lgr_correspondences_dev(lgr_ctx* ctx, const float* d_src, int ns,
 }
 
 extern "C" int lgr_correspondences(lgr_ctx* ctx, const float* src, int ns, const float* tgt, int nt, const lgr_params* p, lgr_corr* out, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (src || ns == 0) && (tgt || nt == 0) && p && n_out && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
     if (ns < 2 || nt < 2) { *n_out = 0; return LGR_OK; }
@@ -575,6 +578,7 @@ extern "C" int lgr_correspondences(lgr_ctx* ctx, const float* src, int ns, const
 }
 
 extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_params* p, lgr_result* res) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_src || ns == 0) && (d_tgt || nt == 0) && p && res && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
     // alignTeaser throws in the reference (src/alignment.cpp:40)
@@ -617,6 +621,7 @@ extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const flo
 }
 
 extern "C" int lgr_align(lgr_ctx* ctx, const float* src, int ns, const float* tgt, int nt, const lgr_params* p, lgr_result* res) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (src || ns == 0) && (tgt || nt == 0) && p && res && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
     if (ns < 2 || nt < 2) return lgr_align_dev(ctx, nullptr, 0, nullptr, 0, p, res);   // identity, not converged

@@ -1,6 +1,47 @@
 // lgr_ctx.hip -- context, workspace, error plumbing of liblgr_hip.so.
 #include "lgr_internal.h"
 
+#include <atomic>
+
+// ---- the device's turn (lgr_turn, lgr_internal.h) ----
+namespace {
+struct DevTurn {
+    std::mutex mu;                 // held by the host thread inside the outermost public entry point of a context
+    unsigned long long last = 0;   // turn_id of the context that held it last
+    hipEvent_t done = nullptr;     // recorded on that context's stream when it gave the turn back
+    bool recorded = false;
+};
+constexpr int MAX_DEV = 64;
+DevTurn g_turn[MAX_DEV];
+std::atomic<unsigned long long> g_next_turn_id{1};
+}  // namespace
+
+lgr_turn::lgr_turn(lgr_ctx* ctx) : c(ctx) {
+    if (!c) return;
+    if (c->turn_depth++ > 0) return;   // an entry point called from another one of the same context
+    if (c->internal || c->opt.concurrent_contexts || c->device < 0 || c->device >= MAX_DEV) return;
+    DevTurn& t = g_turn[c->device];
+    t.mu.lock();
+    held = true;
+    if (t.recorded && t.last != c->turn_id) {   // another context worked last: everything it queued comes first
+        (void) hipSetDevice(c->device);
+        (void) hipStreamWaitEvent(c->stream, t.done, 0);
+    }
+}
+
+lgr_turn::~lgr_turn() {
+    if (!c) return;
+    c->turn_depth--;
+    if (!held) return;
+    DevTurn& t = g_turn[c->device];
+    // (helper streams have been drained or joined into c->stream by the time a public entry point returns: lgr_aux_job, join_b)
+    (void) hipSetDevice(c->device);
+    if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) t.done = nullptr;
+    t.recorded = t.done && hipEventRecord(t.done, c->stream) == hipSuccess;
+    t.last = c->turn_id;
+    t.mu.unlock();
+}
+
 int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line) {
     if (ctx) {
         char b[768];
@@ -70,6 +111,7 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
     for (int i = 0; i < 32; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return LGR_ERR_HIP; }
     for (int i = 0; i < 12; ++i) c->stage_ms[i] = 0.f;
+    c->turn_id = g_next_turn_id++;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     *out = c;
@@ -84,6 +126,7 @@ static int make_internal(lgr_ctx* ctx, lgr_ctx** out, hipEvent_t* ev) {
     LGR_CHECK(ctx, lgr_ctx_create(ctx->device, ctx->opt.helper_contexts ? LGR_STREAM_OWN : (void*) ctx->stream, out) == LGR_OK, LGR_ERR_HIP);
     (*out)->opt = ctx->opt;
     (*out)->mopt = ctx->mopt;
+    (*out)->internal = true;
     if (!*ev) LGR_HIP(ctx, hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return LGR_OK;
 }
@@ -192,7 +235,7 @@ extern "C" int lgr_ctx_set_options(lgr_ctx* ctx, const lgr_ctx_options* opt) {
     lgr_ctx_options o;
     lgr_ctx_default_options(&o);
     if (opt) o = *opt;
-    LGR_CHECK(ctx, o.helper_contexts == 0 || o.helper_contexts == 1, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, (o.helper_contexts == 0 || o.helper_contexts == 1) && (o.concurrent_contexts == 0 || o.concurrent_contexts == 1), LGR_ERR_INVALID_ARG);
     if (o.helper_contexts != ctx->opt.helper_contexts) {
         // the internal contexts are bound to a stream when they are created: drop them (workspaces included), they come back on
         // first use with the stream the new setting asks for
@@ -223,6 +266,7 @@ extern "C" int lgr_ctx_host_threads(lgr_ctx* ctx, int* n) {
 extern "C" int lgr_ctx_sync(lgr_ctx* ctx) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream3) LGR_HIP(ctx, hipStreamSynchronize(ctx->stream3));   // (joined into `stream` by every successful call; an early error exit may leave work on it)
     return LGR_OK;
 }
 
@@ -241,19 +285,23 @@ extern "C" void lgr_match_default_options(lgr_match_options* o) {
     o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0; o->shell_bound = 1;
 }
 
+// (every internal context below this one, however deep: an internal context that runs a pair of jobs itself owns internal contexts too)
+static void propagate_mopt(lgr_ctx* ctx, const lgr_match_options& o) {
+    ctx->mopt = o;
+    if (ctx->aux) propagate_mopt(ctx->aux, o);
+    if (ctx->aux2) propagate_mopt(ctx->aux2, o);
+}
+
 extern "C" int lgr_ctx_set_match_options(lgr_ctx* ctx, const lgr_match_options* opt) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    if (!opt) {
-        lgr_match_default_options(&ctx->mopt);
-        if (ctx->aux) ctx->aux->mopt = ctx->mopt;
-        if (ctx->aux2) ctx->aux2->mopt = ctx->mopt;
-        return LGR_OK;
+    lgr_match_options o;
+    if (!opt) lgr_match_default_options(&o);
+    else {
+        LGR_CHECK(ctx, opt->prune >= -1 && opt->prune <= 1 && opt->leaves >= 0 && opt->leaves <= 64 && opt->near >= 0 &&
+                       opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2, LGR_ERR_INVALID_ARG);
+        o = *opt;
     }
-    LGR_CHECK(ctx, opt->prune >= -1 && opt->prune <= 1 && opt->leaves >= 0 && opt->leaves <= 64 && opt->near >= 0 &&
-                   opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2, LGR_ERR_INVALID_ARG);
-    ctx->mopt = *opt;
-    if (ctx->aux) ctx->aux->mopt = *opt;
-    if (ctx->aux2) ctx->aux2->mopt = *opt;
+    propagate_mopt(ctx, o);
     return LGR_OK;
 }
 

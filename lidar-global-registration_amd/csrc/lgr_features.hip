@@ -97,6 +97,12 @@ __device__ __forceinline__ void normals_finish(float* __restrict__ p, float px, 
     C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
     float Sg[3], V[9];
     lgr_svd3<false>(C, nullptr, Sg, V);   // the normal is V's last column: U is never built
+#ifdef LGR_EXP_NORMALS_SCRATCH   // experiment only (tools/exp_svd_variants.sh): six dead stores to scratch memory, as the round-3 build had
+    {
+        volatile float dead[8];
+        dead[0] = V[0]; dead[2] = V[1]; dead[3] = V[3]; dead[4] = V[4]; dead[6] = V[6]; dead[7] = V[7];
+    }
+#endif
     float nx = V[2], ny = V[5], nz = V[8];
     float eig_sum = C[0] + C[4] + C[8];
     float curv = (eig_sum != 0.f) ? fabsf(Sg[2] / eig_sum) : 0.f;
@@ -770,6 +776,7 @@ static int downsample_core(lgr_ctx* ctx, const float* d_pts, int n, float voxel,
 }
 
 extern "C" int lgr_downsample_dev(lgr_ctx* ctx, const float* d_pts, int n, float voxel, float* d_out, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_pts || n == 0) && (d_out || n == 0) && n_out && n >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -777,6 +784,7 @@ extern "C" int lgr_downsample_dev(lgr_ctx* ctx, const float* d_pts, int n, float
 }
 
 extern "C" int lgr_downsample(lgr_ctx* ctx, const float* pts, int n, float voxel, int order, float* out, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (pts || n == 0) && out && n_out && n >= 0, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, order == LGR_ORDER_REFERENCE || order == LGR_ORDER_CANONICAL, LGR_ERR_INVALID_ARG);
@@ -818,6 +826,7 @@ extern "C" int lgr_downsample(lgr_ctx* ctx, const float* pts, int n, float voxel
 }
 
 extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const float* d_surf, int ns, int k, const float* vp3, int normals_available) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_pts || n == 0) && n >= 0 && k >= 1 && k <= 64, LGR_ERR_INVALID_ARG);
     (void) normals_available;   // no observable effect in the reference (src/common.cpp:597-598 compares a point with itself)
@@ -848,7 +857,11 @@ extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const floa
         const size_t sml = (size_t) NW_WAVES * k * 64 * sizeof(int);
         if (g.n > 0) {
             if (k <= 40) normals_wave_kernel<1><<<grid, 64 * NW_WAVES, sml, ctx->stream>>>(g, S, d_pts, k, vx, vy, vz, r2i);
-            else normals_wave_kernel<2><<<grid, 64 * NW_WAVES, sml, ctx->stream>>>(g, S, d_pts, k, vx, vy, vz, r2i);
+            else {
+                // k >= 58: the index lists (k KB) + the static buffers pass 64 KB per workgroup, which a launch only gets when the kernel says so
+                if (sml + 8192 > 65536) LGR_HIP(ctx, hipFuncSetAttribute((const void*) normals_wave_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sml));
+                normals_wave_kernel<2><<<grid, 64 * NW_WAVES, sml, ctx->stream>>>(g, S, d_pts, k, vx, vy, vz, r2i);
+            }
         }
         if (g.n < n) normals_kernel<<<cdiv(n, NB), NB, sm, ctx->stream>>>(g, S, d_pts, n, k, vx, vy, vz, 2);   // non-finite points: NaN normals
     } else if (!d_surf) {
@@ -862,6 +875,7 @@ extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const floa
 }
 
 extern "C" int lgr_normals_knn(lgr_ctx* ctx, float* pts, int n, const float* surf, int ns, int k, const float* vp3, int normals_available) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (pts || n == 0) && n >= 0, LGR_ERR_INVALID_ARG);
     if (n == 0) return LGR_OK;
@@ -880,6 +894,7 @@ extern "C" int lgr_normals_knn(lgr_ctx* ctx, float* pts, int n, const float* sur
 }
 
 extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float* d_surf, int n, float radius, float* d_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_kps || m == 0) && (d_surf || n == 0) && (d_out || m == 0) && m >= 0 && n >= 0 && radius > 0.f, LGR_ERR_INVALID_ARG);
     if (m == 0) return LGR_OK;
@@ -921,6 +936,7 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
 }
 
 extern "C" int lgr_fpfh(lgr_ctx* ctx, const float* kps, int m, const float* surf, int n, float radius, float* out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (kps || m == 0) && (surf || n == 0) && (out || m == 0) && m >= 0 && n >= 0, LGR_ERR_INVALID_ARG);
     if (m == 0) return LGR_OK;

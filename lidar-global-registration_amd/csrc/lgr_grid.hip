@@ -319,6 +319,7 @@ int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12) {
 }
 
 extern "C" int lgr_bbox_dev(lgr_ctx* ctx, const float* d_pts, int n, float* d_min3_max3) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_pts || n == 0) && d_min3_max3 && n >= 0, LGR_ERR_INVALID_ARG);
     float bb[12];
@@ -391,6 +392,7 @@ int lgr_grid_build(lgr_ctx* ctx, int sb, const float* d_pts, int n, float h, flo
 }
 
 extern "C" int lgr_knn_dev(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, int n, int k, int32_t* d_idx, float* d_d2) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_d2 != nullptr, LGR_ERR_INVALID_ARG);
     return lgr_knn_lists(ctx, d_q, nq, d_pts, n, k, d_idx, d_d2);
@@ -428,6 +430,7 @@ int lgr_knn_lists(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, in
 
 // src/common.cpp:531-547
 extern "C" int lgr_smoothed_densities_dev(lgr_ctx* ctx, const float* d_pts, int n, int k, float* d_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_pts && d_out && n > 1 && k >= 2 && k <= 128, LGR_ERR_INVALID_ARG);   // rassert(pcd->size() > 1 && k >= 2)
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -451,6 +454,7 @@ extern "C" int lgr_smoothed_densities_dev(lgr_ctx* ctx, const float* d_pts, int 
 }
 
 extern "C" int lgr_smoothed_densities(lgr_ctx* ctx, const float* pts, int n, int k, float* out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, pts && out && n > 1, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));

@@ -344,6 +344,7 @@ int gror_degrees(lgr_ctx* ctx, const GrorBuffers& b, int c, float resolution, in
 
 extern "C" int lgr_gror_node_degree_dev(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c, float resolution,
                                         int32_t* d_degree) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && (d_degree || c == 0) && c >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -355,6 +356,7 @@ extern "C" int lgr_gror_node_degree_dev(lgr_ctx* ctx, const float* d_src, const 
 
 extern "C" int lgr_gror_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c, float resolution,
                             int k_optimal, lgr_result* res, uint8_t* d_inlier_mask) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && res && ns > 0 && nt > 0 && (d_corr || c == 0) && c >= 0, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, resolution > 0.f && k_optimal > 0 && k_optimal <= 4096, LGR_ERR_INVALID_ARG);
@@ -443,6 +445,7 @@ extern "C" int lgr_gror_dev(lgr_ctx* ctx, const float* d_src, int ns, const floa
 
 extern "C" int lgr_gror(lgr_ctx* ctx, const float* src, int ns, const float* tgt, int nt, const lgr_corr* corr, int c, float resolution,
                         int k_optimal, lgr_result* res, uint8_t* inlier_mask) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, src && tgt && res && ns > 0 && nt > 0 && (corr || c == 0) && c >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));

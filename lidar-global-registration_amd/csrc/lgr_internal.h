@@ -62,10 +62,27 @@ struct lgr_ctx {
     hipEvent_t aux2_ev = nullptr;
     hipStream_t stream3 = nullptr;  // matcher: the column operands are packed on it while the bounds of pass 0 are computed on `stream` (lgr_ctx_stream3)
     hipEvent_t ev3 = nullptr;
-    lgr_ctx_options opt{1, {0, 0, 0, 0, 0, 0, 0}};   // lgr_ctx_default_options
+    lgr_ctx_options opt{1, 0, {0, 0, 0, 0, 0, 0}};   // lgr_ctx_default_options
     lgr_helper* helper = nullptr;               // of an internal context: the host thread that drives it (opt.helper_contexts)
     lgr_match_stats mstats{};                   // lgr_match_last_*: the last match call of THIS context
     double mcheck[2] = {-1, -1};
+    bool internal = false;                      // an aux / aux2 context: works inside its owner's turn (lgr_turn)
+    int turn_depth = 0;                         // public entry points call each other: only the outermost one takes the device's turn
+    unsigned long long turn_id = 0;             // identity for the turn hand-over (never reused, unlike the address)
+};
+
+// Contexts of ONE device (in one process) take turns: the outermost public entry point on a context holds the device's turn for the
+// duration of the call, and the first call of a context after ANOTHER context's makes its stream wait for everything that context had
+// queued (an event recorded when the turn was given back).  So the device never executes two contexts' work side by side -- what
+// happens INSIDE a context (its helper contexts and streams) is unaffected.  lgr_ctx_options.concurrent_contexts = 1 opts a context
+// out (include/lgr.h says when that is advisable).  Internal contexts never take a turn: they work inside their owner's.
+struct lgr_turn {
+    lgr_ctx* c = nullptr;
+    bool held = false;
+    explicit lgr_turn(lgr_ctx* ctx);
+    ~lgr_turn();
+    lgr_turn(const lgr_turn&) = delete;
+    lgr_turn& operator=(const lgr_turn&) = delete;
 };
 
 int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int line);

@@ -74,6 +74,7 @@ __global__ void iss_emit_kernel(const int* __restrict__ flags, const int* __rest
 
 extern "C" int lgr_iss_keypoints_dev(lgr_ctx* ctx, const float* d_pts, int n, float radius, float gamma21, float gamma32, int min_neighbors,
                                      int32_t* d_idx, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_pts || n == 0) && (d_idx || n == 0) && n_out && n >= 0, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, radius > 0.f && gamma21 > 0.f && gamma32 > 0.f && min_neighbors > 0, LGR_ERR_INVALID_ARG);   // iss_debug.cpp:98-121
@@ -112,6 +113,7 @@ extern "C" int lgr_iss_keypoints_dev(lgr_ctx* ctx, const float* d_pts, int n, fl
 
 extern "C" int lgr_iss_keypoints(lgr_ctx* ctx, const float* pts, int n, float radius, float gamma21, float gamma32, int min_neighbors,
                                  int32_t* idx, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (pts || n == 0) && (idx || n == 0) && n_out && n >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));

@@ -466,6 +466,12 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // operands, which the bounds wait for, take as long as the 3 GB of column sets.)
     hipStream_t sB = ctx->stream;
     if (f16) LGR_TRY(lgr_ctx_stream3(ctx, &sB));
+    // Whatever makes this call return early from here on (an allocation failure, a HIP error): the kernels queued on sB read the
+    // caller's d_b and write this call's buffers, so the stream is drained before the caller gets its buffers back.
+    struct DrainOnExit {
+        hipStream_t s, own;
+        ~DrainOnExit() { if (s != own) (void) hipStreamSynchronize(s); }
+    } drain_sB{sB, ctx->stream};
     auto fork_b = [&]() -> int {
         if (sB != ctx->stream) {
             LGR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
@@ -852,12 +858,14 @@ extern "C" int lgr_match_last_kernel_ms(lgr_ctx* ctx, float* ms) {
 
 extern "C" int lgr_match_bf_dev(lgr_ctx* ctx, const float* d_q33, int mq, const float* d_t33, int mt, int block,
                                 int32_t* d_idx, float* d_dist) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     return match_impl(ctx, d_q33, mq, d_t33, mt, block, d_idx, d_dist, nullptr, nullptr);
 }
 
 extern "C" int lgr_match_bf2_dev(lgr_ctx* ctx, const float* d_a33, int ma, const float* d_b33, int mb, int block,
                                  int32_t* d_ab_idx, float* d_ab_dist, int32_t* d_ba_idx, float* d_ba_dist) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_ba_idx && d_ba_dist) || mb == 0, LGR_ERR_INVALID_ARG);
     return match_impl(ctx, d_a33, ma, d_b33, mb, block, d_ab_idx, d_ab_dist, d_ba_idx, d_ba_dist);
@@ -865,6 +873,7 @@ extern "C" int lgr_match_bf2_dev(lgr_ctx* ctx, const float* d_a33, int ma, const
 
 extern "C" int lgr_match_bf(lgr_ctx* ctx, const float* q33, int mq, const float* t33, int mt, int block,
                             int32_t* idx, float* dist) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (q33 || mq == 0) && (t33 || mt == 0) && (idx || mq == 0) && (dist || mq == 0) && mq >= 0 && mt >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(LB) void local_kernel(GridDev g, const float* __res
 }  // namespace
 
 extern "C" int lgr_match_flann_dev(lgr_ctx* ctx, const float* d_q33, int mq, const float* d_t33, int mt, int32_t* d_idx, float* d_dist) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     // a single train block: the tie rule of the BF kernel is then "lowest index", the oracle's choice for FLANN's unspecified order
     LGR_TRY(lgr_match_bf_dev(ctx, d_q33, mq, d_t33, mt, std::max(mt, 1), d_idx, d_dist));
@@ -122,6 +123,7 @@ extern "C" int lgr_match_flann_dev(lgr_ctx* ctx, const float* d_q33, int mq, con
 
 extern "C" int lgr_match_local_dev(lgr_ctx* ctx, const float* d_qpts, int mq, const float* d_tpts, int mt, const float* d_q33, const float* d_t33,
                                    const float guess16[16], float radius, int32_t* d_idx, float* d_dist) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_qpts || mq == 0) && (d_tpts || mt == 0) && (d_q33 || mq == 0) && (d_t33 || mt == 0) && (d_idx || mq == 0) && (d_dist || mq == 0) &&
                    guess16 && mq >= 0 && mt >= 0 && radius >= 0.f, LGR_ERR_INVALID_ARG);
@@ -150,6 +152,7 @@ extern "C" int lgr_match_local_dev(lgr_ctx* ctx, const float* d_qpts, int mq, co
 }
 
 extern "C" int lgr_match_flann(lgr_ctx* ctx, const float* q33, int mq, const float* t33, int mt, int32_t* idx, float* dist) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (q33 || mq == 0) && (t33 || mt == 0) && (idx || mq == 0) && (dist || mq == 0) && mq >= 0 && mt >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -172,6 +175,7 @@ extern "C" int lgr_match_flann(lgr_ctx* ctx, const float* q33, int mq, const flo
 
 extern "C" int lgr_match_local(lgr_ctx* ctx, const float* qpts, int mq, const float* tpts, int mt, const float* q33, const float* t33,
                                const float guess16[16], float radius, int32_t* idx, float* dist) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (qpts || mq == 0) && (tpts || mt == 0) && (q33 || mq == 0) && (t33 || mt == 0) && (idx || mq == 0) && (dist || mq == 0) &&
                    guess16 && mq >= 0 && mt >= 0, LGR_ERR_INVALID_ARG);

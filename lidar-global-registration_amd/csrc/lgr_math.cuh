@@ -104,7 +104,11 @@ __device__ __forceinline__ void lgr_svd3(const float* A, float* U, float* S, flo
             const float beta = (W[0][q] * W[0][q] + W[1][q] * W[1][q]) + W[2][q] * W[2][q];
             const float gamma = (W[0][p] * W[0][q] + W[1][p] * W[1][q]) + W[2][p] * W[2][q];
             const bool rot = !(gamma * gamma <= 1e-14f * alpha * beta);
+#ifdef LGR_EXP_SVD_DIVERGENT   // experiment only (tools/exp_svd_variants.sh): the round-3 control flow, a lane-divergent skip
+            if (!rot) continue;
+#else
             if (__builtin_amdgcn_ballot_w64(rot) == 0ull) continue;   // wave-uniform
+#endif
             const float zeta = (beta - alpha) / (2.0f * gamma);       // (inf / nan in a lane that does not rotate: discarded below)
             const float az = fabsf(zeta);
             float t = 1.0f / (az + __builtin_sqrtf(1.0f + zeta * zeta));

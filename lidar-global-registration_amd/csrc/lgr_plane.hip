@@ -84,7 +84,11 @@ __global__ __launch_bounds__(PB) void plane_kernel(GridDev g, const float* __res
         // exceed (score so far + points left) / n_sp.  Once that bound (x the hypothesis' correspondence metric under `combination`)
         // is below the best metric of the EARLIER batches and the inlier count cannot reach their record either, the hypothesis can
         // neither become the best (strict >) nor a record: the rest of its subset is only released.  Checked every GATE_ITERS x 256
-        // points on exact block totals, so the decision does not depend on any lane order.
+        // points on exact block totals.  WHICH points form a prefix claimed[0 .. j) depends on how the linear probing of phase A resolved
+        // its collisions (thread timing), so whether and when a hypothesis is abandoned -- and the partial cnt / metric it then reports --
+        // can differ between runs; the bound holds for ANY prefix of the subset, so the best hypothesis, the records and every value a
+        // caller sees for a hypothesis that was NOT abandoned are run independent.  The partial values an abandoned
+        // hypothesis writes stay below best_prev / record_prev (that is the gate's condition), so the batch reduction can pick neither.
         constexpr int GATE_ITERS = 4;
         const bool gated = !pairs_out && !rmse_out && (best_prev > 0.f || record_prev < 0x7fffffff);
         const float fac = (gated && factor) ? factor[h] : 1.f;

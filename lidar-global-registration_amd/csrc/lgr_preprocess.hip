@@ -125,6 +125,7 @@ struct HPtEq {
 }  // namespace
 
 extern "C" int lgr_cloud_density_dev(lgr_ctx* ctx, const float* d_pts, int n, float quantile, float* out_host) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_pts && out_host && n > 1 && quantile >= 0.f && quantile <= 1.f, LGR_ERR_INVALID_ARG);   // rasserts :203, :532
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -132,6 +133,7 @@ extern "C" int lgr_cloud_density_dev(lgr_ctx* ctx, const float* d_pts, int n, fl
 }
 
 extern "C" int lgr_dedupe_dev(lgr_ctx* ctx, const float* d_pts, int n, float* d_out, int* n_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_pts || n == 0) && (d_out || n == 0) && n_out && n >= 0 && d_pts != d_out, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -142,6 +144,7 @@ extern "C" int lgr_dedupe_dev(lgr_ctx* ctx, const float* d_pts, int n, float* d_
 
 extern "C" int lgr_preprocess_dev(lgr_ctx* ctx, const float* d_pts, int n, const float* vp3, int normals_available, float* d_out, int* n_out,
                                   float* voxel_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_pts && d_out && n_out && n > 1 && d_pts != d_out, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -161,6 +164,7 @@ extern "C" int lgr_preprocess_dev(lgr_ctx* ctx, const float* d_pts, int n, const
 
 extern "C" int lgr_preprocess(lgr_ctx* ctx, const float* pts, int n, const float* vp3, int normals_available, int order, float* out, int* n_out,
                               float* voxel_out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, pts && out && n_out && n > 1, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, order == LGR_ORDER_REFERENCE || order == LGR_ORDER_CANONICAL, LGR_ERR_INVALID_ARG);

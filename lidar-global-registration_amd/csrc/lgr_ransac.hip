@@ -895,6 +895,7 @@ int evaluate_one_plane(lgr_ctx* ctx, const float* d_T, const Packed& pk, int c, 
 extern "C" int lgr_evaluate_plane_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const float T16[16], int score_id,
                                       uint64_t seed, uint32_t counter, int* n_inliers, float* rmse, float* metric, float* threshold,
                                       int32_t* pairs, int* n_pairs) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && T16 && n_inliers && rmse && metric && ns > 0 && nt > 1 && score_id >= 0 && score_id <= 3, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -918,6 +919,7 @@ extern "C" int lgr_evaluate_plane_dev(lgr_ctx* ctx, const float* d_src, int ns, 
 }
 
 extern "C" int lgr_ransac_samples_dev(lgr_ctx* ctx, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, n >= 0 && n_corr >= 3 && (d_triples || n == 0) && first >= 0, LGR_ERR_INVALID_ARG);
     if (n == 0) return LGR_OK;
@@ -930,6 +932,7 @@ extern "C" int lgr_ransac_samples_dev(lgr_ctx* ctx, uint64_t seed, int first, in
 extern "C" int lgr_evaluate_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                                 const float T16[16], int metric_id, int score_id,
                                 uint8_t* d_mask, int* n_inliers, float* rmse, float* metric) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && T16 && c >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, metric_id == LGR_METRIC_UNIFORMITY || metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);
@@ -1043,6 +1046,7 @@ static int check_params(lgr_ctx* ctx, const lgr_params* p) {
 extern "C" int lgr_ransac_replay_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                                      const lgr_params* p, const int32_t* d_triples, int n,
                                      uint8_t* d_ok, float* d_T16, int32_t* d_n_inliers, float* d_metric) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_TRY(check_params(ctx, p));
     LGR_CHECK(ctx, p->metric_id == LGR_METRIC_UNIFORMITY || p->metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);   // plane metrics: lgr_evaluate_plane_dev
@@ -1097,6 +1101,7 @@ extern "C" int lgr_ransac_replay_dev(lgr_ctx* ctx, const float* d_src, int ns, c
 
 extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                               const lgr_params* p, lgr_result* res, uint8_t* d_final_mask) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_TRY(check_params(ctx, p));
     LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && res && c >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
@@ -1259,6 +1264,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
 
 extern "C" int lgr_ransac(lgr_ctx* ctx, const float* src, int ns, const float* tgt, int nt, const lgr_corr* corr, int c,
                           const lgr_params* p, lgr_result* res, uint8_t* final_mask) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, src && tgt && (corr || c == 0) && res && ns > 0 && nt > 0 && c >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -1282,6 +1288,7 @@ extern "C" int lgr_ransac(lgr_ctx* ctx, const float* src, int ns, const float* t
 
 extern "C" int lgr_refit_svd_dev(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c,
                                  const uint8_t* d_mask, float T16[16]) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && T16 && c >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -1301,6 +1308,7 @@ extern "C" int lgr_refit_svd_dev(lgr_ctx* ctx, const float* d_src, const float* 
 }
 
 extern "C" int lgr_refit_svd(lgr_ctx* ctx, const float* src, const float* tgt, int ns, int nt, const lgr_corr* inliers, int n, float T16[16]) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, src && tgt && (inliers || n == 0) && T16 && ns > 0 && nt > 0 && n >= 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -1321,6 +1329,7 @@ extern "C" int lgr_refit_svd(lgr_ctx* ctx, const float* src, const float* tgt, i
 // hypotheses.csv side output of the reference (inlier / overlap areas) is not produced.
 extern "C" int lgr_choose_best_hypothesis_dev(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                                               const float* tns16, int n, float T_out16[16], int* best_index, float* uniformities) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, d_src && d_tgt && (d_corr || c == 0) && (tns16 || n == 0) && T_out16 && n >= 0 && c >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));

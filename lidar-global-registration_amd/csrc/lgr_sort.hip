@@ -199,6 +199,7 @@ int lgr_sort_pairs_u64(lgr_ctx* ctx, const unsigned long long* kin, unsigned lon
 }
 
 extern "C" int lgr_sort_pairs_u32_dev(lgr_ctx* ctx, const uint32_t* kin, uint32_t* kout, const int32_t* vin, int32_t* vout, size_t n, int begin_bit, int end_bit) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, begin_bit >= 0 && end_bit <= 32 && begin_bit <= end_bit, LGR_ERR_INVALID_ARG);
     LGR_HIP(ctx, hipSetDevice(ctx->device));
@@ -206,6 +207,7 @@ extern "C" int lgr_sort_pairs_u32_dev(lgr_ctx* ctx, const uint32_t* kin, uint32_
 }
 extern "C" int lgr_sort_pairs_u64_dev(lgr_ctx* ctx, const uint64_t* kin, uint64_t* kout, const int32_t* vin, int32_t* vout, size_t n,
                                       const int* shifts, const int* widths, int n_ranges) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, n_ranges >= 0 && n_ranges <= 8 && (n_ranges == 0 || (shifts && widths)), LGR_ERR_INVALID_ARG);
     for (int i = 0; i < n_ranges; ++i) LGR_CHECK(ctx, shifts[i] >= 0 && widths[i] >= 0 && shifts[i] + widths[i] <= 64, LGR_ERR_INVALID_ARG);

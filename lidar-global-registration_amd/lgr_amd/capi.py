@@ -64,7 +64,7 @@ class MatchOptions(C.Structure):
 
 class CtxOptions(C.Structure):
     """lgr_ctx_options (include/lgr.h): how the context uses host threads and streams, never what it returns."""
-    _fields_ = [("helper_contexts", C.c_int32), ("reserved", C.c_int32 * 7)]
+    _fields_ = [("helper_contexts", C.c_int32), ("concurrent_contexts", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 FORMAT_AUTO, FORMAT_F32, FORMAT_F16, FORMAT_F16R = -1, 0, 1, 2

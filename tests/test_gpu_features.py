@@ -167,6 +167,17 @@ def test_normals(lgr, oracle, pair):
     np.testing.assert_array_equal(bits(tq.cpu().numpy()), bits(want2))
 
 
+@pytest.mark.parametrize("k", [16, 41, 57, 58, 64])
+def test_normals_other_k(lgr, oracle, pair, k):
+    """the wave-per-query search at the edges of its two instantiations (k <= 40 / k > 40) and at the list sizes whose LDS passes 64 KB per
+    workgroup (k >= 58: ADVICE r3)"""
+    ds = oracle.downsample(pair["src"], 0.0236)
+    want = oracle.normals_knn(ds, k, vp=pair["vp_src"])
+    t = cuda(ds)
+    lgr.normals_knn(t, k, vp=pair["vp_src"])
+    np.testing.assert_array_equal(bits(t.cpu().numpy()), bits(want))
+
+
 def test_fpfh(lgr, oracle, pair):
     ds = oracle.normals_knn(oracle.downsample(pair["src"], 0.0236), 30, vp=pair["vp_src"])
     kps = pair["src"][:6000].copy()

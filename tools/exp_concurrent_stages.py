@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--matching", type=int, default=0)
     ap.add_argument("--distinct", type=int, default=2, help="distinct pairs; thread w starts at pair w and alternates")
     ap.add_argument("--single-context", action="store_true")
+    ap.add_argument("--take-turns", action="store_true", help="leave lgr_ctx_options.concurrent_contexts at its default 0 (the product default)")
     ap.add_argument("--align-only", action="store_true", help="only the one-call pipeline (no stand-alone stages, no syncs in between)")
     a = ap.parse_args()
     import torch
@@ -101,8 +102,8 @@ def main():
 
     def worker(w):
         ctx = capi.Context(0, stream=-1)
-        if a.single_context:
-            ctx.set_options(helper_contexts=0)
+        # (concurrent_contexts = 1: the experiment is about contexts that really overlap on the device; by default they take turns)
+        ctx.set_options(helper_contexts=0 if a.single_context else 1, concurrent_contexts=0 if a.take_turns else 1)
         for it in range(a.rounds):
             k = (w + it) % a.distinct
             got = run(ctx, k)
@@ -136,7 +137,9 @@ def main():
         t.start()
     for t in th:
         t.join()
-    print("concurrent runs: %d threads x %d rounds, %d with a difference" % (a.threads, a.rounds, len(bad)), flush=True)
+    from lgr_amd import diagnostics
+    print("concurrent runs: %d threads x %d rounds, %d with a difference (GPU serial %s, library %s)" % (a.threads, a.rounds, len(bad), diagnostics.gpu_serial(),
+                                                                                                         os.environ.get("LGR_HIP_LIB", "in-tree")), flush=True)
     raise SystemExit(1 if bad else 0)
 
 

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic pairs cycled through")
     ap.add_argument("--inflight", type=int, nargs="+", default=[1, 2, 3])
     ap.add_argument("--single-context", action="store_true")
+    ap.add_argument("--take-turns", action="store_true", help="leave lgr_ctx_options.concurrent_contexts at its default 0")
     ap.add_argument("--matching", default="lr")
     a = ap.parse_args()
     import torch
@@ -35,9 +36,8 @@ def main():
     ref = {}
     for P in a.inflight:
         ctxs = [capi.Context(0, stream=-1) for _ in range(P)]         # LGR_STREAM_OWN: a non-blocking stream per context
-        if a.single_context:
-            for c in ctxs:
-                c.set_options(helper_contexts=0)
+        for c in ctxs:   # (concurrent_contexts = 1: contexts that really overlap on the device; the product default makes them take turns)
+            c.set_options(helper_contexts=0 if a.single_context else 1, concurrent_contexts=0 if a.take_turns else 1)
         results = [None] * a.pairs
 
         def worker(w, lo, hi, out):
