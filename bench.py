@@ -60,6 +60,8 @@ def parse():
                     help="after the timed region: check sampled queries of the GPU's 1M x 1M matches against the CPU oracle (parity_sample in the JSON line)")
     ap.add_argument("--verify-queries", type=int, default=4096)
     ap.add_argument("--no-stage-rooflines", action="store_true", help="skip the stand-alone stage timings behind `roofline_stages` (profiling runs)")
+    ap.add_argument("--no-matcher-extremes", action="store_true",
+                    help="skip `matcher_extremes` (the dense schedule on the same pair and the production schedule on structureless rows, outside the timed region)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: still form a (one-rank) process group on --backend and run the path's all-gather / barrier / all-reduce "
                          "through it, i.e. execute the RCCL calls of the N > 1 path on a one-GPU box")
@@ -257,6 +259,52 @@ def stage_rooflines(ctx, capi, torch, pair, src, tgt, params, n_steps_res):
     return out
 
 
+def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
+    """What the headline depends on (outside the timed region).  The matcher's cost is a property of the descriptor
+    distribution: its exact bound-based skipping computes ~10 % of the (row block, stage) tiles of THIS scene's FPFH rows.  Two more
+    measurements of the matcher stage (lgr_match_bf2_dev alone, second of two runs, host wall between stream synchronisations):
+      dense          the same pair's rows with lgr_match_options.prune = 0: every tile computed on the f16 MFMA path, no bounds, no masks
+      structureless  the production schedule on rows no bound can separate: M x 33 rows of three 11-bin blocks, bins i.i.d. uniform,
+                     each block normalised to sum 100 (the FPFH shape with no structure: the worst case for every bound)
+    each with the fraction of tiles it executed and its match_mfma time.  Results are identical in every mode (tests/test_gpu_parity_1m.py);
+    only the time moves."""
+    r = 0.25
+    voxel = float(np.sqrt(np.float32(np.pi * r * r / 352.0)))
+    feats = []
+    for cloud, vp in ((src, pair["vp_src"]), (tgt, pair["vp_tgt"])):
+        surf = ctx.downsample(cloud, voxel).clone()
+        feats.append(ctx.fpfh(cloud, ctx.normals_knn(surf.clone(), 30, vp=vp), r))
+    ctx.sync(); torch.cuda.synchronize()
+
+    def timed(a, b):
+        out = {}
+        for _ in range(2):
+            ctx.sync(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.match_bf2(a, b, params.bf_block_size)
+            ctx.sync(); torch.cuda.synchronize()
+            out = {"match_stage_ms": 1e3 * (time.perf_counter() - t0), "match_mfma_ms": ctx.match_kernel_ms(), "executed_tile_fraction": ctx.match_work(),
+                   "issued_tile_fraction": ctx.match_issued(), "operand_format": ctx.match_format()}
+        return out
+
+    res = {"this_pair": timed(feats[0], feats[1])}
+    ctx.set_match_options(prune=0)
+    try:
+        res["dense"] = timed(feats[0], feats[1])
+    finally:
+        ctx.set_match_options()
+    g = torch.Generator(device="cuda"); g.manual_seed(566)
+    rows = []
+    for n in (int(src.shape[0]), int(tgt.shape[0])):
+        x = torch.rand((n, 3, 11), generator=g, device="cuda", dtype=torch.float32) + 1e-3
+        rows.append((x * (100.0 / x.sum(2, keepdim=True))).reshape(n, 33).contiguous())
+    torch.cuda.synchronize()
+    res["structureless"] = timed(rows[0], rows[1])
+    res["note"] = ("matcher stage alone (lgr_match_bf2_dev, both directions), second of two runs; this_pair = the bench pair's FPFH rows on the production "
+                   "schedule, dense = the same rows with prune = 0, structureless = uniform random 11-bin blocks normalised to 100 on the production schedule")
+    return res
+
+
 def cpu_baseline(pair, g, args, matching, capi):
     """The CPU oracle (the builder's restatement of the reference's algorithm, `kind: "port"` -- the reference itself needs PCL /
     OpenCV and cannot be built here) on the SAME 1M-point pair on this host's cores.  Every stage but the matcher runs IN FULL
@@ -391,13 +439,14 @@ def main():
         res = step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, stage_ms, work, coarse, shell = [], [], [], [], []
+    kernel_ms, stage_ms, work, issued_w, coarse, shell = [], [], [], [], [], []
     for _ in range(args.steps):
         res = step()
         kernel_ms.append(ctx.match_kernel_ms())
         mstats = ctx.match_stats()
         mstats["refilter_pairs_ab"], mstats["refilter_pairs_ba"] = ctx.match_pairs()
         work.append(ctx.match_work())
+        issued_w.append((ctx.match_issued(), ctx.match_issued_pairs()))
         coarse.append(ctx.match_coarse())
         shell.append(ctx.match_shell())
         stage_ms.append(list(res.stage_ms)[:7])
@@ -419,7 +468,8 @@ def main():
         # the kernel issues 7 x v_mfma_f32_32x32x16_f16 steps on two-term f16 splits of the f32 operands (K = 112:
         # 224 FLOP) or 17 x v_mfma_f32_32x32x2_f32 (K = 34: 68 FLOP); `peak` is the dense MFMA peak of that operand
         # type.  The algorithmic 69 FLOP per pair over the same time is reported beside it.
-        executed = float(np.mean(work))
+        executed = float(np.mean(work))          # every (row block, stage) once: <= 1
+        issued_frac, issued_pairs = [float(x) for x in np.mean(np.array(issued_w), 0)]   # the passes summed (a stage straddling two leaves can be computed by two passes): >= executed
         fmt = ctx.match_format()
         flop_per_pair = {"f16": 224.0, "f16r": 192.0, "f32": 68.0}[fmt]
         peak = MFMA_F32_PEAK_TFLOPS if fmt == "f32" else MFMA_F16_PEAK_TFLOPS
@@ -427,7 +477,9 @@ def main():
         c_tested, c_abandoned = [float(x) for x in np.mean(np.array(coarse), 0)]
         # ... and tiles the shell test leaves out of a swept stage issue none
         c_skipped = float(np.mean(shell))
-        issued = flop_per_pair * m * m * executed - ((c_abandoned * (192.0 - 64.0) + c_skipped * 192.0) * 1024.0 if fmt == "f16r" else 0.0)
+        # (issued_pairs counts the PADDED operands' element pairs -- clusters are padded to whole row blocks / column tiles -- which is what the
+        #  kernel multiplies: SQ_INSTS_MFMA x 32768 of the PMC pass agrees with this count, tools/pmc_summary.py)
+        issued = flop_per_pair * issued_pairs - ((c_abandoned * (192.0 - 64.0) + c_skipped * 192.0) * 1024.0 if fmt == "f16r" else 0.0)
         achieved = issued / (k_ms * 1e-3) / 1e12
         effective = alg_flop / (k_ms * 1e-3) / 1e12
         # HBM-side bytes of the same kernel (both launches of one step) from the committed PMC passes (tools/pmc_bench.sh:
@@ -455,7 +507,7 @@ def main():
                          "operand_format": {"f16": "f16 two-term splits, f32 accumulate, K = 112 (224 MFMA FLOP/pair)",
                                             "f16r": "f16 two-term splits of 30 Helmert coordinates, f32 accumulate, K = 96 (192 MFMA FLOP/pair)",
                                             "f32": "f32 (68 MFMA FLOP/pair)"}[fmt],
-                         "kernel_ms": k_ms, "executed_tile_fraction": executed, "coarse_tiles_tested": c_tested, "coarse_tiles_abandoned": c_abandoned, "shell_tiles_skipped": c_skipped,
+                         "kernel_ms": k_ms, "executed_tile_fraction": executed, "issued_tile_fraction": issued_frac, "coarse_tiles_tested": c_tested, "coarse_tiles_abandoned": c_abandoned, "shell_tiles_skipped": c_skipped,
                          "mfma_flop_issued": issued, "effective_tflops_algorithmic": effective,
                          "rerank": mstats, "algorithmic_flop_per_launch": alg_flop, "directions_per_launch": n_dir},
             "stage_ms": dict(zip(["downsample", "normals", "fpfh", "match", "filter", "ransac", "refit"],
@@ -469,6 +521,8 @@ def main():
         }
         if world == 1 and not args.no_stage_rooflines:
             out["roofline_stages"] = stage_rooflines(ctx, capi, torch, pair, src, tgt, params, res)
+        if world == 1 and not args.no_matcher_extremes:
+            out["matcher_extremes"] = matcher_extremes(ctx, capi, torch, pair, src, tgt, params)
         if (not args.no_cpu_baseline or args.verify) and world == 1:   # CPU leg: rank 0 of the 1-GPU run only, outside the timed region
             voxel = float(np.sqrt(np.float32(np.pi * 0.25 * 0.25 / 352.0)))
             g = gpu_stages(ctx, capi, pair, src, tgt, params, voxel, 0.25)

@@ -246,8 +246,11 @@ int lgr_match_local_dev(lgr_ctx*, const float* d_query_pts, int mq, const float*
 int lgr_match_last_stats(lgr_ctx*, unsigned* out6);
 int lgr_match_last_kernel_ms(lgr_ctx*, float* ms);
 /* fraction of the (256-row block x 128-column stage) tiles the MFMA passes of the last match call computed; the exact
- * bound-based skipping leaves the rest out.  1.0 = dense. */
+ * bound-based skipping leaves the rest out.  1.0 = dense.  Every (row block, stage) counts once, so the figure is
+ * never above 1; lgr_match_last_issued sums the passes (a stage that straddles two leaves may be computed by two passes): the work
+ * that was issued, >= the executed fraction. */
 int lgr_match_last_work(lgr_ctx*, double* executed_fraction);
+int lgr_match_last_issued(lgr_ctx*, double* out2 /* [0] issued fraction, [1] issued (row, column) element pairs of the padded operands */);
 /* coarse rejection inside the MFMA filter kernel (rotated format only; lgr_match_options.coarse_rejection = 0 turns it off): 32 x 32 tiles
  * tested after their first two MFMA steps in the last match call, and tiles abandoned there. */
 int lgr_match_last_coarse(lgr_ctx*, double* out2);

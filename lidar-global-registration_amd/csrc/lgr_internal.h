@@ -24,7 +24,7 @@ struct lgr_buf {
 
 // statistics of a context's last match call (bench / diagnostics: lgr_match_last_*): candidate (query, group) items and
 // dense-fallback queries per direction, group counts, the column stages the MFMA passes executed out of all (row block, stage) pairs
-struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all; int f16; double coarse_tested, coarse_rejected; unsigned pairs_ab, pairs_ba; double shell_skipped; };
+struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all, stages_unique; int f16; double coarse_tested, coarse_rejected; unsigned pairs_ab, pairs_ba; double shell_skipped; };
 
 // The one persistent helper host thread of an internal context (lgr_ctx::aux / aux2): started on first use, parked on a condition
 // variable between jobs, joined when the context is destroyed.  One job at a time: post, then wait.

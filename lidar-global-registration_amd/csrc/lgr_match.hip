@@ -46,10 +46,21 @@ extern "C" int lgr_match_last_stats(lgr_ctx* ctx, unsigned* out6) {
     out6[3] = s.dense_ba; out6[4] = (unsigned) s.sub_cols; out6[5] = (unsigned) s.rg_rows;
     return LGR_OK;
 }
-// fraction of the (row block x column stage) tiles of the last match call that the MFMA passes computed (1 = dense)
+// fraction of the (row block x column stage) tiles of the last match call that the MFMA passes computed (1 = dense): every (row block,
+// stage) counted ONCE, however many passes touched it (a stage that straddles two leaves is computed whole by each pass that schedules
+// one of them) -- never above 1
 extern "C" int lgr_match_last_work(lgr_ctx* ctx, double* executed_fraction) {
     if (!ctx || !executed_fraction) return LGR_ERR_INVALID_ARG;
-    *executed_fraction = ctx->mstats.stages_all > 0 ? ctx->mstats.stages_done / ctx->mstats.stages_all : 1.0;
+    *executed_fraction = ctx->mstats.stages_all > 0 ? ctx->mstats.stages_unique / ctx->mstats.stages_all : 1.0;
+    return LGR_OK;
+}
+// the same with every pass's stages summed: the work that was ISSUED (what the bench prices MFMA FLOP with); >= lgr_match_last_work
+// out2[1]: the same as a number of (row, column) element pairs of the PADDED operands (stages x 256 rows x 128 columns) -- what the MFMA
+// FLOP count is made of (clusters are padded to whole row blocks / column tiles: a few per cent more than Mq x Mt)
+extern "C" int lgr_match_last_issued(lgr_ctx* ctx, double* out2) {
+    if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = ctx->mstats.stages_all > 0 ? ctx->mstats.stages_done / ctx->mstats.stages_all : 1.0;
+    out2[1] = ctx->mstats.stages_done * (double) BLOCK_ROWS * (double) STAGE_COLS;
     return LGR_OK;
 }
 extern "C" int lgr_match_last_pairs(lgr_ctx* ctx, unsigned* out2) {
@@ -595,14 +606,14 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const float* chk_uq_cols = nullptr;
     if (!prune) {
         LGR_TRY(launch_mfma(nullptr, CoarseArgs{}));
-        g_last_stats.stages_done = g_last_stats.stages_all;
+        g_last_stats.stages_done = g_last_stats.stages_unique = g_last_stats.stages_all;
     } else {
         // section 3b: lower bounds, pass 1 (nearest tiles), upper bounds, pass 2 (everything the bounds cannot exclude)
         char* pb;
         size_t poff = 0;
         auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
         const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
-        const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
+        const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_macc = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats));
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
@@ -728,7 +739,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             }
             if (pass == 0 && shell0.rshA) LGR_TRY(join_b());   // (the stage shells come from the column norms, written by the packing)
             mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
-                                                                                                         pass > 0 ? shell : shell0, mask, mstats);
+                                                                                                         pass > 0 ? shell : shell0, mask, (unsigned*) (pb + o_macc), mstats);
             init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
                                                                      colmin, (size_t) mb_pad);
             CoarseArgs ca = ca_on;
@@ -746,8 +757,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         g_last_stats.coarse_tested = (double) h_cc[0];
         g_last_stats.coarse_rejected = (double) h_cc[1];
         g_last_stats.shell_skipped = (double) h_cc[2];
+        static_assert(sizeof betas / sizeof betas[0] + 1 <= 7, "MaskStats: slot 7 holds the stages counted once");
         g_last_stats.stages_done = 0;
         for (int k = 0; k <= n_beta; ++k) g_last_stats.stages_done += (double) hs->stages[k];
+        g_last_stats.stages_unique = (double) hs->stages[7];
         if (env_int("LGR_MATCH_DEBUG", 0)) {
             fprintf(stderr, "[lgr] stages per pass:");
             for (int k = 0; k <= n_beta; ++k) fprintf(stderr, " %llu", hs->stages[k]);

@@ -298,11 +298,12 @@ struct ShellArgs {
 };
 __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __restrict__ sched, const int* __restrict__ tile_group,
                                                    int n_rb, int n_cc, int n_leaves, int n_stage_total, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
-                                                   ShellArgs sh, unsigned* __restrict__ mask, MaskStats* __restrict__ stats) {
+                                                   ShellArgs sh, unsigned* __restrict__ mask, unsigned* __restrict__ mask_acc /* [n_rb][n_cc]: stages of all passes so far */,
+                                                   MaskStats* __restrict__ stats) {
     static_assert(STAGES_PER_CHUNK == 32, "a half wave per (row block, chunk) pair");
     const long long n_pairs = (long long) n_rb * n_cc;
     const int s = threadIdx.x & 31;
-    unsigned long long count = 0ull;
+    unsigned long long count = 0ull, fresh = 0ull;   // stages of this pass; those among them that no earlier pass computed
     // (the two half waves of a wave hold consecutive pairs; the upper one may leave the loop one round earlier -- the ballot then
     // simply lacks its lanes, and the count is taken from lane 0)
     for (long long idx = ((long long) blockIdx.x * blockDim.x + threadIdx.x) >> 5; idx < n_pairs; idx += ((long long) gridDim.x * blockDim.x) >> 5) {
@@ -341,16 +342,27 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
             }
         }
         const unsigned long long bal = __ballot(on);
-        if (s == 0) mask[idx] = (unsigned) (bal >> (threadIdx.x & 32));
+        int fresh_here = 0;
+        if (s == 0) {
+            const unsigned m = (unsigned) (bal >> (threadIdx.x & 32));
+            mask[idx] = m;
+            // a stage that straddles two leaves is computed whole by every pass that schedules one of them: count it ONCE for the
+            // executed fraction (lgr_match_last_work); the per-pass sums are the work that was really issued (lgr_match_last_issued)
+            const unsigned before = mask_acc[idx];
+            mask_acc[idx] = before | m;
+            fresh_here = __popc(m & ~before);
+        }
+        fresh += (unsigned long long) (fresh_here + __shfl_xor(fresh_here, 32));
         count += (unsigned long long) __popcll(bal);
     }
     // one atomic per workgroup (a wave each was half a million same-address atomics)
-    __shared__ unsigned long long cnt_s[4];
-    if ((threadIdx.x & 63) == 0) cnt_s[threadIdx.x >> 6] = count;
+    __shared__ unsigned long long cnt_s[4], fresh_s[4];
+    if ((threadIdx.x & 63) == 0) { cnt_s[threadIdx.x >> 6] = count; fresh_s[threadIdx.x >> 6] = fresh; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long c = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+        const unsigned long long c = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3], f = fresh_s[0] + fresh_s[1] + fresh_s[2] + fresh_s[3];
         if (c) atomicAdd(&stats->stages[pass], c);
+        if (f) atomicAdd(&stats->stages[7], f);   // (passes use slots 0 .. 6 at most: LGR_PRUNE_BETAS)
     }
 }
 

@@ -276,6 +276,18 @@ class Context:
         self.check(_lib.lgr_match_last_work(self.h, C.byref(f)))
         return f.value
 
+    def match_issued(self):
+        """the same with the stages of every pass summed (>= match_work): the MFMA work that was issued"""
+        out = (C.c_double * 2)()
+        self.check(_lib.lgr_match_last_issued(self.h, out))
+        return out[0]
+
+    def match_issued_pairs(self):
+        """(row, column) element pairs of the padded operands in the stages the passes of the last match call issued"""
+        out = (C.c_double * 2)()
+        self.check(_lib.lgr_match_last_issued(self.h, out))
+        return out[1]
+
     def match_pairs(self):
         """(query->train, train->query) pairs the MFMA re-filter of the rerank handed to the exact distance in the last match call"""
         out = (C.c_uint * 2)()

@@ -99,8 +99,10 @@ def test_match_statistics_belong_to_the_context():
     import torch
     from lgr_amd import capi
     rng = np.random.default_rng(1)
-    a = torch.from_numpy(np.abs(rng.normal(size=(9000, 33))).astype(np.float32)).cuda()
-    b = torch.from_numpy(np.abs(rng.normal(size=(7000, 33))).astype(np.float32)).cuda()
+    # (rows around 24 well-separated centres, so that the bounds really leave tiles out at this size)
+    cen = rng.uniform(0, 40, size=(24, 33))
+    a = torch.from_numpy((cen[rng.integers(0, 24, 9000)] + rng.normal(size=(9000, 33))).astype(np.float32)).cuda()
+    b = torch.from_numpy((cen[rng.integers(0, 24, 7000)] + rng.normal(size=(7000, 33))).astype(np.float32)).cuda()
     c1, c2 = capi.Context(0), capi.Context(0)
     try:
         c1.set_match_options(prune=1, leaves=4, operand_format=capi.FORMAT_F16)
@@ -109,7 +111,10 @@ def test_match_statistics_belong_to_the_context():
         r2 = [t.cpu().numpy() for t in c2.match_bf2(a, b)]
         c1.sync(); c2.sync()
         assert c1.match_format() == "f16" and c2.match_format() == "f32"       # c1's figures survived c2's call on the same thread
-        assert c2.match_work() == 1.0 and c1.match_work() != 1.0          # (tiny inputs: pass 0 and the final pass overlap, the sum can exceed 1)
+        # executed fraction: every (row block, stage) once, so never above 1 (the passes summed -- match_issued -- can be: a stage that
+        # straddles two leaves is computed whole by every pass that schedules one of them)
+        assert c2.match_work() == 1.0 and c2.match_issued() == 1.0
+        assert 0.0 < c1.match_work() < 1.0 and c1.match_issued() >= c1.match_work()
         assert c1.match_stats()["sub_cols"] != 0 and c1.match_stats() != c2.match_stats()
         for x, y in zip(r1, r2):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))

@@ -16,7 +16,7 @@ for grp in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf "$R"/gpurun_out/pmcs_$i
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmcs_$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-rooflines "$@" > $R/gpurun_out/pmcs_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmcs_$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-stage-rooflines --no-matcher-extremes "$@" > $R/gpurun_out/pmcs_$i.log 2>&1
   echo "pmc group $i done"
 done
 cd $R

@@ -76,6 +76,23 @@ def main():
         if want in ("normals_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_kernel", "match_mfma"):
             print(text)
         if want == "match_mfma":
+            # cross-check of the bench line's issued-FLOP count against the hardware's own instruction count (v_mfma_f32_32x32x16_f16 = 32 768 FLOP)
+            n_mfma = sum(sum(cnt[k].get("SQ_INSTS_MFMA", [])) for k in names)
+            if n_mfma:
+                for d in dirs:
+                    try:
+                        for line in open(d.rstrip("/") + ".log"):
+                            if line.startswith('{"metric"'):
+                                rl = json.loads(line)["roofline"]
+                                steps = max(1, len(cnt[names[0]].get("SQ_INSTS_MFMA", [])) // max(1, len(names) and 1))
+                                per_step = n_mfma * 32768.0 / steps
+                                x = ("cross-check: SQ_INSTS_MFMA x 32768 = %.4g FLOP per step (%d profiled step(s)) vs the bench line's mfma_flop_issued %.4g: ratio %.3f"
+                                     % (per_step, steps, rl["mfma_flop_issued"], per_step / rl["mfma_flop_issued"]))
+                                print(x)
+                                open("gpurun_out/%s_pmc_%s.txt" % (tag, want), "a").write(x + "\n")
+                                raise StopIteration
+                    except (OSError, StopIteration, KeyError):
+                        continue
             fs = sum(sum(cnt[k].get("FETCH_SIZE", [])) for k in names)
             ws = sum(sum(cnt[k].get("WRITE_SIZE", [])) for k in names)
             nl = sum(len(cnt[k].get("FETCH_SIZE", [])) for k in names)
