@@ -15,6 +15,7 @@
 
 #include "lgr_grid.cuh"
 #include "lgr_knn_wave.cuh"
+#include "lgr_seqsum.h"
 #include "lgr_math.cuh"
 
 namespace {
@@ -243,6 +244,97 @@ __device__ __forceinline__ void pair_features2(v2f p1x, v2f p1y, v2f p1z, v2f n1
     f1 = v2f{lgr_atan2f(yy.x, xx.x), lgr_atan2f(yy.y, xx.y)};
 }
 
+// ---- the three bin indices of a pair through a FILTER with a proven decision band (round 4) ----
+// pcl::computePairFeatures is used here for three INTEGERS only (the bins of f1, f2, f3).  pair_bins_fast2 evaluates the same formulas
+// with the hardware's approximate reciprocal / reciprocal square root (v_rcp_f32, v_rsq_f32: 1 ulp) instead of two IEEE square roots and
+// seven IEEE divisions, and the bin arithmetic in float instead of double; every operation that is NOT a division or a square root is
+// the very instruction of the canonical sequence (same operands as long as the swap decision is the same), so the two evaluations
+// differ by bounded amounts:
+//   u = 2^-24.  angle_k: canonical RN(dot / RN(sqrt)) carries 2u, the fast dot * rsq 3u + 2u  ->  |d angle| <= 5u |angle| < 4e-7      (DA = 1e-6)
+//   v / |v|: canonical 2u, fast 3u per component (|v_i / |v|| <= 1)                           ->  |d v_i| <= 3e-7
+//   w = u x v: two products of |.| <= 1 and a difference, three roundings per path            ->  |d w_i| <= 2 * 3e-7 + 6u < 1e-6
+//   f2 = v . m (|m| ~ 1, sum |m_i| <= sqrt 3), five roundings per path                        ->  |d f2| <= 5.2e-7 + 10u < 1.2e-6           (DF2 = 3e-6)
+//   yy = w . m                                                                                 ->  |d yy| <= 1.8e-6 + 10u < 2.4e-6           (DY = 5e-6)
+//   f1 = atan2(yy, xx), xx identical in both: |d f1| <= DY / rho (rho^2 = xx^2 + yy^2, the sensitivity of atan2 to yy) + the two
+//        evaluations' own distance to atan2 (lgr_atan2f: <= 4 ulp of pi each; fast: the same polynomial on rcp quotients, + 6u)     (DF1 = 5e-6 / rho + 3e-6)
+// A bin is floor(t), t = 5.5 (f + 1) (f2, f3) or 11 (f1 + pi) / (2 pi_f) (f1) -- the canonical code evaluates t in double, i.e. exactly
+// at this scale.  The fast t (one fused multiply-add, |t| <= 11: 11 u) is within 5.5 D + 1e-6 (f2, f3) / 1.751 D + 2e-6 (f1) of it, so
+// when the fast t is farther than that from every integer its floor IS the canonical bin.  The swap decision (|angle1| < |angle2|, both
+// <= 1) is certain when the two fast magnitudes are more than 2 DA apart and the larger is below 1 - DA.  Anything else -- a value
+// inside a band, a degenerate pair (coincident points, d parallel to the normal), rho below 1e-2, a NaN anywhere (every test is written
+// so that NaN fails it) -- is NOT decided here: the caller evaluates that pair with the canonical sequence.  On the 1M bench pair
+// about one pair in 10^4 is; the rows are bit-identical to the oracle's (tests/test_gpu_parity_1m.py::test_fpfh_1m_full compares all
+// 2 x 33 M values), and -DLGR_SPFH_CHECK builds a kernel that evaluates BOTH for every pair and counts disagreements (tools/exp_spfh_check.py).
+__device__ __forceinline__ float lgr_atan2f_fast(float y, float x) {   // lgr_atan2f's polynomial on v_rcp_f32 quotients
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = (ax > ay) ? ax : ay;
+    const float mn = (ax > ay) ? ay : ax;
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const bool hi = a > 0.41421356237f;
+    const float z = hi ? (a - 1.0f) * __builtin_amdgcn_rcpf(a + 1.0f) : a;
+    const float z2 = z * z;
+    float p = 8.05374449538e-2f * z2 - 1.38776856032e-1f;
+    p = p * z2 + 1.99777106478e-1f;
+    p = p * z2 - 3.33329491539e-1f;
+    p = p * z2 * z + z;
+    float r = (hi ? 0.78539816339f : 0.0f) + p;
+    if (ay > ax) r = 1.57079632679f - r;
+    if (x < 0.0f) r = 3.14159265359f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+// floor of a fast t when it is farther than `margin` from every integer (clamped like bin11); returns false when it is not
+__device__ __forceinline__ bool bin_decided(float t, float margin, int& b) {
+    const float fl = floorf(t);
+    const float fr = t - fl;                        // in [0, 1): exact (Sterbenz / small integers)
+    b = (int) fminf(fmaxf(fl, 0.0f), 10.0f);
+    return fr > margin && fr < 1.0f - margin;       // (NaN: false)
+}
+// two pairs per lane, like pair_features2.  dec0 / dec1: the pair's three bins were decided (b?_ valid); otherwise the caller runs the
+// canonical evaluation for it.
+__device__ __forceinline__ void pair_bins_fast2(v2f p1x, v2f p1y, v2f p1z, v2f n1x, v2f n1y, v2f n1z, v2f p2x, v2f p2y, v2f p2z, v2f n2x, v2f n2y, v2f n2z,
+                                                int (&b0)[3], int (&b1)[3], bool& dec0, bool& dec1) {
+    constexpr float DA = 1e-6f;
+    v2f dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    const v2f f4s = dot3e2(dx, dy, dz, dx, dy, dz);
+    const v2f rs = v2f{__builtin_amdgcn_rsqf(f4s.x), __builtin_amdgcn_rsqf(f4s.y)};
+    const v2f angle1 = dot3e2(n1x, n1y, n1z, dx, dy, dz) * rs;
+    const v2f angle2 = dot3e2(n2x, n2y, n2z, dx, dy, dz) * rs;
+    const v2f a1 = v2f{fabsf(angle1.x), fabsf(angle1.y)}, a2 = v2f{fabsf(angle2.x), fabsf(angle2.y)};
+    // swap <=> a1 <= 1 && a2 <= 1 && a1 < a2 (canonical); certain "no" when a1 > a2 + 2 DA, certain "yes" when a1 < a2 - 2 DA and a2 < 1 - DA
+    const bool s0 = a1.x < a2.x, s1 = a1.y < a2.y;
+    bool c0 = f4s.x > 1e-30f && (s0 ? (a2.x - a1.x > 2.0f * DA && a2.x < 1.0f - DA) : (a1.x - a2.x > 2.0f * DA));
+    bool c1 = f4s.y > 1e-30f && (s1 ? (a2.y - a1.y > 2.0f * DA && a2.y < 1.0f - DA) : (a1.y - a2.y > 2.0f * DA));
+    const v2f ux = sel2(s0, s1, n2x, n1x), uy = sel2(s0, s1, n2y, n1y), uz = sel2(s0, s1, n2z, n1z);
+    const v2f mx = sel2(s0, s1, n1x, n2x), my = sel2(s0, s1, n1y, n2y), mz = sel2(s0, s1, n1z, n2z);
+    dx = sel2(s0, s1, -dx, dx); dy = sel2(s0, s1, -dy, dy); dz = sel2(s0, s1, -dz, dz);
+    const v2f f3 = sel2(s0, s1, -angle2, angle1);
+    v2f vx = dy * uz - dz * uy, vy = dz * ux - dx * uz, vz = dx * uy - dy * ux;
+    const v2f vn2 = dot3e2(vx, vy, vz, vx, vy, vz);
+    const v2f rv = v2f{__builtin_amdgcn_rsqf(vn2.x), __builtin_amdgcn_rsqf(vn2.y)};
+    c0 = c0 && vn2.x > 1e-30f; c1 = c1 && vn2.y > 1e-30f;
+    vx = vx * rv; vy = vy * rv; vz = vz * rv;
+    const v2f wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
+    const v2f f2 = dot3e2(vx, vy, vz, mx, my, mz);
+    const v2f yy = dot3e2(wx, wy, wz, mx, my, mz), xx = dot3e2(ux, uy, uz, mx, my, mz);
+    const v2f rho2 = xx * xx + yy * yy;
+    const v2f f1 = v2f{lgr_atan2f_fast(yy.x, xx.x), lgr_atan2f_fast(yy.y, xx.y)};
+    const v2f irho = v2f{__builtin_amdgcn_rsqf(rho2.x), __builtin_amdgcn_rsqf(rho2.y)};
+    c0 = c0 && rho2.x > 1e-4f; c1 = c1 && rho2.y > 1e-4f;
+    // t = 11 (f1 + pi) / (2 pi_f): scale and offset of the canonical double expression, rounded to float once
+    constexpr float S1 = (float) (11.0 * (double) (1.0f / (2.0f * 3.14159274101257324f)));
+    constexpr float O1 = (float) (11.0 * 3.14159265358979323846 * (double) (1.0f / (2.0f * 3.14159274101257324f)));
+    const v2f t1 = v2f{__builtin_fmaf(f1.x, S1, O1), __builtin_fmaf(f1.y, S1, O1)};
+    const v2f t2 = v2f{__builtin_fmaf(f2.x, 5.5f, 5.5f), __builtin_fmaf(f2.y, 5.5f, 5.5f)};
+    const v2f t3 = v2f{__builtin_fmaf(f3.x, 5.5f, 5.5f), __builtin_fmaf(f3.y, 5.5f, 5.5f)};
+    const v2f m1 = v2f{__builtin_fmaf(irho.x, 1.751f * 5e-6f, 1.751f * 3e-6f + 2e-6f), __builtin_fmaf(irho.y, 1.751f * 5e-6f, 1.751f * 3e-6f + 2e-6f)};
+    constexpr float M2 = 5.5f * 3e-6f + 1e-6f, M3 = 5.5f * DA + 1e-6f;
+    const bool d01 = bin_decided(t1.x, m1.x, b0[0]), d02 = bin_decided(t2.x, M2, b0[1]), d03 = bin_decided(t3.x, M3, b0[2]);
+    const bool d11 = bin_decided(t1.y, m1.y, b1[0]), d12 = bin_decided(t2.y, M2, b1[1]), d13 = bin_decided(t3.y, M3, b1[2]);
+    dec0 = d01 && d02 && d03 && c0;
+    dec1 = d11 && d12 && d13 && c1;
+}
+
 __device__ __forceinline__ int bin11(double t) {
     double v = floor(11 * t);
     if (!(v == v)) return 0;
@@ -290,10 +382,7 @@ __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uin
     float* row = spfh + (size_t) t * HP;
     float incr = 100.0f / (float) (k - 1);
     for (int b = 0; b < 33; ++b) {
-        int c = cnt[b * SB + threadIdx.x];
-        float s = 0.f;
-        for (int i = 0; i < c; ++i) s += incr;
-        row[b] = s;
+        row[b] = lgr_seqsum(incr, cnt[b * SB + threadIdx.x]);
     }
     for (int b = 33; b < HP; ++b) row[b] = 0.f;
 }
@@ -307,6 +396,9 @@ __global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uin
 // pair-feature arithmetic -- all 64 lanes busy -- and three LDS atomic increments into the point's histogram.  Counts are
 // order free (the canonical value of a bin is the sequential float sum of `count` copies of the increment), so any
 // enumeration that meets every (point, neighbour) pair exactly once gives the oracle's rows bit for bit.
+#ifdef LGR_SPFH_CHECK
+__device__ unsigned long long g_spfh_check[4];   // pairs, pairs the filter left undecided, decided pairs whose bins differ from the canonical ones (must stay 0)
+#endif
 constexpr int ST = 16;          // surface points per wave
 constexpr int SQ = 256;         // pair queue entries: (tile point << 8) | candidate slot
 constexpr int SHP = 36;         // histogram pitch (33 bins + pad)
@@ -348,23 +440,47 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
             const int i0 = (int) (e0 >> 8), i1 = (int) (e1 >> 8);
             const float4 P0 = tp[i0], N0 = tn[i0], Q0 = cp[e0 & 255u], M0 = cn[e0 & 255u];
             const float4 P1 = tp[i1], N1 = tn[i1], Q1 = cp[e1 & 255u], M1 = cn[e1 & 255u];
-            v2f f1, f2, f3;
-            bool ok0, ok1;
-            pair_features2(v2f{P0.x, P1.x}, v2f{P0.y, P1.y}, v2f{P0.z, P1.z}, v2f{N0.x, N1.x}, v2f{N0.y, N1.y}, v2f{N0.z, N1.z},
-                           v2f{Q0.x, Q1.x}, v2f{Q0.y, Q1.y}, v2f{Q0.z, Q1.z}, v2f{M0.x, M1.x}, v2f{M0.y, M1.y}, v2f{M0.z, M1.z}, f1, f2, f3, ok0, ok1);
+            // the bins through the filter (pair_bins_fast2); the few pairs it does not decide go through the canonical sequence
+            int ba[3], bb[3];
+            bool dec0, dec1, ok0 = true, ok1 = true;
+            pair_bins_fast2(v2f{P0.x, P1.x}, v2f{P0.y, P1.y}, v2f{P0.z, P1.z}, v2f{N0.x, N1.x}, v2f{N0.y, N1.y}, v2f{N0.z, N1.z},
+                            v2f{Q0.x, Q1.x}, v2f{Q0.y, Q1.y}, v2f{Q0.z, Q1.z}, v2f{M0.x, M1.x}, v2f{M0.y, M1.y}, v2f{M0.z, M1.z}, ba, bb, dec0, dec1);
+#ifdef LGR_SPFH_CHECK
+            const bool fdec0 = dec0, fdec1 = dec1 && h1;
+            const int fa0 = ba[0], fa1 = ba[1], fa2 = ba[2], fb0 = bb[0], fb1 = bb[1], fb2 = bb[2];
+            dec0 = dec1 = false;   // evaluate the canonical sequence for EVERY pair and compare
+#endif
+            if (!dec0 || (h1 && !dec1)) {
+                v2f f1, f2, f3;
+                bool e0, e1;
+                pair_features2(v2f{P0.x, P1.x}, v2f{P0.y, P1.y}, v2f{P0.z, P1.z}, v2f{N0.x, N1.x}, v2f{N0.y, N1.y}, v2f{N0.z, N1.z},
+                               v2f{Q0.x, Q1.x}, v2f{Q0.y, Q1.y}, v2f{Q0.z, Q1.z}, v2f{M0.x, M1.x}, v2f{M0.y, M1.y}, v2f{M0.z, M1.z}, f1, f2, f3, e0, e1);
+                if (!dec0) {
+                    ok0 = e0;
+                    ba[0] = bin11(((double) f1.x + MPI) * (double) d_pi); ba[1] = bin11(((double) f2.x + 1.0) * 0.5); ba[2] = bin11(((double) f3.x + 1.0) * 0.5);
+                }
+                if (!dec1) {
+                    ok1 = e1;
+                    bb[0] = bin11(((double) f1.y + MPI) * (double) d_pi); bb[1] = bin11(((double) f2.y + 1.0) * 0.5); bb[2] = bin11(((double) f3.y + 1.0) * 0.5);
+                }
+            }
+#ifdef LGR_SPFH_CHECK
+            {
+                const bool bad0 = fdec0 && (!ok0 || fa0 != ba[0] || fa1 != ba[1] || fa2 != ba[2]);
+                const bool bad1 = fdec1 && (!ok1 || fb0 != bb[0] || fb1 != bb[1] || fb2 != bb[2]);
+                const unsigned long long n_pairs = __popcll(__ballot(true)) + __popcll(__ballot(h1));
+                const unsigned long long n_und = __popcll(__ballot(!fdec0)) + __popcll(__ballot(h1 && !fdec1));
+                const unsigned long long n_bad = __popcll(__ballot(bad0)) + __popcll(__ballot(bad1));
+                if (l == 0) { atomicAdd(&g_spfh_check[0], n_pairs); atomicAdd(&g_spfh_check[1], n_und); if (n_bad) atomicAdd(&g_spfh_check[2], n_bad); }
+            }
+#endif
             if (ok0) {
-                const int b1 = bin11(((double) f1.x + MPI) * (double) d_pi);
-                const int b2 = 11 + bin11(((double) f2.x + 1.0) * 0.5);
-                const int b3 = 22 + bin11(((double) f3.x + 1.0) * 0.5);
                 int* h = &hist[l & 1][i0][0];
-                atomicAdd(h + b1, 1); atomicAdd(h + b2, 1); atomicAdd(h + b3, 1);
+                atomicAdd(h + ba[0], 1); atomicAdd(h + 11 + ba[1], 1); atomicAdd(h + 22 + ba[2], 1);
             }
             if (h1 && ok1) {
-                const int b1 = bin11(((double) f1.y + MPI) * (double) d_pi);
-                const int b2 = 11 + bin11(((double) f2.y + 1.0) * 0.5);
-                const int b3 = 22 + bin11(((double) f3.y + 1.0) * 0.5);
                 int* h = &hist[l & 1][i1][0];
-                atomicAdd(h + b1, 1); atomicAdd(h + b2, 1); atomicAdd(h + b3, 1);
+                atomicAdd(h + bb[0], 1); atomicAdd(h + 11 + bb[1], 1); atomicAdd(h + 22 + bb[2], 1);
             }
         }
         qh += nb;
@@ -462,7 +578,7 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
         if (b < 33) {
             const int cnt = hist[0][i][b] + hist[1][i][b];
             const float incr = 100.0f / (float) (kcnt[i] - 1);
-            for (int k = 0; k < cnt; ++k) v += incr;
+            v = lgr_seqsum(incr, cnt);   // = for (k < cnt) v += incr, bit for bit (lgr_seqsum.h)
         }
         spfh[(size_t) ps * HP + b] = v;
     }
@@ -824,6 +940,16 @@ extern "C" int lgr_downsample(lgr_ctx* ctx, const float* pts, int n, float voxel
     *n_out = nv;
     return LGR_OK;
 }
+
+#ifdef LGR_SPFH_CHECK
+// diagnostics of the -DLGR_SPFH_CHECK build (tools/exp_spfh_check.py): {pairs, pairs the filter left undecided, decided pairs whose bins differ}
+extern "C" int lgr_debug_spfh_check(unsigned long long* out3, int reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_spfh_check), 24) != hipSuccess) return LGR_ERR_HIP;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_spfh_check), z, 32) != hipSuccess) return LGR_ERR_HIP;
+    return LGR_OK;
+}
+#endif
 
 extern "C" int lgr_normals_knn_dev(lgr_ctx* ctx, float* d_pts, int n, const float* d_surf, int ns, int k, const float* vp3, int normals_available) {
     lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
