@@ -569,18 +569,19 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
         if (n_buf > 0) test_block(n_buf);
     }
     __syncthreads();
-    // rows: bin value = sequential float sum of `count` copies of 100 / (k - 1); zero padding up to the pitch
-    for (int q = l; q < ST * HP; q += 64) {
-        const int i = q / HP, b = q % HP;
-        const int ps = __float_as_int(tp[i].w);
+    // rows: bin value = sequential float sum of `count` copies of 100 / (k - 1) (lgr_seqsum: the loop's result without the loop); zero
+    // padding up to the pitch
+    for (int q = l; q < ST * 33; q += 64) {
+        const int i = q / 33, b = q % 33;
         if (tile * ST + i >= g.n) continue;
-        float v = 0.f;
-        if (b < 33) {
-            const int cnt = hist[0][i][b] + hist[1][i][b];
-            const float incr = 100.0f / (float) (kcnt[i] - 1);
-            v = lgr_seqsum(incr, cnt);   // = for (k < cnt) v += incr, bit for bit (lgr_seqsum.h)
-        }
-        spfh[(size_t) ps * HP + b] = v;
+        const int ps = __float_as_int(tp[i].w);
+        const float incr = 100.0f / (float) (kcnt[i] - 1);
+        spfh[(size_t) ps * HP + b] = lgr_seqsum(incr, hist[0][i][b] + hist[1][i][b]);
+    }
+    for (int q = l; q < ST * (HP - 33); q += 64) {
+        const int i = q / (HP - 33), b = 33 + q % (HP - 33);
+        if (tile * ST + i >= g.n) continue;
+        spfh[(size_t) __float_as_int(tp[i].w) * HP + b] = 0.f;
     }
 }
 
