@@ -297,7 +297,9 @@ __global__ void density_min(const float* __restrict__ dk, const int32_t* __restr
 
 }  // namespace
 
-int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12) {
+// the reduction only: *d_keys12 = 12 order-preserving keys on the device (key -> float: lgr_bbox_key_inv, lgr_internal.h), valid until the
+// context's next bounding box; no host synchronisation
+int lgr_bbox_launch(lgr_ctx* ctx, const float* d_pts, int n, const unsigned** d_keys12) {
     unsigned* d;
     LGR_TRY(lgr_ws_t(ctx, WS_GRID_MISC, 16, &d));
     unsigned init[12];
@@ -310,6 +312,14 @@ int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12) {
     for (int a = 0; a < 3; ++a) { init[a] = pinf; init[3 + a] = ninf; init[6 + a] = kfmx; init[9 + a] = kfmn; }
     LGR_HIP(ctx, hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     if (n > 0) bbox_kernel<<<std::min(cdiv(n, 256), ctx->n_cu), 256, 0, ctx->stream>>>(d_pts, n, d);
+    LGR_HIP(ctx, hipGetLastError());
+    *d_keys12 = d;
+    return LGR_OK;
+}
+
+int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12) {
+    const unsigned* d;
+    LGR_TRY(lgr_bbox_launch(ctx, d_pts, n, &d));
     unsigned* h;
     LGR_TRY(lgr_pinned(ctx, 64, (void**) &h));
     LGR_HIP(ctx, hipMemcpyAsync(h, d, 48, hipMemcpyDeviceToHost, ctx->stream));

@@ -154,6 +154,14 @@ int lgr_grid_build(lgr_ctx* ctx, int slot_base, const float* d_pts, int n, float
 // both bounding boxes of a cloud: out12 (host) = true min3, true max3 (finite points only; +-inf when empty),
 // reference-quirk min3, max3 (include/common.h:266-280)
 int lgr_bbox_host(lgr_ctx* ctx, const float* d_pts, int n, float* out12);
+// the same twelve values left on the device as order-preserving integer keys (no host synchronisation); lgr_bbox_key_inv turns a key back
+int lgr_bbox_launch(lgr_ctx* ctx, const float* d_pts, int n, const unsigned** d_keys12);
+__host__ __device__ inline float lgr_bbox_key_inv(unsigned k) {
+    const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
 // lgr_knn_dev with an optional distance table (d_d2 == nullptr: index lists only)
 int lgr_knn_lists(lgr_ctx* ctx, const float* d_q, int nq, const float* d_pts, int n, int k, int32_t* d_idx, float* d_d2);
 

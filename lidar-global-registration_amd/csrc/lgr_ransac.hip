@@ -10,6 +10,9 @@
 //   the record inlier set (largest count, ties -> lowest i) tightens the bound through estimateMaxIterations and the
 //   best hypothesis is the maximum metric (strict '>', ties -> lowest i).
 // Float sequences restate the oracle op for op (oracle/src/orc_ransac.cpp); compiled with -ffp-contract=off.
+// Round 4: for the uniformity / correspondences metrics the loop itself runs from the device (RState, ransac_device_schedule below):
+// the host enqueues two rounds and the final block blind and reads one record -- one synchronisation per alignment; the closest-plane
+// metrics keep the host-driven rounds (their sparse subsets are keyed by batch).
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -177,9 +180,12 @@ __device__ __forceinline__ float next_down(float x) { return __uint_as_float(__f
 // coordinate|, max finite s* (float max through integer atomics: all values >= 0).
 constexpr int CP_FLOATS = 16;
 __global__ void pack_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
-                            float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                            const unsigned* __restrict__ bbk /* lgr_bbox_launch's keys: [6..8] the reference's min, [9..11] its max of the source cloud */,
                             float4* __restrict__ P0, float4* __restrict__ P1, float* __restrict__ sstar,
                             float* __restrict__ PP, unsigned* __restrict__ pstats, int cpad) {
+    // (bbk == nullptr: the caller does not use the uniformity bins -- unit box)
+    const float mnx = bbk ? lgr_bbox_key_inv(bbk[6]) : 0.f, mny = bbk ? lgr_bbox_key_inv(bbk[7]) : 0.f, mnz = bbk ? lgr_bbox_key_inv(bbk[8]) : 0.f;
+    const float mxx = bbk ? lgr_bbox_key_inv(bbk[9]) : 1.f, mxy = bbk ? lgr_bbox_key_inv(bbk[10]) : 1.f, mxz = bbk ? lgr_bbox_key_inv(bbk[11]) : 1.f;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) {
         if (PP && i < cpad) {
@@ -251,10 +257,11 @@ typedef float v2f_c __attribute__((ext_vector_type(2)));
 struct CPair { v2f_c sx, sy, sz, qx, qy, qz, ss, rs; };
 static_assert(sizeof(CPair) == CP_FLOATS * 4, "pack_kernel writes this layout");
 
-__global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts, const int* __restrict__ list, int nh,
-                                                    const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* __restrict__ counts,
-                                                    unsigned* __restrict__ maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */, int cch) {
-    const int h = blockIdx.x * CB + threadIdx.x;
+__device__ __forceinline__ void count_item(const int bx /* block of CB hypotheses */, const int by /* chunk of cch correspondences */,
+                                           const float* __restrict__ Ts, const int* __restrict__ list, int nh,
+                                           const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* __restrict__ counts,
+                                           unsigned* __restrict__ maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */, int cch) {
+    const int h = bx * CB + threadIdx.x;
     const bool act = h < nh;
     float T[16];
     {
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts,
     if (!(kh < 3.4028234663852886e38f) || !(eta < 3.4028234663852886e38f)) { kh = __uint_as_float(0x7f800000u); eta = 0.f; }
     const float neg_eta = -eta;
     int ninl = 0, nsup = 0;
-    const int c0 = blockIdx.y * cch, c1 = min(c, c0 + cch);
+    const int c0 = by * cch, c1 = min(c, c0 + cch);
     for (int base = c0; base < c1; base += 64) {
         const CPair* __restrict__ pp = PP + (base >> 1);   // wave-uniform: scalar loads
         unsigned w[2], sd[2] = {0u, 0u};                   // inlier bits; support bits that differ from them (borderline pairs only)
@@ -323,6 +330,31 @@ __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts,
         }
     }
     if (act) { atomicAdd(&counts[h].x, ninl); atomicAdd(&counts[h].y, nsup); }
+}
+// correspondences per work item: shorter chunks when there are few hypotheses (the first round, the lr filter), so that the launch still
+// has a few thousand waves
+__host__ __device__ inline int count_chunk(int nh, int c) {
+    const long long hb = (nh + CB - 1) / CB;
+    return (hb * ((c + CCH - 1) / CCH) >= 4096) ? CCH : ((hb * ((c + 511) / 512) >= 4096) ? 512 : 128);
+}
+__global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts, const int* __restrict__ list, int nh,
+                                                    const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* __restrict__ counts,
+                                                    unsigned* __restrict__ maskT, int cch) {
+    count_item(blockIdx.x, blockIdx.y, Ts, list, nh, PP, pstats, c, counts, maskT, cch);
+}
+// the same over a work list whose size only the device knows (device-driven schedule, lgr_ransac_dev): nh = *nh_dev hypotheses, a fixed
+// grid of single-wave workgroups strides over the (hypothesis block, chunk) items, hypothesis blocks fastest (neighbouring workgroups
+// read the same correspondences)
+__global__ __launch_bounds__(CB) void count_list_kernel(const float* __restrict__ Ts, const int* __restrict__ list, const int* __restrict__ nh_dev,
+                                                         const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* __restrict__ counts,
+                                                         unsigned* __restrict__ maskT, int mask_cap /* hypotheses maskT has room for */) {
+    const int nh = *nh_dev;
+    if (nh <= 0) return;
+    const int hb_n = (nh + CB - 1) / CB, cch = count_chunk(nh, c);
+    const long long items = (long long) hb_n * ((c + cch - 1) / cch);
+    unsigned* const mt = nh <= mask_cap ? maskT : nullptr;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x)
+        count_item((int) (it % hb_n), (int) (it / hb_n), Ts, list, nh, PP, pstats, c, counts, mt, cch);
 }
 
 // ---------------------------------------------------------------------------------------------------- phase 2
@@ -387,21 +419,31 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
                                                      const unsigned* __restrict__ maskT /* count_kernel's inlier bits [words][mask_nh], or nullptr */,
                                                      const int* __restrict__ hpos /* candidate -> column of maskT */, int mask_nh,
                                                      const int* __restrict__ ghist = nullptr /* [30000 + 1]: the uniformity histogram and the inlier count of the ONE
-                                                        hypothesis, already counted by inlier_hist_kernel (single-transform evaluations) */) {
+                                                        hypothesis, already counted by inlier_hist_kernel (single-transform evaluations) */,
+                                                     const int* __restrict__ nh2_dev = nullptr /* device-driven schedule: the number of candidates lives on the
+                                                        device and the grid strides over them; maskT is used when mask_nh_dev[0] <= mask_nh */,
+                                                     const int* __restrict__ mask_nh_dev = nullptr) {
     extern __shared__ int hist[];   // 30000 ints (uniformity) + 64 ints scan scratch
     __shared__ float T[16];
     __shared__ int s_count;
     __shared__ int s_nnz[3];
-    int hb = blockIdx.x;
-    if (hb >= nh2) return;
+    __shared__ float ent[3];
     const int tid = threadIdx.x;
+    if (nh2_dev) {
+        nh2 = *nh2_dev;
+        const int cols = *mask_nh_dev;   // hypotheses count_list_kernel wrote mask columns for (its stride)
+        if (cols > mask_nh) maskT = nullptr;
+        mask_nh = cols;
+    }
+  for (int hb = blockIdx.x; hb < nh2; hb += gridDim.x) {
+    __syncthreads();   // the previous candidate of this workgroup is finished with the shared arrays
     int hyp = list2 ? list2[hb] : hb;
     if (tid < 16) T[tid] = Ts[(size_t) hyp * 16 + tid];
     const bool uni = metric_id == LGR_METRIC_UNIFORMITY;
     if (uni) for (int i = tid; i < 30000; i += MB) hist[i] = 0;
     if (tid == 0) s_count = 0;
     int* scan = hist + 30000;
-    float2* lst = scratch ? scratch + (size_t) hb * c : nullptr;
+    float2* lst = scratch ? scratch + (size_t) blockIdx.x * c : nullptr;   // one list per workgroup
     __syncthreads();
     const bool from_hist = ghist && uni && !lst;
     if (from_hist) {
@@ -472,7 +514,6 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
         // entropy_k = -(sum over bins in ascending order of p log p) / log(1e4)   (src/analysis.cpp:114-127).
         // The terms are computed in parallel, compacted IN BIN ORDER over the (dead) histogram slab, then summed
         // sequentially by one lane per projection: the reference's summation order, without 10^4 serial steps.
-        __shared__ float ent[3];
         float n = (float) n_inl;
         for (int k = 0; k < 3; ++k) {
             int* hk = hist + k * 10000;
@@ -528,6 +569,7 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
         if (!uni) { metric_out[hb] = score / (float) c; ninl_out[hb] = n_inl; }
         if (rmse_out) rmse_out[hb] = n_inl ? __builtin_sqrtf(rm / (float) n_inl) : 3.4028234663852886e38f;
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- batch reduce
@@ -610,7 +652,8 @@ __global__ void compact_pairs_kernel(const float4* __restrict__ P0, const float4
 // six centroid accumulators, then lanes 0..8 the nine entries of H; the SVD and R, t follow on lane 0.
 constexpr int RCH = 2048;   // pairs staged per chunk
 __global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ P0, const float4* __restrict__ P1, const uint8_t* __restrict__ mask, int c,
-                                                    float* __restrict__ Tout) {
+                                                    float* __restrict__ Tout, const int* __restrict__ n_a = nullptr, const int* __restrict__ n_b = nullptr) {
+    if (n_a) c = n_a[0] + n_b[0];   // device-driven schedule: the number of compacted pairs = last exclusive-scan entry + last flag
     // the sums are sequential by definition; the pairs are staged through LDS by the whole block (coalesced loads), so the
     // summing lanes walk LDS instead of waiting on one global load per term
     __shared__ float sp[RCH * 8];     // [pair][sx sy sz tx ty tz - -]: the summing lanes read consecutive words
@@ -706,6 +749,200 @@ _Pragma("unroll")
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- device-driven schedule
+// The whole loop of SampleConsensusPrerejectiveOMP::align (src/sac_prerejective_omp.cpp:156-257) without the host in it (round 4; the
+// closest-plane metrics keep the host-driven rounds).  The schedule's state -- iterations done, the adaptive bound, the record inlier set,
+// the best metric and transform -- lives in an RState on the device.  A ROUND (the first: one batch; then up to MAX_ROUND_BATCHES) is six
+// launches whose sizes are upper bounds and whose real extents are read from the RState:
+//   rs_begin    the round's iteration range, the candidate gate, counters and BatchStats cleared
+//   rs_hyp      sample -> prerejection -> 3-point transform; survivors appended to a list (one atomic per wave; ANY list order gives the
+//               same results: every later reduction carries the iteration number as its tie-break)
+//   count_list  the O(H x C) verification over (hypothesis block, chunk) items, a fixed grid striding over them
+//   rs_cand     hypotheses with enough inliers for the gate -> candidate list
+//   metric      the metric of every candidate, a fixed grid striding over them
+//   rs_replay   per-batch statistics, then ONE lane replays the round's batches in schedule order exactly as the host did: best hypothesis
+//               (strict >, ties -> lowest iteration), record inlier set -> estimateMaxIterations (src/metric.cpp:103-123, in double) ->
+//               bound, batches behind the end of the loop discarded
+// and every kernel returns at once when the loop has ended.  The host enqueues two rounds and the final block (evaluation of the best
+// transform, refit over its inliers, evaluation of the refit: also sized on the device) blind and then reads ONE record; when the loop
+// has not ended by then (max_iterations far above two rounds and no record yet) it repeats.  The adaptive bound is evaluated with the
+// device's double-precision log / pow, the oracle with libm's: both are accurate to an ulp, the bound is the integer part of a quotient of
+// the two, so a difference needs a quotient within ~1e-15 of an integer.
+struct RState {
+    int done, bound, max_iterations, batch, round_cap;
+    int largest, num_rejections, best_iter;
+    float final_metric;
+    int min_inliers;
+    int round_first, round_nb, round_batches;
+    int n_ok, n_cand;
+    int stop;
+    int rounds;
+    int metric_id, c, nr_samples;
+    float confidence;
+    int pad0[3];
+    float best_T[16];
+    float Tn[16];
+    float e_metric; int e_ninl; float e_rmse; int pad1;       // evaluation of best_T (the final block, :265-296)
+    float e2_metric; int e2_ninl; float e2_rmse; int pad2;    // evaluation of the refit
+};
+
+__device__ inline int est_from_support_dev(int count, int c, float confidence, int nr_samples) {   // = est_from_support below
+    float frac = (float) count / (float) c;
+    frac /= 4.f;
+    if (frac <= 0.0 || log(1.0 - pow((double) frac, (double) nr_samples)) >= 0.0) return INT_MAX;
+    const double iterations = log(1.0 - (double) confidence) / log(1.0 - pow((double) frac, (double) nr_samples));
+    return (int) fmin((double) INT_MAX, iterations);
+}
+
+__global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__ st, int first_round) {
+    if (threadIdx.x < MAX_ROUND_BATCHES) { BatchStats z{}; st[threadIdx.x] = z; }
+    if (threadIdx.x != 0) return;
+    S->n_ok = 0; S->n_cand = 0; S->round_nb = 0; S->round_batches = 0;
+    if (S->stop) return;
+    if (S->done >= S->bound || S->done >= S->max_iterations) { S->stop = 1; return; }
+    const long long want = (long long) min(S->bound, S->max_iterations) - S->done;
+    int n_batches = first_round ? 1 : (int) min((long long) S->round_cap, (want + S->batch - 1) / S->batch);
+    const int nb = (int) min((long long) n_batches * S->batch, (long long) S->max_iterations - S->done);
+    n_batches = (nb + S->batch - 1) / S->batch;
+    // candidate gate (see lgr_ransac_dev): a hypothesis whose metric cannot reach the best one so far is not scored
+    int mi = MIN_NR_INLIERS;
+    if (S->final_metric > 0.f && S->metric_id == LGR_METRIC_UNIFORMITY) mi = max(mi, (int) floor(pow(10000.0, (double) S->final_metric / 1.001)) - 1);
+    else if (S->final_metric > 0.f && S->metric_id == LGR_METRIC_CORRESPONDENCES) mi = max(mi, (int) floor((double) S->final_metric * (double) S->c / 1.001) - 1);
+    S->min_inliers = mi;
+    S->round_first = S->done; S->round_nb = nb; S->round_batches = n_batches;
+    S->rounds += 1;
+}
+
+__global__ void rs_hyp_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
+                              unsigned long long seed, RState* __restrict__ S, float edge_thr, float* __restrict__ Ts, int* __restrict__ list,
+                              int* __restrict__ posmap, int2* __restrict__ counts) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = S->round_nb;
+    if (b - (int) threadIdx.x >= nb) return;   // (whole workgroup; S->stop leaves round_nb = 0)
+    bool good = false;
+    if (b < nb) {
+        counts[b] = make_int2(0, 0);   // (list positions are < the survivors' number <= nb)
+        unsigned w[4];
+        philox4x32(seed, (unsigned) (S->round_first + b), w);
+        int r[3] = {(int) (w[0] >> 1), (int) (w[1] >> 1), (int) (w[2] >> 1)}, smp[3];
+        select3(r, c, smp);
+        P3 s[3], t[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { lgr_corr cr = corr[smp[j]]; s[j] = ldp(src, cr.index_query); t[j] = ldp(tgt, cr.index_match); }
+        good = poly_ok(s, t, edge_thr * edge_thr);
+        if (good) {
+            float T[16];
+            umeyama3(s, t, T);
+            float4* o = reinterpret_cast<float4*>(Ts + (size_t) b * 16);
+            o[0] = make_float4(T[0], T[1], T[2], T[3]); o[1] = make_float4(T[4], T[5], T[6], T[7]);
+            o[2] = make_float4(T[8], T[9], T[10], T[11]); o[3] = make_float4(T[12], T[13], T[14], T[15]);
+        }
+    }
+    const unsigned long long m = __ballot(good);
+    if (m == 0ull) return;
+    int base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) base = atomicAdd(&S->n_ok, __popcll(m));
+    base = __shfl(base, 0);
+    if (good) {
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
+        list[pos] = b;
+        posmap[b] = pos;
+    }
+}
+
+// candidates = survivors with enough inliers for the gate.  Up to 2^17 survivors ONE workgroup compacts them in list order (an ordered
+// block scan per 1024 survivors): the metric kernel walks the inlier-mask column hpos[candidate] of every candidate, a 4-byte read per
+// 128 KB row -- neighbouring workgroups then share the cache lines of neighbouring columns (with the candidates in arrival order of an
+// atomic append the same launch took 1.9 instead of 0.5 ms at 9.5 k candidates).  Beyond that all workgroups append unordered.
+__global__ __launch_bounds__(1024) void rs_cand_kernel(RState* __restrict__ S, const int2* __restrict__ counts, const int* __restrict__ list,
+                                                       int* __restrict__ list2, int* __restrict__ hpos) {
+    __shared__ int scan[1024 / 64 + 2];
+    const int n_ok = S->n_ok, mi = S->min_inliers;
+    if (n_ok <= (1 << 17)) {
+        if (blockIdx.x != 0) return;
+        int total = 0;
+        for (int h0 = 0; h0 < n_ok; h0 += 1024) {
+            const int h = h0 + threadIdx.x;
+            const bool cand = h < n_ok && counts[h].x >= mi;
+            int tot;
+            const int pos = total + block_excl_scan_1024(cand ? 1 : 0, scan, threadIdx.x, &tot);
+            if (cand) { list2[pos] = list[h]; hpos[pos] = h; }
+            total += tot;
+        }
+        if (threadIdx.x == 0) S->n_cand = total;
+        return;
+    }
+    for (int h0 = blockIdx.x * blockDim.x; h0 < n_ok; h0 += gridDim.x * blockDim.x) {
+        const int h = h0 + threadIdx.x;
+        const bool cand = h < n_ok && counts[h].x >= mi;
+        const unsigned long long m = __ballot(cand);
+        if (m == 0ull) continue;
+        int base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(&S->n_cand, __popcll(m));
+        base = __shfl(base, 0);
+        if (cand) {
+            const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
+            list2[pos] = list[h];
+            hpos[pos] = h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void rs_replay_kernel(RState* __restrict__ S, const int* __restrict__ list, const int* __restrict__ list2,
+                                                          const float* __restrict__ metric, const int* __restrict__ ninl, const int2* __restrict__ counts,
+                                                          const int* __restrict__ posmap, const float* __restrict__ Ts, BatchStats* __restrict__ st_out) {
+    __shared__ unsigned long long best_key[MAX_ROUND_BATCHES], rec_key[MAX_ROUND_BATCHES];
+    __shared__ int n_ok_b[MAX_ROUND_BATCHES];
+    const int tid = threadIdx.x;
+    if (S->stop || S->round_nb == 0) return;
+    if (tid < MAX_ROUND_BATCHES) { best_key[tid] = 0ull; rec_key[tid] = 0ull; n_ok_b[tid] = 0; }
+    __syncthreads();
+    const int batch = S->batch, n_ok = S->n_ok, n_cand = S->n_cand;
+    for (int j = tid; j < n_cand; j += blockDim.x) {
+        const unsigned off = (unsigned) list2[j];
+        const int bi = (int) (off / (unsigned) batch);
+        atomicMax(&best_key[bi], ((unsigned long long) __float_as_uint(metric[j]) << 32) | (0xffffffffu - off));
+        atomicMax(&rec_key[bi], ((unsigned long long) (unsigned) ninl[j] << 32) | (0xffffffffu - off));
+    }
+    for (int h = tid; h < n_ok; h += blockDim.x) atomicAdd(&n_ok_b[list[h] / batch], 1);
+    __syncthreads();
+    if (tid != 0) return;
+    int done = S->done, bound = S->bound, largest = S->largest, num_rej = S->num_rejections, best_iter = S->best_iter;
+    float final_metric = S->final_metric;
+    const int round_first = done, max_it = S->max_iterations;
+    int best_off = -1;
+    for (int j = 0; j < S->round_batches && done < bound; ++j) {
+        const int nbj = min(batch, max_it - done);
+        num_rej += nbj - n_ok_b[j];
+        st_out[j].n_ok = n_ok_b[j]; st_out[j].best_key = best_key[j]; st_out[j].rec_key = rec_key[j];
+        if (best_key[j]) {
+            const float m = __uint_as_float((unsigned) (best_key[j] >> 32));
+            const int off = (int) (0xffffffffu - (unsigned) (best_key[j] & 0xffffffffull));
+            if (final_metric < m) { final_metric = m; best_iter = round_first + off; best_off = off; }   // src/sac_prerejective_omp.cpp:232-235 / :251-254
+        }
+        if (rec_key[j]) {
+            const int rec_inl = (int) (rec_key[j] >> 32);
+            if (rec_inl > largest) {   // :224-228
+                largest = rec_inl;
+                const int off = (int) (0xffffffffu - (unsigned) (rec_key[j] & 0xffffffffull));
+                bound = min(bound, est_from_support_dev(counts[posmap[off]].y, S->c, S->confidence, S->nr_samples));
+            }
+        }
+        done += nbj;
+        if (done >= max_it) break;
+    }
+    if (best_off >= 0)
+        for (int i = 0; i < 16; ++i) S->best_T[i] = Ts[(size_t) best_off * 16 + i];
+    S->done = done; S->bound = bound; S->largest = largest; S->num_rejections = num_rej; S->best_iter = best_iter; S->final_metric = final_metric;
+    if (done >= bound || done >= max_it) S->stop = 1;
+}
+// the evaluation record of a single transform (metric, inliers, rmse as metric_kernel left them) into the RState
+__global__ void rs_store_eval_kernel(const float* __restrict__ ev /* metric, n_inl bits, rmse */, float* __restrict__ dst3) {
+    if (threadIdx.x < 3) dst3[threadIdx.x] = ev[threadIdx.x];
+}
+__global__ void rs_guess_kernel(RState* __restrict__ S, const float* __restrict__ ev) { S->final_metric = ev[0]; }
+
 // include/utils.h:34-43 calculateCombinationOrMax<int>
 int comb_or_max(int n, int k) {
     double result = 1.0;
@@ -753,8 +990,8 @@ int lgr_check_corr(lgr_ctx* ctx, const lgr_corr* d_corr, int c, int ns, int nt) 
 namespace {
 int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c, Packed* out) {
     LGR_TRY(lgr_check_corr(ctx, d_corr, c, ns, nt));
-    float bb[12];
-    LGR_TRY(lgr_bbox_host(ctx, d_src, ns, bb));   // UniformityMetricEstimator::setSourceCloud (src/metric.cpp:167-170)
+    const unsigned* bbk;
+    LGR_TRY(lgr_bbox_launch(ctx, d_src, ns, &bbk));   // UniformityMetricEstimator::setSourceCloud (src/metric.cpp:167-170); stays on the device
     float4* P;
     const int cpad = (c + 63) & ~63;
     const size_t n4 = (size_t) c * 2 + (size_t) (c + 3) / 4 + 4;                     // P0, P1, sstar
@@ -765,8 +1002,7 @@ int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, c
     out->PP = (const CPair*) PP; out->pstats = pstats;
     LGR_HIP(ctx, hipMemsetAsync(pstats, 0, 16, ctx->stream));
     if (c > 0)
-        pack_kernel<<<cdiv(cpad, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bb[6], bb[7], bb[8], bb[9], bb[10], bb[11],
-                                                              out->P0, out->P1, out->sstar, PP, pstats, cpad);
+        pack_kernel<<<cdiv(cpad, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bbk, out->P0, out->P1, out->sstar, PP, pstats, cpad);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
@@ -988,7 +1224,7 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     if (nh == 0) return LGR_OK;
     LGR_HIP(ctx, hipMemsetAsync(b.counts, 0, (size_t) nh * 8, ctx->stream));
     // few hypotheses (the first round, the lr filter): shorter correspondence chunks, so that the launch still has a few thousand waves
-    const int cch = ((long long) cdiv(nh, CB) * cdiv(c, CCH) >= 4096) ? CCH : (((long long) cdiv(nh, CB) * cdiv(c, 512) >= 4096) ? 512 : 128);
+    const int cch = count_chunk(nh, c);
     dim3 g(cdiv(nh, CB), cdiv(c, cch));
     // inlier bit masks for phase 2 (uniformity / correspondence-count metrics need the inlier set only); skipped when they
     // would not fit 2 GB (then phase 2 tests every correspondence again)
@@ -1030,6 +1266,129 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
         LGR_TRY(metric_launch(ctx, b.Ts, b.list2, nh2, pk, c, p->metric_id, p->score_id, b.metric, b.ninl, nullptr, nullptr, maskT, b.hpos, nh));
     }
     LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+// single-transform evaluation without a read-back: (metric, n_inl bits, rmse) -> d_out3 (device)
+static int evaluate_one_dev(lgr_ctx* ctx, const float* d_T, const Packed& pk, int c, int metric_id, int score_id, uint8_t* d_mask, float* d_scratch3,
+                            float* d_out3) {
+    float* d_metric = d_scratch3; int* d_ninl = (int*) (d_scratch3 + 1); float* d_rmse = d_scratch3 + 2;
+    LGR_HIP(ctx, hipMemsetAsync(d_rmse, 0, 4, ctx->stream));
+    if (metric_id == LGR_METRIC_UNIFORMITY && c > 0) {
+        int* ghist;
+        LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_GHIST, (size_t) 30000 + 64, &ghist));
+        LGR_HIP(ctx, hipMemsetAsync(ghist, 0, (30000 + 1) * 4, ctx->stream));
+        inlier_hist_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_T, pk.P0, pk.P1, pk.sstar, c, d_mask, ghist);
+        metric_kernel<<<1, MB, metric_smem(), ctx->stream>>>(d_T, nullptr, 1, pk.P0, pk.P1, pk.sstar, c, metric_id, score_id, d_metric, d_ninl, nullptr, nullptr,
+                                                             nullptr, nullptr, nullptr, 0, ghist);
+    } else {
+        LGR_TRY(metric_launch(ctx, d_T, nullptr, 1, pk, c, metric_id, score_id, d_metric, d_ninl, nullptr, d_mask));
+    }
+    rs_store_eval_kernel<<<1, 64, 0, ctx->stream>>>(d_scratch3, d_out3);
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+// refit over the inliers flagged in d_mask, the number of inliers staying on the device
+static int refit_launch_dev(lgr_ctx* ctx, const Packed& pk, int c, const uint8_t* d_mask, float* d_Tout) {
+    int* flags;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_HIST, (size_t) 2 * c + 16 + 8 * ((size_t) c + 4), &flags));
+    int* pos = flags + c;
+    float4* Q0 = (float4*) (((uintptr_t) (flags + 2 * (size_t) c) + 15) & ~(uintptr_t) 15);
+    float4* Q1 = Q0 + c;
+    mask_flags_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_mask, c, flags);
+    size_t tb = 0;
+    LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, flags, pos, 0, (size_t) c, rocprim::plus<int>(), ctx->stream));
+    void* tmp;
+    LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
+    LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, flags, pos, 0, (size_t) c, rocprim::plus<int>(), ctx->stream));
+    compact_pairs_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(pk.P0, pk.P1, flags, pos, c, Q0, Q1);
+    refit_kernel<<<1, 256, 0, ctx->stream>>>(Q0, Q1, nullptr, 0, d_Tout, pos + (c - 1), flags + (c - 1));
+    LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+// The device-driven schedule (uniformity / correspondences metrics): see RState.  ONE host synchronisation per pair of rounds -- one per
+// alignment whenever the loop ends within two rounds, i.e. for every max_iterations up to 17 batches and whenever a record inlier set
+// brings the bound below that.
+static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c, const Packed& pk, const lgr_params* p,
+                                  uint64_t seed, int max_iterations, int batch, uint8_t* d_mask, lgr_result* res) {
+    LGR_HIP(ctx, hipFuncSetAttribute((const void*) metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
+    const int nb_max = (int) std::min<long long>((long long) batch * MAX_ROUND_BATCHES, std::max(max_iterations, 1));
+    BatchBuffers b;
+    LGR_TRY(batch_buffers(ctx, nb_max, &b));
+    int* posmap = b.pos;   // [nb_max]: iteration offset in the round -> position in the survivors' list
+    char* misc;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, sizeof(RState) + 256, &misc));
+    RState* dS = (RState*) misc;
+    float* d_ev = (float*) (misc + sizeof(RState));   // scratch of the single-transform evaluations
+    RState* hS;
+    LGR_TRY(lgr_pinned(ctx, sizeof(RState), (void**) &hS));
+    memset(hS, 0, sizeof(RState));
+    hS->bound = max_iterations; hS->max_iterations = max_iterations; hS->batch = batch; hS->round_cap = MAX_ROUND_BATCHES;
+    hS->best_iter = -1; hS->metric_id = p->metric_id; hS->c = c; hS->nr_samples = p->n_samples; hS->confidence = p->confidence;
+    for (int i = 0; i < 16; ++i) hS->best_T[i] = p->has_guess ? p->guess[i] : ((i % 5 == 0) ? 1.f : 0.f);
+    LGR_HIP(ctx, hipMemcpyAsync(dS, hS, sizeof(RState), hipMemcpyHostToDevice, ctx->stream));
+    if (p->has_guess) {
+        // src/sac_prerejective_omp.cpp:134-147: the guess is the hypothesis to beat (final_tn / final_metric)
+        uint8_t* d_gm;
+        LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASK, (size_t) c + 16, &d_gm));
+        LGR_TRY(evaluate_one_dev(ctx, dS->best_T, pk, c, p->metric_id, p->score_id, d_gm, d_ev, d_ev + 4));
+        rs_guess_kernel<<<1, 1, 0, ctx->stream>>>(dS, d_ev + 4);
+    }
+    // inlier bit masks for the uniformity metric: [words][survivors], as many columns as 2 GB hold (more survivors: the metric kernel
+    // tests every correspondence again)
+    unsigned* maskT = nullptr;
+    int mask_cap = 0;
+    if (p->metric_id == LGR_METRIC_UNIFORMITY) {
+        const size_t words = (size_t) ((c + 31) >> 5);
+        mask_cap = (int) std::min<size_t>((size_t) nb_max, ((size_t) 2 << 30) / (words * 4));
+        if (mask_cap > 0) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASKT, words * (size_t) mask_cap, &maskT));
+    }
+    const bool need_list = p->metric_id != LGR_METRIC_UNIFORMITY;
+    const int g_metric = std::max(1, ctx->n_cu), g_count = 128 * std::max(1, ctx->n_cu);   // one 120 KB workgroup per CU; four times the resident single-wave workgroups (the tail evens out)
+    float2* scratch = nullptr;
+    if (need_list) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_LIST, (size_t) g_metric * std::max(c, 1), &scratch));
+    const bool ransac_debug = getenv("LGR_RANSAC_DEBUG") != nullptr;
+    auto enqueue_round = [&](bool first) -> int {
+        const int nb_up = first ? std::min(batch, nb_max) : nb_max;
+        rs_begin_kernel<<<1, 64, 0, ctx->stream>>>(dS, b.st, first ? 1 : 0);
+        rs_hyp_kernel<<<cdiv(nb_up, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, dS, p->edge_thr_coef, b.Ts, b.list, posmap, b.counts);
+        count_list_kernel<<<g_count, CB, 0, ctx->stream>>>(b.Ts, b.list, &dS->n_ok, pk.PP, pk.pstats, c, b.counts, maskT, mask_cap);
+        rs_cand_kernel<<<64, 1024, 0, ctx->stream>>>(dS, b.counts, b.list, b.list2, b.hpos);
+        metric_kernel<<<g_metric, MB, metric_smem(), ctx->stream>>>(b.Ts, b.list2, 0, pk.P0, pk.P1, pk.sstar, c, p->metric_id, p->score_id, b.metric, b.ninl,
+                                                                    nullptr, nullptr, scratch, maskT, b.hpos, mask_cap, nullptr, &dS->n_cand, &dS->n_ok);
+        rs_replay_kernel<<<1, 1024, 0, ctx->stream>>>(dS, b.list, b.list2, b.metric, b.ninl, b.counts, posmap, b.Ts, b.st);
+        LGR_HIP(ctx, hipGetLastError());
+        return LGR_OK;
+    };
+    bool first = true;
+    for (;;) {
+        LGR_TRY(enqueue_round(first));
+        first = false;
+        LGR_TRY(enqueue_round(false));
+        // :265-296 final re-estimation (enqueued blind: redone when the loop turns out not to have ended)
+        LGR_TRY(evaluate_one_dev(ctx, dS->best_T, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e_metric));
+        LGR_TRY(refit_launch_dev(ctx, pk, c, d_mask, dS->Tn));
+        LGR_TRY(evaluate_one_dev(ctx, dS->Tn, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e2_metric));
+        LGR_HIP(ctx, hipMemcpyAsync(hS, dS, sizeof(RState), hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ransac_debug) fprintf(stderr, "[lgr] ransac (device schedule) after %d rounds: done %d bound %d largest %d best metric %.4f stop %d\n", hS->rounds, hS->done, hS->bound,
+                                  hS->largest, hS->final_metric, hS->stop);
+        if (hS->stop) break;
+    }
+    int e_ninl, e2_ninl;
+    memcpy(&e_ninl, &hS->e_ninl, 4); memcpy(&e2_ninl, &hS->e2_ninl, 4);
+    const bool enough = e_ninl > MIN_NR_FINAL_INLIERS || (float) e_ninl > MIN_INLIER_RATE * (float) c;
+    const float min_tol = p->metric_id == LGR_METRIC_UNIFORMITY ? 0.3f : 0.0f;   // include/metric.h:97-99 / 73-75
+    memcpy(res->transformation, hS->Tn, 64);
+    res->iterations = hS->done;
+    res->converged = (enough && hS->e_metric > min_tol) ? 1 : 0;
+    res->n_inliers = e2_ninl;
+    res->metric = hS->e2_metric;
+    res->best_metric_before_refit = hS->final_metric;
+    res->best_iteration = hS->best_iter;
+    res->num_rejections = hS->num_rejections;
+    res->estimated_iters = hS->bound;
     return LGR_OK;
 }
 
@@ -1127,8 +1486,16 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     const bool plane_metric = p->metric_id == LGR_METRIC_CLOSEST_PLANE || p->metric_id == LGR_METRIC_COMBINATION;
+    if (!plane_metric) {
+        // the loop, the final evaluation and the refit driven from the device: one host synchronisation (ransac_device_schedule)
+        uint8_t* d_mask = d_final_mask;
+        if (!d_mask) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASK, (size_t) c + 16, &d_mask));
+        LGR_TRY(ransac_device_schedule(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, max_iterations, batch, d_mask, res));
+        res->time_te = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        return LGR_OK;
+    }
     lgr_plane_dev plane;
-    if (plane_metric) LGR_TRY(lgr_plane_setup(ctx, d_src, ns, d_tgt, nt, seed, &plane));
+    LGR_TRY(lgr_plane_setup(ctx, d_src, ns, d_tgt, nt, seed, &plane));
     if (p->has_guess) {
         // src/sac_prerejective_omp.cpp:134-147: the guess is the hypothesis to beat (final_tn / final_metric).  Its inliers only seed
         // the global largest_inlier_set, which the loop never reads (thread-local sets start empty, :177): the bound is unaffected.
@@ -1295,7 +1662,7 @@ extern "C" int lgr_refit_svd_dev(lgr_ctx* ctx, const float* d_src, const float* 
     float4* P;
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_PACK, (size_t) c * 2 + (size_t) (c + 3) / 4 + 4, &P));
     Packed pk{P, P + c, (float*) (P + 2 * (size_t) c), nullptr, nullptr};
-    if (c > 0) pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, pk.P0, pk.P1, pk.sstar, nullptr, nullptr, c);
+    if (c > 0) pack_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, nullptr, pk.P0, pk.P1, pk.sstar, nullptr, nullptr, c);
     float* dT;
     LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &dT));
     LGR_TRY(refit_launch(ctx, pk, c, d_mask, dT));
