@@ -282,7 +282,7 @@ extern "C" void lgr_match_default_options(lgr_match_options* o) {
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->prune = -1; o->leaves = 0; o->near = 0; o->operand_format = -1; o->box_bounds = 1; o->column_stage = 1;
-    o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0; o->shell_bound = 1;
+    o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0; o->shell_bound = 1; o->split_sweep = 1;
 }
 
 // (every internal context below this one, however deep: an internal context that runs a pair of jobs itself owns internal contexts too)

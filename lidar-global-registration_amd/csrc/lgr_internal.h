@@ -50,7 +50,7 @@ struct lgr_ctx {
     float stage_ms[12];
     int n_cu = 256;
     int mfma_timed = 0;
-    lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, 1, {0, 0, 0, 0}};   // lgr_match_default_options
+    lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, 1, 1, {0, 0, 0}};   // lgr_match_default_options
     bool corr_trusted = false;                  // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
     void* match_prep = nullptr;                 // the matcher's clustering / prepared query side (lgr_match.hip: MatchPrep)
     void (*match_prep_free)(void*) = nullptr;
@@ -111,7 +111,7 @@ int lgr_fail(lgr_ctx* ctx, int code, const char* what, const char* file, int lin
 // workspace slot ids
 enum {
     WS_MATCH_AP = 0, WS_MATCH_BP, WS_MATCH_NA, WS_MATCH_NB, WS_MATCH_ROWMIN, WS_MATCH_COLMIN, WS_MATCH_ITEMS,
-    WS_MATCH_BEST_A, WS_MATCH_BEST_B, WS_MATCH_MISC, WS_MATCH_DENSE, WS_MATCH_SORTED_A, WS_MATCH_SORTED_B, WS_MATCH_PRUNE, WS_MATCH_ITEMS2, WS_MATCH_NORMS, WS_MATCH_PAIRS,
+    WS_MATCH_BEST_A, WS_MATCH_BEST_B, WS_MATCH_MISC, WS_MATCH_DENSE, WS_MATCH_SORTED_A, WS_MATCH_SORTED_B, WS_MATCH_PRUNE, WS_MATCH_ITEMS2, WS_MATCH_NORMS, WS_MATCH_PAIRS, WS_MATCH_KEPT,
     // three independent uniform grids (7 slots each: keys, vals, keys2, vals2, start, xyz, nrm) + shared sort temp
     WS_GRID_A, WS_GRID_B = WS_GRID_A + 7, WS_GRID_C = WS_GRID_B + 7, WS_GRID_TMP = WS_GRID_C + 7, WS_GRID_MISC,
     WS_DS_KEYS, WS_DS_VALS, WS_DS_KEYS2, WS_DS_VALS2, WS_DS_FLAGS, WS_DS_MISC,

@@ -34,6 +34,7 @@
 #include "lgr_match_cluster.cuh"
 #include "lgr_match_pack.cuh"
 #include "lgr_match_mfma.cuh"
+#include "lgr_match_sweep.cuh"
 #include "lgr_match_bounds.cuh"
 #include "lgr_match_rerank.cuh"
 
@@ -551,7 +552,20 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int* xcd_start = ibuf + 4 * (size_t) n_flags;   // [9]
     int* xcd_ctr = xcd_start + 16;                   // [8]
     const int mfma_grid = 8 * (LGR_MM_OCC / 2) * std::max(1, ctx->n_cu / 8);   // resident workgroups: LGR_MM_OCC / 2 per CU
-    auto launch_mfma = [&](const unsigned* mask, CoarseArgs ca) -> int {
+    // final pass as sweep + listed tiles (lgr_match_sweep.cuh): the list, its counter, the per-column thresholds as bf16
+    const unsigned kept_cap = 16u << 20;
+    uint2* kept = nullptr;
+    unsigned* kept_count = nullptr;
+    unsigned short* ucol16 = nullptr;
+    bool split_used = false;
+    if (f16 && rot && prune && mo.coarse_rejection != 0 && mo.split_sweep != 0) {
+        char* kb;
+        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_KEPT, (size_t) kept_cap * sizeof(uint2) + (size_t) mb_pad * 2 + 512, &kb));
+        kept = (uint2*) kb;
+        kept_count = (unsigned*) (kb + (size_t) kept_cap * sizeof(uint2));
+        ucol16 = (unsigned short*) (kb + (size_t) kept_cap * sizeof(uint2) + 256);
+    }
+    auto launch_mfma = [&](const unsigned* mask, CoarseArgs ca, bool allow_split = true) -> int {
         items_flag_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(mask, n_rb, n_cc, item_rb, n_ir, ccx, iflags);
         size_t sb = 0;
         LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, sb, iflags, ipos, 0, (size_t) n_flags, rocprim::plus<int>(), ctx->stream));
@@ -564,7 +578,20 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_TRY(join_b());
         (void) hipEventRecord(ctx->ev[9 + 2 * ctx->mfma_timed], ctx->stream);
 #define LGR_MFMA_ARGS bset_stride, c_scale, out_scale, A.blkcl, nAp, ma_pad, mb_pad, rg_rows, tile_group, mask, rowmin, colmin, n_cc, item_rb, ilist, xcd_start, xcd_ctr, ca
-        if (f16 && rot && ca.u_rb) {
+        if (f16 && rot && ca.u_rb && kept && allow_split) {
+            // the coarse sweep appends the tiles it keeps to a list, a second kernel finishes them
+            split_used = true;
+            LGR_HIP(ctx, hipMemsetAsync(kept_count, 0, 4, ctx->stream));
+            if (ca.u_colv) ucol_pack_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(ca.u_colv, mb_pad, c_scale, ucol16);
+            const int sweep_grid = 8 * (SW_OCC / 2) * std::max(1, ctx->n_cu / 8);
+            match_sweep<<<sweep_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, c_scale, A.blkcl, ma_pad, mb_pad, rg_rows, mask, n_cc,
+                                                              item_rb, ilist, xcd_start, xcd_ctr, ca, ca.u_colv ? ucol16 : nullptr, kept, kept_count, kept_cap);
+            const int tiles_grid = 8 * std::max(1, ctx->n_cu);
+            if (both) match_tiles<true><<<tiles_grid, 64 * TL_WAVES, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, A.blkcl, ma_pad, mb_pad,
+                                                                                       rg_rows, tile_group, rowmin, colmin, kept, kept_count, kept_cap);
+            else match_tiles<false><<<tiles_grid, 64 * TL_WAVES, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, A.blkcl, ma_pad, mb_pad,
+                                                                                   rg_rows, tile_group, rowmin, colmin, kept, kept_count, kept_cap);
+        } else if (f16 && rot && ca.u_rb) {
             if (both) match_mfma<true, FMT_F16R, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
             else match_mfma<false, FMT_F16R, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
         } else if (f16 && rot) {
@@ -753,7 +780,20 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned long long* h_cc = (unsigned long long*) ((char*) hs + 128);
         h_cc[0] = h_cc[1] = h_cc[2] = 0ull;
         if (coarse) LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 24, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned* h_kept = (unsigned*) ((char*) hs + 192);
+        h_kept[0] = 0u;
+        if (split_used) LGR_HIP(ctx, hipMemcpyAsync(h_kept, kept_count, 4, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (split_used && h_kept[0] > kept_cap) {
+            // The sweep kept more tiles than the list holds (descriptors without structure): the last pass again on the fused kernel.  The
+            // tables only ever take minima, so what the listed tiles already contributed stays valid.  (Statistics: the fused launch's.)
+            LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 32, ctx->stream));
+            CoarseArgs ca = ca_on;
+            ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb;
+            LGR_TRY(launch_mfma(mask, ca, false));
+            LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 24, hipMemcpyDeviceToHost, ctx->stream));
+            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
         g_last_stats.coarse_tested = (double) h_cc[0];
         g_last_stats.coarse_rejected = (double) h_cc[1];
         g_last_stats.shell_skipped = (double) h_cc[2];
