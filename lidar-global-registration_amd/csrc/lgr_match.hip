@@ -109,19 +109,29 @@ template <class F>
 static int box_basis(lgr_ctx* ctx, bool raw, const float* smp, const int* smp_ok, int ns, float* d_basis /* [34][33] + 1: V rows, then mu */, F&& meanwhile) {
     std::vector<float> h(34 * 33 + 1, 0.f);
     if (raw) LGR_TRY(meanwhile());
+    // The covariance runs on the context's third stream: `meanwhile` (the ~45 short launches of the Lloyd steps, which everything after the
+    // clustering waits for) then does not queue behind it.  Prepared ahead of the call, both compete with the other cloud's feature kernels for
+    // the device, and the covariance -- 1.6 ms there, in FRONT of the Lloyd chain -- kept the chain on the critical path (round 3 timeline).
+    hipStream_t sC = ctx->stream;
     if (!raw) {
+        LGR_TRY(lgr_ctx_stream3(ctx, &sC));
+        if (sC != ctx->stream) {
+            LGR_HIP(ctx, hipEventRecord(ctx->ev[28], ctx->stream));   // (the sample rows come from km_sample on the context's stream)
+            LGR_HIP(ctx, hipStreamWaitEvent(sC, ctx->ev[28], 0));
+        }
         const int nb = cdiv(ns, COV_ROWS);
         float* part;
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_DENSE, (size_t) nb * (34 * 33 + 1) + 64, &part));   // scratch: the rerank buffers are not live yet
-        LGR_HIP(ctx, hipMemsetAsync(part, 0, (size_t) nb * (34 * 33 + 1) * 4, ctx->stream));   // the a > b product slots are never written
-        cov_kernel<<<nb, COV_THREADS, 0, ctx->stream>>>(smp, smp_ok, ns, part);
-        cov_reduce<<<cdiv(34 * 33 + 1, 256), 256, 0, ctx->stream>>>(part, nb, d_basis);
+        LGR_HIP(ctx, hipMemsetAsync(part, 0, (size_t) nb * (34 * 33 + 1) * 4, sC));   // the a > b product slots are never written
+        cov_kernel<<<nb, COV_THREADS, 0, sC>>>(smp, smp_ok, ns, part);
+        cov_reduce<<<cdiv(34 * 33 + 1, 256), 256, 0, sC>>>(part, nb, d_basis);
         float* hp;
         LGR_TRY(lgr_pinned(ctx, (34 * 33 + 1) * 4, (void**) &hp));
-        LGR_HIP(ctx, hipMemcpyAsync(hp, d_basis, (34 * 33 + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        LGR_HIP(ctx, hipEventRecord(ctx->ev[30], ctx->stream));
-        LGR_TRY(meanwhile());
-        LGR_HIP(ctx, hipEventSynchronize(ctx->ev[30]));
+        LGR_HIP(ctx, hipMemcpyAsync(hp, d_basis, (34 * 33 + 1) * 4, hipMemcpyDeviceToHost, sC));
+        LGR_HIP(ctx, hipEventRecord(ctx->ev[30], sC));
+        const int rc_m = meanwhile();
+        LGR_HIP(ctx, hipEventSynchronize(ctx->ev[30]));   // (also when `meanwhile` failed: nothing of this call may stay queued on sC)
+        LGR_TRY(rc_m);
         memcpy(h.data(), hp, (34 * 33 + 1) * 4);
     }
     const double n = h[34 * 33];
@@ -167,8 +177,8 @@ static int box_basis(lgr_ctx* ctx, bool raw, const float* smp, const int* smp_ok
     }
     for (int i = 0; i < 33 * 33; ++i) h[i] = (float) Vd[i];
     for (int k = 0; k < 33; ++k) h[33 * 33 + k] = (float) mu[k];
-    LGR_HIP(ctx, hipMemcpyAsync(d_basis, h.data(), 34 * 33 * 4, hipMemcpyHostToDevice, ctx->stream));
-    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h goes out of scope
+    LGR_HIP(ctx, hipMemcpyAsync(d_basis, h.data(), 34 * 33 * 4, hipMemcpyHostToDevice, sC));
+    LGR_HIP(ctx, hipStreamSynchronize(sC));   // h goes out of scope; the basis is in place before anything the host enqueues from here on
     return LGR_OK;
 }
 
@@ -764,11 +774,20 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 sched_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(both ? 1 : 0, bsq, LBsq, u_rb, u_leaf, n_rb, n_leaves,
                                                                                             colstage && pass == n_beta ? 1 : 0, pass == 1 && shell0.rshA ? 1 : 0, done, sched);
             }
+            // the table initialisation of the pass needs the schedule only: on the third stream, beside mask_kernel (0.27 + 0.28 ms in a row
+            // in front of pass 0, 0.30 + 0.37 between the passes); the MFMA launch waits for both
+            const bool init_aside = sB != ctx->stream;
+            if (init_aside) {
+                LGR_HIP(ctx, hipEventRecord(ctx->ev[28], ctx->stream));
+                LGR_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev[28], 0));
+            }
+            init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, init_aside ? sB : ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
+                                                                                                    (size_t) ma_pad, colmin, (size_t) mb_pad);
+            if (init_aside) LGR_HIP(ctx, hipEventRecord(ctx->ev[29], sB));
             if (pass == 0 && shell0.rshA) LGR_TRY(join_b());   // (the stage shells come from the column norms, written by the packing)
             mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
                                                                                                          pass > 0 ? shell : shell0, mask, (unsigned*) (pb + o_macc), mstats);
-            init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin, (size_t) ma_pad,
-                                                                     colmin, (size_t) mb_pad);
+            if (init_aside) LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[29], 0));
             CoarseArgs ca = ca_on;
             if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb; }
             LGR_TRY(launch_mfma(mask, ca));
