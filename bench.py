@@ -10,7 +10,8 @@ are already resident in HBM.  Scan pairs shard across ranks (one independent pai
 collective is one all-gather of the 96-byte per-pair result record per step (RCCL when N > 1).
 
 Rank 0 prints ONE JSON line with the contract keys plus
-  "roofline"     : the dominant kernel (match_mfma, the MFMA distance filter of the matcher; both masked launches of a
+  "roofline"     : the dominant kernels (the MFMA distance filter of the matcher: match_mfma for pass 0, match_sweep + match_tiles for the
+                   final pass -- one hipEvent pair around each pass; both masked passes of a
                    step): MFMA FLOP issued (224 per computed pair on f16-split operands x M x M x executed tile
                    fraction) / launch duration measured with hipEvents on the launch stream, against the dense f16
                    MFMA peak of MI355X; the algorithmic 69 * Mq * Mt over the same time is given beside it
@@ -480,6 +481,8 @@ def main():
         # (issued_pairs counts the PADDED operands' element pairs -- clusters are padded to whole row blocks / column tiles -- which is what the
         #  kernel multiplies: SQ_INSTS_MFMA x 32768 of the PMC pass agrees with this count, tools/pmc_summary.py)
         issued = flop_per_pair * issued_pairs - ((c_abandoned * (192.0 - 64.0) + c_skipped * 192.0) * 1024.0 if fmt == "f16r" else 0.0)
+        # (the tiles the sweep keeps are finished by a kernel of their own, from the first step: their two coarse steps are issued twice)
+        issued += (c_tested - c_abandoned) * 64.0 * 1024.0 if fmt == "f16r" else 0.0
         achieved = issued / (k_ms * 1e-3) / 1e12
         effective = alg_flop / (k_ms * 1e-3) / 1e12
         # HBM-side bytes of the same kernel (both launches of one step) from the committed PMC passes (tools/pmc_bench.sh:
@@ -502,7 +505,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic 1M-pt pair, random SE(3) + Gaussian noise (5 mm), FPFH r=0.25 m",
                        "points_per_cloud": m, "pairs_per_step": world, "matching": args.matching, "metric_id": "uniformity",
                        "bf_block_size": 200000, "max_iterations": 1000000, "parallelism": f"pairs sharded over {world} GPU(s)"},
-            "roofline": {"kernel": "match_mfma<both directions> (all masked passes of one step)", "bound": "mfma", "achieved": achieved, "peak": peak,
+            "roofline": {"kernel": "the MFMA passes of the matcher: match_mfma (pass 0) + match_sweep + match_tiles (final pass), both directions at once", "bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "operand_format": {"f16": "f16 two-term splits, f32 accumulate, K = 112 (224 MFMA FLOP/pair)",
                                             "f16r": "f16 two-term splits of 30 Helmert coordinates, f32 accumulate, K = 96 (192 MFMA FLOP/pair)",

@@ -11,7 +11,7 @@ import json
 import re
 import sys
 
-KERNELS = ["normals_kernel", "normals_wave_kernel", "knn_wave_kernel", "knn_tile_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_kernel", "match_mfma", "knn_kernel", "metric_kernel", "plane_kernel",
+KERNELS = ["normals_kernel", "normals_wave_kernel", "knn_wave_kernel", "knn_tile_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_kernel", "count_list_kernel", "match_mfma", "match_sweep", "match_tiles", "knn_kernel", "metric_kernel", "plane_kernel",
            "assign_kernel", "pack16_kernel", "rerank_refilter", "init_tables_kernel", "voxel_accumulate", "filter_flags"]
 
 
@@ -73,9 +73,10 @@ def main():
             lines.append("")
         text = "\n".join(lines)
         open("gpurun_out/%s_pmc_%s.txt" % (tag, want), "w").write(text)
-        if want in ("normals_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_kernel", "match_mfma"):
+        if want in ("normals_wave_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_list_kernel", "match_mfma", "match_sweep", "match_tiles"):
             print(text)
         if want == "match_mfma":
+            names = sorted(k for k in cnt if "match_mfma" in k or "match_sweep" in k or "match_tiles" in k)   # all MFMA passes of a step (round 4: the final pass is two kernels)
             # cross-check of the bench line's issued-FLOP count against the hardware's own instruction count (v_mfma_f32_32x32x16_f16 = 32 768 FLOP)
             n_mfma = sum(sum(cnt[k].get("SQ_INSTS_MFMA", [])) for k in names)
             if n_mfma:
@@ -105,7 +106,7 @@ def main():
                             fmt = "f16r" if "K = 96" in of else ("f32" if of.startswith("f32") else "f16")
                 except OSError:
                     pass
-                traffic = {"kernel": "match_mfma (all masked launches of one 1M-pt bench step)", "fetch_bytes_corrected": 2.0 * 1024.0 * fs, "write_bytes": 1024.0 * ws,
+                traffic = {"kernel": "match_mfma + match_sweep + match_tiles (all masked MFMA passes of one 1M-pt bench step)", "fetch_bytes_corrected": 2.0 * 1024.0 * fs, "write_bytes": 1024.0 * ws,
                            "traffic_bytes": 2.0 * 1024.0 * fs + 1024.0 * ws, "launches": nl, "operand_format": fmt,
                            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/pmc_stages.sh; FETCH_SIZE x2 (gfx950)"}
     if traffic:
