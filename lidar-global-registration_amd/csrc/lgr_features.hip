@@ -451,17 +451,17 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
             dec0 = dec1 = false;   // evaluate the canonical sequence for EVERY pair and compare
 #endif
             if (!dec0 || (h1 && !dec1)) {
-                v2f f1, f2, f3;
-                bool e0, e1;
-                pair_features2(v2f{P0.x, P1.x}, v2f{P0.y, P1.y}, v2f{P0.z, P1.z}, v2f{N0.x, N1.x}, v2f{N0.y, N1.y}, v2f{N0.z, N1.z},
-                               v2f{Q0.x, Q1.x}, v2f{Q0.y, Q1.y}, v2f{Q0.z, Q1.z}, v2f{M0.x, M1.x}, v2f{M0.y, M1.y}, v2f{M0.z, M1.z}, f1, f2, f3, e0, e1);
-                if (!dec0) {
-                    ok0 = e0;
-                    ba[0] = bin11(((double) f1.x + MPI) * (double) d_pi); ba[1] = bin11(((double) f2.x + 1.0) * 0.5); ba[2] = bin11(((double) f3.x + 1.0) * 0.5);
-                }
-                if (!dec1) {
-                    ok1 = e1;
-                    bb[0] = bin11(((double) f1.y + MPI) * (double) d_pi); bb[1] = bin11(((double) f2.y + 1.0) * 0.5); bb[2] = bin11(((double) f3.y + 1.0) * 0.5);
+                // the canonical sequence, ONE pair at a time in a loop that is not unrolled: it runs for 2e-4 of the pairs, and as a two-pair
+                // evaluation it set the kernel's register count (109 VGPRs, four waves per SIMD)
+#pragma unroll 1
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (hh == 0 ? dec0 : (dec1 || !h1)) continue;
+                    const float4 P = hh ? P1 : P0, N = hh ? N1 : N0, Q = hh ? Q1 : Q0, M = hh ? M1 : M0;
+                    float f1, f2, f3;
+                    const bool e = pair_features(P.x, P.y, P.z, N.x, N.y, N.z, Q.x, Q.y, Q.z, M.x, M.y, M.z, f1, f2, f3);
+                    const int c0 = bin11(((double) f1 + MPI) * (double) d_pi), c1 = bin11(((double) f2 + 1.0) * 0.5), c2 = bin11(((double) f3 + 1.0) * 0.5);
+                    if (hh) { ok1 = e; bb[0] = c0; bb[1] = c1; bb[2] = c2; }
+                    else { ok0 = e; ba[0] = c0; ba[1] = c1; ba[2] = c2; }
                 }
             }
 #ifdef LGR_SPFH_CHECK
