@@ -133,7 +133,8 @@ typedef struct {
     int32_t operand_format;   /* -1 auto (f16 two-term splits, rotated to 30 coordinates when the rows allow it), 0 f32, 1 f16, 2 f16 rotated */
     int32_t box_bounds;       /* bounding-box lower bounds beside the ball bounds: 1 PCA basis (default), 2 raw coordinates, 0 off */
     int32_t column_stage;     /* per-stage column criterion in the final schedule: 1 (default) / 0 */
-    int32_t coarse_rejection; /* two-step coarse test inside the final MFMA pass: 1 (default) / 0 */
+    int32_t coarse_rejection; /* two-step coarse test in the final MFMA pass: 1 (default: unless the pass schedules more than half of all tiles --
+                               * descriptors the bounds cannot separate --, then the plain six-step kernel), 2 (always), 0 (never) */
     int32_t rerank_refilter;  /* MFMA re-filter of the rerank's candidate groups: 1 (default) / 0 (whole-group exact scan) */
     int32_t pair_cap;         /* pairs per rerank item the re-filter may emit before falling back to the group scan: -1 default (8) */
     int32_t poison_tables;    /* diagnostics: fill never-computed minimum-table entries with 0 (nothing may read them) */

@@ -556,7 +556,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const int item_rb = both ? std::min(rg_rows / BLOCK_ROWS, 16) : 4;
     const int n_ir = cdiv(n_rb, item_rb), ccx = cdiv(n_cc, 8), n_flags = 8 * ccx * n_ir;
     int* ibuf;
-    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS2, (size_t) 4 * n_flags + 64, &ibuf));
+    LGR_TRY(lgr_ws_t(ctx, WS_MATCH_ITEMS2, (size_t) 4 * n_flags + 128, &ibuf));
     int *iflags = ibuf, *ipos = ibuf + n_flags;
     int2* ilist = (int2*) (ibuf + 2 * (size_t) n_flags);
     int* xcd_start = ibuf + 4 * (size_t) n_flags;   // [9]
@@ -575,6 +575,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         kept_count = (unsigned*) (kb + (size_t) kept_cap * sizeof(uint2));
         ucol16 = (unsigned short*) (kb + (size_t) kept_cap * sizeof(uint2) + 256);
     }
+    const unsigned long long* cur_pass_stages = nullptr;   // device: the stage count of the pass being launched (mask_kernel's statistics)
     auto launch_mfma = [&](const unsigned* mask, CoarseArgs ca, bool allow_split = true) -> int {
         items_flag_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(mask, n_rb, n_cc, item_rb, n_ir, ccx, iflags);
         size_t sb = 0;
@@ -593,14 +594,30 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             split_used = true;
             LGR_HIP(ctx, hipMemsetAsync(kept_count, 0, 4, ctx->stream));
             if (ca.u_colv) ucol_pack_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(ca.u_colv, mb_pad, c_scale, ucol16);
+            // Descriptors the bounds cannot separate (structureless rows: every stage is scheduled) gain nothing from the coarse sweep -- nearly every
+            // tile passes it and is then computed a second time in full.  The device decides from the pass's stage count (no host round trip: a
+            // synchronisation here cost the pass 2.6 ms): above half of all stages the work list goes to the plain six-step kernel, otherwise to
+            // the sweep; the other kernel finds an empty list.
+            int* xs_sweep = xcd_start + 32;
+            int* xs_plain = xcd_start + 48;
+            pass_select_kernel<<<1, 16, 0, ctx->stream>>>(mo.coarse_rejection == 2 ? nullptr : cur_pass_stages, 0.5 * g_last_stats.stages_all, xcd_start, xs_sweep, xs_plain);
             const int sweep_grid = 8 * (SW_OCC / 2) * std::max(1, ctx->n_cu / 8);
             match_sweep<<<sweep_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, c_scale, A.blkcl, ma_pad, mb_pad, rg_rows, mask, n_cc,
-                                                              item_rb, ilist, xcd_start, xcd_ctr, ca, ca.u_colv ? ucol16 : nullptr, kept, kept_count, kept_cap);
+                                                              item_rb, ilist, xs_sweep, xcd_ctr, ca, ca.u_colv ? ucol16 : nullptr, kept, kept_count, kept_cap);
             const int tiles_grid = 8 * std::max(1, ctx->n_cu);
             if (both) match_tiles<true><<<tiles_grid, 64 * TL_WAVES, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, A.blkcl, ma_pad, mb_pad,
                                                                                        rg_rows, tile_group, rowmin, colmin, kept, kept_count, kept_cap);
             else match_tiles<false><<<tiles_grid, 64 * TL_WAVES, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, A.blkcl, ma_pad, mb_pad,
                                                                                    rg_rows, tile_group, rowmin, colmin, kept, kept_count, kept_cap);
+            {
+                const CoarseArgs none{};
+                const CoarseArgs& ca = none;
+                int* const xcd_start_real = xcd_start;
+                int* xcd_start = xs_plain;   // (LGR_MFMA_ARGS names xcd_start and ca)
+                (void) xcd_start_real;
+                if (both) match_mfma<true, FMT_F16R, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+                else match_mfma<false, FMT_F16R, false><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
+            }
         } else if (f16 && rot && ca.u_rb) {
             if (both) match_mfma<true, FMT_F16R, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
             else match_mfma<false, FMT_F16R, true><<<mfma_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, LGR_MFMA_ARGS);
@@ -790,6 +807,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             if (init_aside) LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[29], 0));
             CoarseArgs ca = ca_on;
             if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb; }
+            cur_pass_stages = &mstats->stages[pass];
             LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NTHR, CO ? LGR_MM_OCC_CO : LGR_MM_OCC) void match_m
 
   for (;;) {
     __syncthreads();   // all waves are done with the previous item (tg_s, item_s, cmin_s)
-    if (tid == 0) item_s = atomicAdd(&xcd_ctr[xcd], 1);
+    if (tid == 0) item_s = n_items > 0 ? atomicAdd(&xcd_ctr[xcd], 1) : 0x7fffffff;   // (an empty list leaves the counter alone: another kernel may own it)
     __syncthreads();
     const int it = item_s;
     if (it >= n_items) break;

@@ -39,6 +39,16 @@ __global__ void ucol_pack_kernel(const float* __restrict__ u_colv, int mb_pad, f
     out[col] = (unsigned short) (min(bits + 0xffffu, 0x7f800000u) >> 16);
 }
 
+// which kernel takes the pass's work list (see launch_mfma): the list's per-XCD offsets go to one of them, zeros to the other
+__global__ void pass_select_kernel(const unsigned long long* __restrict__ pass_stages, double half_of_all, const int* __restrict__ xcd_start /* [9] */,
+                                   int* __restrict__ xs_sweep, int* __restrict__ xs_plain) {
+    const int i = threadIdx.x;
+    if (i >= 9) return;
+    const bool plain = pass_stages && (double) pass_stages[0] > half_of_all;
+    xs_sweep[i] = plain ? 0 : xcd_start[i];
+    xs_plain[i] = plain ? xcd_start[i] : 0;
+}
+
 __global__ __launch_bounds__(NTHR, SW_OCC) void match_sweep(const f16x8* __restrict__ Ap, const f16x8* __restrict__ Bp, size_t bset_stride /* fragments */,
                                                             float c_scale, const int* __restrict__ blkcl, int ma_pad, int mb_pad, int rg_rows,
                                                             const unsigned* __restrict__ stage_mask, int n_cc, int item_rb, const int2* __restrict__ items,
@@ -64,7 +74,9 @@ __global__ __launch_bounds__(NTHR, SW_OCC) void match_sweep(const f16x8* __restr
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) item_s = atomicAdd(&xcd_ctr[xcd], 1);
+        // (an empty list leaves the counter alone: another kernel may own it.  No early exit on a full list: looking at the list's counter -- the
+        //  hottest address of the launch -- once per item cost 1 ms of 5.6; an overflowing pass is repeated by the fused kernel either way)
+        if (tid == 0) item_s = n_items > 0 ? atomicAdd(&xcd_ctr[xcd], 1) : 0x7fffffff;
         __syncthreads();
         const int it = item_s;
         if (it >= n_items) break;
@@ -280,7 +292,8 @@ __global__ __launch_bounds__(64 * TL_WAVES) void match_tiles(const f16x8* __rest
     constexpr int KS = OpFmt<FMT_F16R>::KS;
     constexpr int IINF = 0x7f800000;
     const int lane = threadIdx.x & 63, half = lane >> 5;
-    const unsigned n = min(*kept_count, kept_cap);
+    if (*kept_count > kept_cap) return;   // overflow: the fused kernel repeats the whole pass
+    const unsigned n = *kept_count;
     const unsigned n_waves = gridDim.x * TL_WAVES, w_id = blockIdx.x * TL_WAVES + (threadIdx.x >> 6);
     const int rg_blocks = rg_rows / BLOCK_ROWS;
     const f32x16 nav = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -219,7 +219,7 @@ def test_coarse_rejection(lgr, oracle, matcher_mode):
         return (100.0 * x / x.sum(2, keepdims=True)).reshape(m, 33).astype(np.float32)
     # half tight clusters, half one broad distribution (there the bounds exclude little: the final pass has tiles to test)
     a = np.concatenate([cloud(6000), fpfh_like(rng, 6000)]); b = np.concatenate([fpfh_like(rng, 8000), cloud(7000)])
-    opts(lgr, self_check=1)
+    opts(lgr, self_check=1, coarse_rejection=2)   # (2: the sweep also when the pass schedules most of the tiles, as it does at this size)
     oi, ri = run_both(lgr, oracle, a, b, 4000)
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     on = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
@@ -257,7 +257,7 @@ def test_shell_bound(lgr, oracle, matcher_mode):
         return (100.0 * x / x.sum(2, keepdims=True)).reshape(m, 33).astype(np.float32)
     a = np.concatenate([cloud(9000), fpfh_like(rng, 3000)]); b = np.concatenate([fpfh_like(rng, 4000), cloud(11000)])
     a[17] = b[40]; a[18] = b[40]                                   # exact ties across the two sets
-    opts(lgr, self_check=1)
+    opts(lgr, self_check=1, coarse_rejection=2)   # (2: the sweep also when the pass schedules most of the tiles)
     run_both(lgr, oracle, a, b, 4000)
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     on = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
@@ -267,7 +267,7 @@ def test_shell_bound(lgr, oracle, matcher_mode):
     r_rows, r_cols = lgr.match_check()
     assert 0.0 <= r_rows <= 1.0 and 0.0 <= r_cols <= 1.0, (r_rows, r_cols)
     one = [t.cpu().numpy() for t in lgr.match_bf(ta, tb, 4000)]
-    opts(lgr, self_check=1, shell_bound=0)
+    opts(lgr, self_check=1, shell_bound=0, coarse_rejection=2)
     off = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
     lgr.sync()
     assert lgr.match_shell() == 0.0

@@ -79,8 +79,8 @@ def main():
             names = sorted(k for k in cnt if "match_mfma" in k or "match_sweep" in k or "match_tiles" in k)   # all MFMA passes of a step (round 4: the final pass is two kernels)
             # cross-check of the bench line's issued-FLOP count against the hardware's own instruction count (v_mfma_f32_32x32x16_f16 = 32 768 FLOP)
             n_mfma = sum(sum(cnt[k].get("SQ_INSTS_MFMA", [])) for k in names)
-            if n_mfma:
-                for d in dirs:
+            if n_mfma and want == "match_mfma":
+                for d in dirs[:1]:
                     try:
                         for line in open(d.rstrip("/") + ".log"):
                             if line.startswith('{"metric"'):
