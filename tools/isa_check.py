@@ -17,7 +17,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lidar-global-registration_amd", "csrc")
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+OBJDUMP = next((p for p in (os.path.join(b, "lib", "llvm", "bin", "llvm-objdump") for b in (os.environ.get("ROCM_PATH"), "/opt/rocm") if b) if os.path.exists(p)), None) or __import__("shutil").which("llvm-objdump") or "llvm-objdump"
 
 
 def disassemble(obj):
