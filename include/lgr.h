@@ -220,6 +220,11 @@ int lgr_normals_knn_dev(lgr_ctx*, float* d_pts, int n, const float* d_surf, int 
 /* ---- include/common.h:322-332 estimateFeatures<FPFH>(kps, surface, features, radius, params) ---- */
 int lgr_fpfh(lgr_ctx*, const float* kps, int m, const float* surf, int n, float radius, float* out_m_x_33);
 int lgr_fpfh_dev(lgr_ctx*, const float* d_kps, int m, const float* d_surf, int n, float radius, float* d_out);
+/* Device self-check of the FPFH weighting kernel's reciprocal (v_rcp_f32 + one Newton step in place of the IEEE division sequence;
+ * include/common.h:322-332 -> pcl::FPFHEstimation::weightPointSPFHSignature's 1.0f / dists[idx]): every float whose bit pattern lies in
+ * [lo_bits, hi_bits] goes through both; out2[0] = values where they differ (must be 0 on [1e-36, 1e36], the range the kernel uses it on),
+ * out2[1] = values tested. */
+int lgr_selfcheck_rcp(lgr_ctx*, unsigned lo_bits, unsigned hi_bits, unsigned long long* out2);
 
 /* ---- include/matching.h:373-376 matchBF<FPFH>(query, train, params), randomness = 1 ----
  * idx[i] = matched train row or -1 (invalid / NaN query), dist[i] = L2 distance (sqrt) */

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -343,50 +344,15 @@ __device__ __forceinline__ int bin11(double t) {
     return (int) v;
 }
 
-constexpr int SB = 128;
 // SPFH rows are kept in the SORTED order of the grid (row t = the point at sorted position t, so the points of a cell --
-// the candidates the weighting step streams -- are consecutive rows) with a pitch of HP = 48 floats: bins 0..32, then 15
-// zeros.  48 = three 16-column MFMA operand tiles of 64 B each; the zeros make the third tile (bin 32 alone) a plain load.
+// the candidates the weighting step streams -- are consecutive rows) with a pitch of HP = 48 floats: bins 0..32 and 15 zeros
+// = three 16-column MFMA operand tiles; the zeros make the third tile (bin 32 alone) a plain load.  Stored interleaved (spfh_slot).
 constexpr int HP = 48;
+// Slot of bin b in an SPFH row: the weighting kernel's lane i multiplies bins i, 16 + i and 32 + i (one column of each 16-bin MFMA tile), so those
+// three are stored next to each other and arrive as ONE 12-byte load per lane and candidate (three 64-byte segments per candidate before).
+__host__ __device__ constexpr int spfh_slot(int b) { return (b & 15) * 3 + (b >> 4); }
 // SPFH rows for the surface points listed in the sorted order of the grid (thread t handles sorted position order[t]).
 // Counters live in LDS as [bin][thread] (bank = thread % 32: conflict-free).
-__global__ __launch_bounds__(SB) void spfh_kernel(GridDev g, float r2, const uint8_t* __restrict__ need /* by original index or NULL */,
-                                                   const int* __restrict__ order /* processing order of the sorted positions or NULL */,
-                                                   float* __restrict__ spfh /* [n_surface][HP] by SORTED position */) {
-    __shared__ int cnt[33 * SB];
-    int t = blockIdx.x * SB + threadIdx.x;
-    if (t >= g.n) return;
-    if (order) t = order[t];
-    float4 P = g.pxyz[t];
-    float4 N = g.pnrm[t];
-    int p = __float_as_int(P.w);
-    if (need && !need[p]) return;
-    for (int b = 0; b < 33; ++b) cnt[b * SB + threadIdx.x] = 0;
-    int k = 0;
-    const float d_pi = 1.0f / (2.0f * 3.14159274101257324f);   // 1.0f / (2.0f * static_cast<float>(M_PI))
-    const double MPI = 3.14159265358979323846;
-    lgr_visit27(g, P.x, P.y, P.z, [&](int s, float4 Q) {
-        float d2 = lgr_dist2(P.x, P.y, P.z, Q.x, Q.y, Q.z);
-        if (!(d2 < r2)) return;
-        ++k;
-        if (s == t) return;
-        float4 M = g.pnrm[s];
-        float f1, f2, f3;
-        if (!pair_features(P.x, P.y, P.z, N.x, N.y, N.z, Q.x, Q.y, Q.z, M.x, M.y, M.z, f1, f2, f3)) return;
-        int b1 = bin11(((double) f1 + MPI) * (double) d_pi);
-        int b2 = 11 + bin11(((double) f2 + 1.0) * 0.5);
-        int b3 = 22 + bin11(((double) f3 + 1.0) * 0.5);
-        // no-return LDS adds (ds_add_u32): nothing waits on the counters until the end of the kernel
-        atomicAdd(&cnt[b1 * SB + threadIdx.x], 1); atomicAdd(&cnt[b2 * SB + threadIdx.x], 1); atomicAdd(&cnt[b3 * SB + threadIdx.x], 1);
-    });
-    float* row = spfh + (size_t) t * HP;
-    float incr = 100.0f / (float) (k - 1);
-    for (int b = 0; b < 33; ++b) {
-        row[b] = lgr_seqsum(incr, cnt[b * SB + threadIdx.x]);
-    }
-    for (int b = 33; b < HP; ++b) row[b] = 0.f;
-}
-
 // SPFH rows of 16 surface points per wave with the expensive part (pcl::computePairFeatures: two square roots, three divisions,
 // an atan2, three bin indices) run on COMPACTED work: a thread-per-point loop over the 27-cell candidates keeps only the ~35 % of
 // its lanes busy that accept their current candidate.  Here lane = candidate: the points of the 27 cells around a run of tile
@@ -576,24 +542,13 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
         if (tile * ST + i >= g.n) continue;
         const int ps = __float_as_int(tp[i].w);
         const float incr = 100.0f / (float) (kcnt[i] - 1);
-        spfh[(size_t) ps * HP + b] = lgr_seqsum(incr, hist[0][i][b] + hist[1][i][b]);
+        spfh[(size_t) ps * HP + spfh_slot(b)] = lgr_seqsum(incr, hist[0][i][b] + hist[1][i][b]);
     }
     for (int q = l; q < ST * (HP - 33); q += 64) {
         const int i = q / (HP - 33), b = 33 + q % (HP - 33);
         if (tile * ST + i >= g.n) continue;
-        spfh[(size_t) __float_as_int(tp[i].w) * HP + b] = 0.f;
+        spfh[(size_t) __float_as_int(tp[i].w) * HP + spfh_slot(b)] = 0.f;
     }
-}
-
-// marks the surface points within r of any keypoint (PCL's spfh_indices set)
-__global__ void need_kernel(GridDev g, const float* __restrict__ kps, int m, float r2, uint8_t* __restrict__ need) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    float x = kps[(size_t) i * 12], y = kps[(size_t) i * 12 + 1], z = kps[(size_t) i * 12 + 2];
-    if (!lgr_finite3(x, y, z)) return;
-    lgr_visit27(g, x, y, z, [&](int s, float4 Q) {
-        if (lgr_dist2(x, y, z, Q.x, Q.y, Q.z) < r2) need[__float_as_int(Q.w)] = 1;
-    });
 }
 
 // FPFH rows of 16 key points per wave on the f32 matrix cores (include/common.h:322-332 -> pcl::FPFHEstimation::weightPointSPFHSignature).
@@ -614,11 +569,60 @@ __global__ void need_kernel(GridDev g, const float* __restrict__ kps, int m, flo
 // Lanes of other runs in the same wave are masked (+0), so a tile may straddle cells.  Epilogue: accumulators -> LDS, one lane
 // per (key point, 11-bin block): block sum in double (ascending bins), 100 / sum, scaled bins to the key point's output row.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+// 1.0f / x for the weights, without the IEEE division sequence (v_div_scale x 2, v_rcp, five fma, v_div_fmas, v_div_fixup: 11 instructions,
+// a quarter of the weighting loop): v_rcp_f32 (1 ulp) and LGR_RCP_STEPS Newton steps y += y * (1 - x y), each two fma (packed: one
+// v_pk_fma_f32 per two candidates).  The result is the correctly rounded quotient for every x in [LGR_RCP_LO, LGR_RCP_HI] -- not argued, CHECKED:
+// lgr_selfcheck_rcp compares the sequence with the division for every float of that range on the device it runs on
+// (tests/test_gpu_features.py; 2.0e9 values).  Outside the range (a squared distance below 1e-36) the callers divide.
+#ifndef LGR_RCP_STEPS
+#define LGR_RCP_STEPS 1
+#endif
+constexpr float LGR_RCP_LO = 1e-36f;   // (upper end 1e36: lgr_fpfh_dev checks the radius)
+__device__ __forceinline__ v2f lgr_rcp2(v2f x) {
+    v2f y{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    const v2f one{1.f, 1.f};
+#pragma unroll
+    for (int s = 0; s < LGR_RCP_STEPS; ++s) {
+        const v2f e = __builtin_elementwise_fma(-x, y, one);
+        y = __builtin_elementwise_fma(e, y, y);
+    }
+    return y;
+}
+__device__ __forceinline__ float lgr_rcp1(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+#pragma unroll
+    for (int s = 0; s < LGR_RCP_STEPS; ++s) {
+        const float e = fmaf(-x, y, 1.f);
+        y = fmaf(e, y, y);
+    }
+    return y;
+}
+// out[0] += floats of [lo_bits, hi_bits] whose lgr_rcp1 / lgr_rcp2 differs from 1.0f / x, out[1] += floats tested
+__global__ void rcp_check_kernel(unsigned lo_bits, unsigned hi_bits, unsigned long long* __restrict__ out) {
+    unsigned long long bad = 0, cnt = 0;
+    const unsigned long long span = (unsigned long long) hi_bits - lo_bits + 1ull;
+    for (unsigned long long o = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; o < span; o += (unsigned long long) gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(lo_bits + (unsigned) o);
+        const float q = 1.0f / x;
+        const v2f r2 = lgr_rcp2(v2f{x, x});
+        bad += (__float_as_uint(lgr_rcp1(x)) != __float_as_uint(q)) || (__float_as_uint(r2.x) != __float_as_uint(q)) || (__float_as_uint(r2.y) != __float_as_uint(q));
+        ++cnt;
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); cnt += __shfl_xor(cnt, o); }
+    if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&out[0], bad); atomicAdd(&out[1], cnt); }
+}
 constexpr int FT = 16;        // key points per wave
-constexpr int FRING = 128;    // live-candidate ring entries (float4: x, y, z, bits(sorted position))
+constexpr int FRING = 128;    // live-candidate ring entries (float4: x, y, z, bits(sorted position * HP))
 constexpr int FP_PITCH = 36;  // LDS pitch of the epilogue rows (4 * 36 mod 32 == 16: the four row groups of a store hit different banks)
 
-__global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m, float r2,
+#ifndef LGR_EXP_FPFH_WAVES
+#define LGR_EXP_FPFH_WAVES 1
+#endif
+#ifndef LGR_EXP_FPFH_ROUND
+#define LGR_EXP_FPFH_ROUND 4
+#endif
+__global__ __launch_bounds__(64, LGR_EXP_FPFH_WAVES) void fpfh_mfma_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m, float r2,
                                                        const float* __restrict__ Hs /* [g.n + 1][HP], last row zero */, float* __restrict__ out) {
     __shared__ float4 ring[FRING];
     __shared__ float fpl[FT * FP_PITCH];
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
     bool found = false;
     const float r2box = r2 * 1.0001f + 1e-30f;
-    const float* hbase = Hs + i;   // lane (i, k) supplies column i of every 16-bin tile
+    const float* hload = Hs + 3 * i;   // lane (i, k) supplies column i of every 16-bin tile (spfh_slot: bins i, 16 + i, 32 + i are adjacent); row offsets in 32 bits (lgr_fpfh_dev checks the size)
     // runs of key points with the same cell (the tile is sorted by cell; -1 cells are skipped)
     for (int p = 0; p < FT;) {
         const int c = __builtin_amdgcn_readlane(cell, p);
@@ -659,49 +663,77 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
             by0 = fminf(by0, __shfl_xor(by0, o)); by1 = fmaxf(by1, __shfl_xor(by1, o));
             bz0 = fminf(bz0, __shfl_xor(bz0, o)); bz1 = fmaxf(bz1, __shfl_xor(bz1, o));
         }
+        // (the same in every lane after the reduction: kept in scalar registers, six vector registers fewer across the loops below)
+        auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        bx0 = uni(bx0); bx1 = uni(bx1); by0 = uni(by0); by1 = uni(by1); bz0 = uni(bz0); bz1 = uni(bz1);
         const int cz = c / (g.dx * g.dy), cy = (c / g.dx) % g.dy, cx = c % g.dx;
         int head = 0, tail = 0;   // ring positions (monotone; entry e lives at e & (FRING - 1))
+        // A round of G groups (4 G candidates): the ring entries are read together, the SPFH loads of the round (one 12-byte load per lane and
+        // group) are in flight together while the squared distances (lgr_dist2's operations, two candidates per packed instruction) and the
+        // reciprocals (lgr_rcp2) are computed, and the groups' MFMAs follow each other in candidate order -- the same products in the same
+        // order as one group at a time.  Every group is loaded and multiplied, used or not: a candidate no key point of the run accepts has
+        // weight +0 in all its lanes and leaves the accumulators as they are (the skip cost a ballot and a branch per group to save ~10 % of
+        // the loads).  (History: one group per round left the MFMAs waiting for a dependent L2 round trip each time; the IEEE division and a
+        // 64-bit multiply per address were 40 % of the loop's vector instructions.)
+        auto round = [&](auto GC) {
+            constexpr int G = decltype(GC)::value;
+            float4 e[G];
+            f32x3 hv[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) e[u] = ring[(head + 4 * u + k) & (FRING - 1)];
+#pragma unroll
+            for (int u = 0; u < G; ++u) hv[u] = *reinterpret_cast<const f32x3*>(hload + (unsigned) __float_as_int(e[u].w));   // (the ring holds the row offsets)
+            const v2f X{x, x}, Y{y, y}, Z{z, z};
+            float d2[G], w[G];
+#pragma unroll
+            for (int h2 = 0; h2 < G / 2; ++h2) {
+                const v2f dx = X - v2f{e[2 * h2].x, e[2 * h2 + 1].x}, dy = Y - v2f{e[2 * h2].y, e[2 * h2 + 1].y}, dz = Z - v2f{e[2 * h2].z, e[2 * h2 + 1].z};
+                const v2f dd = (dx * dx + dy * dy) + dz * dz;   // lgr_dist2
+                const v2f ww = lgr_rcp2(dd);
+                d2[2 * h2] = dd.x; d2[2 * h2 + 1] = dd.y; w[2 * h2] = ww.x; w[2 * h2 + 1] = ww.y;
+            }
+            bool odd = false;
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const bool in = active & (d2[u] < r2);
+                found = found | in;
+                const bool use = in & (d2[u] != 0.f);
+                odd = odd | (use & !(d2[u] >= LGR_RCP_LO));
+                w[u] = use ? w[u] : 0.f;
+            }
+            if (__ballot(odd) != 0ull) {   // (never on real clouds: a squared distance below 1e-36 -- the division, as the canonical definition has it)
+#pragma unroll
+                for (int u = 0; u < G; ++u) w[u] = (active & (d2[u] < r2) & (d2[u] != 0.f)) ? 1.0f / d2[u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], hv[u].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], hv[u].y, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], hv[u].z, acc2, 0, 0, 0);
+            }
+            head += 4 * G;
+        };
         auto consume = [&](int n_groups) {
             int gq = 0;
-            // Four groups (16 candidates) per round, their twelve SPFH loads in flight together: one group per round left the MFMAs waiting for
-            // a dependent L2 round trip each time (PMC: 17 % of the wave cycles active, 49 % parked).  Same products in the same order: the
-            // groups' MFMAs follow each other in candidate order; a group nobody uses is left out as before.
-            for (; gq + 4 <= n_groups; gq += 4, head += 16) {
-                float w[4], b0[4], b1[4], b2[4];
-                bool used[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 e = ring[(head + 4 * u + k) & (FRING - 1)];
-                    const float d2 = lgr_dist2(x, y, z, e.x, e.y, e.z);
-                    const bool in = active && d2 < r2;
-                    found = found || in;
-                    const bool use = in && d2 != 0.f;
-                    used[u] = __ballot(use) != 0ull;   // (wave uniform)
-                    w[u] = 0.f; b0[u] = 0.f; b1[u] = 0.f; b2[u] = 0.f;
-                    if (used[u]) {
-                        w[u] = use ? 1.0f / d2 : 0.f;
-                        const float* h = hbase + (size_t) __float_as_int(e.w) * HP;
-                        b0[u] = h[0]; b1[u] = h[16]; b2[u] = h[32];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!used[u]) continue;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], b0[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], b1[u], acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u], b2[u], acc2, 0, 0, 0);
-                }
-            }
+#if LGR_EXP_FPFH_ROUND >= 8
+            for (; gq + 8 <= n_groups; gq += 8) round(std::integral_constant<int, 8>{});
+#endif
+            for (; gq + 4 <= n_groups; gq += 4) round(std::integral_constant<int, 4>{});
+#if LGR_EXP_FPFH_ROUND == 2 || LGR_EXP_FPFH_ROUND == 82
+            for (; gq + 2 <= n_groups; gq += 2) round(std::integral_constant<int, 2>{});
+#endif
             for (; gq < n_groups; ++gq, head += 4) {
                 const float4 e = ring[(head + k) & (FRING - 1)];
                 const float d2 = lgr_dist2(x, y, z, e.x, e.y, e.z);
-                const bool in = active && d2 < r2;
-                found = found || in;
-                const bool use = in && d2 != 0.f;
+                const bool in = active & (d2 < r2);
+                found = found | in;
+                const bool use = in & (d2 != 0.f);
                 if (__ballot(use) == 0ull) continue;
-                const float w = use ? 1.0f / d2 : 0.f;
-                const float* h = hbase + (size_t) __float_as_int(e.w) * HP;
-                const float b0 = h[0], b1 = h[16], b2 = h[32];
+                float w = lgr_rcp1(d2);
+                if (__ballot(use & !(d2 >= LGR_RCP_LO)) != 0ull) w = 1.0f / d2;
+                w = use ? w : 0.f;
+                const f32x3 hv = *reinterpret_cast<const f32x3*>(hload + (unsigned) __float_as_int(e.w));
+                const float b0 = hv.x, b1 = hv.y, b2 = hv.z;
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b1, acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b2, acc2, 0, 0, 0);
@@ -725,7 +757,7 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
                     if (lm == 0ull) continue;
                     if (live) {
                         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) lm, 0u));
-                        ring[(tail + rank) & (FRING - 1)] = make_float4(P.x, P.y, P.z, __int_as_float(t));
+                        ring[(tail + rank) & (FRING - 1)] = make_float4(P.x, P.y, P.z, __uint_as_float((unsigned) t * (unsigned) HP));   // .w: element offset of the SPFH row
                     }
                     tail += __popcll(lm);
                     __syncthreads();   // one wave per workgroup: orders the LDS stores before the reads below
@@ -735,7 +767,7 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
             }
         // the last 1..3 candidates of the run: pad the group with the all-zero SPFH row (position g.n) far away
         if (tail > head) {
-            if (l < 4 - (tail - head)) ring[(tail + l) & (FRING - 1)] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __int_as_float(g.n));
+            if (l < 4 - (tail - head)) ring[(tail + l) & (FRING - 1)] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __uint_as_float((unsigned) g.n * (unsigned) HP));
             __syncthreads();
             consume(1);
             __syncthreads();
@@ -942,6 +974,22 @@ extern "C" int lgr_downsample(lgr_ctx* ctx, const float* pts, int n, float voxel
     return LGR_OK;
 }
 
+// lgr.h: every float of [lo_bits, hi_bits] through the weighting kernel's reciprocal (lgr_rcp1 / lgr_rcp2) and through the division
+extern "C" int lgr_selfcheck_rcp(lgr_ctx* ctx, unsigned lo_bits, unsigned hi_bits, unsigned long long* out2) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, out2 && lo_bits <= hi_bits, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) 2, &d));
+    LGR_HIP(ctx, hipMemsetAsync(d, 0, 16, ctx->stream));
+    rcp_check_kernel<<<8 * ctx->n_cu, 256, 0, ctx->stream>>>(lo_bits, hi_bits, d);
+    LGR_HIP(ctx, hipGetLastError());
+    LGR_HIP(ctx, hipMemcpyAsync(out2, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LGR_OK;
+}
+
 #ifdef LGR_SPFH_CHECK
 // diagnostics of the -DLGR_SPFH_CHECK build (tools/exp_spfh_check.py): {pairs, pairs the filter left undecided, decided pairs whose bins differ}
 extern "C" int lgr_debug_spfh_check(unsigned long long* out3, int reset) {
@@ -1024,6 +1072,8 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_CHECK(ctx, (d_kps || m == 0) && (d_surf || n == 0) && (d_out || m == 0) && m >= 0 && n >= 0 && radius > 0.f, LGR_ERR_INVALID_ARG);
+    // the weighting kernel's reciprocal is checked for squared distances up to 1e36 (lgr_rcp2) and addresses SPFH rows with 32-bit element offsets
+    LGR_CHECK(ctx, radius <= 1e18f && (size_t) n + 1 <= ((size_t) 1 << 32) / HP - 1, LGR_ERR_UNSUPPORTED);
     if (m == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     GridDev g;

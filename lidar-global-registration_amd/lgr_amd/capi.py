@@ -276,6 +276,13 @@ class Context:
         self.check(_lib.lgr_match_last_work(self.h, C.byref(f)))
         return f.value
 
+    def selfcheck_rcp(self, lo, hi):
+        """(differing, tested) over every float in [lo, hi]: the FPFH weighting kernel's reciprocal against the IEEE division"""
+        out = (C.c_ulonglong * 2)()
+        lo_b, hi_b = (int(np.float32(v).view(np.uint32)) for v in (lo, hi))
+        self.check(_lib.lgr_selfcheck_rcp(self.h, C.c_uint(lo_b), C.c_uint(hi_b), out))
+        return int(out[0]), int(out[1])
+
     def match_issued(self):
         """the same with the stages of every pass summed (>= match_work): the MFMA work that was issued"""
         out = (C.c_double * 2)()

@@ -195,3 +195,27 @@ def test_fpfh(lgr, oracle, pair):
     # keypoints == surface (the reference's tests/flann_bf_matcher.h:55-56 call shape), host entry point
     sub = ds[:4000]
     np.testing.assert_array_equal(bits(lgr.fpfh_host(sub, sub, 0.25)), bits(oracle.fpfh(sub, sub, 0.25)))
+
+
+def test_fpfh_weight_reciprocal_is_the_division(lgr):
+    """The weighting kernel computes 1 / d2 as v_rcp_f32 + one Newton step (lgr_rcp2, lgr_features.hip) in place of the IEEE division
+    sequence; the canonical definition (oracle orc_fpfh; PCL's 1.0f / dists[idx]) is the division.  EVERY float of the range the kernel
+    uses the sequence on, [1e-36, 1e36] (2.0e9 values), goes through both on the device: not one may differ."""
+    bad, tested = lgr.selfcheck_rcp(1e-36, 1e36)
+    assert tested == int(np.float32(1e36).view(np.uint32)) - int(np.float32(1e-36).view(np.uint32)) + 1
+    assert bad == 0, f"{bad} of {tested} reciprocals differ from the division"
+
+
+def test_fpfh_tiny_distances_divide(lgr, oracle):
+    """squared distances below the checked range of the reciprocal (1e-36) take the division: two surface points 5e-19 apart"""
+    rng = np.random.default_rng(11)
+    from lgr_amd.synthetic import make_points
+    xyz = rng.uniform(0, 1, (3000, 3)).astype(np.float32)
+    xyz[1] = xyz[0]; xyz[1, 0] = np.nextafter(xyz[0, 0], np.float32(2))    # ~6e-8 apart: d2 ~ 3.5e-15 (inside the range)
+    xyz[2] = [5e-19, 0, 0]; xyz[3] = [0, 0, 0]                            # d2 = 2.5e-37: a normal float below the range
+    ds = oracle.normals_knn(make_points(xyz), 10)
+    want = oracle.fpfh(ds, ds, 0.2)
+    got = lgr.fpfh(cuda(ds), cuda(ds), 0.2).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_array_equal(bits(got)[ok], bits(want)[ok])
