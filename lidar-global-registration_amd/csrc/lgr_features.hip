@@ -616,13 +616,7 @@ constexpr int FT = 16;        // key points per wave
 constexpr int FRING = 128;    // live-candidate ring entries (float4: x, y, z, bits(sorted position * HP))
 constexpr int FP_PITCH = 36;  // LDS pitch of the epilogue rows (4 * 36 mod 32 == 16: the four row groups of a store hit different banks)
 
-#ifndef LGR_EXP_FPFH_WAVES
-#define LGR_EXP_FPFH_WAVES 1
-#endif
-#ifndef LGR_EXP_FPFH_ROUND
-#define LGR_EXP_FPFH_ROUND 4
-#endif
-__global__ __launch_bounds__(64, LGR_EXP_FPFH_WAVES) void fpfh_mfma_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m, float r2,
+__global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m, float r2,
                                                        const float* __restrict__ Hs /* [g.n + 1][HP], last row zero */, float* __restrict__ out) {
     __shared__ float4 ring[FRING];
     __shared__ float fpl[FT * FP_PITCH];
@@ -715,13 +709,7 @@ __global__ __launch_bounds__(64, LGR_EXP_FPFH_WAVES) void fpfh_mfma_kernel(GridD
         };
         auto consume = [&](int n_groups) {
             int gq = 0;
-#if LGR_EXP_FPFH_ROUND >= 8
-            for (; gq + 8 <= n_groups; gq += 8) round(std::integral_constant<int, 8>{});
-#endif
             for (; gq + 4 <= n_groups; gq += 4) round(std::integral_constant<int, 4>{});
-#if LGR_EXP_FPFH_ROUND == 2 || LGR_EXP_FPFH_ROUND == 82
-            for (; gq + 2 <= n_groups; gq += 2) round(std::integral_constant<int, 2>{});
-#endif
             for (; gq < n_groups; ++gq, head += 4) {
                 const float4 e = ring[(head + k) & (FRING - 1)];
                 const float d2 = lgr_dist2(x, y, z, e.x, e.y, e.z);
