@@ -777,6 +777,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         // bounds cannot exclude
         static const float betas[] = {LGR_PRUNE_BETAS};
         const int n_beta = (int) (sizeof betas / sizeof betas[0]);
+        // (an intermediate sweeping pass whose tile list overflows would go unrepaired: the repair below re-runs the LAST pass's mask only, and
+        //  every launch resets the list's counter -- seen as wrong matches with -DLGR_PRUNE_BETAS=0.5f,1.0f at pass-0 widths 6 and 12)
+        static_assert(sizeof betas / sizeof betas[0] == 1, "LGR_PRUNE_BETAS: one final pass only (lgr_match_common.cuh)");
         for (int pass = 0; pass <= n_beta; ++pass) {
             if (pass > 0) {
                 build_comp();
