@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-/* ABI revision.  4 (round 4): lgr_match_options.split_sweep and lgr_ctx_options.concurrent_contexts (former reserved words: a host that
- * zeroes them switches the split off and keeps the contexts exclusive), lgr_match_last_issued added.  3 (round 3): lgr_match_options.shell_bound (one of the reserved words: a host that zeroes them would switch the shell
+/* ABI revision.  4 (round 4): lgr_match_options.split_sweep / kept_cap and lgr_ctx_options.concurrent_contexts (former reserved words: a host that
+ * zeroes them switches the split off and keeps the contexts exclusive), lgr_match_last_issued, lgr_selfcheck_rcp added.  3 (round 3): lgr_match_options.shell_bound (one of the reserved words: a host that zeroes them would switch the shell
  * bound off), lgr_match_last_shell added.  2 (round 3): lgr_match_last_* take the context, lgr_ctx_options / lgr_ctx_host_threads added;
  * lgr_params grew in revision 1 -> 2 as well (use_bfmatcher, has_guess, match_search_radius, guess).  A host built against another revision must not
  * call in: check lgr_version() == LGR_VERSION once after loading (lgr_amd/capi.py and host/lgr_compat.hpp do). */
@@ -142,7 +142,8 @@ typedef struct {
     int32_t shell_bound;      /* radial shell bound per (row block, column stage) in the passes that have upper bounds: 1 (default) / 0 */
     int32_t split_sweep;      /* final pass of the rotated format as two kernels -- the coarse sweep appends the tiles it keeps to a list, a second
                                * kernel finishes them: 1 (default) / 0 (one fused kernel, round 3) */
-    int32_t reserved[3];
+    int32_t kept_cap;         /* capacity of that list in tiles: 0 default (16 M); a pass that keeps more is repeated on the fused kernel (tests: force it) */
+    int32_t reserved[2];
 } lgr_match_options;
 
 /* ---- context ---- */

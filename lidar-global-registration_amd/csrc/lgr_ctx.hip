@@ -298,7 +298,7 @@ extern "C" int lgr_ctx_set_match_options(lgr_ctx* ctx, const lgr_match_options* 
     if (!opt) lgr_match_default_options(&o);
     else {
         LGR_CHECK(ctx, opt->prune >= -1 && opt->prune <= 1 && opt->leaves >= 0 && opt->leaves <= 64 && opt->near >= 0 &&
-                       opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2, LGR_ERR_INVALID_ARG);
+                       opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2 && opt->kept_cap >= 0, LGR_ERR_INVALID_ARG);
         o = *opt;
     }
     propagate_mopt(ctx, o);

@@ -50,7 +50,7 @@ struct lgr_ctx {
     float stage_ms[12];
     int n_cu = 256;
     int mfma_timed = 0;
-    lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, 1, 1, {0, 0, 0}};   // lgr_match_default_options
+    lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, 1, 1, 0, {0, 0}};   // lgr_match_default_options
     bool corr_trusted = false;                  // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
     void* match_prep = nullptr;                 // the matcher's clustering / prepared query side (lgr_match.hip: MatchPrep)
     void (*match_prep_free)(void*) = nullptr;

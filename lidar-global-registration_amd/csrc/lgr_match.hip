@@ -563,7 +563,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     int* xcd_ctr = xcd_start + 16;                   // [8]
     const int mfma_grid = 8 * (LGR_MM_OCC / 2) * std::max(1, ctx->n_cu / 8);   // resident workgroups: LGR_MM_OCC / 2 per CU
     // final pass as sweep + listed tiles (lgr_match_sweep.cuh): the list, its counter, the per-column thresholds as bf16
-    const unsigned kept_cap = 16u << 20;
+    const unsigned kept_cap = mo.kept_cap > 0 ? (unsigned) mo.kept_cap : (16u << 20);
     uint2* kept = nullptr;
     unsigned* kept_count = nullptr;
     unsigned short* ucol16 = nullptr;

@@ -59,7 +59,7 @@ class MatchOptions(C.Structure):
     """lgr_match_options (include/lgr.h): how the matcher runs, never what it returns."""
     _fields_ = [("prune", C.c_int32), ("leaves", C.c_int32), ("near", C.c_int32), ("operand_format", C.c_int32), ("box_bounds", C.c_int32),
                 ("column_stage", C.c_int32), ("coarse_rejection", C.c_int32), ("rerank_refilter", C.c_int32), ("pair_cap", C.c_int32),
-                ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("shell_bound", C.c_int32), ("split_sweep", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("shell_bound", C.c_int32), ("split_sweep", C.c_int32), ("kept_cap", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class CtxOptions(C.Structure):

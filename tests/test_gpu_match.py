@@ -238,6 +238,38 @@ def test_coarse_rejection(lgr, oracle, matcher_mode):
     print(f"coarse rejection [{matcher_mode}]: {abandoned:.0f} of {tested:.0f} tiles abandoned")
 
 
+def test_final_pass_implementations_agree(lgr, oracle, matcher_mode):
+    """The final pass of the rotated format runs as a coarse sweep that lists the tiles it keeps plus a kernel that finishes the listed
+    tiles (lgr_match_options.split_sweep = 1, the default), as ONE fused kernel (split_sweep = 0, round 3), or -- when the sweep keeps
+    more tiles than its list holds (kept_cap) -- as the sweep followed by the fused kernel over the same schedule.  All three must give the
+    oracle's matches and distance bits, in both directions."""
+    import torch
+    if matcher_mode not in ("prune_sub4", "prune_sub64"):
+        pytest.skip("needs the skipping passes (upper bounds) and the default schedule")
+    rng = np.random.default_rng(31337)
+    centres = fpfh_like(rng, 32)
+    def cloud(m):
+        x = centres[rng.integers(0, 32, m)].astype(np.float64).reshape(m, 3, 11)
+        x = np.abs(x + rng.normal(0, 1.5, x.shape)) + 1e-3
+        return (100.0 * x / x.sum(2, keepdims=True)).reshape(m, 33).astype(np.float32)
+    a = np.concatenate([cloud(5000), fpfh_like(rng, 7000)]); b = np.concatenate([fpfh_like(rng, 6000), cloud(8000)])
+    a[5] = b[77]; a[6] = b[77]                                     # exact ties across the two sets
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    results = {}
+    for name, extra in (("split", dict(split_sweep=1)), ("fused", dict(split_sweep=0)), ("overflow", dict(split_sweep=1, kept_cap=64))):
+        opts(lgr, self_check=1, coarse_rejection=2, **extra)
+        run_both(lgr, oracle, a, b, 4000)                          # both directions against the oracle
+        results[name] = [t.cpu().numpy() for t in lgr.match_bf2(ta, tb, 4000)]
+        lgr.sync()
+        assert lgr.match_format() == "f16r"
+        tested, abandoned = lgr.match_coarse()
+        assert tested > 0 and 0 < abandoned < tested, (name, tested, abandoned)   # (some tiles are kept: more than the 64 the small list holds)
+        assert tested - abandoned > 64 or name != "overflow", (tested, abandoned)
+    for name in ("fused", "overflow"):
+        for x, y in zip(results["split"], results[name]):
+            np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
 def test_shell_bound(lgr, oracle, matcher_mode):
     """Rows and columns lie in radial shells about their cluster centre (they are sorted by that radius inside their leaves), and
     |a - b| >= | |a - c| - |b - c| |.  Pass 0 takes only the stages whose shell overlaps the row block's, the later passes drop stages
