@@ -371,12 +371,26 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             box_kernel<<<n_leaves, 256, 0, s2>>>(d_b, B.perm, B.leaf_start, n_leaves, basis, basis + 33 * 33, 1, boxBt, rmax2);
             LGR_HIP(ctx, hipEventRecord(ctx->ev[30], s2));
         }
-        // the sorted copies are for the exact rerank (and the f32 ball bounds): nothing before the MFMA passes reads them
+        LGR_HIP(ctx, hipGetLastError());
+    }
+    // The sorted copies are for the exact rerank (and the f32 ball bounds): with the f16 formats nothing before the MFMA passes reads them, so
+    // they are gathered UNDER pass 0 (launch_sorted_copies, called where that pass is queued: the set-up phase in front of it is bound by
+    // HBM -- 3.1 GB of column operands -- and the passes are not).
+    bool sorted_launched = false;
+    auto launch_sorted_copies = [&](bool behind_main) -> int {
+        if (sorted_launched) return LGR_OK;
+        sorted_launched = true;
+        hipStream_t s2 = ctx->aux->stream;
+        if (behind_main) {   // not before the work queued on the main stream so far
+            LGR_HIP(ctx, hipEventRecord(ctx->ev[26], ctx->stream));
+            LGR_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev[26], 0));
+        }
         gather_rows_kernel<<<cdiv((long long) mb_pad * 33, 256), 256, 0, s2>>>(d_b, B.perm, mb_pad, sortedB);
         if (sortedA) gather_rows_kernel<<<cdiv((long long) ma_pad * 33, 256), 256, 0, s2>>>(d_a, A.perm, ma_pad, sortedA);
         LGR_HIP(ctx, hipGetLastError());
         LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, s2));
-    }
+        return LGR_OK;
+    };
 
     // ---- 3. pack operands, group maxima, stage -> leaf map
     const bool f16 = mo.operand_format != 0;
@@ -534,6 +548,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // (sortedA / sortedB / the boxes: forked onto the second stream above; joined where they are first read)
     bool sorted_joined = false;
     auto join_sorted = [&]() -> int {
+        LGR_TRY(launch_sorted_copies(false));   // (a reader in front of the passes: the f32 ball bounds)
         if (!sorted_joined) LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev, 0));
         sorted_joined = true;
         return LGR_OK;
@@ -659,6 +674,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const float* chk_uq_rows = nullptr;
     const float* chk_uq_cols = nullptr;
     if (!prune) {
+        LGR_TRY(launch_sorted_copies(true));
         LGR_TRY(launch_mfma(nullptr, CoarseArgs{}));
         g_last_stats.stages_done = g_last_stats.stages_unique = g_last_stats.stages_all;
     } else {
@@ -811,6 +827,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             CoarseArgs ca = ca_on;
             if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb; }
             cur_pass_stages = &mstats->stages[pass];
+            if (pass == 0) LGR_TRY(launch_sorted_copies(true));
             LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans
