@@ -218,7 +218,9 @@ int lgr_downsample_dev(lgr_ctx*, const float* d_pts, int n, float voxel, float* 
 int lgr_normals_knn(lgr_ctx*, float* pts, int n, const float* surf, int ns, int k, const float* vp3, int normals_available);
 int lgr_normals_knn_dev(lgr_ctx*, float* d_pts, int n, const float* d_surf, int ns, int k, const float* vp3 /* host */, int normals_available);
 
-/* ---- include/common.h:322-332 estimateFeatures<FPFH>(kps, surface, features, radius, params) ---- */
+/* ---- include/common.h:322-332 estimateFeatures<FPFH>(kps, surface, features, radius, params) ----
+ * LGR_ERR_UNSUPPORTED for radius > 1e18 (the weighting kernel's reciprocal is checked for squared distances up to 1e36) and for
+ * more than 2^32 / 48 - 2 surface points (32-bit row offsets into the SPFH table). */
 int lgr_fpfh(lgr_ctx*, const float* kps, int m, const float* surf, int n, float radius, float* out_m_x_33);
 int lgr_fpfh_dev(lgr_ctx*, const float* d_kps, int m, const float* d_surf, int n, float radius, float* d_out);
 /* Device self-check of the FPFH weighting kernel's reciprocal (v_rcp_f32 + one Newton step in place of the IEEE division sequence;
