@@ -30,12 +30,14 @@
 extern "C" {
 #endif
 
-/* ABI revision.  4 (round 4): lgr_match_options.split_sweep / kept_cap and lgr_ctx_options.concurrent_contexts (former reserved words: a host that
+/* ABI revision.  5 (round 5): lgr_ctx_options.arithmetic / pcl_neighbour_cap (former reserved words: a host that zeroes them keeps the default),
+ * lgr_selfcheck_libm added; the DEFAULT arithmetic of the normals and pair features changed to PCL's own sequences (results differ from
+ * revision 4 at rounding level).  4 (round 4): lgr_match_options.split_sweep / kept_cap and lgr_ctx_options.concurrent_contexts (former reserved words: a host that
  * zeroes them switches the split off and keeps the contexts exclusive), lgr_match_last_issued, lgr_selfcheck_rcp added.  3 (round 3): lgr_match_options.shell_bound (one of the reserved words: a host that zeroes them would switch the shell
  * bound off), lgr_match_last_shell added.  2 (round 3): lgr_match_last_* take the context, lgr_ctx_options / lgr_ctx_host_threads added;
  * lgr_params grew in revision 1 -> 2 as well (use_bfmatcher, has_guess, match_search_radius, guess).  A host built against another revision must not
  * call in: check lgr_version() == LGR_VERSION once after loading (lgr_amd/capi.py and host/lgr_compat.hpp do). */
-#define LGR_VERSION 4
+#define LGR_VERSION 5
 
 enum {
     LGR_OK = 0,
@@ -120,8 +122,20 @@ typedef struct {
                                    * (1-500 ulp) between runs when 2-3 contexts worked at once; round 4 could not reproduce that -- not even
                                    * with the round-3 binary -- on the unit it was given (DESIGN.md section 10 has the full record), so the
                                    * cause is not established and the default stays exclusive.  One process per GPU is unaffected. */
-    int32_t reserved[6];
+    int32_t arithmetic;           /* LGR_ARITH_FAST (0, default) / LGR_ARITH_PCL (1): see below */
+    int32_t pcl_neighbour_cap;    /* LGR_ARITH_PCL: neighbours of a key point sorted at once; 0 default (1024), 64 (tests: drives the shell path).  Never changes results */
+    int32_t reserved[4];
 } lgr_ctx_options;
+/* Arithmetic of the third-party pieces (normals, pair features, FPFH weighting: PCL 1.12.1 behind include/common.h:322-332 and
+ * src/common.cpp:644-655).  In BOTH modes the normals are pcl::eigen33's closed form and the pair features use the acosf swap test and the
+ * atan2f of the named libm (GNU libc 2.35's float routines restated op for op: csrc/lgr_libm.cuh, pinned against the running libm by
+ * tests/test_oracle_libm.py) -- PCL's own sequences since round 5.  The modes differ in the FPFH weighting only:
+ *   LGR_ARITH_FAST  one fused multiply-add chain per bin over the neighbours in grid order (what v_mfma_f32_16x16x4_f32 computes), block
+ *                   normaliser from the finished bins: rounding-level deviation from PCL (measured: profiles/r5_pcl_order_by_piece_1M.json);
+ *   LGR_ARITH_PCL   pcl::FPFHEstimation::weightPointSPFHSignature as written: neighbours by ascending (squared distance, index),
+ *                   val = hist * w rounded, float adds, double block sums of the vals (a sort per key point: several ms per 1M-point cloud).
+ * Each mode is bit-identical to the oracle's mode of the same name (ORC_ARITH_CANONICAL / ORC_ARITH_PCL). */
+enum { LGR_ARITH_FAST = 0, LGR_ARITH_PCL = 1 };
 
 /* How the brute-force matcher runs (NEVER what it returns: every setting gives the same matches and distance bits).  The
  * defaults are the production schedule; the other values exist so that tests can drive every path at small sizes and so that
@@ -228,6 +242,10 @@ int lgr_fpfh_dev(lgr_ctx*, const float* d_kps, int m, const float* d_surf, int n
  * [lo_bits, hi_bits] goes through both; out2[0] = values where they differ (must be 0 on [1e-36, 1e36], the range the kernel uses it on),
  * out2[1] = values tested. */
 int lgr_selfcheck_rcp(lgr_ctx*, unsigned lo_bits, unsigned hi_bits, unsigned long long* out2);
+/* the named libm's float routines as the device evaluates them (csrc/lgr_libm.cuh: GNU libc 2.35's acosf / atanf / atan2f / sinf / cosf restated op
+ * for op), element-wise on host arrays: fn 0 acosf(a), 1 atanf(a), 2 atan2f(a, b), 3 sinf(a), 4 cosf(a) (sinf / cosf: |a| < 120).  A host
+ * can compare them with its own libm (tests/test_gpu_pcl_arith.py compares with the oracle's restatement, which is pinned against glibc). */
+int lgr_selfcheck_libm(lgr_ctx*, int fn, const float* a, const float* b, long long n, float* out);
 
 /* ---- include/matching.h:373-376 matchBF<FPFH>(query, train, params), randomness = 1 ----
  * idx[i] = matched train row or -1 (invalid / NaN query), dist[i] = L2 distance (sqrt) */

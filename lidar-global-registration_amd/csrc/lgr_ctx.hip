@@ -236,6 +236,7 @@ extern "C" int lgr_ctx_set_options(lgr_ctx* ctx, const lgr_ctx_options* opt) {
     lgr_ctx_default_options(&o);
     if (opt) o = *opt;
     LGR_CHECK(ctx, (o.helper_contexts == 0 || o.helper_contexts == 1) && (o.concurrent_contexts == 0 || o.concurrent_contexts == 1), LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, (o.arithmetic == LGR_ARITH_FAST || o.arithmetic == LGR_ARITH_PCL) && (o.pcl_neighbour_cap == 0 || o.pcl_neighbour_cap == 64 || o.pcl_neighbour_cap == 1024), LGR_ERR_INVALID_ARG);
     if (o.helper_contexts != ctx->opt.helper_contexts) {
         // the internal contexts are bound to a stream when they are created: drop them (workspaces included), they come back on
         // first use with the stream the new setting asks for
@@ -244,6 +245,9 @@ extern "C" int lgr_ctx_set_options(lgr_ctx* ctx, const lgr_ctx_options* opt) {
         drop_internal(ctx);
     }
     ctx->opt = o;
+    // the internal contexts run whole stages of the path (the target cloud's features on ctx->aux): they follow their owner's options
+    std::function<void(lgr_ctx*)> push = [&](lgr_ctx* c) { if (!c) return; c->opt = o; push(c->aux); push(c->aux2); };
+    push(ctx->aux); push(ctx->aux2);
     return LGR_OK;
 }
 

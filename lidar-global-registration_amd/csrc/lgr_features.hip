@@ -18,6 +18,7 @@
 #include "lgr_knn_wave.cuh"
 #include "lgr_seqsum.h"
 #include "lgr_math.cuh"
+#include "lgr_libm.cuh"
 
 namespace {
 
@@ -97,17 +98,12 @@ __device__ __forceinline__ void normals_finish(float* __restrict__ p, float px, 
     C[0] = a0 - a6 * a6; C[1] = a1 - a6 * a7; C[2] = a2 - a6 * a8;
     C[4] = a3 - a7 * a7; C[5] = a4 - a7 * a8; C[8] = a5 - a8 * a8;
     C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-    float Sg[3], V[9];
-    lgr_svd3<false>(C, nullptr, Sg, V);   // the normal is V's last column: U is never built
-#ifdef LGR_EXP_NORMALS_SCRATCH   // experiment only (tools/exp_svd_variants.sh): six dead stores to scratch memory, as the round-3 build had
-    {
-        volatile float dead[8];
-        dead[0] = V[0]; dead[2] = V[1]; dead[3] = V[3]; dead[4] = V[4]; dead[6] = V[6]; dead[7] = V[7];
-    }
-#endif
-    float nx = V[2], ny = V[5], nz = V[8];
+    // pcl::solvePlaneParameters -> pcl::eigen33: smallest eigenvalue and its eigenvector, PCL's closed form (lgr_libm.cuh; rounds 1-4 used a
+    // Jacobi solver here, a declared deviation of ~1e-6 that moved 0.3 % of the match indices: profiles/r5_pcl_order_by_piece_1M.json)
+    float lambda_min, nx, ny, nz;
+    lgr_pcl_eigen33(C, lambda_min, nx, ny, nz);
     float eig_sum = C[0] + C[4] + C[8];
-    float curv = (eig_sum != 0.f) ? fabsf(Sg[2] / eig_sum) : 0.f;
+    float curv = (eig_sum != 0.f) ? fabsf(lambda_min / eig_sum) : 0.f;
     float dx = vpx - px, dy = vpy - py, dz = vpz - pz;
     float cos_theta = (dx * nx + dy * ny + dz * nz);
     if (cos_theta < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
@@ -195,7 +191,7 @@ __device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, f
     float angle2 = dot3e(n2x, n2y, n2z, dx, dy, dz) / f4;
     float ux = n1x, uy = n1y, uz = n1z, mx = n2x, my = n2y, mz = n2z;
     float a1 = fabsf(angle1), a2 = fabsf(angle2);
-    if (a1 <= 1.0f && a2 <= 1.0f && a1 < a2) {
+    if (lgr_glibc::acosf_(a1) > lgr_glibc::acosf_(a2)) {   // PCL: std::acos (std::fabs (angle1)) > std::acos (std::fabs (angle2)) on floats (lgr_libm.cuh)
         ux = n2x; uy = n2y; uz = n2z; mx = n1x; my = n1y; mz = n1z;
         dx = -dx; dy = -dy; dz = -dz;
         f3 = -angle2;
@@ -209,41 +205,13 @@ __device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, f
     float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
     f2 = dot3e(vx, vy, vz, mx, my, mz);
     float yy = dot3e(wx, wy, wz, mx, my, mz), xx = dot3e(ux, uy, uz, mx, my, mz);
-    f1 = lgr_atan2f(yy, xx);
+    f1 = lgr_glibc::atan2f_(yy, xx);   // std::atan2 on floats (lgr_libm.cuh)
     return true;
 }
 
-// The same for TWO pairs at once: every operation is elementwise on 2-vectors (v_pk_mul_f32 / v_pk_add_f32 where the hardware has a
-// packed form -- IEEE, no fused multiply-add --, component by component for the square roots, divisions, selects and the atan2), so
-// each component sees exactly the scalar sequence above.  A pair that the scalar function skips has ok = false (its other
-// outputs are then meaningless: a division by zero may have produced inf / NaN).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f dot3e2(v2f ax, v2f ay, v2f az, v2f bx, v2f by, v2f bz) { return (ax * bx + az * bz) + ay * by; }
 __device__ __forceinline__ v2f sel2(bool c0, bool c1, v2f a, v2f b) { return v2f{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
-__device__ __forceinline__ void pair_features2(v2f p1x, v2f p1y, v2f p1z, v2f n1x, v2f n1y, v2f n1z, v2f p2x, v2f p2y, v2f p2z, v2f n2x, v2f n2y, v2f n2z,
-                                               v2f& f1, v2f& f2, v2f& f3, bool& ok0, bool& ok1) {
-    v2f dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
-    const v2f f4s = dot3e2(dx, dy, dz, dx, dy, dz);
-    const v2f f4 = v2f{__builtin_sqrtf(f4s.x), __builtin_sqrtf(f4s.y)};
-    ok0 = f4.x != 0.0f; ok1 = f4.y != 0.0f;
-    const v2f angle1 = dot3e2(n1x, n1y, n1z, dx, dy, dz) / f4;
-    const v2f angle2 = dot3e2(n2x, n2y, n2z, dx, dy, dz) / f4;
-    const v2f a1 = v2f{fabsf(angle1.x), fabsf(angle1.y)}, a2 = v2f{fabsf(angle2.x), fabsf(angle2.y)};
-    const bool s0 = a1.x <= 1.0f && a2.x <= 1.0f && a1.x < a2.x, s1 = a1.y <= 1.0f && a2.y <= 1.0f && a1.y < a2.y;
-    const v2f ux = sel2(s0, s1, n2x, n1x), uy = sel2(s0, s1, n2y, n1y), uz = sel2(s0, s1, n2z, n1z);
-    const v2f mx = sel2(s0, s1, n1x, n2x), my = sel2(s0, s1, n1y, n2y), mz = sel2(s0, s1, n1z, n2z);
-    dx = sel2(s0, s1, -dx, dx); dy = sel2(s0, s1, -dy, dy); dz = sel2(s0, s1, -dz, dz);
-    f3 = sel2(s0, s1, -angle2, angle1);
-    v2f vx = dy * uz - dz * uy, vy = dz * ux - dx * uz, vz = dx * uy - dy * ux;
-    const v2f vn2 = dot3e2(vx, vy, vz, vx, vy, vz);
-    const v2f v_norm = v2f{__builtin_sqrtf(vn2.x), __builtin_sqrtf(vn2.y)};
-    ok0 = ok0 && v_norm.x != 0.0f; ok1 = ok1 && v_norm.y != 0.0f;
-    vx = vx / v_norm; vy = vy / v_norm; vz = vz / v_norm;
-    const v2f wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
-    f2 = dot3e2(vx, vy, vz, mx, my, mz);
-    const v2f yy = dot3e2(wx, wy, wz, mx, my, mz), xx = dot3e2(ux, uy, uz, mx, my, mz);
-    f1 = v2f{lgr_atan2f(yy.x, xx.x), lgr_atan2f(yy.y, xx.y)};
-}
 
 // ---- the three bin indices of a pair through a FILTER with a proven decision band (round 4) ----
 // pcl::computePairFeatures is used here for three INTEGERS only (the bins of f1, f2, f3).  pair_bins_fast2 evaluates the same formulas
@@ -257,11 +225,13 @@ __device__ __forceinline__ void pair_features2(v2f p1x, v2f p1y, v2f p1z, v2f n1
 //   f2 = v . m (|m| ~ 1, sum |m_i| <= sqrt 3), five roundings per path                        ->  |d f2| <= 5.2e-7 + 10u < 1.2e-6           (DF2 = 3e-6)
 //   yy = w . m                                                                                 ->  |d yy| <= 1.8e-6 + 10u < 2.4e-6           (DY = 5e-6)
 //   f1 = atan2(yy, xx), xx identical in both: |d f1| <= DY / rho (rho^2 = xx^2 + yy^2, the sensitivity of atan2 to yy) + the two
-//        evaluations' own distance to atan2 (lgr_atan2f: <= 4 ulp of pi each; fast: the same polynomial on rcp quotients, + 6u)     (DF1 = 5e-6 / rho + 3e-6)
+//        evaluations' own distance to atan2 (glibc's atan2f: < 1 ulp of pi; fast: a Cephes polynomial on rcp quotients, <= 4 ulp of pi + 6u)   (DF1 = 5e-6 / rho + 3e-6)
 // A bin is floor(t), t = 5.5 (f + 1) (f2, f3) or 11 (f1 + pi) / (2 pi_f) (f1) -- the canonical code evaluates t in double, i.e. exactly
 // at this scale.  The fast t (one fused multiply-add, |t| <= 11: 11 u) is within 5.5 D + 1e-6 (f2, f3) / 1.751 D + 2e-6 (f1) of it, so
-// when the fast t is farther than that from every integer its floor IS the canonical bin.  The swap decision (|angle1| < |angle2|, both
-// <= 1) is certain when the two fast magnitudes are more than 2 DA apart and the larger is below 1 - DA.  Anything else -- a value
+// when the fast t is farther than that from every integer its floor IS the canonical bin.  The swap decision (PCL: acosf(|angle1|) >
+// acosf(|angle2|); acos decreases with slope <= -1 and glibc's acosf is within an ulp (1.2e-7) of it, so canonical magnitudes more than 1.2e-6
+// apart order their acosf values strictly, and a magnitude above 1 gives NaN = "no swap") is certain when the two fast magnitudes are
+// more than 2 DA apart and, for "swap", the larger is below 1 - DA.  Anything else -- a value
 // inside a band, a degenerate pair (coincident points, d parallel to the normal), rho below 1e-2, a NaN anywhere (every test is written
 // so that NaN fails it) -- is NOT decided here: the caller evaluates that pair with the canonical sequence.  On the 1M bench pair
 // about one pair in 10^4 is; the rows are bit-identical to the oracle's (tests/test_gpu_parity_1m.py::test_fpfh_1m_full compares all
@@ -302,7 +272,7 @@ __device__ __forceinline__ void pair_bins_fast2(v2f p1x, v2f p1y, v2f p1z, v2f n
     const v2f angle1 = dot3e2(n1x, n1y, n1z, dx, dy, dz) * rs;
     const v2f angle2 = dot3e2(n2x, n2y, n2z, dx, dy, dz) * rs;
     const v2f a1 = v2f{fabsf(angle1.x), fabsf(angle1.y)}, a2 = v2f{fabsf(angle2.x), fabsf(angle2.y)};
-    // swap <=> a1 <= 1 && a2 <= 1 && a1 < a2 (canonical); certain "no" when a1 > a2 + 2 DA, certain "yes" when a1 < a2 - 2 DA and a2 < 1 - DA
+    // swap <=> acosf(a1) > acosf(a2) (canonical = PCL); certain "no" when a1 > a2 + 2 DA, certain "yes" when a1 < a2 - 2 DA and a2 < 1 - DA
     const bool s0 = a1.x < a2.x, s1 = a1.y < a2.y;
     bool c0 = f4s.x > 1e-30f && (s0 ? (a2.x - a1.x > 2.0f * DA && a2.x < 1.0f - DA) : (a1.x - a2.x > 2.0f * DA));
     bool c1 = f4s.y > 1e-30f && (s1 ? (a2.y - a1.y > 2.0f * DA && a2.y < 1.0f - DA) : (a1.y - a2.y > 2.0f * DA));
@@ -399,7 +369,8 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
     const float d_pi = 1.0f / (2.0f * 3.14159274101257324f);   // 1.0f / (2.0f * static_cast<float>(M_PI))
     const double MPI = 3.14159265358979323846;
     int qh = 0, qt = 0;
-    auto process = [&](int nb) {   // the first nb (<= 128) queued pairs, two per lane: entries l and 64 + l
+    // (always_inline: left to its heuristics hipcc turns a lambda of this size into a CALL, with the captures in scratch memory)
+    auto process = [&](int nb) __attribute__((always_inline)) {   // the first nb (<= 128) queued pairs, two per lane: entries l and 64 + l
         const bool h0 = l < nb, h1 = 64 + l < nb;
         if (h0) {   // (every lane with a second pair also has a first one)
             const unsigned e0 = queue[(qh + l) & (SQ - 1)], e1 = h1 ? queue[(qh + 64 + l) & (SQ - 1)] : e0;
@@ -422,9 +393,12 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
 #pragma unroll 1
                 for (int hh = 0; hh < 2; ++hh) {
                     if (hh == 0 ? dec0 : (dec1 || !h1)) continue;
-                    const float4 P = hh ? P1 : P0, N = hh ? N1 : N0, Q = hh ? Q1 : Q0, M = hh ? M1 : M0;
+                    // (operands re-read from LDS: the fast path's 32 operand registers are dead here, the slow sequence -- two acosf, an atan2f -- reuses them)
+                    const int ii = hh ? i1 : i0, cc = (int) ((hh ? e1 : e0) & 255u);
+                    const float Px = tp[ii].x, Py = tp[ii].y, Pz = tp[ii].z, Nx = tn[ii].x, Ny = tn[ii].y, Nz = tn[ii].z;
+                    const float Qx = cp[cc].x, Qy = cp[cc].y, Qz = cp[cc].z, Mx = cn[cc].x, My = cn[cc].y, Mz = cn[cc].z;
                     float f1, f2, f3;
-                    const bool e = pair_features(P.x, P.y, P.z, N.x, N.y, N.z, Q.x, Q.y, Q.z, M.x, M.y, M.z, f1, f2, f3);
+                    const bool e = pair_features(Px, Py, Pz, Nx, Ny, Nz, Qx, Qy, Qz, Mx, My, Mz, f1, f2, f3);
                     const int c0 = bin11(((double) f1 + MPI) * (double) d_pi), c1 = bin11(((double) f2 + 1.0) * 0.5), c2 = bin11(((double) f3 + 1.0) * 0.5);
                     if (hh) { ok1 = e; bb[0] = c0; bb[1] = c1; bb[2] = c2; }
                     else { ok0 = e; ba[0] = c0; ba[1] = c1; ba[2] = c2; }
@@ -470,7 +444,7 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
         int n_buf = 0;   // live candidates waiting in cp / cn [0, n_buf)
         // every tile point of the run against the first n_c buffered candidates (lane = candidate), accepted pairs queued and
         // processed 64 at a time; the queue is drained before the candidate slots are reused
-        auto test_block = [&](int n_c) {
+        auto test_block = [&](int n_c) __attribute__((always_inline)) {
             float4 Q = make_float4(0.f, 0.f, 0.f, 0.f);
             if (l < n_c) Q = cp[l];
             for (int i = p0; i < p0 + n_run; ++i) {
@@ -799,6 +773,204 @@ __global__ __launch_bounds__(64) void fpfh_mfma_kernel(GridDev g, const float* _
     }
 }
 
+// ---- FPFH weighting exactly as PCL writes it (lgr_ctx_options.arithmetic = LGR_ARITH_PCL) ----
+// pcl::FPFHEstimation::weightPointSPFHSignature [3P, PCL 1.12.1 features/impl/fpfh.hpp; call site include/common.h:326-331]: the neighbours
+// of a key point in the order radiusSearch returns them -- ascending squared distance (ties: index, the oracle's rule; FLANN leaves them
+// open) --, per neighbour and bin  val = hist * (1.0f / d2)  ROUNDED to float,  fpfh[bin] += val  in float,  sum_block += val  in double, and
+// at the end fpfh[bin] * (100.0 / sum_block) in double, stored as float.  The default mode's fused chain in grid order (fpfh_mfma_kernel)
+// differs from this in rounding only (all three pieces measured alone: profiles/r5_pcl_order_by_piece_1M.json); this kernel restates
+// oracle orc_fpfh under ORC_ARITH_PCL bit for bit.  One wave per key point:
+//   gather  every candidate of the 27 cells with d2 < r2 as (bits(d2) << 32 | original index, sorted position) into LDS, up to PW_CAP;
+//           a key point with more neighbours than that is processed in SHELLS of ascending key ranges [lo, hi) found by bisection on the
+//           64-bit keys (any neighbour count works, the order of processing is the same);
+//   sort    bitonic, ascending keys;
+//   weigh   lane b < 33 owns bin b: val, float add and a double sum of its own vals, neighbour by neighbour in sorted order.
+// The block sums: PCL adds the 11 vals of a neighbour, neighbour after neighbour, into one double.  All vals are non-negative floats, i.e.
+// multiples of U = the smallest ulp among them; when the total T satisfies T < 2^53 U every partial sum of ANY order is a multiple of U
+// below 2^53 U and therefore exact -- all orders give the same double, so the per-lane sums added across the block's lanes ARE PCL's
+// sum.  The kernel tracks U and T and checks that condition at the end; when it fails (a neighbour ~1e-6 of the radius away, NaN / inf
+// values) the key point is done again in STRICT mode: the vals of a neighbour go through LDS and one lane per block adds them in PCL's
+// order.  tests/test_gpu_pcl_arith.py drives both paths and the shells (PW_CAP is a template parameter).
+template <int PW_CAP>
+__global__ __launch_bounds__(64) void fpfh_pcl_kernel(GridDev g, const float* __restrict__ kps, const int* __restrict__ order, int m, float r2,
+                                                      const float* __restrict__ Hs /* [g.n][HP] */, float* __restrict__ out) {
+    __shared__ unsigned long long skey[PW_CAP];
+    __shared__ unsigned spos[PW_CAP];
+    __shared__ float sval[64];
+    const int l = threadIdx.x;
+    const int tile = lgr_xcd_tile(blockIdx.x, m);
+    if (tile >= m) return;
+    const int kp = order[tile];
+    const float x = kps[(size_t) kp * 12], y = kps[(size_t) kp * 12 + 1], z = kps[(size_t) kp * 12 + 2];
+    const float nanv = __uint_as_float(0x7fc00000u);
+    float* o = out + (size_t) kp * 33;
+    if (!lgr_finite3(x, y, z) || g.n == 0) {
+        if (l < 33) o[l] = nanv;
+        return;
+    }
+    const int cx = min(max(lgr_cellc(x, g.ox, g.h), 0), g.dx - 1), cy = min(max(lgr_cellc(y, g.oy, g.h), 0), g.dy - 1), cz = min(max(lgr_cellc(z, g.oz, g.h), 0), g.dz - 1);
+    const unsigned long long key_end = (unsigned long long) __float_as_uint(r2) << 32;   // keys of neighbours are below it (d2 < r2, both non-negative)
+    // one pass over the candidates: count the neighbours with lo <= key < hi and (store) keep the first PW_CAP of them
+    auto scan = [&](unsigned long long lo, unsigned long long hi, bool store) -> int {
+        int cnt = 0;
+        for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dz - 1); ++zz)
+            for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dy - 1); ++yy) {
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
+                const size_t c0 = ((size_t) zz * g.dy + yy) * g.dx;
+                const int b = g.cell_start[c0 + x0], e = g.cell_start[c0 + x1 + 1];
+                for (int t0 = b; t0 < e; t0 += 64) {
+                    const int t = t0 + l;
+                    bool in = false;
+                    unsigned long long key = 0ull;
+                    if (t < e) {
+                        const float4 P = g.pxyz[t];
+                        const float d2 = lgr_dist2(x, y, z, P.x, P.y, P.z);
+                        key = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned) __float_as_int(P.w);
+                        in = d2 < r2 && key >= lo && key < hi;
+                    }
+                    const unsigned long long bm = __ballot(in);
+                    if (bm == 0ull) continue;
+                    if (store && in) {
+                        const int slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned) (bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bm, 0u));
+                        if (slot < PW_CAP) { skey[slot] = key; spos[slot] = (unsigned) t; }
+                    }
+                    cnt += __popcll(bm);
+                }
+            }
+        return cnt;
+    };
+    const int bin = min(l, 32);
+    const float* hcol = Hs + spfh_slot(bin);
+    for (int strict = 0; strict < 2; ++strict) {
+        float fp = 0.f;
+        double dsum = 0.0;          // strict: lanes 0..2 hold the block sums; otherwise every bin lane holds the double sum of its own vals
+        int emin = 255;             // smallest biased exponent among the nonzero vals of this lane (0 counted as 1: denormals share the ulp of the first binade)
+        bool bad = false;           // a val that is NaN, inf or negative: the exactness argument does not apply
+        int total = 0;
+        unsigned long long lo = 0ull;
+        while (lo < key_end) {
+            unsigned long long hi = key_end;
+            __syncthreads();        // the previous shell's reads of skey / spos are done
+            int cnt = scan(lo, hi, true);
+            if (cnt > PW_CAP) {
+                // more neighbours than the buffer holds: a shell [lo, hi) with PW_CAP / 4 <= count <= PW_CAP (keys are unique, so a one-key range holds <= 1)
+                unsigned long long a = lo, bnd = hi;   // count(lo, a) <= PW_CAP, count(lo, bnd) > PW_CAP
+                for (;;) {
+                    const unsigned long long mid = a + ((bnd - a) >> 1);
+                    const int c = scan(lo, mid, false);
+                    if (c > PW_CAP) bnd = mid;
+                    else { a = mid; if (c >= PW_CAP / 4 || bnd - a <= 1ull) break; }
+                }
+                hi = a;
+                __syncthreads();
+                cnt = scan(lo, hi, true);
+            }
+            total += cnt;
+            // bitonic sort of skey[0, n_pad) with spos as payload
+            int n_pad = 64;
+            while (n_pad < cnt) n_pad <<= 1;
+            for (int q = cnt + l; q < n_pad; q += 64) { skey[q] = ~0ull; spos[q] = 0u; }
+            __syncthreads();
+            for (int k2 = 2; k2 <= n_pad; k2 <<= 1)
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    for (int q = l; q < (n_pad >> 1); q += 64) {
+                        const int i0 = ((q & ~(j - 1)) << 1) | (q & (j - 1)), i1 = i0 | j;   // the q-th pair of this step
+                        const unsigned long long ka = skey[i0], kb = skey[i1];
+                        const bool up = (i0 & k2) == 0;
+                        if ((ka > kb) == up) {
+                            skey[i0] = kb; skey[i1] = ka;
+                            const unsigned pa = spos[i0]; spos[i0] = spos[i1]; spos[i1] = pa;
+                        }
+                    }
+                    __syncthreads();
+                }
+            // entries -> (bits(1.0f / d2) << 32 | sorted position * HP); weight 0 marks the key point itself (d2 == 0: skipped)
+            for (int q = l; q < cnt; q += 64) {
+                const float d2 = __uint_as_float((unsigned) (skey[q] >> 32));
+                const float w = d2 == 0.f ? 0.f : 1.0f / d2;
+                skey[q] = ((unsigned long long) __float_as_uint(w) << 32) | (spos[q] * (unsigned) HP);
+            }
+            __syncthreads();
+            if (!strict) {
+                int q = 0;
+                for (; q + 4 <= cnt; q += 4) {   // four SPFH loads in flight; the adds in neighbour order
+                    const unsigned long long e0 = skey[q], e1 = skey[q + 1], e2 = skey[q + 2], e3 = skey[q + 3];
+                    const float h0 = hcol[(unsigned) e0], h1 = hcol[(unsigned) e1], h2 = hcol[(unsigned) e2], h3 = hcol[(unsigned) e3];
+                    const float w0 = __uint_as_float((unsigned) (e0 >> 32)), w1 = __uint_as_float((unsigned) (e1 >> 32)), w2 = __uint_as_float((unsigned) (e2 >> 32)), w3 = __uint_as_float((unsigned) (e3 >> 32));
+                    const float v[4] = {h0 * w0, h1 * w1, h2 * w2, h3 * w3};
+                    const float ws[4] = {w0, w1, w2, w3};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ws[u] == 0.f) continue;   // (wave-uniform)
+                        fp += v[u];
+                        dsum += (double) v[u];
+                        const int eb = (int) ((__float_as_uint(v[u]) >> 23) & 0xffu);
+                        bad = bad || !(v[u] >= 0.f) || eb == 255;
+                        if (v[u] != 0.f) emin = min(emin, max(eb, 1));
+                    }
+                }
+                for (; q < cnt; ++q) {
+                    const unsigned long long e0 = skey[q];
+                    const float w0 = __uint_as_float((unsigned) (e0 >> 32));
+                    if (w0 == 0.f) continue;
+                    const float v0 = hcol[(unsigned) e0] * w0;
+                    fp += v0;
+                    dsum += (double) v0;
+                    const int eb = (int) ((__float_as_uint(v0) >> 23) & 0xffu);
+                    bad = bad || !(v0 >= 0.f) || eb == 255;
+                    if (v0 != 0.f) emin = min(emin, max(eb, 1));
+                }
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    const unsigned long long e0 = skey[q];
+                    const float w0 = __uint_as_float((unsigned) (e0 >> 32));
+                    if (w0 == 0.f) continue;
+                    const float v0 = hcol[(unsigned) e0] * w0;
+                    fp += v0;
+                    sval[l] = v0;
+                    __syncthreads();
+                    if (l < 3) {
+#pragma unroll
+                        for (int u = 0; u < 11; ++u) dsum += (double) sval[11 * l + u];   // sum_f += val_f, bin after bin
+                    }
+                    __syncthreads();
+                }
+            }
+            lo = hi;
+        }
+        if (total == 0) {           // no neighbour at all (the key point itself counts as one): a NaN row
+            if (l < 33) o[l] = nanv;
+            return;
+        }
+        // the block sums in the lanes of their bins
+        double bsum;
+        if (!strict) {
+            // exactness of every partial sum of every order: T < 2^53 U, U = 2^(emin - 150), T <= the sum of all lane sums (+ slack for their own rounding)
+            double t_all = l < 33 ? dsum : 0.0;
+            int e_all = l < 33 ? emin : 255;
+            bool b_all = l < 33 && bad;
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                t_all += __shfl_xor(t_all, s2);
+                e_all = min(e_all, __shfl_xor(e_all, s2));
+            }
+            b_all = __ballot(b_all) != 0ull;
+            const bool exact_here = !b_all && (e_all == 255 || t_all * 1.000001 < ldexp(1.0, 53 + e_all - 150));
+            if (__ballot(!exact_here) != 0ull) continue;   // (one decision per wave) again, in PCL's literal order
+            // sum of the block's 11 lane sums (exact, any order): lanes 11 blk .. 11 blk + 10
+            const int blk = bin / 11;
+            bsum = 0.0;
+#pragma unroll
+            for (int u = 0; u < 11; ++u) bsum += __shfl(dsum, 11 * blk + u);
+        } else {
+            bsum = __shfl(dsum, bin / 11);
+        }
+        if (bsum != 0) bsum = 100.0 / bsum;
+        if (l < 33) o[l] = (float) ((double) fp * bsum);
+        return;
+    }
+}
+
 // Processing order of key points / surface points: grid cell, then a Morton code of the position inside the cell
 // (2^sb steps per axis).  A wave then holds 64 spatially close points: its lanes walk the same 27 cells in lockstep
 // (wave-uniform loads) and mostly agree on which candidates lie within the radius, so fewer lanes idle through the
@@ -978,6 +1150,40 @@ extern "C" int lgr_selfcheck_rcp(lgr_ctx* ctx, unsigned lo_bits, unsigned hi_bit
     return LGR_OK;
 }
 
+// lgr.h: lgr_libm.cuh element-wise on the device (fn 0 acosf(a), 1 atanf(a), 2 atan2f(a, b), 3 sinf(a), 4 cosf(a)); host arrays
+__global__ void libm_eval_kernel(int fn, const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ out) {
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const float x = a[i];
+        float r;
+        switch (fn) {
+            case 0: r = lgr_glibc::acosf_(x); break;
+            case 1: r = lgr_glibc::atanf_(x); break;
+            case 2: r = lgr_glibc::atan2f_(x, b[i]); break;
+            case 3: r = lgr_glibc::sinf_(x); break;
+            default: r = lgr_glibc::cosf_(x); break;
+        }
+        out[i] = r;
+    }
+}
+extern "C" int lgr_selfcheck_libm(lgr_ctx* ctx, int fn, const float* a, const float* b, long long n, float* out) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, fn >= 0 && fn <= 4 && a && out && n >= 0 && (fn != 2 || b), LGR_ERR_INVALID_ARG);
+    if (n == 0) return LGR_OK;
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    float *da, *db, *dout;
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_A, (size_t) n, &da));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_B, (size_t) n, &db));
+    LGR_TRY(lgr_ws_t(ctx, WS_HOST_C, (size_t) n, &dout));
+    LGR_HIP(ctx, hipMemcpyAsync(da, a, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (fn == 2) LGR_HIP(ctx, hipMemcpyAsync(db, b, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    libm_eval_kernel<<<8 * ctx->n_cu, 256, 0, ctx->stream>>>(fn, da, db, n, dout);
+    LGR_HIP(ctx, hipGetLastError());
+    LGR_HIP(ctx, hipMemcpyAsync(out, dout, (size_t) n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LGR_OK;
+}
+
 #ifdef LGR_SPFH_CHECK
 // diagnostics of the -DLGR_SPFH_CHECK build (tools/exp_spfh_check.py): {pairs, pairs the filter left undecided, decided pairs whose bins differ}
 extern "C" int lgr_debug_spfh_check(unsigned long long* out3, int reset) {
@@ -1095,7 +1301,13 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
         LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) g.n, 0, key_bits));
         spfh_tile_kernel<<<lgr_xcd_grid(cdiv(g.n, ST)), 64, 0, ctx->stream>>>(g, r2, vals2, spfh);
     }
-    fpfh_mfma_kernel<<<lgr_xcd_grid(cdiv(m, FT)), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
+    if (ctx->opt.arithmetic == LGR_ARITH_PCL) {
+        // PCL's own weighting order and rounding steps (fpfh_pcl_kernel); pcl_neighbour_cap: neighbours sorted at once (tests shrink it to drive the shells)
+        if (ctx->opt.pcl_neighbour_cap == 64) fpfh_pcl_kernel<64><<<lgr_xcd_grid(m), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
+        else fpfh_pcl_kernel<1024><<<lgr_xcd_grid(m), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
+    } else {
+        fpfh_mfma_kernel<<<lgr_xcd_grid(cdiv(m, FT)), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
+    }
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }

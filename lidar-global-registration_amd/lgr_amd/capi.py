@@ -64,7 +64,12 @@ class MatchOptions(C.Structure):
 
 class CtxOptions(C.Structure):
     """lgr_ctx_options (include/lgr.h): how the context uses host threads and streams, never what it returns."""
-    _fields_ = [("helper_contexts", C.c_int32), ("concurrent_contexts", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("helper_contexts", C.c_int32), ("concurrent_contexts", C.c_int32), ("arithmetic", C.c_int32), ("pcl_neighbour_cap", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+
+ARITH_FAST, ARITH_PCL = 0, 1   # lgr_ctx_options.arithmetic (include/lgr.h): the FPFH weighting as one fused chain in grid order / exactly as PCL writes it
+LIBM_ACOSF, LIBM_ATANF, LIBM_ATAN2F, LIBM_SINF, LIBM_COSF = 0, 1, 2, 3, 4
 
 
 FORMAT_AUTO, FORMAT_F32, FORMAT_F16, FORMAT_F16R = -1, 0, 1, 2
@@ -82,7 +87,7 @@ def load():
     return C.CDLL(LIB_PATH)
 
 
-ABI_VERSION = 4      # LGR_VERSION of the include/lgr.h these structures mirror
+ABI_VERSION = 5      # LGR_VERSION of the include/lgr.h these structures mirror
 
 _lib = load()
 _lib.lgr_last_error.restype = C.c_char_p
@@ -282,6 +287,14 @@ class Context:
         lo_b, hi_b = (int(np.float32(v).view(np.uint32)) for v in (lo, hi))
         self.check(_lib.lgr_selfcheck_rcp(self.h, C.c_uint(lo_b), C.c_uint(hi_b), out))
         return int(out[0]), int(out[1])
+
+    def selfcheck_libm(self, fn, a, b=None):
+        """csrc/lgr_libm.cuh (glibc 2.35's float acosf / atanf / atan2f / sinf / cosf restated) evaluated on the device, element-wise"""
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(a if b is None else b, np.float32)
+        out = np.empty_like(a)
+        self.check(_lib.lgr_selfcheck_libm(self.h, int(fn), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_longlong(a.size), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def match_issued(self):
         """the same with the stages of every pass summed (>= match_work): the MFMA work that was issued"""

@@ -31,8 +31,17 @@ typedef struct { int32_t query, match; float distance, threshold; } lgr_orc_corr
 
 enum { ORC_ORDER_LIBSTDCXX = 0, ORC_ORDER_CANONICAL = 1 };
 /* arithmetic of the third-party pieces: the canonical orders the HIP path restates, or PCL 1.12.1's own (measurement only) */
-enum { ORC_ARITH_CANONICAL = 0, ORC_ARITH_PCL_EIGEN33 = 1 /* normals: pcl::eigen33 */, ORC_ARITH_PCL_LIBM = 2 /* pair features: acosf swap test, atan2f */,
-       ORC_ARITH_PCL_WEIGHTING = 4 /* FPFH: ascending-distance neighbours, mul then add, double sums of the vals */, ORC_ARITH_PCL = 7 };
+enum { ORC_ARITH_ROUND4 = 0,        /* none of the pieces below: the canonical orders of rounds 1-4 (kept for measurement: tools/pcl_order_report.py) */
+       ORC_ARITH_PCL_EIGEN33 = 1,   /* normals: pcl::eigen33 (closed form; atan2f / cosf / sinf of glibc 2.35, src/orc_libm.h) instead of the Jacobi solver */
+       ORC_ARITH_PCL_ACOS = 2,      /* pair features: swap test acosf(|a1|) > acosf(|a2|) of glibc 2.35 instead of the comparison of the arguments */
+       ORC_ARITH_PCL_W_ORDER = 4,   /* FPFH weighting: neighbours by ascending (d2, index) instead of grid order */
+       ORC_ARITH_PCL_W_ROUND = 8,   /* FPFH weighting: val = hist * w rounded, then added, instead of one fused chain per bin */
+       ORC_ARITH_PCL_W_NORM = 16,   /* FPFH weighting: block normaliser from the running double sum of the vals instead of the finished bins */
+       ORC_ARITH_PCL_ATAN2 = 32,    /* pair features: f1 by atan2f of glibc 2.35 instead of the round-4 polynomial */
+       ORC_ARITH_PCL_LIBM = 2 | 32, ORC_ARITH_PCL_WEIGHTING = 4 | 8 | 16,
+       ORC_ARITH_CANONICAL = 1 | 2 | 32,   /* DEFAULT since round 5 = what liblgr_hip.so restates by default (LGR_ARITH_FAST): PCL's own normals and pair
+                                            * features; only the weighting keeps the grid-order fused chain that runs on the matrix cores */
+       ORC_ARITH_PCL = 63 };               /* every piece = PCL 1.12.1's own arithmetic = lgr_ctx_options.arithmetic LGR_ARITH_PCL */
 enum { ORC_METRIC_CORRESPONDENCES = 0, ORC_METRIC_UNIFORMITY = 1, ORC_METRIC_CLOSEST_PLANE = 2, ORC_METRIC_COMBINATION = 3 };
 enum { ORC_SCORE_CONSTANT = 0, ORC_SCORE_MAE = 1, ORC_SCORE_MSE = 2, ORC_SCORE_EXP = 3 };
 enum { ORC_MATCH_LR = 0, ORC_MATCH_ONE_SIDED = 1, ORC_MATCH_CLUSTER = 2 };
@@ -87,8 +96,12 @@ typedef struct {
 void orc_default_params(lgr_orc_params* p);
 int  orc_num_threads(void);
 void orc_set_num_threads(int n);
-void orc_set_arith_mode(int mode);   /* process-wide; ORC_ARITH_CANONICAL by default */
+void orc_set_arith_mode(int mode);   /* process-wide bit mask; ORC_ARITH_CANONICAL by default */
 int  orc_arith_mode(void);
+/* src/orc_libm.h: fn 0 acosf(a), 1 atanf(a), 2 atan2f(a, b), 3 sinf(a), 4 cosf(a) (sinf / cosf: |a| < 120) */
+int  orc_libm_eval(int fn, const float* a, const float* b, long n, float* out);
+long orc_libm_check_range(int fn, uint32_t lo_bits, uint32_t hi_bits);   /* results differing from the running libm's */
+long orc_libm_check_atan2(const float* y, const float* x, long n);
 
 /* include/common.h:266-280 (FLT_MIN-initialised max quirk reproduced) */
 int orc_bbox(const float* pts, int n, float* mn3, float* mx3);

@@ -164,13 +164,43 @@ def default_params(**kw):
     return p
 
 
-ARITH_CANONICAL, ARITH_PCL_EIGEN33, ARITH_PCL_LIBM, ARITH_PCL_WEIGHTING, ARITH_PCL = 0, 1, 2, 4, 7
+# bit mask (lgr_oracle.h): single pieces of PCL 1.12.1's own arithmetic can be switched alone
+ARITH_ROUND4, ARITH_PCL_EIGEN33, ARITH_PCL_ACOS, ARITH_PCL_W_ORDER, ARITH_PCL_W_ROUND, ARITH_PCL_W_NORM, ARITH_PCL_ATAN2 = 0, 1, 2, 4, 8, 16, 32
+ARITH_PCL_LIBM, ARITH_PCL_WEIGHTING, ARITH_PCL = 2 | 32, 4 | 8 | 16, 63
+ARITH_CANONICAL = 1 | 2 | 32   # the default since round 5: PCL's own normals and pair features; the weighting in grid order (what the HIP default restates)
+ARITH_PIECES = {"eigen33_normals": 1, "acosf_swap_test": 2, "weighting_neighbour_order": 4, "weighting_rounded_product": 8,
+                "weighting_running_normaliser": 16, "atan2f_f1": 32}
+LIBM_ACOSF, LIBM_ATANF, LIBM_ATAN2F, LIBM_SINF, LIBM_COSF = 0, 1, 2, 3, 4
 
 
 def set_arith_mode(mode):
-    """ARITH_CANONICAL (default: the orders the HIP path restates) or ARITH_PCL (PCL 1.12.1's own neighbour order, rounding steps, libm
-    calls and eigen33 -- CPU-only measurement mode, see orc_features.cpp)"""
+    """ARITH_CANONICAL (default: what the HIP library's default mode restates -- PCL's eigen33 normals and glibc 2.35 pair features, the
+    FPFH weighting as one fused chain in grid order), ARITH_PCL (also PCL 1.12.1's own weighting order and rounding steps: what
+    lgr_ctx_options.arithmetic = LGR_ARITH_PCL restates), ARITH_ROUND4 (rounds 1-4's canonical orders), or any mask of pieces"""
     lib().orc_set_arith_mode(int(mode))
+
+
+def libm_eval(fn, a, b=None):
+    """orc_libm.h (glibc 2.35's acosf / atanf / atan2f / sinf / cosf restated) element-wise"""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(a if b is None else b, np.float32)
+    out = np.empty_like(a)
+    lib().orc_libm_eval(int(fn), _p(a), _p(b), C.c_long(a.size), _p(out))
+    return out
+
+
+def libm_check_range(fn, lo_bits, hi_bits):
+    """number of floats with bits in [lo_bits, hi_bits] whose restated result differs from the running libm's"""
+    f = lib().orc_libm_check_range
+    f.restype = C.c_long
+    return int(f(int(fn), C.c_uint32(lo_bits), C.c_uint32(hi_bits)))
+
+
+def libm_check_atan2(y, x):
+    y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
+    f = lib().orc_libm_check_atan2
+    f.restype = C.c_long
+    return int(f(_p(y), _p(x), C.c_long(y.size)))
 
 
 def arith_mode():

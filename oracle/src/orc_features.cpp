@@ -14,15 +14,20 @@
 #include "../lgr_oracle.h"
 #include "orc_grid.h"
 #include "orc_math.h"
+#include "orc_libm.h"
 
 using namespace orc;
 
-// Arithmetic mode of the third-party pieces (normals eigen-solver, pair-feature swap test / atan2, FPFH weighting order):
-//   ORC_ARITH_CANONICAL (default): the fixed orders DESIGN.md section 4 defines and the HIP kernels restate bit for bit;
-//   ORC_ARITH_PCL: the orders PCL 1.12.1 itself uses (restated from the pinned upstream version: neighbours by ascending distance,
-//   val = hist * w rounded then added, double block sums of the vals, libm acosf / atan2f, pcl::eigen33 closed form).  CPU only; it
-//   exists to MEASURE what the documented deviations do to the north-star observables (tests/test_oracle_pcl_order.py,
-//   tools/pcl_order_report.py) -- nothing is compared bit for bit against it.
+// Arithmetic mode of the third-party pieces (normals eigen-solver, pair-feature swap test / atan2, FPFH weighting) -- a bit mask
+// (lgr_oracle.h), so that every piece can be switched alone and its effect on the north-star observables measured
+// (tools/pcl_order_report.py --by-piece -> profiles/r5_pcl_order_by_piece*.json):
+//   ORC_ARITH_CANONICAL (default; EIGEN33 | ACOS | ATAN2): what the HIP library restates bit for bit in its default mode.  Since round 5
+//     the normals and the pair features ARE PCL 1.12.1's own sequences: pcl::eigen33's closed form and the acosf / atan2f / cosf / sinf
+//     of glibc 2.35, restated op for op in orc_libm.h and pinned against the running libm (tests/test_oracle_libm.py).  Only the FPFH
+//     weighting keeps its own order (one fused chain per bin in grid order = what v_mfma_f32_16x16x4_f32 computes).
+//   ORC_ARITH_PCL (all bits): also the weighting as PCL writes it (neighbours by ascending distance, val = hist * w rounded then added,
+//     double block sums of the vals) = lgr_ctx_options.arithmetic LGR_ARITH_PCL; tests/test_gpu_pcl_arith.py compares the two bit for bit.
+//   ORC_ARITH_ROUND4 (0): the canonical orders of rounds 1-4 (Jacobi normals, comparison of the arguments, own atan2 polynomial); measurement only.
 static int g_arith_mode = ORC_ARITH_CANONICAL;
 extern "C" void orc_set_arith_mode(int mode) { g_arith_mode = mode & ORC_ARITH_PCL; }   // bit mask: single deviations can be switched alone
 extern "C" int orc_arith_mode(void) { return g_arith_mode; }
@@ -183,8 +188,8 @@ inline void pcl_roots(const float m[9], float r[3]) {
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.f) q = 0.f;
     float rho = std::sqrt(-a_over_3);
-    float theta = std::atan2(std::sqrt(-q), half_b) * s_inv3;
-    float cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+    float theta = glibc235::atan2f_(std::sqrt(-q), half_b) * s_inv3;   // std::atan2 / std::cos / std::sin on floats: glibc 2.35's routines (orc_libm.h)
+    float cos_theta = glibc235::cosf_(theta), sin_theta = glibc235::sinf_(theta);
     r[0] = c2_over_3 + 2.f * rho * cos_theta;
     r[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     r[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
@@ -249,7 +254,7 @@ extern "C" int orc_normals_knn(float* pts, int n, const float* surf, int ns, int
             float nx, ny, nz, lambda_min;
             if (g_arith_mode & ORC_ARITH_PCL_EIGEN33) {
                 float v[3];
-                pcl_eigen33(C, lambda_min, v);
+                pcl_eigen33(C, lambda_min, v);   // (atan2f / cosf / sinf inside: orc_libm.h)
                 nx = v[0]; ny = v[1]; nz = v[2];
             } else {
                 float U[9], Sg[3], V[9];
@@ -291,7 +296,7 @@ inline bool pair_features(const float* p1, const float* n1, const float* p2, con
     // reference: if (acos(|angle1|) > acos(|angle2|)) swap.  acos is decreasing on [0,1] and NaN outside, so this is
     // restated as (|a1| <= 1 && |a2| <= 1 && |a1| < |a2|)  (no libm call; differs from libm only when two distinct
     // arguments round to the same acosf value).
-    const bool swap = (g_arith_mode & ORC_ARITH_PCL_LIBM) ? (std::acos(a1) > std::acos(a2))     // libm acosf on floats, as PCL writes it
+    const bool swap = (g_arith_mode & ORC_ARITH_PCL_ACOS) ? (glibc235::acosf_(a1) > glibc235::acosf_(a2))   // acosf on floats, as PCL writes it (orc_libm.h)
                                                       : (a1 <= 1.0f && a2 <= 1.0f && a1 < a2);
     if (swap) {
         u = n2; m2 = n1;
@@ -309,7 +314,7 @@ inline bool pair_features(const float* p1, const float* n1, const float* p2, con
     float w[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
     f2 = dot3(v, m2);
     float yy = dot3(w, m2), xx = dot3(u, m2);
-    f1 = (libm || (g_arith_mode & ORC_ARITH_PCL_LIBM)) ? std::atan2(yy, xx) : c_atan2f(yy, xx);
+    f1 = (g_arith_mode & ORC_ARITH_PCL_ATAN2) ? glibc235::atan2f_(yy, xx) : libm ? std::atan2(yy, xx) : c_atan2f(yy, xx);
     return true;
 }
 
@@ -398,17 +403,25 @@ extern "C" int orc_fpfh(const float* kps, int m, const float* surf, int n, float
             // pcl::FPFHEstimation::weightPointSPFHSignature [3P, PCL 1.12.1 features/impl/fpfh.hpp]: radiusSearch returns the neighbours
             // by ascending squared distance (sorted results; ties: index); per neighbour and bin val = hist * weight (rounded to float),
             // sum_f += val in double, fpfh[bin] += val in float; finally fpfh[bin] * (100.0 / sum_f) in double, stored as float.
+            // The three pieces (W_ORDER: the visiting order, W_ROUND: rounded product then add instead of one fused chain, W_NORM: the
+            // normaliser from the running double sum of the vals instead of the finished bins) can be switched alone.
+            const bool w_order = g_arith_mode & ORC_ARITH_PCL_W_ORDER, w_round = g_arith_mode & ORC_ARITH_PCL_W_ROUND, w_norm = g_arith_mode & ORC_ARITH_PCL_W_NORM;
             std::vector<std::pair<float, int>> nb;
             if (finite3(P)) g.visit27(P, [&](int q) { float d2 = dist2(P, surf + 12 * (size_t) q); if (d2 < r2) nb.emplace_back(d2, q); });
             if (nb.empty()) { for (int b = 0; b < 33; ++b) o[b] = std::numeric_limits<float>::quiet_NaN(); continue; }
-            std::sort(nb.begin(), nb.end());
+            if (w_order) std::sort(nb.begin(), nb.end());
             double sum[3] = {0, 0, 0};
             for (const auto& e : nb) {
                 if (e.first == 0.f) continue;
                 float weight = 1.0f / e.first;
                 const float* h = spfh.data() + 33 * (size_t) e.second;
-                for (int b = 0; b < 33; ++b) { float val = h[b] * weight; sum[b / 11] += val; fp[b] += val; }
+                for (int b = 0; b < 33; ++b) {
+                    float val = h[b] * weight;
+                    sum[b / 11] += val;
+                    fp[b] = w_round ? fp[b] + val : std::fmaf(weight, h[b], fp[b]);
+                }
             }
+            if (!w_norm) { sum[0] = sum[1] = sum[2] = 0; for (int b = 0; b < 33; ++b) sum[b / 11] += (double) fp[b]; }
             for (int s3 = 0; s3 < 3; ++s3) if (sum[s3] != 0) sum[s3] = 100.0 / sum[s3];
             for (int b = 0; b < 33; ++b) o[b] = (float) ((double) fp[b] * sum[b / 11]);
             continue;
@@ -434,4 +447,47 @@ extern "C" int orc_fpfh(const float* kps, int m, const float* surf, int n, float
         for (int b = 0; b < 33; ++b) o[b] = (float) ((double) fp[b] * sum[b / 11]);
     }
     return 0;
+}
+
+// ---- orc_libm.h against the libm this process runs on (tests/test_oracle_libm.py) and element-wise evaluation (tests compare the HIP
+// library's restatement, lgr_selfcheck_libm, with these)
+extern "C" int orc_libm_eval(int fn, const float* a, const float* b, long n, float* out) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        switch (fn) {
+            case 0: out[i] = glibc235::acosf_(a[i]); break;
+            case 1: out[i] = glibc235::atanf_(a[i]); break;
+            case 2: out[i] = glibc235::atan2f_(a[i], b[i]); break;
+            case 3: out[i] = glibc235::sinf_(a[i]); break;
+            default: out[i] = glibc235::cosf_(a[i]); break;
+        }
+    }
+    return 0;
+}
+// every float with bits in [lo_bits, hi_bits] (fn 0 acosf, 1 atanf, 3 sinf, 4 cosf) against std:: of the running libm: returns the number of
+// results that differ in any bit (two NaNs count as equal)
+extern "C" long orc_libm_check_range(int fn, uint32_t lo_bits, uint32_t hi_bits) {
+    long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long long bb = lo_bits; bb <= (long long) hi_bits; ++bb) {
+        const float x = glibc235::wfu((uint32_t) bb);
+        float r, l;
+        switch (fn) {
+            case 0: r = glibc235::acosf_(x); l = std::acos(x); break;
+            case 1: r = glibc235::atanf_(x); l = std::atan(x); break;
+            case 3: r = glibc235::sinf_(x); l = std::sin(x); break;
+            default: r = glibc235::cosf_(x); l = std::cos(x); break;
+        }
+        if (glibc235::fw(r) != glibc235::fw(l) && !(r != r && l != l)) ++bad;
+    }
+    return bad;
+}
+extern "C" long orc_libm_check_atan2(const float* y, const float* x, long n) {
+    long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long i = 0; i < n; ++i) {
+        const float r = glibc235::atan2f_(y[i], x[i]), l = std::atan2(y[i], x[i]);
+        if (glibc235::fw(r) != glibc235::fw(l) && !(r != r && l != l)) ++bad;
+    }
+    return bad;
 }

@@ -53,7 +53,7 @@ def test_struct_layout_matches_c_compiler(capi, tmp_path):
 
 def test_host_only_entry_points(capi):
     lib = capi.lib()
-    assert lib.lgr_version() == 4
+    assert lib.lgr_version() == 5
     p = capi.default_params()
     # defaults of src/common.cpp:216-223, 335-413 / include/common.h:38-57
     assert (p.feature_nr_points, p.normal_nr_points, p.bf_block_size, p.cluster_k, p.randomness, p.n_samples) == (352, 30, 10000, 40, 1, 3)

@@ -222,3 +222,52 @@ def test_cluster_1m_full(lgr, st, matches, oracle):
     full = lgr.align(st["src"]["cloud"], st["tgt"]["cloud"], p_g)
     np.testing.assert_array_equal(bits(full.matrix()), bits(res.matrix()))
     assert (full.iterations, full.n_inliers, full.n_correspondences) == (res.iterations, res.n_inliers, len(got))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# PCL 1.12.1's own arithmetic at BASELINE size: lgr_ctx_options.arithmetic = LGR_ARITH_PCL vs the oracle's ORC_ARITH_PCL.
+# Normals and pair features are PCL's sequences in BOTH modes (test_normals_1m_full / test_fpfh_1m_full above compare them with the
+# oracle's default, which is eigen33 + glibc 2.35's acosf / atan2f); the mode adds weightPointSPFHSignature's order and rounding steps.
+@pytest.fixture(scope="module")
+def pcl_feats(st):
+    import torch
+    from lgr_amd import capi
+    ctx = capi.Context(0)
+    ctx.set_options(arithmetic=capi.ARITH_PCL)
+    out = {}
+    for side in ("src", "tgt"):
+        f = ctx.fpfh(st[side]["cloud"], st[side]["nrm"], float(R))
+        ctx.sync()
+        out[side] = dict(feat=f, feat_h=f.cpu().numpy())
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("side", ["src", "tgt"])
+def test_fpfh_1m_full_pcl_arithmetic(st, pcl_feats, oracle, side):
+    oracle.set_arith_mode(oracle.ARITH_PCL)
+    try:
+        want = oracle.fpfh(st["pair"][side], st[side]["nrm_h"], float(R))
+    finally:
+        oracle.set_arith_mode(oracle.ARITH_CANONICAL)
+    got = pcl_feats[side]["feat_h"]
+    np.testing.assert_array_equal(bits(got), bits(want))       # 33 M values per cloud, NaN rows included
+    fast = st[side]["feat_h"]
+    ok = ~np.isnan(want).any(1)
+    # the default mode's weighting differs from PCL's at rounding level only
+    assert (bits(fast[ok]) != bits(want[ok])).any(1).mean() > 0.9 and np.abs(fast[ok] - want[ok]).max() < 2e-3
+
+
+def test_match_1m_pcl_arithmetic_rows_through_the_existing_matcher(lgr, pcl_feats, oracle):
+    """the match tables of the PCL-arithmetic FPFH rows: the exact matcher is indifferent to where its rows come from; sampled queries of
+    both directions against the oracle's exhaustive scan (index and distance bits)"""
+    ab_i, ab_d, ba_i, ba_d = [x.cpu().numpy() for x in lgr.match_bf2(pcl_feats["src"]["feat"], pcl_feats["tgt"]["feat"], BLOCK)]
+    lgr.sync()
+    fs, ft = pcl_feats["src"]["feat_h"], pcl_feats["tgt"]["feat_h"]
+    rng = np.random.default_rng(20261005)
+    for q, t, gi, gd in ((fs, ft, ab_i, ab_d), (ft, fs, ba_i, ba_d)):
+        sel = np.sort(rng.choice(q.shape[0], N_SAMPLE, replace=False)).astype(np.int32)
+        oi, od = oracle.match_bf_subset(q, sel, t, BLOCK)
+        valid = oi >= 0
+        np.testing.assert_array_equal(gi[sel], oi)
+        np.testing.assert_array_equal(bits(gd[sel])[valid], bits(od)[valid])

@@ -1,0 +1,149 @@
+"""GPU parity for the pieces of the path whose arithmetic is PCL 1.12.1's own.
+
+Since round 5 the DEFAULT mode's normals (pcl::eigen33, src/common.cpp:644-655 -> pcl::NormalEstimationOMP) and pair features
+(pcl::computePairFeatures behind include/common.h:322-332: acosf swap test, atan2f) are PCL's own sequences with the float routines of ONE
+named libm (GNU libc 2.35, restated op for op in oracle/src/orc_libm.h and csrc/lgr_libm.cuh; the oracle's restatement is pinned against
+the running libm.so.6 by tests/test_oracle_libm.py).  lgr_ctx_options.arithmetic = LGR_ARITH_PCL adds PCL's FPFH weighting
+(pcl::FPFHEstimation::weightPointSPFHSignature: ascending-distance neighbour order, rounded product, float adds, double block sums).
+Here: the device's libm restatement == the oracle's, element-wise; HIP(PCL) == oracle(PCL) bit for bit for FPFH rows incl. the shell path
+(more neighbours than the sort buffer), the strict-order path (block sums whose partial sums are not exact), NaN rows, lattice ties; the
+whole alignment in PCL mode == the oracle's.  Bar: bit-exact, tolerance 0 (transform: 1e-4, north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def pcl_ctx():
+    """a second context in LGR_ARITH_PCL (options are per context; the session's `lgr` context stays in the default mode)"""
+    import torch
+    assert torch.cuda.is_available()
+    from lgr_amd import capi
+    ctx = capi.Context(0)
+    o = ctx.set_options(arithmetic=capi.ARITH_PCL)
+    assert o.arithmetic == capi.ARITH_PCL
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture()
+def pcl_oracle(oracle):
+    oracle.set_arith_mode(oracle.ARITH_PCL)
+    yield oracle
+    oracle.set_arith_mode(oracle.ARITH_CANONICAL)
+
+
+def test_device_libm_equals_the_oracles_restatement(lgr, oracle):
+    from lgr_amd import capi
+    rng = np.random.default_rng(566)
+    n = 4_000_000
+    sp = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, np.inf, -np.inf, np.nan, 1e-38, -1e-38, 3e38, 1e-45, 2.0 ** -26, 2.0 ** -27, 2.0 ** -29, 2.0 ** 25, 2.0 ** 61,
+                   0.4375, 0.6875, 1.1875, 2.4375, np.pi / 4, np.pi / 3, 2.0 ** -12, 1.0000001, 0.99999994], np.float32)
+    # acosf: all of [-1.0000001, 1.0000001] by random bits + every special value
+    a = np.concatenate([rng.uniform(-1, 1, n).astype(np.float32), (rng.integers(0, 0x3f800001, n, dtype=np.uint32)).view(np.float32), sp])
+    assert (bits(lgr.selfcheck_libm(capi.LIBM_ACOSF, a)) == bits(oracle.libm_eval(oracle.LIBM_ACOSF, a))).all()
+    # atanf: random bit patterns of the whole float range
+    a = np.concatenate([rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32), sp])
+    g, w = lgr.selfcheck_libm(capi.LIBM_ATANF, a), oracle.libm_eval(oracle.LIBM_ATANF, a)
+    assert ((bits(g) == bits(w)) | (np.isnan(g) & np.isnan(w))).all()
+    # atan2f: unit-scale operands (the pair features' dot products), tiny operands (eigen33's), every pair of special values
+    y = np.concatenate([rng.uniform(-1.5, 1.5, n).astype(np.float32), np.abs(rng.standard_normal(n)).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 0, n).astype(np.float32)])
+    x = np.concatenate([rng.uniform(-1.5, 1.5, n).astype(np.float32), rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 0, n).astype(np.float32)])
+    x[9::1024] = 1.0; x[5::1024] = 0.0; y[7::1024] = 0.0
+    yy, xx = [v.ravel() for v in np.meshgrid(sp, sp)]
+    y = np.concatenate([y, yy]); x = np.concatenate([x, xx])
+    g, w = lgr.selfcheck_libm(capi.LIBM_ATAN2F, y, x), oracle.libm_eval(oracle.LIBM_ATAN2F, y, x)
+    assert ((bits(g) == bits(w)) | (np.isnan(g) & np.isnan(w))).all()
+    # sinf / cosf on [-8, 8] (eigen33 uses [0, pi / 3]; the wider range also covers the negated-cosine table)
+    a = np.concatenate([rng.uniform(-8, 8, n).astype(np.float32), rng.uniform(0, 1.1, n).astype(np.float32), sp[np.abs(np.nan_to_num(sp, nan=1e9, posinf=1e9, neginf=1e9)) < 100]])
+    for fn_g, fn_o in ((capi.LIBM_SINF, oracle.LIBM_SINF), (capi.LIBM_COSF, oracle.LIBM_COSF)):
+        assert (bits(lgr.selfcheck_libm(fn_g, a)) == bits(oracle.libm_eval(fn_o, a))).all()
+
+
+def _surface(n, seed):
+    from lgr_amd import synthetic
+    pair = synthetic.make_pair(n, seed=seed)
+    return pair
+
+
+@pytest.mark.parametrize("cap", [0, 64])
+def test_fpfh_pcl_mode_equals_oracle_pcl_mode(pcl_ctx, lgr, pcl_oracle, cap):
+    """cap = 64: every key point has more neighbours than the sort buffer -> processed in ascending shells; same rows"""
+    from lgr_amd import capi
+    pair = _surface(20000, 7)
+    o = pcl_oracle
+    surf = o.downsample(pair["src"], 0.0236)
+    nrm = o.normals_knn(surf, 30, vp=pair["vp_src"])
+    nrm[5, 4:7] = np.nan                                     # a NaN normal propagates into the rows around it (PCL does not filter it)
+    kps = pair["src"].copy()
+    kps[11, 0] = np.inf                                      # invalid key point -> NaN row
+    kps[12, :3] = [1e4, 1e4, 1e4]                            # no neighbour -> NaN row
+    want = o.fpfh(kps, nrm, 0.25)
+    pcl_ctx.set_options(arithmetic=capi.ARITH_PCL, pcl_neighbour_cap=cap)
+    got = pcl_ctx.fpfh(cuda(kps), cuda(nrm), 0.25).cpu().numpy()
+    pcl_ctx.set_options(arithmetic=capi.ARITH_PCL)
+    np.testing.assert_array_equal(bits(got), bits(want))
+    assert np.isnan(want[11]).all() and np.isnan(want[12]).all() and np.isnan(want).any(1).sum() > 50
+    # and it is NOT the default mode's result (the weighting really differs at rounding level) while staying within 1e-3 of it
+    fast = lgr.fpfh(cuda(kps), cuda(nrm), 0.25).cpu().numpy()
+    ok = ~np.isnan(want).any(1)
+    assert (bits(fast[ok]) != bits(want[ok])).any(1).mean() > 0.9 and np.abs(fast[ok] - want[ok]).max() < 1e-3
+
+
+def test_fpfh_pcl_mode_strict_block_sums_and_lattice_ties(pcl_ctx, pcl_oracle):
+    """(i) a neighbour 1e-6 away: val ~ 1e13 beside vals ~ 5 -> the partial block sums are not exact, the kernel must add them in PCL's
+    literal order (strict path); (ii) a regular lattice: many neighbours at exactly equal squared distances -> (d2, index) order"""
+    from lgr_amd.synthetic import make_points
+    o = pcl_oracle
+    rng = np.random.default_rng(3)
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(40), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.05)
+    pts = make_points(g)
+    pts[:, 4:7] = rng.normal(size=(len(pts), 3)).astype(np.float32)
+    pts[:, 4:7] /= np.linalg.norm(pts[:, 4:7], axis=1, keepdims=True)
+    extra = pts[:200].copy()
+    extra[:, :3] += rng.uniform(0.5e-6, 2e-6, (200, 3)).astype(np.float32)      # near-coincident twins of 200 lattice points
+    extra[:, 4:7] = rng.normal(size=(200, 3)).astype(np.float32)
+    extra[:, 4:7] /= np.linalg.norm(extra[:, 4:7], axis=1, keepdims=True)
+    surf = np.concatenate([pts, extra])
+    want = o.fpfh(surf, surf, 0.25)
+    got = pcl_ctx.fpfh(cuda(surf), cuda(surf), 0.25).cpu().numpy()
+    np.testing.assert_array_equal(bits(got), bits(want))
+    assert np.isfinite(want).all()
+
+
+def test_align_in_pcl_mode_equals_the_oracle_in_pcl_mode(pcl_ctx, pcl_oracle):
+    """the whole path (both clouds' features on the context's helper contexts: the option must reach them) in PCL's own arithmetic"""
+    from lgr_amd import capi, synthetic
+    o = pcl_oracle
+    pair = synthetic.make_pair(30000, seed=11)
+    kw = dict(matching_id=0, bf_block_size=200000, max_iterations=50000, distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"])
+    src, tgt = cuda(pair["src"]), cuda(pair["tgt"])
+    p_g = capi.default_params(**kw)
+    corr = pcl_ctx.correspondences(src, tgt, p_g).cpu().numpy().view(capi.CORR_DTYPE).reshape(-1)
+    res = pcl_ctx.align(src, tgt, p_g)
+    ores, ocorr, _ = o.align(pair["src"], pair["tgt"], o.default_params(rng_mode=o.RNG_PHILOX, **kw))
+    assert len(corr) == len(ocorr) and (corr["index_query"] == ocorr["query"]).all() and (corr["index_match"] == ocorr["match"]).all()
+    assert (bits(corr["distance"]) == bits(ocorr["distance"])).all()
+    assert res.n_inliers == ores.n_inliers and res.iterations == ores.iterations
+    assert np.abs(res.matrix() - ores.matrix()).max() <= 1e-4
+
+
+def test_options_validate_and_report(lgr):
+    from lgr_amd import capi
+    o = lgr.set_options()
+    assert o.arithmetic == capi.ARITH_FAST and o.pcl_neighbour_cap == 0
+    with pytest.raises(Exception):
+        lgr.set_options(arithmetic=2)
+    with pytest.raises(Exception):
+        lgr.set_options(pcl_neighbour_cap=100)
+    lgr.set_options()

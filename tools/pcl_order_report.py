@@ -1,8 +1,8 @@
 """What the oracle's documented deviations from PCL 1.12.1's arithmetic do to the north-star observables.
 
 The CPU oracle runs the BASELINE configs[1] profile twice on the same synthetic pair -- ARITH_CANONICAL (the orders the HIP path
-restates bit for bit) and ARITH_PCL (PCL's own: eigen33 closed-form normals, libm acosf swap test and atan2f, FPFH neighbours by
-ascending distance with val = hist * w rounded, float bin adds, double block sums) -- and reports, stage by stage:
+restates bit for bit) and ARITH_PCL (PCL's own: eigen33 closed-form normals, glibc 2.35's acosf swap test and atan2f, FPFH neighbours by
+ascending distance with val = hist * w rounded, float bin adds, double block sums; --by-piece: each of the six pieces alone) -- and reports, stage by stage:
 normals that differ in any bit / by more than 1e-5, FPFH rows that differ in any bit and the largest element difference, match
 indices that differ (both directions), correspondences that differ, and max |dT| of the final 4x4 after RANSAC + refit.
 
@@ -90,7 +90,11 @@ def main():
     ap.add_argument("--seed", type=int, default=566)
     ap.add_argument("--matching", default="lr", choices=["lr", "cluster"])
     ap.add_argument("--gpu-matcher", action="store_true")
-    ap.add_argument("--mode", type=int, default=7, help="bit mask of PCL-order pieces: 1 eigen33 normals, 2 libm acosf / atan2f, 4 FPFH weighting order; 7 = all")
+    ap.add_argument("--mode", type=int, default=63, help="bit mask of PCL-arithmetic pieces (oracle.ARITH_PIECES): 1 eigen33 normals, 2 acosf swap test, 4 weighting neighbour "
+                    "order, 8 weighting rounded product, 16 weighting running normaliser, 32 atan2f; 63 = all")
+    ap.add_argument("--base", type=int, default=None, help="arithmetic mask of the run everything is compared WITH: default oracle.ARITH_CANONICAL (35: what the HIP library's default "
+                    "mode restates since round 5); 0 = the canonical orders of rounds 1-4.  --by-piece always uses 0")
+    ap.add_argument("--by-piece", action="store_true", help="every piece switched ALONE against the canonical run, then all together: one JSON with a summary row per piece")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     import oracle as o
@@ -117,13 +121,45 @@ def main():
             return ab[0], ab[1], ba[0], ba[1]
     mid = o.MATCH_LR if a.matching == "lr" else o.MATCH_CLUSTER
     t0 = time.time()
-    can = run_mode(o, pair, o.ARITH_CANONICAL, matcher, mid)
-    pcl = run_mode(o, pair, a.mode, matcher, mid)
+    base = 0 if a.by_piece else (o.ARITH_CANONICAL if a.base is None else a.base)
+    can = run_mode(o, pair, base, matcher, mid)
     rep = {"workload": "BASELINE configs[1] profile, %d points per cloud, seed %d, matching %s" % (a.points, a.seed, a.matching),
-           "pcl_order_pieces": {"eigen33_normals": bool(a.mode & 1), "libm_acosf_atan2f": bool(a.mode & 2), "weighting_order": bool(a.mode & 4)},
-           "matcher": "liblgr_hip.so (exact, bit-identical to the oracle)" if a.gpu_matcher else "oracle",
-           "seconds": time.time() - t0}
-    rep.update(compare(can, pcl, pair))
+           "libm": "glibc 2.35 float routines restated (oracle/src/orc_libm.h)", "base_mode_bits": base,
+           "matcher": "liblgr_hip.so (exact, bit-identical to the oracle)" if a.gpu_matcher else "oracle"}
+    if a.by_piece:
+        rows = {}
+        # every piece ALONE against rounds 1-4's canonical orders (mask 0); then the round-5 default (eigen33 + acosf + atan2f) and all pieces
+        # against mask 0; finally what is LEFT between the round-5 default (LGR_ARITH_FAST) and PCL's own arithmetic (LGR_ARITH_PCL)
+        dflt = None
+        for name, bit in list(o.ARITH_PIECES.items()) + [("round5_default_vs_round4", o.ARITH_CANONICAL), ("all_pieces_vs_round4", o.ARITH_PCL), ("all_pieces_vs_round5_default", o.ARITH_PCL)]:
+            other = run_mode(o, pair, bit, matcher, mid)
+            if name == "round5_default_vs_round4":
+                dflt = other
+            c = compare(dflt if name == "all_pieces_vs_round5_default" else can, other, pair)
+            rows[name] = {"mode_bits": bit,
+                          "normals_differ_in_any_bit": c["normals_src"]["differ_in_any_bit"] + c["normals_tgt"]["differ_in_any_bit"],
+                          "normals_max_abs_component_diff": max(c["normals_src"]["max_abs_component_diff"], c["normals_tgt"]["max_abs_component_diff"]),
+                          "fpfh_rows_differ_in_any_bit": c["fpfh_src"]["rows_differ_in_any_bit"] + c["fpfh_tgt"]["rows_differ_in_any_bit"],
+                          "fpfh_max_abs_bin_diff": max(c["fpfh_src"]["max_abs_bin_diff"], c["fpfh_tgt"]["max_abs_bin_diff"]),
+                          "fpfh_rows_with_a_bin_moved_by_more_than_0.5": c["fpfh_src"]["rows_with_a_bin_moved_by_more_than_0.5"] + c["fpfh_tgt"]["rows_with_a_bin_moved_by_more_than_0.5"],
+                          "match_indices_differ": c["match"]["src_to_tgt_indices_differ"] + c["match"]["tgt_to_src_indices_differ"],
+                          "match_queries": c["match"]["queries"],
+                          "correspondences_only_canonical": c["correspondences"]["only_canonical"],
+                          "correspondences_only_piece": c["correspondences"]["only_pcl_order"],
+                          "correspondences_canonical": c["correspondences"]["canonical"],
+                          "inliers": [c["ransac"]["canonical"]["inliers"], c["ransac"]["pcl_order"]["inliers"]],
+                          "max_abs_dT": c["ransac"]["max_abs_dT"],
+                          "max_abs_err_vs_ground_truth": c["ransac"]["max_abs_err_vs_ground_truth"]}
+            if name.startswith("all_pieces"):
+                rep[name + "_detail"] = c
+            print("# %-30s match indices %7d  correspondences -%d +%d  |dT| %.3e" % (name, rows[name]["match_indices_differ"], rows[name]["correspondences_only_canonical"],
+                                                                                   rows[name]["correspondences_only_piece"], rows[name]["max_abs_dT"]), file=sys.stderr, flush=True)
+        rep["by_piece"] = rows
+    else:
+        pcl = run_mode(o, pair, a.mode, matcher, mid)
+        rep["pcl_order_pieces"] = {k: bool(a.mode & v) for k, v in o.ARITH_PIECES.items()}
+        rep.update(compare(can, pcl, pair))
+    rep["seconds"] = time.time() - t0
     line = json.dumps(rep)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
