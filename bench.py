@@ -68,6 +68,14 @@ def parse():
                          "through it, i.e. execute the RCCL calls of the N > 1 path on a one-GPU box")
     ap.add_argument("--single-context", action="store_true",
                     help="lgr_ctx_options.helper_contexts = 0: no helper host threads / streams (for hosts with fewer than 3 cores per rank)")
+    ap.add_argument("--job", default=None, choices=["tests156"],
+                    help="instead of the headline step: BASELINE configs[2] as a JOB -- 156 synthetic pairs with a 1e5 .. 1e6 size mix (the shape of "
+                         "data/tests.yaml, src/main.cpp:384-407) through distributed.run_pairs on this rank's GPU; pairs/s, ms per pair by size, and the "
+                         "8-rank makespan each sharding policy would have from the measured per-pair times")
+    ap.add_argument("--job-pairs", type=int, default=156)
+    ap.add_argument("--policy", default="lpt", choices=["round_robin", "lpt"], help="sharding policy of --job when N > 1")
+    ap.add_argument("--arithmetic", default="fast", choices=["fast", "pcl"],
+                    help="lgr_ctx_options.arithmetic: fast (default) or PCL's own FPFH weighting order and rounding steps (include/lgr.h)")
     ap.add_argument("--match-opt", action="append", default=[], metavar="FIELD=VALUE",
                     help="lgr_match_options override for ablations / profiles (e.g. coarse_rejection=0); never changes results")
     return ap.parse_args()
@@ -136,6 +144,104 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
     if not ok:
         raise SystemExit(3)
+
+
+def job_sizes(n_pairs, seed=566):
+    """points per cloud of the job's pairs: log-uniform in [1e5, 1e6], multiples of 10 000, one draw per pair from default_rng(seed) -- the
+    reference's data/tests.yaml lists 156 pairs of WHU-TLS / kizhi / arch / ... scans (clouds not shipped) that its loader voxel-filters
+    into this range (src/common.cpp:429-470); src and tgt of a pair get the same size"""
+    rng = np.random.default_rng(seed)
+    return [int(round(10 ** u / 1e4) * 1e4) for u in rng.uniform(5.0, 6.0, n_pairs)]
+
+
+def _job_make(args):
+    from lgr_amd import synthetic
+    pid, n = args
+    return pid, synthetic.make_pair(n, seed=synthetic.SEED + pid)
+
+
+def run_job(args, world, rank, local):
+    """BASELINE configs[2] (data/tests.yaml: 156 pairs, src/main.cpp:384-407 loops them sequentially) as a job on this rank's GPU.  Pairs are
+    generated by a small pool of CPU processes ahead of the GPU (started BEFORE this process touches HIP), uploaded, aligned through
+    distributed.run_pairs (the record's time_cs + time_te is the device-synchronised alignment time, include/analysis.h:68-70); rank 0 prints one
+    JSON line: pairs/s over the summed alignment time and over the job's wall (generation and upload included), ms per pair by size class, and
+    the makespan each sharding policy would give 8 ranks from the measured per-pair times."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    n_pairs = args.job_pairs
+    sizes = job_sizes(n_pairs)
+    sys.path.insert(0, os.path.join(ROOT, "lidar-global-registration_amd"))
+    from lgr_amd import distributed
+    costs = [distributed.pair_cost(n, n) for n in sizes]
+    mine = distributed.shard_pairs(n_pairs, world, rank, args.policy, costs)
+    pool = ProcessPoolExecutor(max_workers=max(1, min(6, _usable_cores() // max(1, world) - 1)), mp_context=mp.get_context("spawn"))
+    window = 8
+    futs = {}
+    nxt = 0
+
+    def prefetch():
+        nonlocal nxt
+        while nxt < len(mine) and len(futs) < window:
+            futs[mine[nxt]] = pool.submit(_job_make, (mine[nxt], sizes[mine[nxt]]))
+            nxt += 1
+    prefetch()
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the product and has no CPU fallback")
+    use_pg = world > 1
+    if use_pg:
+        _rendezvous_defaults(world)
+        dist.init_process_group("nccl" if args.backend == "nccl" else "gloo", **({"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}))
+    torch.cuda.set_device(local)
+    from lgr_amd import capi
+    ctx = capi.Context(local)
+    ctx.set_options(helper_contexts=0 if args.single_context else 1, arithmetic=capi.ARITH_PCL if args.arithmetic == "pcl" else capi.ARITH_FAST)
+    per = {}
+
+    def align_fn(pid):
+        _, pair = futs.pop(pid).result()
+        prefetch()
+        src = torch.from_numpy(pair["src"]).cuda(local)
+        tgt = torch.from_numpy(pair["tgt"]).cuda(local)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = ctx.align(src, tgt, make_params(capi, pair, args.matching))
+        torch.cuda.synchronize()
+        per[pid] = dict(ms=1e3 * (time.perf_counter() - t0), err=float(np.abs(res.matrix().astype(np.float64) - pair["T_gt"]).max()), converged=int(res.converged))
+        return distributed.pack_record(pid, res.transformation, res.converged, res.iterations, res.n_inliers, res.time_cs, res.time_te)
+
+    t0 = time.perf_counter()
+    allr = distributed.run_pairs(n_pairs, world, rank, align_fn, device=(f"cuda:{local}" if use_pg and args.backend == "nccl" else None), policy=args.policy, costs=costs)
+    wall = time.perf_counter() - t0
+    pool.shutdown()
+    if rank == 0:
+        recs = [distributed.unpack_record(r) for r in allr]
+        assert [r["pair_id"] for r in recs] == list(range(n_pairs))
+        t_pair = [r["time_cs"] + r["time_te"] for r in recs]           # seconds, device-synchronised, every rank's pairs
+        classes = {}
+        for n, t in zip(sizes, t_pair):
+            c = "%dk-%dk" % (100 * (n // 100000), 100 * (n // 100000) + 100) if n < 1000000 else "1000k"
+            classes.setdefault(c, []).append(1e3 * t)
+        pred8 = {pol: distributed.makespan(t_pair, 8, pol, costs) for pol in ("round_robin", "lpt")}
+        pred_cost8 = {pol: distributed.makespan(costs, 8, pol, costs) for pol in ("round_robin", "lpt")}
+        out = {"metric": "scan-pair registrations/sec (job)", "value": n_pairs / max(t_pair_sum := sum(t_pair), 1e-9) if world == 1 else n_pairs / wall, "unit": "registrations/s", "n_gpus": world,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[2] stand-in: %d synthetic pairs, 1e5 .. 1e6 points per cloud (log-uniform, seed 566), the configs[1] parameter profile" % n_pairs,
+                          "pairs": n_pairs, "matching": args.matching, "policy": args.policy, "arithmetic": args.arithmetic, "parallelism": f"pairs sharded over {world} GPU(s) by {args.policy}"},
+               "job": {"sum_alignment_seconds": sum(t_pair), "wall_seconds_incl_generation_and_upload": wall,
+                       "registrations_per_s_alignment_only": n_pairs / max(sum(t_pair), 1e-9), "registrations_per_s_wall": n_pairs / wall,
+                       "ms_per_pair_by_size": {c: {"pairs": len(v), "mean_ms": float(np.mean(v)), "min_ms": float(np.min(v)), "max_ms": float(np.max(v))} for c, v in sorted(classes.items())},
+                       "sizes_min_median_max": [int(min(sizes)), int(np.median(sizes)), int(max(sizes))],
+                       "converged": int(sum(r["converged"] for r in recs)),
+                       "max_abs_err_vs_gt_local_pairs": max((v["err"] for v in per.values()), default=None),
+                       "predicted_8_rank_makespan_seconds_from_measured_times": pred8,
+                       "predicted_8_rank_speedup_over_one_rank": {k: sum(t_pair) / v for k, v in pred8.items()},
+                       "cost_model_makespan_ratio_rr_over_lpt": pred_cost8["round_robin"] / pred_cost8["lpt"],
+                       "cost_model_fit": {"corrcoef_cost_vs_time": float(np.corrcoef(costs, t_pair)[0, 1]) if n_pairs > 2 else None}}}
+        print(json.dumps(out), flush=True)
+    if use_pg:
+        dist.destroy_process_group()
 
 
 def make_params(capi, pair, matching):
@@ -391,6 +497,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher formed WORLD_SIZE={world} ranks")
     if args.dry_run:
         return dry_run(args, world, rank)
+    if args.job:
+        return run_job(args, world, rank, local)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -407,8 +515,7 @@ def main():
     torch.cuda.set_device(local)
     from lgr_amd import capi, synthetic, distributed
     ctx = capi.Context(local)
-    if args.single_context:
-        ctx.set_options(helper_contexts=0)
+    ctx.set_options(helper_contexts=0 if args.single_context else 1, arithmetic=capi.ARITH_PCL if args.arithmetic == "pcl" else capi.ARITH_FAST)
     if args.match_opt:
         ctx.set_match_options(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.match_opt)})
 

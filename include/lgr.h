@@ -324,6 +324,9 @@ int lgr_ransac_replay_dev(lgr_ctx*, const float* d_src, int ns, const float* d_t
                           uint8_t* d_ok, float* d_T16, int32_t* d_n_inliers, float* d_metric);
 /* the on-device sampler alone: triples of iterations [first, first+n) (Philox4x32-10 + selectCorrespondences :33-77) */
 int lgr_ransac_samples_dev(lgr_ctx*, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples);
+/* one Philox4x32-10 block from the device's generator (the sampler above uses counter = (iteration, 0, 0, 0), key = seed; the closest-plane
+ * metric's subsets the full counter): key = (k0 | k1 << 32).  For Random123's known-answer vectors. */
+int lgr_selfcheck_philox(lgr_ctx*, uint64_t key, const uint32_t counter4[4], uint32_t out4[4]);
 /* src/metric.cpp:125-179 buildInliersAndEstimateMetric for one transform */
 int lgr_evaluate_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                      const float T16[16] /* host */, int metric_id, int score_id,

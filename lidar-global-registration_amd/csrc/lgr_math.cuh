@@ -1,33 +1,27 @@
 // lgr_math.cuh -- device elementary functions with a FIXED binary32 operation sequence (gfx950).
 //
-// libm results (std::atan2 in pcl::computePairFeatures, std::log / std::cbrt in src/analysis.cpp:95-130, std::exp
-// in src/metric.cpp:72) and Eigen::JacobiSVD (src/transformation.cpp:27, pcl::umeyama) are not reproducible bit for
+// libm results (std::log / std::cbrt in src/analysis.cpp:95-130, std::exp in src/metric.cpp:72; the acos / atan2 / cos / sin PCL calls are
+// restated from ONE named libm in lgr_libm.cuh) and Eigen::JacobiSVD (src/transformation.cpp:27, pcl::umeyama) are not reproducible bit for
 // bit across CPU and GPU math libraries.  The parity contract therefore fixes each of them as a sequence of IEEE
 // + - * / sqrt operations (documented in DESIGN.md "canonical elementary functions"); this header is the device
 // statement of those sequences and must be compiled with -ffp-contract=off.  Accuracy vs libm: <= 2 ulp.
 #pragma once
 #include <hip/hip_runtime.h>
 
-// atan2: Cephes-style atanf polynomial on min/max in [0,1] (two ranges), then octant fix-up.
-__device__ __forceinline__ float lgr_atan2f(float y, float x) {
-    float ax = fabsf(x), ay = fabsf(y);
-    float mx = (ax > ay) ? ax : ay;
-    float mn = (ax > ay) ? ay : ax;
-    if (mx == 0.0f) return 0.0f;
-    float a = mn / mx;
-    float base = 0.0f;
-    float z = a;
-    if (a > 0.41421356237f) { base = 0.78539816339f; z = (a - 1.0f) / (a + 1.0f); }
-    float z2 = z * z;
-    float p = 8.05374449538e-2f * z2 - 1.38776856032e-1f;
-    p = p * z2 + 1.99777106478e-1f;
-    p = p * z2 - 3.33329491539e-1f;
-    p = p * z2 * z + z;
-    float r = base + p;
-    if (ay > ax) r = 1.57079632679f - r;
-    if (x < 0.0f) r = 3.14159265359f - r;
-    if (y < 0.0f) r = -r;
-    return r;
+// Philox4x32-10 (Salmon et al., SC'11), key = (seed_lo, seed_hi): the RANSAC sampler's stream (counter = (iteration, 0, 0, 0)) and the
+// closest-plane metric's sparse subsets (lgr_plane.hip).  Pinned by Random123's three known-answer vectors through the full counter
+// (lgr_selfcheck_philox, tests/test_gpu_ransac.py; the oracle's copy in tests/test_oracle_golden.py).
+__device__ __forceinline__ void lgr_philox4(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned out[4]) {
+    unsigned k0 = (unsigned) seed, k1 = (unsigned) (seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        unsigned n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
 // log for normal x > 0: x = m 2^e with m in (sqrt(1/2), sqrt(2)], log m = 2 atanh((m-1)/(m+1)), 4-term series.

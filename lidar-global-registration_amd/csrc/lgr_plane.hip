@@ -22,18 +22,7 @@
 
 namespace {
 
-__device__ __forceinline__ void philox4(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned out[4]) {
-    unsigned k0 = (unsigned) seed, k1 = (unsigned) (seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        unsigned n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+__device__ __forceinline__ void philox4(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned out[4]) { lgr_philox4(seed, c0, c1, c2, c3, out); }
 
 constexpr int PB = 256;
 

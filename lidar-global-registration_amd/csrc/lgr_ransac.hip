@@ -31,19 +31,7 @@ constexpr int MIN_NR_FINAL_INLIERS = 20;   // :9
 constexpr double MIN_INLIER_RATE = 0.15;   // :10
 
 // ---------------------------------------------------------------------------------------------------- sampling
-__device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned iter, unsigned out[4]) {
-    unsigned c0 = iter, c1 = 0, c2 = 0, c3 = 0;
-    unsigned k0 = (unsigned) seed, k1 = (unsigned) (seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        unsigned n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+__device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned iter, unsigned out[4]) { lgr_philox4(seed, iter, 0u, 0u, 0u, out); }
 
 // src/sac_prerejective_omp.cpp:33-77 selectCorrespondences, nr_samples = 3 (control flow kept literally)
 __device__ __forceinline__ void select3(const int r[3], int n_corr, int sample[3]) {
@@ -1162,6 +1150,26 @@ extern "C" int lgr_ransac_samples_dev(lgr_ctx* ctx, uint64_t seed, int first, in
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     samples_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(seed, first, n, n_corr, d_triples);
     LGR_HIP(ctx, hipGetLastError());
+    return LGR_OK;
+}
+
+// lgr.h: one Philox4x32-10 block through the device's generator (known-answer tests)
+__global__ void philox_kernel(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned* __restrict__ out) {
+    unsigned w[4];
+    lgr_philox4(seed, c0, c1, c2, c3, w);
+    out[0] = w[0]; out[1] = w[1]; out[2] = w[2]; out[3] = w[3];
+}
+extern "C" int lgr_selfcheck_philox(lgr_ctx* ctx, uint64_t key, const uint32_t counter4[4], uint32_t out4[4]) {
+    lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
+    if (!ctx) return LGR_ERR_INVALID_ARG;
+    LGR_CHECK(ctx, counter4 && out4, LGR_ERR_INVALID_ARG);
+    LGR_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned* d;
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &d));
+    philox_kernel<<<1, 1, 0, ctx->stream>>>(key, counter4[0], counter4[1], counter4[2], counter4[3], d);
+    LGR_HIP(ctx, hipGetLastError());
+    LGR_HIP(ctx, hipMemcpyAsync(out4, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LGR_OK;
 }
 

@@ -288,6 +288,13 @@ class Context:
         self.check(_lib.lgr_selfcheck_rcp(self.h, C.c_uint(lo_b), C.c_uint(hi_b), out))
         return int(out[0]), int(out[1])
 
+    def selfcheck_philox(self, key, counter4):
+        """one Philox4x32-10 block from the device's generator (full counter; key = k0 | k1 << 32)"""
+        c = (C.c_uint32 * 4)(*[int(x) for x in counter4])
+        out = (C.c_uint32 * 4)()
+        self.check(_lib.lgr_selfcheck_philox(self.h, C.c_uint64(key), c, out))
+        return list(out)
+
     def selfcheck_libm(self, fn, a, b=None):
         """csrc/lgr_libm.cuh (glibc 2.35's float acosf / atanf / atan2f / sinf / cosf restated) evaluated on the device, element-wise"""
         a = np.ascontiguousarray(a, np.float32)

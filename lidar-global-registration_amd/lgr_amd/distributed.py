@@ -14,9 +14,45 @@ RECORD_FLOATS = 24   # one 96-byte record = 24 four-byte words: 16 x f32 transfo
 _I_CONV, _I_ITER, _I_INL, _F_TCS, _F_TTE, _I_PAIR = 16, 17, 18, 19, 20, 21
 
 
-def shard_pairs(n_pairs, world, rank):
-    """indices of the pairs owned by `rank` (round-robin, like the static shard of SURVEY 8e)."""
-    return list(range(rank, n_pairs, world))
+def assign_pairs(n_pairs, world, policy="round_robin", costs=None):
+    """owner rank of every pair -- identical on every rank (pure function of its arguments, no communication).
+      round_robin  pair p -> rank p mod world: the static shard of SURVEY 8(e);
+      lpt          longest processing time first, SURVEY 8(e)'s "greedy by point count": pairs in order of decreasing predicted cost
+                   (ties: lower pair id) each go to the rank with the least load so far (ties: lower rank).  costs[p] = predicted cost of
+                   pair p, e.g. pair_cost(M_src, M_tgt).  With the size mix of data/tests.yaml (the brute-force matcher makes a 1M-point pair
+                   cost ~10 x a 100 k one) round-robin's makespan is whatever rank draws the most large pairs; LPT's is within 4/3 of optimal."""
+    if policy == "round_robin":
+        return [p % world for p in range(n_pairs)]
+    if policy != "lpt":
+        raise ValueError("policy must be 'round_robin' or 'lpt'")
+    if costs is None or len(costs) != n_pairs:
+        raise ValueError("lpt needs one predicted cost per pair")
+    load = [0.0] * world
+    owner = [0] * n_pairs
+    for p in sorted(range(n_pairs), key=lambda q: (-float(costs[q]), q)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[p] = r
+        load[r] += float(costs[p])
+    return owner
+
+
+def shard_pairs(n_pairs, world, rank, policy="round_robin", costs=None):
+    """indices of the pairs owned by `rank`, ascending (assign_pairs)."""
+    return [p for p, r in enumerate(assign_pairs(n_pairs, world, policy, costs)) if r == rank]
+
+
+def pair_cost(m_src, m_tgt):
+    """predicted relative cost of aligning a pair: the brute-force matcher's M_src * M_tgt (include/matching.h:594-634; 60 % of a 1M-point
+    pair's time) plus a per-point term for the feature stages; the constants are the measured 1M / 100 k split of profiles/r5_job_tests156.json"""
+    return 1.3e-11 * float(m_src) * float(m_tgt) + 6.0e-9 * (float(m_src) + float(m_tgt)) + 1.0e-3
+
+
+def makespan(times, world, policy="round_robin", costs=None):
+    """max over ranks of the summed `times` of the pairs a policy assigns to it (times: measured or predicted seconds per pair)"""
+    load = [0.0] * world
+    for p, r in enumerate(assign_pairs(len(times), world, policy, costs)):
+        load[r] += float(times[p])
+    return max(load) if load else 0.0
 
 
 def pack_record(pair_id, T_colmajor16, converged, iterations, n_inliers, time_cs, time_te):
@@ -54,12 +90,13 @@ def gather_records(local_records, world, device=None, force=False):
     return torch.cat(out, 0)
 
 
-def run_pairs(n_pairs, world, rank, align_fn, device=None):
+def run_pairs(n_pairs, world, rank, align_fn, device=None, policy="round_robin", costs=None):
     """Process this rank's shard with align_fn(pair_id) -> record (numpy [RECORD_FLOATS]); all-gather; return the
-    records of all pairs ordered by pair id (numpy [n_pairs, RECORD_FLOATS])."""
+    records of all pairs ordered by pair id (numpy [n_pairs, RECORD_FLOATS]).  policy / costs: assign_pairs."""
     import torch
-    mine = shard_pairs(n_pairs, world, rank)
-    k = (n_pairs + world - 1) // world
+    owner = assign_pairs(n_pairs, world, policy, costs)
+    mine = [p for p, r in enumerate(owner) if r == rank]
+    k = max([owner.count(r) for r in range(world)] + [0])      # shards are padded to the largest one (equal counts per rank for the all-gather)
     local = np.zeros((k, RECORD_FLOATS), np.float32)
     local.view(np.int32)[:, _I_PAIR] = -1
     for s, p in enumerate(mine):

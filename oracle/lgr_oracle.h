@@ -173,6 +173,7 @@ uint64_t orc_voxel_hash(int ix, int iy, int iz);         /* include/common.h:212
 uint64_t orc_point_hash(float x, float y, float z);      /* include/common.h:202-210 */
 /* Philox4x32-10: counter=(iter,0,0,0) key=(seed_lo,seed_hi) -> 4 words */
 void orc_philox(uint64_t seed, uint32_t iter, uint32_t out[4]);
+void orc_philox_full(uint64_t key, const uint32_t counter4[4], uint32_t out[4]);   /* key = k0 | k1 << 32 */
 /* src/sac_prerejective_omp.cpp:33-77 given the three raw draws r[3] (already non-negative) */
 void orc_select3(const int r[3], int n_corr, int sample[3]);
 /* pcl CorrespondenceRejectorPoly::thresholdPolygon (call site src/sac_prerejective_omp.cpp:214) */

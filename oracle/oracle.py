@@ -366,6 +366,14 @@ def philox(seed, it):
     return list(out)
 
 
+def philox_full(key, counter4):
+    """Philox4x32-10 with the full 128-bit counter; key = k0 | k1 << 32"""
+    c = (C.c_uint32 * 4)(*[int(x) for x in counter4])
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox_full(C.c_uint64(key), c, out)
+    return list(out)
+
+
 def select3(r, n_corr):
     rr = (C.c_int * 3)(*[int(x) for x in r])
     s = (C.c_int * 3)()

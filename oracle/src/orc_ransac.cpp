@@ -45,6 +45,7 @@ extern "C" void orc_default_params(lgr_orc_params* p) {
 // Philox4x32-10 (Salmon et al. 2011), counter = (iter, 0, 0, 0), key = (seed_lo, seed_hi).
 static void philox4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
 extern "C" void orc_philox(uint64_t seed, uint32_t iter, uint32_t out[4]) { philox4(seed, iter, 0, 0, 0, out); }
+extern "C" void orc_philox_full(uint64_t key, const uint32_t c[4], uint32_t out[4]) { philox4(key, c[0], c[1], c[2], c[3], out); }   // Random123's known-answer vectors
 static void philox4(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
     uint32_t k0 = (uint32_t) seed, k1 = (uint32_t) (seed >> 32);
     for (int r = 0; r < 10; ++r) {

@@ -42,6 +42,22 @@ def params_pair(oracle, capi, **kw):
     return p_o, p_g
 
 
+def test_philox_known_answer_vectors_on_the_device(lgr, oracle):
+    """all three Random123 philox4x32-10 known-answer vectors through the device generator's FULL counter (the one function behind the RANSAC
+    sampler and the closest-plane subsets), and the all-zero one through lgr_ransac_samples_dev: its triple is select3 of the vector's words"""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "philox_kat.json")))
+    assert len(g["vectors"]) == 3
+    for v in g["vectors"]:
+        key = int(v["key"][0], 16) | int(v["key"][1], 16) << 32
+        out = lgr.selfcheck_philox(key, [int(c, 16) for c in v["counter"]])
+        assert [f"{x:08x}" for x in out] == v["out"]
+    w = [int(x, 16) for x in g["vectors"][0]["out"]]
+    for c in (5, 1000, 2 ** 30):
+        got = lgr.ransac_samples(0, 0, 1, c).cpu().numpy()[0]
+        np.testing.assert_array_equal(got, oracle.select3([x >> 1 for x in w[:3]], c))
+
+
 def test_sampler_matches_oracle(lgr, oracle):
     for c in (3, 4, 17, 6000, 200000):
         got = lgr.ransac_samples(566, 1000, 5000, c).cpu().numpy()
