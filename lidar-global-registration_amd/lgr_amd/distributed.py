@@ -42,9 +42,10 @@ def shard_pairs(n_pairs, world, rank, policy="round_robin", costs=None):
 
 
 def pair_cost(m_src, m_tgt):
-    """predicted relative cost of aligning a pair: the brute-force matcher's M_src * M_tgt (include/matching.h:594-634; 60 % of a 1M-point
-    pair's time) plus a per-point term for the feature stages; the constants are the measured 1M / 100 k split of profiles/r5_job_tests156.json"""
-    return 1.3e-11 * float(m_src) * float(m_tgt) + 6.0e-9 * (float(m_src) + float(m_tgt)) + 1.0e-3
+    """predicted seconds of aligning a pair on one MI355X: the brute-force matcher's M_src * M_tgt term (include/matching.h:594-634; 16 of a
+    1M-point pair's 24.5 ms) + a per-point term for the feature stages + a fixed part (RANSAC, launches); fitted to profiles/r5_job_tests156.json.
+    Only the ORDER of the costs matters to assign_pairs."""
+    return 1.6e-14 * float(m_src) * float(m_tgt) + 3.5e-9 * (float(m_src) + float(m_tgt)) + 1.5e-3
 
 
 def makespan(times, world, policy="round_robin", costs=None):

@@ -42,6 +42,35 @@ def test_shard_pairs_partition(n, world):
     assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
 
 
+def _job_costs(n=156):
+    import importlib.util, os as _os
+    spec = importlib.util.spec_from_file_location("bench_mod", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    sizes = b.job_sizes(n)
+    return sizes, [distributed.pair_cost(m, m) for m in sizes]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_lpt_sharding_partitions_and_beats_round_robin_on_the_tests_yaml_size_mix(world):
+    """"pair p -> GPU p mod G (or greedy by point count)".  On the 156-pair job's size mix (1e5 .. 1e6 points, cost ~ M_src M_tgt)
+    the LPT shard's makespan is never above round-robin's, it is deterministic, and it partitions the pairs."""
+    sizes, costs = _job_costs()
+    assert min(sizes) >= 100000 and max(sizes) <= 1000000 and len(set(sizes)) > 20
+    own = distributed.assign_pairs(len(costs), world, "lpt", costs)
+    assert own == distributed.assign_pairs(len(costs), world, "lpt", list(costs))          # pure function: every rank computes the same owners
+    shards = [distributed.shard_pairs(len(costs), world, r, "lpt", costs) for r in range(world)]
+    assert sorted(x for s in shards for x in s) == list(range(len(costs))) and all(s == sorted(s) for s in shards)
+    rr, lpt = distributed.makespan(costs, world, "round_robin"), distributed.makespan(costs, world, "lpt", costs)
+    assert lpt <= rr and lpt <= 1.02 * sum(costs) / world + max(costs) * 0.34                # LPT bound: within 4/3 of the optimum
+    # an adversarial order for round-robin: every world-th pair large
+    adv = [distributed.pair_cost(1_000_000, 1_000_000) if p % world == 0 else distributed.pair_cost(100_000, 100_000) for p in range(64)]
+    assert distributed.makespan(adv, world, "lpt", adv) < 0.6 * distributed.makespan(adv, world, "round_robin")
+    with pytest.raises(ValueError):
+        distributed.assign_pairs(4, 2, "lpt", None)
+    with pytest.raises(ValueError):
+        distributed.assign_pairs(4, 2, "random")
+
+
 def test_record_roundtrip():
     T = synthetic.random_se3(np.random.default_rng(0)).astype(np.float32)
     rec = distributed.pack_record(17, T.T.reshape(16), 1, 123456, 789, 0.5, 0.25)
@@ -60,25 +89,29 @@ def _fake_align(pair_id):
     return distributed.pack_record(pair_id, T.T.reshape(16), pair_id % 2, 2**31 - 1 - 10 * pair_id, pair_id + 5, 0.1, 0.2)
 
 
-def _worker(rank, world, port, n_pairs, q):
+def _worker(rank, world, port, n_pairs, q, policy="round_robin"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out = distributed.run_pairs(n_pairs, world, rank, _fake_align)
+        costs = [1.0 + (7 * p) % 5 for p in range(n_pairs)] if policy == "lpt" else None     # uneven shards: 4 / 3 pairs, LPT's own grouping
+        out = distributed.run_pairs(n_pairs, world, rank, _fake_align, policy=policy, costs=costs)
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_gloo_allgather():
+@pytest.mark.parametrize("policy", ["round_robin", "lpt"])
+def test_two_ranks_gloo_allgather(policy):
+    """world-size-2 gloo: shard (round-robin, and LPT with uneven shards) -> per-pair records -> ONE all_gather -> every rank holds every
+    pair's record in pair order, whatever rank aligned it"""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     n_pairs, world = 7, 2
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q, policy)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
