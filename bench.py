@@ -390,9 +390,20 @@ def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
             t0 = time.perf_counter()
             ctx.match_bf2(a, b, params.bf_block_size)
             ctx.sync(); torch.cuda.synchronize()
-            out = {"match_stage_ms": 1e3 * (time.perf_counter() - t0), "match_mfma_ms": ctx.match_kernel_ms(), "executed_tile_fraction": ctx.match_work(),
-                   "issued_tile_fraction": ctx.match_issued(), "operand_format": ctx.match_format()}
+            dt = time.perf_counter() - t0
+            z, f = ctx.match_lbstats()
+            out = {"match_stage_ms": 1e3 * dt, "match_mfma_ms": ctx.match_kernel_ms(), "executed_tile_fraction": ctx.match_work(),
+                   "issued_tile_fraction": ctx.match_issued(), "operand_format": ctx.match_format(), "zero_lower_bound_fraction": (z / f) if f > 0 else None}
         return out
+
+    def features_of(pr):
+        fs = []
+        for side in ("src", "tgt"):
+            cloud = torch.from_numpy(pr[side]).cuda()
+            surf = ctx.downsample(cloud, voxel).clone()
+            fs.append(ctx.fpfh(cloud, ctx.normals_knn(surf.clone(), 30, vp=pr["vp_" + side]), r))
+        ctx.sync(); torch.cuda.synchronize()
+        return fs
 
     res = {"this_pair": timed(feats[0], feats[1])}
     ctx.set_match_options(prune=0)
@@ -407,8 +418,22 @@ def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
         rows.append((x * (100.0 / x.sum(2, keepdim=True))).reshape(n, 33).contiguous())
     torch.cuda.synchronize()
     res["structureless"] = timed(rows[0], rows[1])
+    ctx.set_match_options(prune=0)
+    try:
+        res["structureless_dense"] = timed(rows[0], rows[1])      # the SAME rows on the dense schedule: what `structureless` has to be compared with
+    finally:
+        ctx.set_match_options()
+    del rows
+    # a third scene family: man-made planes (the shape of the reference's WHU-TLS / kizhi configs, data/tests.yaml): 85 % of the points on 41 rectangles
+    from lgr_amd import synthetic
+    pp = synthetic.make_planar_pair(int(src.shape[0]), seed=synthetic.SEED)
+    pf = features_of(pp)
+    res["planar"] = timed(pf[0], pf[1])
+    res["planar"]["scene"] = "%d rectangles (ground + 8 buildings), %.0f %% of the points on them, 15 %% clutter blobs, noise 5 mm" % (pp["n_planes"], 100 * pp["plane_frac"])
     res["note"] = ("matcher stage alone (lgr_match_bf2_dev, both directions), second of two runs; this_pair = the bench pair's FPFH rows on the production "
-                   "schedule, dense = the same rows with prune = 0, structureless = uniform random 11-bin blocks normalised to 100 on the production schedule")
+                   "schedule, dense = the same rows with prune = 0, structureless = uniform random 11-bin blocks normalised to 100 on the production schedule "
+                   "(lgr_match_options.auto_dense: >= 90 % zero lower bounds -> pass 0 computes everything), structureless_dense = the same random rows with "
+                   "prune = 0, planar = FPFH rows of a planar-dominated pair on the production schedule")
     return res
 
 

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-/* ABI revision.  5 (round 5): lgr_ctx_options.arithmetic / pcl_neighbour_cap (former reserved words: a host that zeroes them keeps the default),
+/* ABI revision.  5 (round 5): lgr_ctx_options.arithmetic / pcl_neighbour_cap and lgr_match_options.auto_dense (former reserved words: a host that zeroes
+ * them keeps the default arithmetic and switches auto_dense off), lgr_match_last_lbstats, lgr_selfcheck_philox,
  * lgr_selfcheck_libm added; the DEFAULT arithmetic of the normals and pair features changed to PCL's own sequences (results differ from
  * revision 4 at rounding level).  4 (round 4): lgr_match_options.split_sweep / kept_cap and lgr_ctx_options.concurrent_contexts (former reserved words: a host that
  * zeroes them switches the split off and keeps the contexts exclusive), lgr_match_last_issued, lgr_selfcheck_rcp added.  3 (round 3): lgr_match_options.shell_bound (one of the reserved words: a host that zeroes them would switch the shell
@@ -116,12 +117,15 @@ typedef struct lgr_ctx lgr_ctx;
 typedef struct {
     int32_t helper_contexts;      /* 1 (default) / 0 */
     int32_t concurrent_contexts;  /* 0 (default): the contexts of one device take turns call by call -- the device never executes two
-                                   * contexts' work side by side (a context's own helper streams are not affected).  1: this context does
-                                   * not wait its turn.  Several pairs in flight per GPU bought +5 % throughput at best (DESIGN.md section
-                                   * 10), and in round 3 the builder's MI355X boxes returned normals that differed at rounding level
-                                   * (1-500 ulp) between runs when 2-3 contexts worked at once; round 4 could not reproduce that -- not even
-                                   * with the round-3 binary -- on the unit it was given (DESIGN.md section 10 has the full record), so the
-                                   * cause is not established and the default stays exclusive.  One process per GPU is unaffected. */
+                                   * contexts' work side by side (a context's own helper streams are not affected).  1 (EXPERIMENTAL): this
+                                   * context does not wait its turn.  Several pairs in flight per GPU bought +5 % throughput at best
+                                   * (DESIGN.md section 10).  Every kernel is deterministic and contexts share no state, so results must not
+                                   * depend on it, and the -m gpu suite asserts exactly that (tests/test_gpu_concurrent_contexts.py: three
+                                   * overlapping contexts bit-equal to the serial run); but in round 3 the builder's MI355X boxes returned
+                                   * normals that differed at rounding level between runs when 2-3 contexts worked at once, and rounds 4-5
+                                   * could not reproduce that on the units they were given -- not even with the round-3 binary -- so the
+                                   * cause is not established.  Do not enable it where bit-reproducibility is a requirement.  One process per
+                                   * GPU (the multi-GPU layout) never has two contexts on a device. */
     int32_t arithmetic;           /* LGR_ARITH_FAST (0, default) / LGR_ARITH_PCL (1): see below */
     int32_t pcl_neighbour_cap;    /* LGR_ARITH_PCL: neighbours of a key point sorted at once; 0 default (1024), 64 (tests: drives the shell path).  Never changes results */
     int32_t reserved[4];
@@ -157,7 +161,10 @@ typedef struct {
     int32_t split_sweep;      /* final pass of the rotated format as two kernels -- the coarse sweep appends the tiles it keeps to a list, a second
                                * kernel finishes them: 1 (default) / 0 (one fused kernel, round 3) */
     int32_t kept_cap;         /* capacity of that list in tiles: 0 default (16 M); a pass that keeps more is repeated on the fused kernel (tests: force it) */
-    int32_t reserved[2];
+    int32_t auto_dense;       /* 1 (default): when the bounds can separate (almost) nothing -- >= 90 % of the (row block, leaf) lower bounds are zero:
+                               * descriptors without cluster structure -- pass 0 computes everything and the final pass finds an empty schedule, decided on
+                               * the device (lgr_match_last_lbstats reports the counts).  0: never */
+    int32_t reserved[1];
 } lgr_match_options;
 
 /* ---- context ---- */
@@ -295,6 +302,8 @@ int lgr_match_last_pairs(lgr_ctx*, unsigned* out2);
  * 30 Helmert coordinates, K = 96 (chosen when every 11-bin block of all rows has the same sum, as FPFH rows do); 0 = f32
  * operands on v_mfma_f32_32x32x2_f32 (lgr_match_options.operand_format selects one explicitly).  Results do not depend on it. */
 int lgr_match_last_format(lgr_ctx*, int* f16);
+/* (row block, leaf) pairs whose lower bound is zero / finite in the last pruned match call (lgr_match_options.auto_dense) */
+int lgr_match_last_lbstats(lgr_ctx*, double* out2);
 /* self-check of the matcher's filter bound (lgr_match_options.self_check = 1, test sizes): worst |filtered - exact| / eps over
  * sampled table entries of the last match call, rows then columns; -1 = not run.  Must be <= 1. */
 int lgr_match_last_check(lgr_ctx*, double* out2);

@@ -271,6 +271,8 @@ extern "C" int lgr_ctx_sync(lgr_ctx* ctx) {
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stream3) LGR_HIP(ctx, hipStreamSynchronize(ctx->stream3));   // (joined into `stream` by every successful call; an early error exit may leave work on it)
+    for (lgr_ctx* ax : {ctx->aux, ctx->aux2})                              // ... and so for the helper contexts' streams
+        if (ax && ax->stream != ctx->stream) LGR_HIP(ctx, hipStreamSynchronize(ax->stream));
     return LGR_OK;
 }
 
@@ -286,7 +288,7 @@ extern "C" void lgr_match_default_options(lgr_match_options* o) {
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->prune = -1; o->leaves = 0; o->near = 0; o->operand_format = -1; o->box_bounds = 1; o->column_stage = 1;
-    o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0; o->shell_bound = 1; o->split_sweep = 1;
+    o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0; o->shell_bound = 1; o->split_sweep = 1; o->auto_dense = 1;
 }
 
 // (every internal context below this one, however deep: an internal context that runs a pair of jobs itself owns internal contexts too)
@@ -302,7 +304,8 @@ extern "C" int lgr_ctx_set_match_options(lgr_ctx* ctx, const lgr_match_options* 
     if (!opt) lgr_match_default_options(&o);
     else {
         LGR_CHECK(ctx, opt->prune >= -1 && opt->prune <= 1 && opt->leaves >= 0 && opt->leaves <= 64 && opt->near >= 0 &&
-                       opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2 && opt->kept_cap >= 0, LGR_ERR_INVALID_ARG);
+                       opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2 && opt->kept_cap >= 0 &&
+                       (opt->auto_dense == 0 || opt->auto_dense == 1), LGR_ERR_INVALID_ARG);
         o = *opt;
     }
     propagate_mopt(ctx, o);

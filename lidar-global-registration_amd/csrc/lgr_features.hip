@@ -337,11 +337,14 @@ __device__ unsigned long long g_spfh_check[4];   // pairs, pairs the filter left
 #endif
 constexpr int ST = 16;          // surface points per wave
 constexpr int SQ = 256;         // pair queue entries: (tile point << 8) | candidate slot
-constexpr int SHP = 36;         // histogram pitch (33 bins + pad)
+constexpr int SHP = 33;         // histogram pitch (lanes of one tile point hit bins = banks; the pad of rounds 1-4 bought nothing)
 
-__global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, const int* __restrict__ order, float* __restrict__ spfh /* [n][HP], sorted positions */) {
+#ifndef LGR_SPFH_WAVES
+#define LGR_SPFH_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, LGR_SPFH_WAVES))) void spfh_tile_kernel(GridDev g, float r2, const int* __restrict__ order, float* __restrict__ spfh /* [n][HP], sorted positions */) {
     __shared__ float4 tp[ST], tn[ST];
-    __shared__ float4 cp[128], cn[128];   // live candidates: tested 64 at a time, the rest waits for the next chunks
+    __shared__ float4 cp[64], cn[64];     // live candidates: tested when 64 are buffered (round 5: a chunk's overflow waits in registers, not in a second half of the buffer)
     __shared__ unsigned short queue[SQ];
     __shared__ int hist[2][ST][SHP];
     __shared__ int kcnt[ST];
@@ -486,23 +489,22 @@ __global__ __launch_bounds__(64) void spfh_tile_kernel(GridDev g, float r2, cons
                     }
                     const unsigned long long lm = __ballot(live);
                     if (lm == 0ull) continue;
+                    // the chunk's live candidates fill the 64-entry buffer; what does not fit stays in its lane's registers until the full buffer
+                    // has been tested and goes to the front of the empty one (same candidates, same order as one 128-entry buffer: half the LDS)
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) lm, 0u));
+                    const int fit = min(__popcll(lm), 64 - n_buf);
+                    float4 Nq = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (live) {
-                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned) (lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) lm, 0u));
-                        cp[n_buf + rank] = make_float4(P.x, P.y, P.z, __int_as_float(t));
-                        cn[n_buf + rank] = g.pnrm[t];
+                        Nq = g.pnrm[t];
+                        if (rank < fit) { cp[n_buf + rank] = make_float4(P.x, P.y, P.z, __int_as_float(t)); cn[n_buf + rank] = Nq; }
                     }
-                    n_buf += __popcll(lm);
+                    n_buf += fit;
                     __syncthreads();
-                    if (n_buf >= 64) {
+                    if (n_buf == 64) {
                         test_block(64);
-                        // the candidates beyond the first 64 move to the front
-                        const int rest = n_buf - 64;
-                        float4 mp = make_float4(0.f, 0.f, 0.f, 0.f), mn = mp;
-                        if (l < rest) { mp = cp[64 + l]; mn = cn[64 + l]; }
+                        if (live && rank >= fit) { cp[rank - fit] = make_float4(P.x, P.y, P.z, __int_as_float(t)); cn[rank - fit] = Nq; }
+                        n_buf = __popcll(lm) - fit;
                         __syncthreads();
-                        if (l < rest) { cp[l] = mp; cn[l] = mn; }
-                        __syncthreads();
-                        n_buf = rest;
                     }
                 }
             }

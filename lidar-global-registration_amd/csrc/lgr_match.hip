@@ -74,6 +74,13 @@ extern "C" int lgr_match_last_shell(lgr_ctx* ctx, double* tiles_skipped) {
     *tiles_skipped = ctx->mstats.shell_skipped;
     return LGR_OK;
 }
+// (row block, leaf) pairs of the last pruned match call whose lower bound is zero -- never excludable -- and pairs with a finite bound at all:
+// what lgr_match_options.auto_dense decides on
+extern "C" int lgr_match_last_lbstats(lgr_ctx* ctx, double* out2) {
+    if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
+    out2[0] = ctx->mstats.lb_zero; out2[1] = ctx->mstats.lb_finite;
+    return LGR_OK;
+}
 extern "C" int lgr_match_last_coarse(lgr_ctx* ctx, double* out2) {
     if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
     out2[0] = ctx->mstats.coarse_tested; out2[1] = ctx->mstats.coarse_rejected;
@@ -359,8 +366,17 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         boxBt = boxA + (size_t) n_rb * 66;
         rmax2 = (unsigned*) (boxBt + (size_t) n_leaves * 66);
     }
+    // Whatever makes this call return early from here on (an allocation failure, a HIP error): kernels queued on the helper streams read the
+    // caller's d_a / d_b and write this call's buffers, so those streams are drained before the caller gets its buffers back -- and before the
+    // device's turn goes to another context (lgr_turn records its hand-over event on ctx->stream only).  On the normal path both streams have
+    // been joined into ctx->stream long before, and the synchronisation returns at once.
+    struct DrainOnExit {
+        hipStream_t s, own;
+        ~DrainOnExit() { if (s && s != own) (void) hipStreamSynchronize(s); }
+    };
+    LGR_TRY(lgr_ctx_aux(ctx));
+    DrainOnExit drain_aux{ctx->aux->stream, ctx->stream};   // box_kernel / gather_rows_kernel (launch_sorted_copies)
     {
-        LGR_TRY(lgr_ctx_aux(ctx));
         hipStream_t s2 = ctx->aux->stream;
         LGR_HIP(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
         LGR_HIP(ctx, hipStreamWaitEvent(s2, ctx->aux_ev, 0));
@@ -502,12 +518,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // operands, which the bounds wait for, take as long as the 3 GB of column sets.)
     hipStream_t sB = ctx->stream;
     if (f16) LGR_TRY(lgr_ctx_stream3(ctx, &sB));
-    // Whatever makes this call return early from here on (an allocation failure, a HIP error): the kernels queued on sB read the
-    // caller's d_b and write this call's buffers, so the stream is drained before the caller gets its buffers back.
-    struct DrainOnExit {
-        hipStream_t s, own;
-        ~DrainOnExit() { if (s != own) (void) hipStreamSynchronize(s); }
-    } drain_sB{sB, ctx->stream};
+    DrainOnExit drain_sB{sB, ctx->stream};   // (the third stream: column operands, table initialisation)
     auto fork_b = [&]() -> int {
         if (sB != ctx->stream) {
             LGR_HIP(ctx, hipEventRecord(ctx->ev3, ctx->stream));
@@ -777,13 +788,18 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
         }
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
+        // do the bounds separate anything?  (lb_stats_kernel / lb_widen_kernel: when nearly every lower bound is zero, pass 0 takes everything)
+        unsigned long long* lbstat = &mstats->stages[5];   // [5] zero, [6] finite lower bounds (MaskStats slots the passes do not use)
+        unsigned* widen = (unsigned*) (misc + 224);
+        lb_stats_kernel<<<std::min(cdiv((long long) n_rb * n_leaves, 1024), 1024), 256, 0, ctx->stream>>>(LBsq, (size_t) n_rb * n_leaves, lbstat);
+        lb_widen_kernel<<<1, 1, 0, ctx->stream>>>(lbstat, mo.auto_dense ? LGR_AUTO_DENSE_FRAC : 0.f, widen);
         auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {
             if (len <= NEAR_LDS_MAX) {
                 if ((size_t) len * 4 > 64 * 1024)
                     LGR_HIP(ctx, hipFuncSetAttribute((const void*) near_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, len * 4));
-                near_kernel<true><<<n_vec, NEAR_THREADS, (size_t) len * 4, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es);
+                near_kernel<true><<<n_vec, NEAR_THREADS, (size_t) len * 4, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, widen);
             } else {
-                near_kernel<false><<<n_vec, NEAR_THREADS, 0, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es);
+                near_kernel<false><<<n_vec, NEAR_THREADS, 0, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, widen);
             }
             return LGR_OK;
         };
@@ -858,6 +874,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         g_last_stats.stages_done = 0;
         for (int k = 0; k <= n_beta; ++k) g_last_stats.stages_done += (double) hs->stages[k];
         g_last_stats.stages_unique = (double) hs->stages[7];
+        g_last_stats.lb_zero = (double) hs->stages[5]; g_last_stats.lb_finite = (double) hs->stages[6];
         if (env_int("LGR_MATCH_DEBUG", 0)) {
             fprintf(stderr, "[lgr] stages per pass:");
             for (int k = 0; k <= n_beta; ++k) fprintf(stderr, " %llu", hs->stages[k]);

@@ -271,6 +271,28 @@ __global__ __launch_bounds__(256) void box_lb_kernel(const float* __restrict__ b
     }
 }
 
+// Can the bounds separate anything at all?  A (row block, leaf) pair whose lower bound is ZERO -- the two balls overlap and so do the boxes --
+// can never be excluded, whatever upper bounds the passes find.  lb_stats_kernel counts those pairs among the finite entries; when they are
+// (nearly) all of them (descriptors without cluster structure: bench.py's `structureless` extreme) pass 0's selection of the nearest leaves,
+// the second pass and its bookkeeping only add to a dense computation.  lb_widen_kernel then raises a device flag that makes near_kernel
+// mark EVERYTHING for pass 0 (near_t = the whole vector): pass 0 becomes the dense pass, the final pass finds nothing left to schedule, and
+// the rest of the machinery runs over empty work lists -- decided on the device, no host round trip (a read-back at this point stalls the
+// launch queue for longer than the decision is worth).  Results never depend on it (a wider pass 0 is still an exact schedule).
+__global__ void lb_stats_kernel(const float* __restrict__ LBsq, size_t n, unsigned long long* __restrict__ out2 /* zero, finite */) {
+    unsigned long long z = 0, f = 0;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        const float v = LBsq[i];
+        const bool fin = v < FLT_BIG;
+        f += fin ? 1 : 0;
+        z += (fin && v <= 0.f) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o); f += __shfl_xor(f, o); }
+    if ((threadIdx.x & 63) == 0) { if (z) atomicAdd(&out2[0], z); if (f) atomicAdd(&out2[1], f); }
+}
+__global__ void lb_widen_kernel(const unsigned long long* __restrict__ stats2, float frac, unsigned* __restrict__ flag) {
+    flag[0] = (frac > 0.f && stats2[1] > 0ull && (double) stats2[0] >= (double) frac * (double) stats2[1]) ? 1u : 0u;
+}
+
 // the near_t smallest finite entries of a strided vector -> need1 = 1; ties go to the lowest index.  One 256-thread block
 // per vector: the vector is read once into LDS (dynamic: len words), a bitwise radix select finds the near_t-th smallest
 // key (entries are >= 0, so the float bits order like the values), then everything below it and the first ties are marked.
@@ -278,12 +300,17 @@ constexpr int NEAR_THREADS = 256;
 constexpr int NEAR_LDS_MAX = 36 * 1024;   // entries that fit the dynamic LDS slab (144 KB); longer vectors are re-read from global
 template <bool IN_LDS>
 __global__ __launch_bounds__(NEAR_THREADS) void near_kernel(int near_t, const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
-                                                            uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride) {
+                                                            uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride, const unsigned* __restrict__ widen) {
     extern __shared__ unsigned keys[];
     __shared__ int cnt_s, base_s;
     __shared__ int wave_cnt[NEAR_THREADS / 64];
     const int vec = blockIdx.x, tid = threadIdx.x;
     if (vec >= n_vec) return;
+    if (widen && widen[0]) {   // (uniform) the bounds separate nothing: every finite entry is "near" (lb_widen_kernel)
+        for (int e = tid; e < len; e += NEAR_THREADS)
+            if (LBsq[vec * vec_stride + e * elem_stride] < FLT_BIG) need1[vec * need_vec_stride + e * need_elem_stride] = 1;
+        return;
+    }
     constexpr unsigned INF = 0x7f800000u;
     auto load = [&](int e) {
         unsigned k = __float_as_uint(LBsq[vec * vec_stride + e * elem_stride]);

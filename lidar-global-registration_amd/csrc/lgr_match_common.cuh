@@ -43,6 +43,9 @@ constexpr int KM2_ITERS = LGR_KM2_ITERS;
 #define LGR_NEAR_T 40
 #endif
 constexpr int NEAR_T = LGR_NEAR_T;          // pass 0 visits the NEAR_T nearest leaves of a row block / row blocks of a leaf (measured at 1M: 16 / 24 / 32 / 48 / 64 -> 75.5 / 73.1 / 72.2 / 73.7 / 76.4 ms per pair in round 1; with the per-tile coarse thresholds of round 2 the final pass is cheaper per tile: 16 / 20 / 24 / 28 / 32 -> 40.4 / 39.8 / 39.4 / 39.45 / 39.8-40.1; round 3, pass 0 takes only the stages of overlapping shells of those leaves and is three times cheaper per leaf: 28 / 36 / 48 / 64 -> 30.7-31.2 / 29.9-30.5 / 30.0-30.6 / 30.6)
+#ifndef LGR_AUTO_DENSE_FRAC
+#define LGR_AUTO_DENSE_FRAC 0.9f   // lgr_match_options.auto_dense: pass 0 takes everything when this fraction of the (row block, leaf) lower bounds is zero
+#endif
 #ifndef LGR_PRUNE_BETAS
 #define LGR_PRUNE_BETAS 1.0f   // ONE final pass.  Intermediate thresholds (0.5f, 1.0f / 0.7f, 1.0f: a sweeping pass between pass 0 and the final one) were measured
                                // again in round 4 with the sweep kernel: 26.6-27.4 ms per pair against 25.4 at pass-0 widths 24-40 (a pass boundary costs 1.2 ms).  More than one

@@ -796,6 +796,10 @@ __global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__
     int mi = MIN_NR_INLIERS;
     if (S->final_metric > 0.f && S->metric_id == LGR_METRIC_UNIFORMITY) mi = max(mi, (int) floor(pow(10000.0, (double) S->final_metric / 1.001)) - 1);
     else if (S->final_metric > 0.f && S->metric_id == LGR_METRIC_CORRESPONDENCES) mi = max(mi, (int) floor((double) S->final_metric * (double) S->c / 1.001) - 1);
+    // ... and it must not hide a RECORD inlier set (:224-228 feed the adaptive bound from every hypothesis with >= MIN_NR_INLIERS): only counts
+    // up to the record so far are safe to drop.  When the best metric is a loop hypothesis's, its own count already is >= the gate and <= the
+    // record, so this changes nothing; a GUESS (:134-147) sets the metric to beat without ever entering the record.
+    mi = min(mi, max(MIN_NR_INLIERS, S->largest + 1));
     S->min_inliers = mi;
     S->round_first = S->done; S->round_nb = nb; S->round_batches = n_batches;
     S->rounds += 1;
@@ -1538,12 +1542,13 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
         // bound is below m: uniformity <= ln(n) / ln(10^4) (entropy of n points over 10^4 cells, src/analysis.cpp:95-130),
         // correspondences <= n / C (scores <= 1, src/metric.cpp:55-81) -- such hypotheses are not scored (0.1 % slack for
         // the float evaluation).  The record inlier set is unaffected: a new record has more inliers than the best
-        // hypothesis, which itself passes the gate.
+        // hypothesis, which itself passes the gate -- and where the metric to beat is a guess's, the gate is capped at the record + 1.
         int min_inliers = MIN_NR_INLIERS;
         if (final_metric > 0.f && p->metric_id == LGR_METRIC_UNIFORMITY)
             min_inliers = std::max(min_inliers, (int) std::floor(std::pow(10000.0, (double) final_metric / 1.001)) - 1);
         else if (final_metric > 0.f && p->metric_id == LGR_METRIC_CORRESPONDENCES)
             min_inliers = std::max(min_inliers, (int) std::floor((double) final_metric * (double) c / 1.001) - 1);
+        min_inliers = std::min(min_inliers, std::max(MIN_NR_INLIERS, largest + 1));   // never above the record so far + 1 (a guess sets the metric, not the record)
         LGR_HIP(ctx, hipMemsetAsync(b.st, 0, sizeof(BatchStats) * n_batches, ctx->stream));
         LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand, plane_metric ? &plane : nullptr, min_inliers,
                           final_metric, largest));

@@ -59,7 +59,8 @@ class MatchOptions(C.Structure):
     """lgr_match_options (include/lgr.h): how the matcher runs, never what it returns."""
     _fields_ = [("prune", C.c_int32), ("leaves", C.c_int32), ("near", C.c_int32), ("operand_format", C.c_int32), ("box_bounds", C.c_int32),
                 ("column_stage", C.c_int32), ("coarse_rejection", C.c_int32), ("rerank_refilter", C.c_int32), ("pair_cap", C.c_int32),
-                ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("shell_bound", C.c_int32), ("split_sweep", C.c_int32), ("kept_cap", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("shell_bound", C.c_int32), ("split_sweep", C.c_int32), ("kept_cap", C.c_int32), ("auto_dense", C.c_int32),
+                ("reserved", C.c_int32 * 1)]
 
 
 class CtxOptions(C.Structure):
@@ -287,6 +288,12 @@ class Context:
         lo_b, hi_b = (int(np.float32(v).view(np.uint32)) for v in (lo, hi))
         self.check(_lib.lgr_selfcheck_rcp(self.h, C.c_uint(lo_b), C.c_uint(hi_b), out))
         return int(out[0]), int(out[1])
+
+    def match_lbstats(self):
+        """(zero, finite) lower bounds among the (row block, leaf) pairs of the last pruned match call: what lgr_match_options.auto_dense decides on"""
+        out = (C.c_double * 2)()
+        self.check(_lib.lgr_match_last_lbstats(self.h, out))
+        return out[0], out[1]
 
     def selfcheck_philox(self, key, counter4):
         """one Philox4x32-10 block from the device's generator (full counter; key = k0 | k1 << 32)"""

@@ -62,3 +62,27 @@ def gpu_serial():
         return m.group(1) if m else ""
     except Exception:
         return ""
+
+
+def box_identity():
+    """what identifies the unit and software an observation was made on: GPU serial, VBIOS / firmware versions (rocm-smi), ROCm and HIP runtime
+    versions -- printed by tests/test_gpu_concurrent_contexts.py on every run, so that a difference arrives with its box identified"""
+    import subprocess
+    out = {"gpu_serial": gpu_serial()}
+    for key, argv in (("vbios", ["rocm-smi", "--showvbios"]), ("firmware", ["rocm-smi", "--showfwinfo"]), ("driver", ["rocm-smi", "--showdriverversion"])):
+        try:
+            t = subprocess.run(argv, capture_output=True, text=True, timeout=30).stdout
+            out[key] = " | ".join(ln.strip() for ln in t.splitlines() if "GPU[0]" in ln or "Driver version" in ln)[:1500]
+        except Exception:
+            out[key] = ""
+    try:
+        out["rocm"] = open("/opt/rocm/.info/version").read().strip()
+    except Exception:
+        out["rocm"] = ""
+    try:
+        import torch
+        out["torch_hip"] = str(torch.version.hip)
+        out["device"] = torch.cuda.get_device_name(0)
+    except Exception:
+        pass
+    return out

@@ -128,6 +128,24 @@ def test_ransac_whole_loop(lgr, oracle, problem, metric, batch, iters):
     assert res.iterations < iters or metric == 1    # the adaptive bound fires on this 40 % inlier problem
 
 
+@pytest.mark.parametrize("metric,batch,iters", [(1, 1000, 20000), (0, 256, 30000), (1, 4096, 60000)])
+def test_ransac_whole_loop_with_a_good_guess(lgr, oracle, problem, metric, batch, iters):
+    """a guess (src/sac_prerejective_omp.cpp:134-147) sets the metric to beat but never enters the loop's record inlier set, so the
+    candidate gate derived from that metric must not hide hypotheses that are records for the adaptive bound (:224-228): with a GOOD guess
+    (the ground truth: nearly every hypothesis scores below it) iterations / estimated_iters must still be the oracle's, which applies no gate"""
+    from lgr_amd import capi
+    G = problem["T_gt"].astype(np.float32)
+    p_o, p_g = params_pair(oracle, capi, metric_id=metric, score_id=2, max_iterations=iters, ransac_batch=batch, guess=G)
+    corr = problem["corr"]
+    res, mask = lgr.ransac(cuda(problem["src"]), cuda(problem["tgt"]), corr, p_g)
+    ores, omask = oracle.ransac(problem["src"], problem["tgt"], to_orc_corr(oracle, corr), p_o)
+    assert (res.iterations, res.estimated_iters, res.num_rejections, res.best_iteration) == (ores.iterations, ores.estimated_iters, ores.num_rejections, ores.best_iteration)
+    assert res.iterations < iters                          # the bound fired although (almost) nothing beats the guess's metric
+    assert res.converged == ores.converged == 1 and res.n_inliers == ores.n_inliers
+    np.testing.assert_array_equal(mask, omask)
+    np.testing.assert_array_equal(bits(res.matrix()), bits(ores.matrix()))
+
+
 def test_ransac_degenerate(lgr, oracle, problem):
     from lgr_amd import capi
     p_o, p_g = params_pair(oracle, capi, metric_id=1, max_iterations=2000)
