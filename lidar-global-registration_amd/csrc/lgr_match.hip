@@ -591,14 +591,14 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // final pass as sweep + listed tiles (lgr_match_sweep.cuh): the list, its counter, the per-column thresholds as bf16
     const unsigned kept_cap = mo.kept_cap > 0 ? (unsigned) mo.kept_cap : (16u << 20);
     uint2* kept = nullptr;
-    unsigned* kept_count = nullptr;
+    unsigned long long* kept_count = nullptr;
     unsigned short* ucol16 = nullptr;
     bool split_used = false;
     if (f16 && rot && prune && mo.coarse_rejection != 0 && mo.split_sweep != 0) {
         char* kb;
         LGR_TRY(lgr_ws_t(ctx, WS_MATCH_KEPT, (size_t) kept_cap * sizeof(uint2) + (size_t) mb_pad * 2 + 512, &kb));
         kept = (uint2*) kb;
-        kept_count = (unsigned*) (kb + (size_t) kept_cap * sizeof(uint2));
+        kept_count = (unsigned long long*) (kb + (size_t) kept_cap * sizeof(uint2));
         ucol16 = (unsigned short*) (kb + (size_t) kept_cap * sizeof(uint2) + 256);
     }
     const unsigned long long* cur_pass_stages = nullptr;   // device: the stage count of the pass being launched (mask_kernel's statistics)
@@ -618,7 +618,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         if (f16 && rot && ca.u_rb && kept && allow_split) {
             // the coarse sweep appends the tiles it keeps to a list, a second kernel finishes them
             split_used = true;
-            LGR_HIP(ctx, hipMemsetAsync(kept_count, 0, 4, ctx->stream));
+            LGR_HIP(ctx, hipMemsetAsync(kept_count, 0, 8, ctx->stream));
             if (ca.u_colv) ucol_pack_kernel<<<cdiv(mb_pad, 256), 256, 0, ctx->stream>>>(ca.u_colv, mb_pad, c_scale, ucol16);
             // Descriptors the bounds cannot separate (structureless rows: every stage is scheduled) gain nothing from the coarse sweep -- nearly every
             // tile passes it and is then computed a second time in full.  The device decides from the pass's stage count (no host round trip: a
@@ -853,11 +853,11 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         unsigned long long* h_cc = (unsigned long long*) ((char*) hs + 128);
         h_cc[0] = h_cc[1] = h_cc[2] = 0ull;
         if (coarse) LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 24, hipMemcpyDeviceToHost, ctx->stream));
-        unsigned* h_kept = (unsigned*) ((char*) hs + 192);
-        h_kept[0] = 0u;
-        if (split_used) LGR_HIP(ctx, hipMemcpyAsync(h_kept, kept_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long* h_kept = (unsigned long long*) ((char*) hs + 192);
+        h_kept[0] = 0ull;
+        if (split_used) LGR_HIP(ctx, hipMemcpyAsync(h_kept, kept_count, 8, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (split_used && h_kept[0] > kept_cap) {
+        if (split_used && h_kept[0] > (unsigned long long) kept_cap) {
             // The sweep kept more tiles than the list holds (descriptors without structure): the last pass again on the fused kernel.  The
             // tables only ever take minima, so what the listed tiles already contributed stays valid.  (Statistics: the fused launch's.)
             LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 32, ctx->stream));

@@ -304,11 +304,13 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
     const long long n_pairs = (long long) n_rb * n_cc;
     const int s = threadIdx.x & 31;
     unsigned long long count = 0ull, fresh = 0ull;   // stages of this pass; those among them that no earlier pass computed
-    // (the two half waves of a wave hold consecutive pairs; the upper one may leave the loop one round earlier -- the ballot then
-    // simply lacks its lanes, and the count is taken from lane 0)
-    for (long long idx = ((long long) blockIdx.x * blockDim.x + threadIdx.x) >> 5; idx < n_pairs; idx += ((long long) gridDim.x * blockDim.x) >> 5) {
+    // (the two half waves of a wave hold consecutive pairs.  The loop's trip count is the WAVE's: the upper half wave of the last round may
+    // have no pair left and then runs the body predicated off -- the cross-half shuffle below never reads a lane that has left the loop)
+    for (long long idx0 = (((long long) blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 1; idx0 < n_pairs; idx0 += ((long long) gridDim.x * blockDim.x) >> 5) {
+        const long long idx = idx0 + ((threadIdx.x >> 5) & 1);
+        const bool valid = idx < n_pairs;
         bool on = false;
-        {
+        if (valid) {
             const int rb = (int) (idx / n_cc), cc = (int) (idx % n_cc);
             const int gst = cc * STAGES_PER_CHUNK + s;
             if (gst < n_stage_total) {
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
         }
         const unsigned long long bal = __ballot(on);
         int fresh_here = 0;
-        if (s == 0) {
+        if (s == 0 && valid) {
             const unsigned m = (unsigned) (bal >> (threadIdx.x & 32));
             mask[idx] = m;
             // a stage that straddles two leaves is computed whole by every pass that schedules one of them: count it ONCE for the

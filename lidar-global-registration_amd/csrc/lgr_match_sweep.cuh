@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NTHR, SW_OCC) void match_sweep(const f16x8* __restr
                                                             const unsigned* __restrict__ stage_mask, int n_cc, int item_rb, const int2* __restrict__ items,
                                                             const int* __restrict__ xcd_start, int* __restrict__ xcd_ctr, CoarseArgs ca,
                                                             const unsigned short* __restrict__ ucol16 /* [mb_pad] or nullptr */,
-                                                            uint2* __restrict__ kept_out, unsigned* __restrict__ kept_count, unsigned kept_cap) {
+                                                            uint2* __restrict__ kept_out, unsigned long long* __restrict__ kept_count /* 64 bits: never wraps below the capacity */, unsigned kept_cap) {
     typedef f16x8 frag;
     constexpr int KS = OpFmt<FMT_F16R>::KS;
     constexpr int STAGE_FRAGS = STAGE_TILES * KS * 64;
@@ -258,9 +258,9 @@ __global__ __launch_bounds__(NTHR, SW_OCC) void match_sweep(const f16x8* __restr
                 n_rejected += swept - sk_now - nk;
             }
             if (nk) {   // append this wave's tiles: one atomic per wave and visit
-                unsigned base = 0u;
-                if (lane == 0) base = atomicAdd(kept_count, nk);
-                base = (unsigned) __builtin_amdgcn_readfirstlane((int) base);
+                unsigned long long base = 0ull;
+                if (lane == 0) base = atomicAdd(kept_count, (unsigned long long) nk);
+                base = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (base >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) base);
                 unsigned off = 0u;
 #pragma unroll
                 for (int r = 0; r < SW_RB; ++r)
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(NTHR, SW_OCC) void match_sweep(const f16x8* __restr
                     for (int ct = 0; ct < STAGE_TILES; ++ct) {
                         const unsigned m = kept[r][ct];
                         if (lane < 32 && ((m >> lane) & 1u)) {
-                            const unsigned pos = base + off + (unsigned) __builtin_popcount(m & ((1u << lane) - 1u));
-                            if (pos < kept_cap) kept_out[pos] = make_uint2((unsigned) row_tile[r], (unsigned) (col_tile0 + lane * STAGE_TILES + ct));
+                            const unsigned long long pos = base + off + (unsigned) __builtin_popcount(m & ((1u << lane) - 1u));
+                            if (pos < (unsigned long long) kept_cap) kept_out[pos] = make_uint2((unsigned) row_tile[r], (unsigned) (col_tile0 + lane * STAGE_TILES + ct));
                         }
                         off += (unsigned) __builtin_popcount(m);
                     }
@@ -289,13 +289,13 @@ template <bool COLDIR>
 __global__ __launch_bounds__(64 * TL_WAVES) void match_tiles(const f16x8* __restrict__ Ap, const f16x8* __restrict__ Bp, size_t bset_stride, float out_scale,
                                                              const int* __restrict__ blkcl, int ma_pad, int mb_pad, int rg_rows, const int* __restrict__ tile_group,
                                                              int* __restrict__ rowmin, int* __restrict__ colmin, const uint2* __restrict__ kept,
-                                                             const unsigned* __restrict__ kept_count, unsigned kept_cap) {
+                                                             const unsigned long long* __restrict__ kept_count, unsigned kept_cap) {
     typedef f16x8 frag;
     constexpr int KS = OpFmt<FMT_F16R>::KS;
     constexpr int IINF = 0x7f800000;
     const int lane = threadIdx.x & 63, half = lane >> 5;
-    if (*kept_count > kept_cap) return;   // overflow: the fused kernel repeats the whole pass
-    const unsigned n = *kept_count;
+    if (*kept_count > (unsigned long long) kept_cap) return;   // overflow: the fused kernel repeats the whole pass
+    const unsigned n = (unsigned) *kept_count;
     const unsigned n_waves = gridDim.x * TL_WAVES, w_id = blockIdx.x * TL_WAVES + (threadIdx.x >> 6);
     const int rg_blocks = rg_rows / BLOCK_ROWS;
     const f32x16 nav = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
