@@ -393,7 +393,7 @@ def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
             dt = time.perf_counter() - t0
             z, f = ctx.match_lbstats()
             out = {"match_stage_ms": 1e3 * dt, "match_mfma_ms": ctx.match_kernel_ms(), "executed_tile_fraction": ctx.match_work(),
-                   "issued_tile_fraction": ctx.match_issued(), "operand_format": ctx.match_format(), "zero_lower_bound_fraction": (z / f) if f > 0 else None}
+                   "issued_tile_fraction": ctx.match_issued(), "operand_format": ctx.match_format(), "zero_lower_bound_fraction": (z / f) if f > 0 else None, "irregular_rows": list(ctx.match_irregular()[:2])}
         return out
 
     def features_of(pr):
@@ -433,7 +433,8 @@ def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
     res["note"] = ("matcher stage alone (lgr_match_bf2_dev, both directions), second of two runs; this_pair = the bench pair's FPFH rows on the production "
                    "schedule, dense = the same rows with prune = 0, structureless = uniform random 11-bin blocks normalised to 100 on the production schedule "
                    "(lgr_match_options.auto_dense: >= 90 % zero lower bounds -> pass 0 computes everything), structureless_dense = the same random rows with "
-                   "prune = 0, planar = FPFH rows of a planar-dominated pair on the production schedule")
+                   "prune = 0, planar = FPFH rows of a planar-dominated pair on the production schedule; irregular_rows = rows per side off the block-sum consensus "
+                   "(all-zero FPFH rows of isolated points) that took the exact side scan instead of costing the pair the rotated format")
     return res
 
 

@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-/* ABI revision.  5 (round 5): lgr_ctx_options.arithmetic / pcl_neighbour_cap and lgr_match_options.auto_dense (former reserved words: a host that zeroes
- * them keeps the default arithmetic and switches auto_dense off), lgr_match_last_lbstats, lgr_selfcheck_philox,
+/* ABI revision.  5 (round 5): lgr_ctx_options.arithmetic / pcl_neighbour_cap and lgr_match_options.auto_dense / irregular_rows (former reserved words: a host that zeroes
+ * them keeps the default arithmetic and switches auto_dense and the irregular-row lane off), lgr_match_last_lbstats, lgr_match_last_irregular, lgr_selfcheck_philox,
  * lgr_selfcheck_libm added; the DEFAULT arithmetic of the normals and pair features changed to PCL's own sequences (results differ from
  * revision 4 at rounding level).  4 (round 4): lgr_match_options.split_sweep / kept_cap and lgr_ctx_options.concurrent_contexts (former reserved words: a host that
  * zeroes them switches the split off and keeps the contexts exclusive), lgr_match_last_issued, lgr_selfcheck_rcp added.  3 (round 3): lgr_match_options.shell_bound (one of the reserved words: a host that zeroes them would switch the shell
@@ -164,7 +164,10 @@ typedef struct {
     int32_t auto_dense;       /* 1 (default): when the bounds can separate (almost) nothing -- >= 90 % of the (row block, leaf) lower bounds are zero:
                                * descriptors without cluster structure -- pass 0 computes everything and the final pass finds an empty schedule, decided on
                                * the device (lgr_match_last_lbstats reports the counts).  0: never */
-    int32_t reserved[1];
+    int32_t irregular_rows;   /* 1 (default): the few finite rows whose three 11-bin block sums differ from the consensus of the sets (FPFH: an all-zero row of an
+                               * isolated point among rows whose blocks sum to 100) are kept out of the MFMA filter -- one of them would cost both sets the
+                               * rotated 30-coordinate format -- and matched by an exact side scan instead (lgr_match_last_irregular reports the counts; at
+                               * most 1024 per side, else they stay in the filter as before).  0: never */
 } lgr_match_options;
 
 /* ---- context ---- */
@@ -304,6 +307,10 @@ int lgr_match_last_pairs(lgr_ctx*, unsigned* out2);
 int lgr_match_last_format(lgr_ctx*, int* f16);
 /* (row block, leaf) pairs whose lower bound is zero / finite in the last pruned match call (lgr_match_options.auto_dense) */
 int lgr_match_last_lbstats(lgr_ctx*, double* out2);
+/* irregular rows of the last match call (lgr_match_options.irregular_rows): [0] query side, [1] train side: rows that were matched by the
+ * exact side scan instead of the MFMA filter (0 when the lane was off, found no consensus among the block sums, or gave up); [2] = 1 when it
+ * gave up (more than 1024 such rows on a side: the call was rebuilt with every finite row in the filter). */
+int lgr_match_last_irregular(lgr_ctx*, unsigned* out3);
 /* self-check of the matcher's filter bound (lgr_match_options.self_check = 1, test sizes): worst |filtered - exact| / eps over
  * sampled table entries of the last match call, rows then columns; -1 = not run.  Must be <= 1. */
 int lgr_match_last_check(lgr_ctx*, double* out2);

@@ -288,7 +288,7 @@ extern "C" void lgr_match_default_options(lgr_match_options* o) {
     if (!o) return;
     memset(o, 0, sizeof(*o));
     o->prune = -1; o->leaves = 0; o->near = 0; o->operand_format = -1; o->box_bounds = 1; o->column_stage = 1;
-    o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0; o->shell_bound = 1; o->split_sweep = 1; o->auto_dense = 1;
+    o->coarse_rejection = 1; o->rerank_refilter = 1; o->pair_cap = -1; o->poison_tables = 0; o->self_check = 0; o->shell_bound = 1; o->split_sweep = 1; o->auto_dense = 1; o->irregular_rows = 1;
 }
 
 // (every internal context below this one, however deep: an internal context that runs a pair of jobs itself owns internal contexts too)
@@ -305,7 +305,7 @@ extern "C" int lgr_ctx_set_match_options(lgr_ctx* ctx, const lgr_match_options* 
     else {
         LGR_CHECK(ctx, opt->prune >= -1 && opt->prune <= 1 && opt->leaves >= 0 && opt->leaves <= 64 && opt->near >= 0 &&
                        opt->operand_format >= -1 && opt->operand_format <= 2 && opt->box_bounds >= 0 && opt->box_bounds <= 2 && opt->kept_cap >= 0 &&
-                       (opt->auto_dense == 0 || opt->auto_dense == 1), LGR_ERR_INVALID_ARG);
+                       (opt->auto_dense == 0 || opt->auto_dense == 1) && (opt->irregular_rows == 0 || opt->irregular_rows == 1), LGR_ERR_INVALID_ARG);
         o = *opt;
     }
     propagate_mopt(ctx, o);

@@ -24,7 +24,7 @@ struct lgr_buf {
 
 // statistics of a context's last match call (bench / diagnostics: lgr_match_last_*): candidate (query, group) items and
 // dense-fallback queries per direction, group counts, the column stages the MFMA passes executed out of all (row block, stage) pairs
-struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all, stages_unique; int f16; double coarse_tested, coarse_rejected; unsigned pairs_ab, pairs_ba; double shell_skipped; double lb_zero, lb_finite; };
+struct lgr_match_stats { unsigned items_ab, dense_ab, items_ba, dense_ba; int sub_cols, rg_rows; double stages_done, stages_all, stages_unique; int f16; double coarse_tested, coarse_rejected; unsigned pairs_ab, pairs_ba; double shell_skipped; double lb_zero, lb_finite; unsigned irr_a, irr_b, irr_gave_up; };
 
 // The one persistent helper host thread of an internal context (lgr_ctx::aux / aux2): started on first use, parked on a condition
 // variable between jobs, joined when the context is destroyed.  One job at a time: post, then wait.
@@ -50,7 +50,7 @@ struct lgr_ctx {
     float stage_ms[12];
     int n_cu = 256;
     int mfma_timed = 0;
-    lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, 1, 1, 0, 1, {0}};   // lgr_match_default_options
+    lgr_match_options mopt{-1, 0, 0, -1, 1, 1, 1, 1, -1, 0, 0, 1, 1, 0, 1, 1};   // lgr_match_default_options
     bool corr_trusted = false;                  // set by lgr_align* around its own RANSAC / GROR call: the correspondences came from the pipeline itself
     void* match_prep = nullptr;                 // the matcher's clustering / prepared query side (lgr_match.hip: MatchPrep)
     void (*match_prep_free)(void*) = nullptr;

@@ -81,6 +81,12 @@ extern "C" int lgr_match_last_lbstats(lgr_ctx* ctx, double* out2) {
     out2[0] = ctx->mstats.lb_zero; out2[1] = ctx->mstats.lb_finite;
     return LGR_OK;
 }
+// irregular rows of the last match call that went through the exact side scan: [query side, train side, 1 = the lane gave up]
+extern "C" int lgr_match_last_irregular(lgr_ctx* ctx, unsigned* out3) {
+    if (!ctx || !out3) return LGR_ERR_INVALID_ARG;
+    out3[0] = ctx->mstats.irr_a; out3[1] = ctx->mstats.irr_b; out3[2] = ctx->mstats.irr_gave_up;
+    return LGR_OK;
+}
 extern "C" int lgr_match_last_coarse(lgr_ctx* ctx, double* out2) {
     if (!ctx || !out2) return LGR_ERR_INVALID_ARG;
     out2[0] = ctx->mstats.coarse_tested; out2[1] = ctx->mstats.coarse_rejected;
@@ -200,6 +206,7 @@ struct MatchPrep {
     int sub = 1, rg_rows = BLOCK_ROWS, ns = 0;
     float *cen = nullptr, *cen2 = nullptr, *smp = nullptr, *basis = nullptr;   // in WS_MATCH_MISC
     int* smp_ok = nullptr;
+    IrrRef* irr = nullptr;         // the block-sum consensus (km_consensus / km_sample), or nullptr: irregular-row lane off
     bool basis_ready = false;
     Side A;
 };
@@ -231,7 +238,7 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
     const size_t o_cbuf = carve((size_t) 2 * KCL * 33 * 4), o_basis = carve((size_t) (34 * 33 + 64) * 4);
     const size_t o_skeys = carve((size_t) 2 * ns * 4), o_svals = carve((size_t) ns * 4), o_sidx = carve((size_t) ns * 4), o_coff = carve(256);
     const size_t o_zero = off;   // zeroed once per call: largest sample magnitude, one set of level-1 sums per Lloyd step, the level-2 sums
-    const size_t o_kmax = carve(256), o_acc1 = carve((size_t) KM_ITERS * KCL * sizeof(KmAcc)), o_acc2 = carve((size_t) MAXLEAF * sizeof(KmAcc));
+    const size_t o_kmax = carve(256), o_irr = carve(sizeof(IrrRef)), o_acc1 = carve((size_t) KM_ITERS * KCL * sizeof(KmAcc)), o_acc2 = carve((size_t) MAXLEAF * sizeof(KmAcc));
     const size_t zero_bytes = off - o_zero;
     LGR_TRY(lgr_ws_t(ctx, WS_MATCH_MISC, off, &misc));
     float* cen = (float*) (misc + 256);                 // [KCL][33]
@@ -249,7 +256,10 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
     KmAcc* acc1 = (KmAcc*) (misc + o_acc1);
     KmAcc* acc2 = (KmAcc*) (misc + o_acc2);
     LGR_HIP(ctx, hipMemsetAsync(misc + o_zero, 0, zero_bytes, ctx->stream));
-    km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok, kmax);
+    // irregular rows: a vote over the sample rows finds the consensus of the block sums; km_sample leaves rows off it out of the sample
+    IrrRef* irr = mo.irregular_rows ? (IrrRef*) (misc + o_irr) : nullptr;
+    if (irr) km_consensus<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, irr);
+    km_sample<<<cdiv(ns, 256), 256, 0, ctx->stream>>>(d_a, ma, d_b, mb, KM_SAMPLE, smp, smp_ok, kmax, irr);
     auto lloyd = [&](lgr_ctx* cx) -> int {
         km_init<<<1, 64, 0, cx->stream>>>(smp, smp_ok, ns, cbuf);
         for (int it = 0; it <= KM_ITERS; ++it) {   // Lloyd with order-free integer sums; the last launch labels with the final centres
@@ -288,7 +298,7 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
     if (ma <= 65536) rg_rows = BLOCK_ROWS;                                     // small inputs: keep the cluster padding small
     P->d_a = d_a; P->ma = ma; P->mb = mb; P->both = both; P->mopt = mo;
     P->sub = sub; P->rg_rows = rg_rows; P->ns = ns;
-    P->cen = cen; P->cen2 = cen2; P->smp = smp; P->smp_ok = smp_ok; P->basis = basis; P->basis_ready = want_basis;
+    P->cen = cen; P->cen2 = cen2; P->smp = smp; P->smp_ok = smp_ok; P->basis = basis; P->basis_ready = want_basis; P->irr = irr;
     return LGR_OK;
 }
 
@@ -338,9 +348,19 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     Side B;
     if (!prepared) LGR_TRY(match_cluster(ctx, d_a, ma, d_b, mb, both, true, P));
     // the two sides are independent (assign, sort, two host read-backs each): side by side on the two contexts
-    LGR_TRY(lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, 0, &P->A); },
-                         [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, 1, &B); }));
+    auto build_sides = [&](const IrrRef* irr) {
+        return lgr_run_pair(ctx, [&](lgr_ctx* cx) { return build_side(cx, d_a, ma, P->cen, P->cen2, P->sub, 1, P->rg_rows, WS_MATCH_NA, WS_MATCH_AP, 0, irr, &P->A); },
+                            [&](lgr_ctx* cx) { return build_side(cx, d_b, mb, P->cen, P->cen2, P->sub, TILE, PAD, WS_MATCH_NB, WS_MATCH_BP, 1, irr, &B); });
+    };
+    LGR_TRY(build_sides(P->irr));
+    // the irregular-row lane gives up when a side has more such rows than its list holds, or when they are all a side has (the centres then
+    // come from the other side alone and nothing is left for the filter): both sides again with every finite row in the operands
+    if (P->A.n_irr > IRR_CAP || B.n_irr > IRR_CAP || ((P->A.n_irr || B.n_irr) && (P->A.n_valid == 0 || B.n_valid == 0))) {
+        g_last_stats.irr_gave_up = 1u;
+        LGR_TRY(build_sides(nullptr));
+    }
     const Side& A = P->A;
+    g_last_stats.irr_a = (unsigned) A.n_irr; g_last_stats.irr_b = (unsigned) B.n_irr;
     const int sub = P->sub, n_leaves = KCL * sub, rg_rows = P->rg_rows, ns = P->ns;
     float *const cen = P->cen, *const cen2 = P->cen2, *const smp = P->smp;
     int* const smp_ok = P->smp_ok;
@@ -434,6 +454,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         // term, so the choice below only trades speed.  FPFH rows: every block sums to 100 -> max |u|^2 ~ 1e-7.
         const int rot_env = mo.operand_format < 0 ? -1 : (mo.operand_format == 2 ? 1 : 0);
         rot = rot_env >= 0 ? rot_env != 0 : (4.0 * (double) drop2 <= 1e-8 * (double) r2);
+        if (env_int("LGR_MATCH_DEBUG", 0))
+            fprintf(stderr, "[lgr] operand statistics: max |x - c|^2 %.6g, dropped energy %.6g (A %.6g, B %.6g) -> %s; irregular rows %d + %d\n", (double) r2, (double) drop2,
+                    (double) A.nstat_drop, (double) B.nstat_drop, rot ? "rotated" : "plain", A.n_irr, B.n_irr);
         double R = std::sqrt((double) r2);
         int sexp = R > 0 ? (int) std::floor(std::log2(16384.0 / R)) : 14;
         sexp = std::max(-40, std::min(14, sexp));
@@ -547,10 +570,17 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     }
     group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
-    bool b_joined = sB == ctx->stream;
+    bool b_joined = sB == ctx->stream, b_recorded = false;
+    // (the event is recorded behind the last PRODUCER on sB -- record_b, called where the set-up has been enqueued -- not where the first reader
+    //  joins: by then sB also holds pass 0's init_tables_kernel, which mask_kernel is meant to run beside, not behind; it has an event of its own)
+    auto record_b = [&]() -> int {
+        if (!b_joined && !b_recorded) LGR_HIP(ctx, hipEventRecord(ctx->ev3, sB));
+        b_recorded = true;
+        return LGR_OK;
+    };
     auto join_b = [&]() -> int {   // everything that reads the column operands, their norms or maxima comes after this
         if (!b_joined) {
-            LGR_HIP(ctx, hipEventRecord(ctx->ev3, sB));
+            LGR_TRY(record_b());
             LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev3, 0));
         }
         b_joined = true;
@@ -783,23 +813,24 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         };
         if (!f16) LGR_TRY(join_sorted());   // lb_kernel reads sortedA
         LGR_TRY(launch_lb(ctx));
+        // do the bounds separate anything?  (zero / finite lower bounds: counted by box_lb_kernel where it writes the final bounds, by lb_stats_kernel
+        // without boxes; near_kernel: when nearly every lower bound is zero, pass 0 takes everything)
+        unsigned long long* lbstat = &mstats->stages[5];   // [5] zero, [6] finite lower bounds (MaskStats slots the passes do not use)
         if (boxes) {
             LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[30], 0));
-            box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq);
+            box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq, lbstat);
+        } else {
+            lb_stats_kernel<<<std::min(cdiv((long long) n_rb * n_leaves, 1024), 1024), 256, 0, ctx->stream>>>(LBsq, (size_t) n_rb * n_leaves, lbstat);
         }
         // pass 0: the NEAR_T nearest leaves of every row block and the NEAR_T nearest row blocks of every leaf
-        // do the bounds separate anything?  (lb_stats_kernel / lb_widen_kernel: when nearly every lower bound is zero, pass 0 takes everything)
-        unsigned long long* lbstat = &mstats->stages[5];   // [5] zero, [6] finite lower bounds (MaskStats slots the passes do not use)
-        unsigned* widen = (unsigned*) (misc + 224);
-        lb_stats_kernel<<<std::min(cdiv((long long) n_rb * n_leaves, 1024), 1024), 256, 0, ctx->stream>>>(LBsq, (size_t) n_rb * n_leaves, lbstat);
-        lb_widen_kernel<<<1, 1, 0, ctx->stream>>>(lbstat, mo.auto_dense ? LGR_AUTO_DENSE_FRAC : 0.f, widen);
+        const float widen_frac = mo.auto_dense ? LGR_AUTO_DENSE_FRAC : 0.f;
         auto launch_near = [&](int n_vec, int len, size_t vs, size_t es) -> int {
             if (len <= NEAR_LDS_MAX) {
                 if ((size_t) len * 4 > 64 * 1024)
                     LGR_HIP(ctx, hipFuncSetAttribute((const void*) near_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, len * 4));
-                near_kernel<true><<<n_vec, NEAR_THREADS, (size_t) len * 4, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, widen);
+                near_kernel<true><<<n_vec, NEAR_THREADS, (size_t) len * 4, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, lbstat, widen_frac);
             } else {
-                near_kernel<false><<<n_vec, NEAR_THREADS, 0, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, widen);
+                near_kernel<false><<<n_vec, NEAR_THREADS, 0, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, lbstat, widen_frac);
             }
             return LGR_OK;
         };
@@ -812,6 +843,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         // (an intermediate sweeping pass whose tile list overflows would go unrepaired: the repair below re-runs the LAST pass's mask only, and
         //  every launch resets the list's counter -- seen as wrong matches with -DLGR_PRUNE_BETAS=0.5f,1.0f at pass-0 widths 6 and 12)
         static_assert(sizeof betas / sizeof betas[0] == 1, "LGR_PRUNE_BETAS: one final pass only (lgr_match_common.cuh)");
+        LGR_TRY(record_b());   // sB: the column operands, their maxima and shells, the rerank's tables -- everything a reader of join_b() waits for
         for (int pass = 0; pass <= n_beta; ++pass) {
             if (pass > 0) {
                 build_comp();
@@ -930,6 +962,12 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     LGR_HIP(ctx, hipGetLastError());
 
     LGR_TRY(join_sorted());   // the self-check and the exact rerank read the sorted rows
+    // irregular rows: every pair they are part of, both roles (irregular_scan); the exact rerank below never sees them
+    {
+        const int nb_a = (ma + block - 1) / block, nb_b = (mb + block - 1) / block;
+        if (B.n_irr) irregular_scan<<<cdiv(ma, 256), 256, 0, ctx->stream>>>(d_a, A.valid, ma, d_b, B.irr_list, B.n_irr, block, nb_a, nb_b, bestA, both ? bestB : nullptr);
+        if (A.n_irr) irregular_scan<<<cdiv(mb, 256), 256, 0, ctx->stream>>>(d_b, B.valid, mb, d_a, A.irr_list, A.n_irr, block, nb_b, nb_a, both ? bestB : nullptr, bestA);
+    }
     if (mo.self_check && sortedA) {
         unsigned* d_worst = (unsigned*) (misc + 192);
         LGR_HIP(ctx, hipMemsetAsync(d_worst, 0, 8, ctx->stream));

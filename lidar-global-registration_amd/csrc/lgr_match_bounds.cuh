@@ -251,8 +251,10 @@ __global__ __launch_bounds__(256, 4) void box_kernel(const float* __restrict__ X
 }
 // LBsq[rb][leaf] = max(ball bound, box bound)
 __global__ __launch_bounds__(256) void box_lb_kernel(const float* __restrict__ boxA /* [n_rb][66] */, const float* __restrict__ boxBt /* [66][n_leaves] */,
-                                                     int n_leaves, const unsigned* __restrict__ rmax2, float* __restrict__ LBsq) {
+                                                     int n_leaves, const unsigned* __restrict__ rmax2, float* __restrict__ LBsq,
+                                                     unsigned long long* __restrict__ stats2 /* zero, finite final bounds (lb_stats_kernel's counts), or nullptr */) {
     __shared__ float a[66];
+    unsigned n_zero = 0u, n_fin = 0u;
     const int rb = blockIdx.x;
     if (threadIdx.x < 66) a[threadIdx.x] = boxA[(size_t) rb * 66 + threadIdx.x];
     __syncthreads();
@@ -267,14 +269,22 @@ __global__ __launch_bounds__(256) void box_lb_kernel(const float* __restrict__ b
         const size_t idx = (size_t) rb * n_leaves + g;
         const float old = LBsq[idx];
         const float lb = s * (LB_SHRINK * LB_SHRINK * LB_SHRINK);
-        if (old < FLT_BIG && lb > old && lb < FLT_BIG) LBsq[idx] = lb;   // (the box alone: 19.4 % of the tiles, the ball alone 22.2 %, both 17.4 %)
+        const bool raise = old < FLT_BIG && lb > old && lb < FLT_BIG;
+        if (raise) LBsq[idx] = lb;   // (the box alone: 19.4 % of the tiles, the ball alone 22.2 %, both 17.4 %)
+        const float fin = raise ? lb : old;
+        n_fin += fin < FLT_BIG ? 1u : 0u;
+        n_zero += (fin < FLT_BIG && fin <= 0.f) ? 1u : 0u;
+    }
+    if (stats2) {   // the statistics auto_dense decides on, counted where the final bounds are written (a pass of its own over the table: 0.1 ms on the critical chain)
+        for (int o = 32; o > 0; o >>= 1) { n_zero += __shfl_xor(n_zero, o); n_fin += __shfl_xor(n_fin, o); }
+        if ((threadIdx.x & 63) == 0) { if (n_zero) atomicAdd(&stats2[0], (unsigned long long) n_zero); if (n_fin) atomicAdd(&stats2[1], (unsigned long long) n_fin); }
     }
 }
 
 // Can the bounds separate anything at all?  A (row block, leaf) pair whose lower bound is ZERO -- the two balls overlap and so do the boxes --
 // can never be excluded, whatever upper bounds the passes find.  lb_stats_kernel counts those pairs among the finite entries; when they are
 // (nearly) all of them (descriptors without cluster structure: bench.py's `structureless` extreme) pass 0's selection of the nearest leaves,
-// the second pass and its bookkeeping only add to a dense computation.  lb_widen_kernel then raises a device flag that makes near_kernel
+// the second pass and its bookkeeping only add to a dense computation.  lb_widen() then makes near_kernel
 // mark EVERYTHING for pass 0 (near_t = the whole vector): pass 0 becomes the dense pass, the final pass finds nothing left to schedule, and
 // the rest of the machinery runs over empty work lists -- decided on the device, no host round trip (a read-back at this point stalls the
 // launch queue for longer than the decision is worth).  Results never depend on it (a wider pass 0 is still an exact schedule).
@@ -289,8 +299,9 @@ __global__ void lb_stats_kernel(const float* __restrict__ LBsq, size_t n, unsign
     for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o); f += __shfl_xor(f, o); }
     if ((threadIdx.x & 63) == 0) { if (z) atomicAdd(&out2[0], z); if (f) atomicAdd(&out2[1], f); }
 }
-__global__ void lb_widen_kernel(const unsigned long long* __restrict__ stats2, float frac, unsigned* __restrict__ flag) {
-    flag[0] = (frac > 0.f && stats2[1] > 0ull && (double) stats2[0] >= (double) frac * (double) stats2[1]) ? 1u : 0u;
+// (the decision itself: every workgroup of near_kernel evaluates it from the same two counts)
+__device__ __forceinline__ bool lb_widen(const unsigned long long* __restrict__ stats2, float frac) {
+    return frac > 0.f && stats2[1] > 0ull && (double) stats2[0] >= (double) frac * (double) stats2[1];
 }
 
 // the near_t smallest finite entries of a strided vector -> need1 = 1; ties go to the lowest index.  One 256-thread block
@@ -300,13 +311,14 @@ constexpr int NEAR_THREADS = 256;
 constexpr int NEAR_LDS_MAX = 36 * 1024;   // entries that fit the dynamic LDS slab (144 KB); longer vectors are re-read from global
 template <bool IN_LDS>
 __global__ __launch_bounds__(NEAR_THREADS) void near_kernel(int near_t, const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
-                                                            uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride, const unsigned* __restrict__ widen) {
+                                                            uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride,
+                                                            const unsigned long long* __restrict__ stats2, float widen_frac) {
     extern __shared__ unsigned keys[];
     __shared__ int cnt_s, base_s;
     __shared__ int wave_cnt[NEAR_THREADS / 64];
     const int vec = blockIdx.x, tid = threadIdx.x;
     if (vec >= n_vec) return;
-    if (widen && widen[0]) {   // (uniform) the bounds separate nothing: every finite entry is "near" (lb_widen_kernel)
+    if (lb_widen(stats2, widen_frac)) {   // (uniform) the bounds separate nothing: every finite entry is "near"
         for (int e = tid; e < len; e += NEAR_THREADS)
             if (LBsq[vec * vec_stride + e * elem_stride] < FLT_BIG) need1[vec * need_vec_stride + e * need_elem_stride] = 1;
         return;

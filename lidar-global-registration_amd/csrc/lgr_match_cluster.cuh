@@ -15,19 +15,102 @@ struct KmAcc { long long sum[33]; long long cnt; };
 __device__ __forceinline__ double km_scale(unsigned kmax_bits) {   // 2^(40 - e), 2^e <= largest |sample value| < 2^(e+1)
     return kmax_bits ? ldexp(1.0, 40 - ((int) (kmax_bits >> 23) - 127)) : 1.0;
 }
+// ---- irregular rows (round 5).  The rotated 30-coordinate operand format (FMT_F16R: six MFMA steps instead of seven, and the only format
+// the coarse sweep of the final pass exists for) needs every 11-bin block of every row to have the same sum.  FPFH rows do -- except the
+// all-zero rows PCL writes for points whose neighbours carry no weight; 99 + 62 such rows among the 2 M of the planar scene used to cost
+// the pair the format (match stage 37 ms instead of 19).  So: the consensus of the three block sums is found by a vote over the k-means
+// sample (IRR_CAND candidate rows; the winner needs 99.5 % of the finite sample rows within 1e-5 of its sums, otherwise the lane stays
+// off -- rows of arbitrary floats have no consensus), rows off the consensus are IRREGULAR: left out of the sample, the clustering and the
+// operand packing (assign_kernel lists them), and matched by an exact side scan in both roles (irregular_scan, lgr_match_rerank.cuh)
+// that feeds the same packed atomicMin tables as the exact rerank.  More than IRR_CAP of them on a side: the call is
+// rebuilt with the lane off.  Results cannot depend on any of this: every (query, train) pair is still covered by an exact path.
+constexpr int IRR_CAND = 16;
+constexpr int IRR_CAP = 1024;
+struct IrrRef { double s[3]; double tol; int enabled; int best; unsigned n_ok; unsigned agree[IRR_CAND]; };   // zeroed per call
+__device__ __forceinline__ void block_sums(const float* v, double& s0, double& s1, double& s2) {
+    s0 = 0.0; s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { s0 += (double) v[k]; s1 += (double) v[11 + k]; s2 += (double) v[22 + k]; }
+}
+__device__ __forceinline__ bool sums_agree(double a0, double a1, double a2, double r0, double r1, double r2, double tol) {
+    return fabs(a0 - r0) <= tol && fabs(a1 - r1) <= tol && fabs(a2 - r2) <= tol;   // (NaN: false)
+}
+__device__ __forceinline__ double sums_tol(double r0, double r1, double r2) { return 1e-5 * fmax(fmax(fabs(r0), fabs(r1)), fabs(r2)); }
+// row of sample s (the same rows km_sample takes): B == nullptr: all 2 * per_side samples from A (evenly spaced), otherwise per_side from each set
+__device__ __forceinline__ const float* sample_row(int s, const float* __restrict__ A, int ma, const float* __restrict__ B, int mb, int per_side) {
+    const bool fromA = !B || s < per_side;
+    const float* X = fromA ? A : B;
+    const int m = fromA ? ma : mb;
+    if (m <= 0) return nullptr;
+    const int t = fromA ? s : s - per_side;
+    const long long i = (long long) t * m / (B ? per_side : 2 * per_side);
+    return X + (size_t) i * 33;
+}
+// the winner of the vote (lowest candidate among equals) and whether it carries a consensus; the same for every thread that asks
+__device__ __forceinline__ bool irr_decide(const IrrRef* __restrict__ ref, int& best) {
+    unsigned top = 0u;
+    best = 0;
+    for (int c = 0; c < IRR_CAND; ++c) { const unsigned a = ref->agree[c]; if (a > top) { top = a; best = c; } }
+    const unsigned n_ok = ref->n_ok;
+    return n_ok >= 256u && (unsigned long long) top * 1000ull >= (unsigned long long) n_ok * 995ull;
+}
+__global__ __launch_bounds__(256) void km_consensus(const float* __restrict__ A, int ma, const float* __restrict__ B, int mb, int per_side, IrrRef* __restrict__ ref) {
+    __shared__ double cs[IRR_CAND][3];
+    __shared__ int cok[IRR_CAND];
+    const int ns = 2 * per_side;
+    if (threadIdx.x < IRR_CAND) {
+        const float* r = sample_row((int) ((long long) threadIdx.x * ns / IRR_CAND), A, ma, B, mb, per_side);
+        float v[33];
+        const bool ok = r && row_finite(r, v);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (ok) block_sums(v, s0, s1, s2);
+        cs[threadIdx.x][0] = s0; cs[threadIdx.x][1] = s1; cs[threadIdx.x][2] = s2;
+        cok[threadIdx.x] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (s < ns) {
+        const float* r = sample_row(s, A, ma, B, mb, per_side);
+        float v[33];
+        ok = r && row_finite(r, v);
+        if (ok) block_sums(v, s0, s1, s2);
+    }
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < IRR_CAND; ++c) {
+        const bool a = ok && cok[c] && sums_agree(s0, s1, s2, cs[c][0], cs[c][1], cs[c][2], sums_tol(cs[c][0], cs[c][1], cs[c][2]));
+        const int n = __popcll(__ballot(a));
+        if (lane == 0 && n) atomicAdd(&ref->agree[c], (unsigned) n);
+    }
+    const int n_ok = __popcll(__ballot(ok));
+    if (lane == 0 && n_ok) atomicAdd(&ref->n_ok, (unsigned) n_ok);
+}
+// irr_ref: the vote of km_consensus (nullptr: lane off).  Sample rows off the consensus are left out like non-finite ones; thread 0 publishes
+// the decision (reference sums, tolerance, enabled) for assign_kernel.
 __global__ void km_sample(const float* __restrict__ A, int ma, const float* __restrict__ B, int mb, int per_side,
-                          float* __restrict__ smp, int* __restrict__ smp_ok, unsigned* __restrict__ kmax /* zeroed: max |v| bits */) {
+                          float* __restrict__ smp, int* __restrict__ smp_ok, unsigned* __restrict__ kmax /* zeroed: max |v| bits */, IrrRef* __restrict__ irr_ref) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= 2 * per_side) return;
-    // B == nullptr: all 2 * per_side samples from A (evenly spaced), otherwise per_side from each set
-    const float* X = (!B || s < per_side) ? A : B;
-    int m = (!B || s < per_side) ? ma : mb;
-    int t = (!B || s < per_side) ? s : s - per_side;
+    const float* r = sample_row(s, A, ma, B, mb, per_side);
     float v[33];
-    bool ok = false;
-    if (m > 0) {
-        long long i = (long long) t * m / (B ? per_side : 2 * per_side);
-        ok = row_finite(X + (size_t) i * 33, v);
+    bool ok = r && row_finite(r, v);
+    if (irr_ref) {
+        int best;
+        const bool on = irr_decide(irr_ref, best);
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        if (on) {
+            const float* rr = sample_row((int) ((long long) best * (2 * per_side) / IRR_CAND), A, ma, B, mb, per_side);
+            float w[33];
+            (void) row_finite(rr, w);   // (a winner is a finite row)
+            block_sums(w, r0, r1, r2);
+            if (ok) {
+                double s0, s1, s2;
+                block_sums(v, s0, s1, s2);
+                ok = sums_agree(s0, s1, s2, r0, r1, r2, sums_tol(r0, r1, r2));
+            }
+        }
+        if (s == 0) { irr_ref->s[0] = r0; irr_ref->s[1] = r1; irr_ref->s[2] = r2; irr_ref->tol = sums_tol(r0, r1, r2); irr_ref->best = best; irr_ref->enabled = on ? 1 : 0; }
     }
     float mx = 0.f;
     for (int k = 0; k < 33; ++k) { smp[(size_t) s * 33 + k] = ok ? v[k] : 0.f; if (ok) mx = fmaxf(mx, fabsf(v[k])); }
@@ -192,11 +275,12 @@ constexpr int ASSIGN_THREADS = 1024;   // the sub-centres (up to 135 KB of LDS) 
 // both sets): [0] largest finite |x - c|^2 (float bits) over the centres the row will be packed against -- its own cluster's
 // (role 0, query side) or all KCL (role 1, train side: one operand copy per column set) --, [1] the largest energy of the three
 // coordinates the rotated 30-D format drops (u_j = block sum of x - c over sqrt(11); summed in double, rounded up: the same
-// expression as the packing kernel's), [2] set when such a |x - c|^2 overflows float.
+// expression as the packing kernel's), [2] set when such a |x - c|^2 overflows float, [3] the number of irregular rows (all of them, listed or not).
 __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __restrict__ X, int m, const float* __restrict__ cen, const float* __restrict__ cen2, int sub,
                                                                 unsigned* __restrict__ keys, int* __restrict__ vals, uint8_t* __restrict__ valid,
                                                                 int* __restrict__ counts /* [MAXLEAF+1] */, unsigned* __restrict__ rmax /* [MAXLEAF] */,
-                                                                int role, unsigned* __restrict__ nstat /* [3] */) {
+                                                                int role, unsigned* __restrict__ nstat /* [4] */,
+                                                                const IrrRef* __restrict__ irr_ref /* or nullptr: no irregular-row lane */, int* __restrict__ irr_list /* [IRR_CAP] */) {
     // All sub-centres live in LDS (dynamic; up to 16 x 64 x 33 floats = 135 KB): every lane walks the sub-centres of ITS
     // cluster, which from global memory is a per-lane gather of 33 x sub words.  The odd pitch per cluster keeps lanes of
     // different clusters on different banks; lanes of one cluster read the same word (broadcast).
@@ -214,7 +298,19 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
         float v[33], r2;
         bool ok = row_finite(X + (size_t) i * 33, v);
         unsigned key = 0xffffffffu;
-        if (ok) {
+        // irregular rows (see km_consensus): finite, but off the consensus of the block sums -- listed for the exact side scan, kept out of
+        // the clustering statistics and the operands (valid = 2: a train row for the exact scans, not a row of the filter)
+        bool irr = false;
+        if (ok && irr_ref && irr_ref->enabled) {
+            double s0, s1, s2;
+            block_sums(v, s0, s1, s2);
+            irr = !sums_agree(s0, s1, s2, irr_ref->s[0], irr_ref->s[1], irr_ref->s[2], irr_ref->tol);
+            if (irr) {
+                const unsigned pos = atomicAdd(&nstat[3], 1u);
+                if (pos < (unsigned) IRR_CAP) irr_list[pos] = i;
+            }
+        }
+        if (ok && !irr) {
             // a finite row whose squared distance to every centre overflows float stays a valid row (its exact distance to
             // a duplicate of itself is 0 in the reference); it lands in leaf 0 of cluster 0 with an infinite radius, and
             // the overflow sends the whole call down the exact dense path (match_impl, force_dense)
@@ -252,8 +348,8 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
             atomicAdd(&lc[leaf], 1);
             atomicMax(&lr[leaf], __float_as_uint(rl2));
         }
-        if (!ok) atomicAdd(&lc[MAXLEAF], 1);
-        keys[i] = key; vals[i] = i; valid[i] = ok ? 1 : 0;
+        if (!ok || irr) atomicAdd(&lc[MAXLEAF], 1);
+        keys[i] = key; vals[i] = i; valid[i] = ok ? (irr ? 2 : 1) : 0;
     }
     __syncthreads();
     for (int l = threadIdx.x; l <= MAXLEAF; l += blockDim.x) {

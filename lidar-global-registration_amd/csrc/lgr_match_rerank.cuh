@@ -2,6 +2,7 @@
 // Part of the brute-force FPFH matcher; see the header of lgr_match.hip and DESIGN.md section 3.
 #pragma once
 #include "lgr_match_common.cuh"
+#include "lgr_match_cluster.cuh"
 
 namespace {
 
@@ -806,6 +807,53 @@ __global__ __launch_bounds__(256) void rerank_dense(const float* __restrict__ Q,
     }
 }
 
+// 4d. irregular rows (lgr_match_cluster.cuh, km_consensus): they are in no operand set and no table, so every pair they are part of is
+// computed here -- the listed rows of one set (a few dozen of a million; at most IRR_CAP) against every finite row of the other, exact
+// distances folded into the same packed keys as every other exact path, for BOTH roles at once: thread j holds row x_j of the full set and
+// keeps the best listed row for it (best_x: the listed rows as train rows), and the wave folds its 64 distances to listed row y_i into one
+// atomicMin on best_y[y_i] (the listed rows as queries).  (rerank_dense, the path of queries that scan everything, runs a thread per QUERY:
+// 161 queries of the planar scene kept two waves per workgroup busy for 5.8 ms; here the million rows are the parallel dimension: 0.5 ms.)
+__global__ __launch_bounds__(256) void irregular_scan(const float* __restrict__ X, const uint8_t* __restrict__ validX, int nx, const float* __restrict__ Y,
+                                                      const int* __restrict__ irr_list, int n_irr, int block, int nblocks_x, int nblocks_y,
+                                                      unsigned long long* __restrict__ best_x /* [nx] keys over Y's indices, or nullptr */,
+                                                      unsigned long long* __restrict__ best_y /* [ny] keys over X's indices, or nullptr */) {
+    __shared__ float Ys[64 * 33];
+    __shared__ int Yj[64];
+    const int xj = blockIdx.x * 256 + threadIdx.x;
+    const bool act = xj < nx && validX[xj] != 0;
+    float x[33];
+#pragma unroll
+    for (int k = 0; k < 33; ++k) x[k] = act ? X[(size_t) xj * 33 + k] : 0.f;
+    const unsigned rank_x = act ? tie_rank(xj, block, nblocks_x) : 0u;
+    unsigned long long bk = ~0ull;
+    for (int j0 = 0; j0 < n_irr; j0 += 64) {
+        __syncthreads();
+        const int nj = min(64, n_irr - j0);
+        if (threadIdx.x < nj) Yj[threadIdx.x] = irr_list[j0 + threadIdx.x];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nj * 33; i += 256) Ys[i] = Y[(size_t) Yj[i / 33] * 33 + i % 33];
+        __syncthreads();
+        for (int jj = 0; jj < nj; ++jj) {
+            const float d = exact_l2(x, Ys + jj * 33);
+            const bool fin = act && d < FLT_BIG;
+            if (fin && best_x) {
+                const unsigned long long key = ((unsigned long long) __float_as_uint(d) << 32) | tie_rank(Yj[jj], block, nblocks_y);
+                bk = key < bk ? key : bk;
+            }
+            if (best_y) {
+                unsigned long long ky = fin ? (((unsigned long long) __float_as_uint(d) << 32) | rank_x) : ~0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(ky, o);
+                    ky = other < ky ? other : ky;
+                }
+                if ((threadIdx.x & 63) == 0 && ky != ~0ull) atomicMin(&best_y[Yj[jj]], ky);
+            }
+        }
+    }
+    if (act && best_x && bk != ~0ull) atomicMin(&best_x[xj], bk);
+}
+
 __global__ void fill_u64(unsigned long long* __restrict__ p, int n, unsigned long long v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -837,6 +885,8 @@ struct Side {
     unsigned* r2max = nullptr;    // [MAXLEAF] squared leaf radius bits (device)
     float nstat_n2 = 0.f, nstat_drop = 0.f;   // assign_kernel's packing statistics of this side (largest |x - c|^2, dropped energy)
     bool nstat_ovf = false;
+    int n_irr = 0;                // irregular rows (finite, off the block-sum consensus: km_consensus); > IRR_CAP: the list is incomplete, the caller rebuilds without the lane
+    int* irr_list = nullptr;      // [min(n_irr, IRR_CAP)] original row indices (device)
     std::vector<int> h_blkcl;     // host copies
     std::vector<int> h_leaf_start;
 };
@@ -844,14 +894,14 @@ struct Side {
 // assign + sort + place one side.  Leaves start at multiples of leaf_unit, clusters at multiples of cluster_unit
 // (a multiple of 256 and of leaf_unit); padding positions carry perm = -1.
 int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const float* cen2, int sub, int leaf_unit, int cluster_unit,
-               int ws_keys, int ws_perm, int role, Side* s) {
+               int ws_keys, int ws_perm, int role, const IrrRef* irr_ref, Side* s) {
     s->m = m;
     const int n_leaves = KCL * sub;
     unsigned *keys, *keys2;
     int *vals, *vals2;
     char* kbuf;
     size_t body = (((size_t) m * 17 + 255) & ~(size_t) 255);
-    LGR_TRY(lgr_ws_t(ctx, ws_keys, body + 16384, &kbuf));
+    LGR_TRY(lgr_ws_t(ctx, ws_keys, body + 16384 + (size_t) IRR_CAP * 4, &kbuf));
     keys = (unsigned*) kbuf; keys2 = keys + m; vals = (int*) (keys2 + m); vals2 = vals + m;
     s->valid = (uint8_t*) (vals2 + m);
     int* counts = (int*) (kbuf + body);               // [MAXLEAF + 1]
@@ -860,17 +910,19 @@ int build_side(lgr_ctx* ctx, const float* d_x, int m, const float* cen, const fl
     LGR_HIP(ctx, hipMemsetAsync(counts, 0, 16384, ctx->stream));
     const size_t assign_lds = ((size_t) KCL * (sub * 33 + 1) + 2 * MAXLEAF + 1) * 4;
     if (assign_lds > 64 * 1024) LGR_HIP(ctx, hipFuncSetAttribute((const void*) assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) assign_lds));
-    unsigned* nstat = (unsigned*) (kbuf + body + 12288);   // [3], inside the 16 KB cleared above
-    assign_kernel<<<cdiv(m, ASSIGN_THREADS), ASSIGN_THREADS, assign_lds, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax, role, nstat);
+    unsigned* nstat = (unsigned*) (kbuf + body + 12288);   // [4], inside the 16 KB cleared above
+    s->irr_list = (int*) (kbuf + body + 16384);
+    assign_kernel<<<cdiv(m, ASSIGN_THREADS), ASSIGN_THREADS, assign_lds, ctx->stream>>>(d_x, m, cen, cen2, sub, keys, vals, s->valid, counts, rmax, role, nstat, irr_ref, s->irr_list);
     LGR_TRY(lgr_sort_pairs_u32(ctx, keys, keys2, vals, vals2, (size_t) m, 0, 32));
     int* h;
     LGR_TRY(lgr_pinned(ctx, 8192, (void**) &h));
     LGR_HIP(ctx, hipMemcpyAsync(h, counts, (MAXLEAF + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    LGR_HIP(ctx, hipMemcpyAsync(h + MAXLEAF + 8, nstat, 12, hipMemcpyDeviceToHost, ctx->stream));
+    LGR_HIP(ctx, hipMemcpyAsync(h + MAXLEAF + 8, nstat, 16, hipMemcpyDeviceToHost, ctx->stream));
     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(&s->nstat_n2, h + MAXLEAF + 8, 4);
     memcpy(&s->nstat_drop, h + MAXLEAF + 9, 4);
     s->nstat_ovf = h[MAXLEAF + 10] != 0;
+    s->n_irr = h[MAXLEAF + 11];
     std::vector<int> starts(2 * (size_t) MAXLEAF + 2, 0);   // [0..MAXLEAF): sorted start, [MAXLEAF..2*MAXLEAF]: padded start
     int acc = 0, pacc = 0;
     s->h_blkcl.clear();

@@ -60,7 +60,7 @@ class MatchOptions(C.Structure):
     _fields_ = [("prune", C.c_int32), ("leaves", C.c_int32), ("near", C.c_int32), ("operand_format", C.c_int32), ("box_bounds", C.c_int32),
                 ("column_stage", C.c_int32), ("coarse_rejection", C.c_int32), ("rerank_refilter", C.c_int32), ("pair_cap", C.c_int32),
                 ("poison_tables", C.c_int32), ("self_check", C.c_int32), ("shell_bound", C.c_int32), ("split_sweep", C.c_int32), ("kept_cap", C.c_int32), ("auto_dense", C.c_int32),
-                ("reserved", C.c_int32 * 1)]
+                ("irregular_rows", C.c_int32)]
 
 
 class CtxOptions(C.Structure):
@@ -294,6 +294,12 @@ class Context:
         out = (C.c_double * 2)()
         self.check(_lib.lgr_match_last_lbstats(self.h, out))
         return out[0], out[1]
+
+    def match_irregular(self):
+        """(query side, train side, gave up) of the last match call: rows that went through the exact side scan (lgr_match_options.irregular_rows)"""
+        out = (C.c_uint * 3)()
+        self.check(_lib.lgr_match_last_irregular(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def selfcheck_philox(self, key, counter4):
         """one Philox4x32-10 block from the device's generator (full counter; key = k0 | k1 << 32)"""

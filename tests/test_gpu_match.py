@@ -348,7 +348,8 @@ def test_rerank_refilter(lgr, oracle, matcher_mode):
 
 def test_rotated_format_selection(lgr, oracle, matcher_mode):
     """FPFH-like rows (every 11-bin block sums to 100) take the 30-coordinate operand format on their own; one row with a
-    different block sum switches the call back to 33 coordinates; both give the oracle's result."""
+    different block sum goes through the exact side scan (round 5) and the rest keeps the format -- with that lane switched off
+    the row switches the call back to 33 coordinates; all give the oracle's result."""
     import torch
     if matcher_mode != "auto":
         pytest.skip("format selection does not depend on the skipping mode")
@@ -358,7 +359,10 @@ def test_rotated_format_selection(lgr, oracle, matcher_mode):
     assert lgr.match_format() == "f16r"
     b[77, 3] += 0.25
     run_both(lgr, oracle, a, b, 1000)
-    assert lgr.match_format() == "f16"
+    assert lgr.match_format() == "f16r" and lgr.match_irregular() == (0, 1, 0)
+    opts(lgr, irregular_rows=0)
+    run_both(lgr, oracle, a, b, 1000)
+    assert lgr.match_format() == "f16" and lgr.match_irregular() == (0, 0, 0)
 
 
 def test_extreme_magnitudes_do_not_break_the_bounds(lgr, oracle, matcher_mode):
@@ -368,3 +372,69 @@ def test_extreme_magnitudes_do_not_break_the_bounds(lgr, oracle, matcher_mode):
     a, b = fpfh_like(rng, 3000), fpfh_like(rng, 4000)
     a[::97] *= 1e18; b[::89] *= 1e18; b[5] = a[97]; a[11] = b[89 * 3]
     run_both(lgr, oracle, a, b, 1500)
+
+
+def with_irregular(rng, a, n_zero, n_half=2):
+    """a copy of FPFH-like rows with n_zero all-zero rows (what PCL writes for a point whose neighbours carry no weight) and n_half rows
+    whose middle block sums to 50, at random positions; returns (rows, positions)"""
+    a = a.copy()
+    pos = rng.choice(a.shape[0], n_zero + n_half, replace=False)
+    a[pos[:n_zero]] = 0.0
+    a[pos[n_zero:], 11:22] *= 0.5
+    return a, np.sort(pos)
+
+
+def test_match_irregular_rows(lgr, oracle, matcher_mode):
+    """Rows off the consensus of the block sums (round 5: lgr_match_options.irregular_rows) take the exact side scan -- as queries and as
+    train rows, with the reference's tie rules (several zero rows on the train side: equal distances inside a bf block and across blocks),
+    beside NaN rows -- and the rest keeps the rotated 30-coordinate format.  With the lane switched off the matches are the same."""
+    import torch
+    rng = np.random.default_rng(2024)
+    a, pa = with_irregular(rng, clustered(rng, 9000, spread=0.3), 7)
+    b, pb = with_irregular(rng, clustered(rng, 12000, spread=0.3), 11)
+    # clustered() rows do not have constant block sums: make them so (the regular rows of both sets share the sums 100, 100, 100)
+    def normalise(x, keep):
+        y = x.reshape(-1, 3, 11).astype(np.float64)
+        s = y.sum(2, keepdims=True)
+        y = np.where(s > 0, 100.0 * y / np.where(s > 0, s, 1.0), y).reshape(-1, 33).astype(np.float32)
+        y[keep] = x[keep]
+        return y
+    a, b = normalise(a, pa), normalise(b, pb)
+    a[100, 3] = np.nan; b[200, :] = np.nan
+    a[300] = b[pb[0]]                      # a zero query row: distance 0 to every zero train row -> tie rules of the side scan
+    b[400] = a[301]                        # an ordinary exact duplicate beside it
+    run_both(lgr, oracle, a, b, 2500)
+    lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 2500)
+    lgr.sync()
+    def n_irregular(x):
+        fin = np.isfinite(x).all(1)
+        return int((fin & (np.abs(x.reshape(-1, 3, 11).astype(np.float64).sum(2) - 100.0) > 1e-3).any(1)).sum())
+    assert n_irregular(a) >= len(pa) and n_irregular(b) >= len(pb) - 1
+    assert lgr.match_irregular() == (n_irregular(a), n_irregular(b), 0)
+    if not matcher_mode.startswith("auto"):
+        assert lgr.match_format() == "f16r"
+    opts(lgr, irregular_rows=0)
+    run_both(lgr, oracle, a, b, 2500)
+    lgr.match_bf2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 2500)
+    lgr.sync()
+    assert lgr.match_irregular() == (0, 0, 0)
+
+
+def test_match_irregular_rows_give_up(lgr, oracle, matcher_mode):
+    """More irregular rows than the side scan's list holds (1024 per side), and a side that consists of nothing else: the call is
+    rebuilt with every finite row in the operands; no consensus at all (rows of arbitrary floats): the lane stays off.  Same matches."""
+    import torch
+    if matcher_mode not in ("auto", "prune_sub4"):
+        pytest.skip("host-side decision: one automatic and one forced-skipping mode")
+    rng = np.random.default_rng(31)
+    a = fpfh_like(rng, 2500)
+    b = fpfh_like(rng, 230000)
+    b[rng.choice(b.shape[0], 1100, replace=False)] = 0.0     # 0.48 % of the rows: a consensus exists, the list overflows
+    run_both(lgr, oracle, a, b, 100000)
+    assert lgr.match_irregular() == (0, 0, 1)                 # gave up: the rebuilt call has them in the operands
+    assert lgr.match_format() != "f16r"
+    z = np.zeros((40, 33), np.float32)                        # a query side of zero rows only, among regular train rows
+    run_both(lgr, oracle, z, fpfh_like(rng, 3000), 1000)
+    x = rng.normal(size=(3000, 33)).astype(np.float32)        # no consensus
+    run_both(lgr, oracle, x, rng.normal(size=(2000, 33)).astype(np.float32), 1000)
+    assert lgr.match_irregular() == (0, 0, 0)
