@@ -1,4 +1,5 @@
 // lgr_ctx.hip -- context, workspace, error plumbing of liblgr_hip.so.
+#include <vector>
 #include "lgr_internal.h"
 
 #include <atomic>
@@ -122,7 +123,9 @@ extern "C" int lgr_ctx_create(int device, void* stream, lgr_ctx** out) {
 static int make_internal(lgr_ctx* ctx, lgr_ctx** out, hipEvent_t* ev) {
     if (*out) return LGR_OK;
     // (LGR_STREAM_OWN_LOW was measured for the helpers: -0.1 ms under `lr`, but the cluster filter's second 40-NN table then slides from the
-    // feature phase under pass 0 of the matcher and costs it 2 ms: plain priority)
+    // feature phase under pass 0 of the matcher and costs it 2 ms: plain priority.  Round 5: a helper stream with every 16th / 8th compute unit
+    // masked out (hipExtStreamCreateWithCUMask), so that the caller's chains of short launches always find room beside the helper's big feature
+    // kernels: 33.1 / 29.5 ms per pair instead of 25.4 -- launches on a masked queue take far longer to start: dropped)
     LGR_CHECK(ctx, lgr_ctx_create(ctx->device, ctx->opt.helper_contexts ? LGR_STREAM_OWN : (void*) ctx->stream, out) == LGR_OK, LGR_ERR_HIP);
     (*out)->opt = ctx->opt;
     (*out)->mopt = ctx->mopt;

@@ -725,7 +725,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
         const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_macc = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
-        const size_t o_stats = pcarve(sizeof(MaskStats));
+        const size_t o_stats = pcarve(sizeof(MaskStats)), o_lbpart = pcarve((size_t) n_rb * sizeof(uint2));
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
         const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
         const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
@@ -816,9 +816,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         // do the bounds separate anything?  (zero / finite lower bounds: counted by box_lb_kernel where it writes the final bounds, by lb_stats_kernel
         // without boxes; near_kernel: when nearly every lower bound is zero, pass 0 takes everything)
         unsigned long long* lbstat = &mstats->stages[5];   // [5] zero, [6] finite lower bounds (MaskStats slots the passes do not use)
+        uint2* lb_part = boxes ? (uint2*) (pb + o_lbpart) : nullptr;   // (box_lb_kernel's counts per row block; summed by near_kernel)
         if (boxes) {
             LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[30], 0));
-            box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq, lbstat);
+            box_lb_kernel<<<n_rb, 256, 0, ctx->stream>>>(boxA, boxBt, n_leaves, rmax2, LBsq, lb_part);
         } else {
             lb_stats_kernel<<<std::min(cdiv((long long) n_rb * n_leaves, 1024), 1024), 256, 0, ctx->stream>>>(LBsq, (size_t) n_rb * n_leaves, lbstat);
         }
@@ -828,9 +829,9 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             if (len <= NEAR_LDS_MAX) {
                 if ((size_t) len * 4 > 64 * 1024)
                     LGR_HIP(ctx, hipFuncSetAttribute((const void*) near_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, len * 4));
-                near_kernel<true><<<n_vec, NEAR_THREADS, (size_t) len * 4, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, lbstat, widen_frac);
+                near_kernel<true><<<n_vec, NEAR_THREADS, (size_t) len * 4, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, lbstat, lb_part, n_rb, widen_frac);
             } else {
-                near_kernel<false><<<n_vec, NEAR_THREADS, 0, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, lbstat, widen_frac);
+                near_kernel<false><<<n_vec, NEAR_THREADS, 0, ctx->stream>>>(near_t, LBsq, n_vec, len, vs, es, sched, vs, es, lbstat, lb_part, n_rb, widen_frac);
             }
             return LGR_OK;
         };
@@ -939,6 +940,44 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 }
             const double tot = (double) n_rb * mb_pad;
             fprintf(stderr, "[lgr] final pass by criterion: rows only %.4f, columns only %.4f, both %.4f of the tiles\n", by_rows / tot, by_cols / tot, by_both / tot);
+            if (coarse && both && env_int("LGR_MATCH_DEBUG", 0) >= 2) {
+                // What would homogeneous tiles be worth?  (Round 5, bench pair: scheduled pairs 1.57e8 tiles, tile maxima in the present order 1.03e8,
+                // element level 6.8e7 -- rows and columns sorted by U would lose the radial shells, which take 88 M tile slots to 54 M tested, for at
+                // most a third fewer; and the leaf's bound tested per tile inside the sweep took 54.4 M tested tiles to 47.4 M for 0.1 ms and four
+                // spilled VGPRs: the (row block, leaf) bounds themselves are what limits the final pass, not the granularity of the upper bounds.)  32 x 32 tiles of the scheduled (row block, leaf) pairs that ANY element-level criterion
+                // needs (LB^2 <= U^2 of the row or of the column), counted (i) per (row block, leaf) as scheduled, (ii) per tile with the present
+                // row / column order (tile maxima), (iii) as if rows and columns were sorted by U inside their block / leaf (the fraction of
+                // rows and of columns that need the pair).
+                std::vector<float> hur(ma_pad), huc(mb_pad);
+                LGR_HIP(ctx, hipMemcpy(hur.data(), u_row, hur.size() * 4, hipMemcpyDeviceToHost));
+                LGR_HIP(ctx, hipMemcpy(huc.data(), u_colv, huc.size() * 4, hipMemcpyDeviceToHost));
+                std::vector<std::vector<float>> rs(n_rb), cs(n_leaves), rts(n_rb), cts(n_leaves);
+                for (int rb = 0; rb < n_rb; ++rb) {
+                    for (int r = 0; r < BLOCK_ROWS; ++r) rs[rb].push_back(std::max(hur[(size_t) rb * BLOCK_ROWS + r], 0.f));
+                    for (int t = 0; t < BLOCK_ROWS / TILE; ++t) rts[rb].push_back(*std::max_element(rs[rb].begin() + t * TILE, rs[rb].begin() + (t + 1) * TILE));
+                    std::sort(rs[rb].begin(), rs[rb].end()); std::sort(rts[rb].begin(), rts[rb].end());
+                }
+                for (int l = 0; l < n_leaves; ++l) {
+                    for (int c = B.h_leaf_start[l]; c < B.h_leaf_start[l + 1]; ++c) cs[l].push_back(std::max(huc[c], 0.f));
+                    for (size_t t = 0; t + TILE <= cs[l].size(); t += TILE) cts[l].push_back(*std::max_element(cs[l].begin() + t, cs[l].begin() + t + TILE));
+                    std::sort(cs[l].begin(), cs[l].end()); std::sort(cts[l].begin(), cts[l].end());
+                }
+                auto frac_ge = [](const std::vector<float>& v, float x) { return v.empty() ? 0.0 : (double) (v.end() - std::lower_bound(v.begin(), v.end(), x)) / (double) v.size(); };
+                double t_sched = 0, t_tile = 0, t_ideal = 0, t_rows_ideal = 0, t_cols_ideal = 0;
+                for (int rb = 0; rb < n_rb; ++rb)
+                    for (int l = 0; l < n_leaves; ++l) {
+                        if (!hsch[(size_t) rb * n_leaves + l]) continue;
+                        const float lb = hlb[(size_t) rb * n_leaves + l] / 1.00001f;
+                        const double tiles = 8.0 * (double) cts[l].size();
+                        const double pa = frac_ge(rs[rb], lb), pb = frac_ge(cs[l], lb), ta_ = frac_ge(rts[rb], lb), tb_ = frac_ge(cts[l], lb);
+                        t_sched += tiles;
+                        t_tile += tiles * (1.0 - (1.0 - ta_) * (1.0 - tb_));
+                        t_ideal += tiles * (1.0 - (1.0 - pa) * (1.0 - pb));
+                        t_rows_ideal += tiles * pa; t_cols_ideal += tiles * pb;
+                    }
+                fprintf(stderr, "[lgr] final pass, 32 x 32 tiles by granularity of the criterion: scheduled pairs %.3g, tile maxima (present order) %.3g, element level (U-sorted tiles) %.3g "
+                                "(rows alone %.3g, columns alone %.3g)\n", t_sched, t_tile, t_ideal, t_rows_ideal, t_cols_ideal);
+            }
             if (coarse) {
                 // how loose are the tile-level maxima the sweep's shell test uses?  quantiles of the rows' own bounds and of (tile max / tile median)
                 std::vector<float> hu(ma_pad);

@@ -252,13 +252,16 @@ __global__ __launch_bounds__(256, 4) void box_kernel(const float* __restrict__ X
 // LBsq[rb][leaf] = max(ball bound, box bound)
 __global__ __launch_bounds__(256) void box_lb_kernel(const float* __restrict__ boxA /* [n_rb][66] */, const float* __restrict__ boxBt /* [66][n_leaves] */,
                                                      int n_leaves, const unsigned* __restrict__ rmax2, float* __restrict__ LBsq,
-                                                     unsigned long long* __restrict__ stats2 /* zero, finite final bounds (lb_stats_kernel's counts), or nullptr */) {
+                                                     uint2* __restrict__ part /* [n_rb]: zero, finite final bounds of this row block (what lb_stats_kernel counts), or nullptr */) {
     __shared__ float a[66];
+    __shared__ unsigned cnt_s[2];
     unsigned n_zero = 0u, n_fin = 0u;
+    if (threadIdx.x < 2) cnt_s[threadIdx.x] = 0u;
     const int rb = blockIdx.x;
     if (threadIdx.x < 66) a[threadIdx.x] = boxA[(size_t) rb * 66 + threadIdx.x];
     __syncthreads();
     const float delta = 4.1e-6f * sqrtf(__uint_as_float(*rmax2)) * 1.01f;
+#pragma unroll 1   // (with the counters carried across it hipcc unrolled this loop as well: 512 VGPRs, 945 spilled, 0.66 ms instead of 0.07)
     for (int g = threadIdx.x; g < n_leaves; g += 256) {
         float s = 0.f;
 #pragma unroll
@@ -275,9 +278,14 @@ __global__ __launch_bounds__(256) void box_lb_kernel(const float* __restrict__ b
         n_fin += fin < FLT_BIG ? 1u : 0u;
         n_zero += (fin < FLT_BIG && fin <= 0.f) ? 1u : 0u;
     }
-    if (stats2) {   // the statistics auto_dense decides on, counted where the final bounds are written (a pass of its own over the table: 0.1 ms on the critical chain)
+    if (part) {
+        // the statistics auto_dense decides on, counted where the final bounds are written (as a pass of its own over the table: 0.1 ms on the
+        // critical chain) -- one pair of counts per row block, summed by near_kernel (two global counters instead: 31 000 atomics on two
+        // addresses made this kernel 0.77 ms instead of 0.07)
         for (int o = 32; o > 0; o >>= 1) { n_zero += __shfl_xor(n_zero, o); n_fin += __shfl_xor(n_fin, o); }
-        if ((threadIdx.x & 63) == 0) { if (n_zero) atomicAdd(&stats2[0], (unsigned long long) n_zero); if (n_fin) atomicAdd(&stats2[1], (unsigned long long) n_fin); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&cnt_s[0], n_zero); atomicAdd(&cnt_s[1], n_fin); }
+        __syncthreads();
+        if (threadIdx.x == 0) part[rb] = make_uint2(cnt_s[0], cnt_s[1]);
     }
 }
 
@@ -299,9 +307,24 @@ __global__ void lb_stats_kernel(const float* __restrict__ LBsq, size_t n, unsign
     for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o); f += __shfl_xor(f, o); }
     if ((threadIdx.x & 63) == 0) { if (z) atomicAdd(&out2[0], z); if (f) atomicAdd(&out2[1], f); }
 }
-// (the decision itself: every workgroup of near_kernel evaluates it from the same two counts)
-__device__ __forceinline__ bool lb_widen(const unsigned long long* __restrict__ stats2, float frac) {
-    return frac > 0.f && stats2[1] > 0ull && (double) stats2[0] >= (double) frac * (double) stats2[1];
+// (the decision itself: every workgroup of near_kernel evaluates it from the same counts -- stats2 from lb_stats_kernel, or the per-row-block
+//  pairs of box_lb_kernel, which workgroup 0 also sums into stats2 for the host's report.  Every thread of the workgroup must call it.)
+__device__ __forceinline__ bool lb_widen(unsigned long long* __restrict__ stats2, const uint2* __restrict__ part, int n_part, float frac) {
+    __shared__ unsigned long long sum_s[2];
+    unsigned long long z, f;
+    if (part) {
+        if (threadIdx.x < 2) sum_s[threadIdx.x] = 0ull;
+        __syncthreads();
+        unsigned long long pz = 0ull, pf = 0ull;
+        for (int i = threadIdx.x; i < n_part; i += blockDim.x) { const uint2 p = part[i]; pz += p.x; pf += p.y; }
+        for (int o = 32; o > 0; o >>= 1) { pz += __shfl_xor(pz, o); pf += __shfl_xor(pf, o); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&sum_s[0], pz); atomicAdd(&sum_s[1], pf); }
+        __syncthreads();
+        z = sum_s[0]; f = sum_s[1];
+        if (blockIdx.x == 0 && threadIdx.x == 0) { stats2[0] = z; stats2[1] = f; }
+        __syncthreads();
+    } else { z = stats2[0]; f = stats2[1]; }
+    return frac > 0.f && f > 0ull && (double) z >= (double) frac * (double) f;
 }
 
 // the near_t smallest finite entries of a strided vector -> need1 = 1; ties go to the lowest index.  One 256-thread block
@@ -312,13 +335,13 @@ constexpr int NEAR_LDS_MAX = 36 * 1024;   // entries that fit the dynamic LDS sl
 template <bool IN_LDS>
 __global__ __launch_bounds__(NEAR_THREADS) void near_kernel(int near_t, const float* __restrict__ LBsq, int n_vec, int len, size_t vec_stride, size_t elem_stride,
                                                             uint8_t* __restrict__ need1, size_t need_vec_stride, size_t need_elem_stride,
-                                                            const unsigned long long* __restrict__ stats2, float widen_frac) {
+                                                            unsigned long long* __restrict__ stats2, const uint2* __restrict__ lb_part, int n_part, float widen_frac) {
     extern __shared__ unsigned keys[];
     __shared__ int cnt_s, base_s;
     __shared__ int wave_cnt[NEAR_THREADS / 64];
     const int vec = blockIdx.x, tid = threadIdx.x;
     if (vec >= n_vec) return;
-    if (lb_widen(stats2, widen_frac)) {   // (uniform) the bounds separate nothing: every finite entry is "near"
+    if (lb_widen(stats2, lb_part, n_part, widen_frac)) {   // (uniform) the bounds separate nothing: every finite entry is "near"
         for (int e = tid; e < len; e += NEAR_THREADS)
             if (LBsq[vec * vec_stride + e * elem_stride] < FLT_BIG) need1[vec * need_vec_stride + e * need_elem_stride] = 1;
         return;

@@ -364,6 +364,9 @@ GATED = ["normals_kernel", "normals_wave_kernel", "refit_kernel", "hypotheses_ke
          "count_kernel", "count_list_kernel", "match_sweep", "match_tiles", "rs_hyp_kernel", "rs_store_eval_kernel"]
 
 
+SCRATCH_ANY = 64   # bytes of scratch memory per work item that no kernel of the library may exceed (the gated ones: none at all)
+
+
 def main(argv):
     objs = sorted(glob.glob(os.path.join(CSRC, "*.o")))
     if not objs:
@@ -387,6 +390,11 @@ def main(argv):
                             print("%-14s %-70s scratch %3d B  sgpr spills %3d  vgpr spills %3d  (vgpr %d, sgpr %d)%s" % (os.path.basename(obj), k[:70], r["scratch"], r["sgpr_spill"],
                                   r["vgpr_spill"], r["vgpr"], r["sgpr"], "   <-- gated" if gated else ""))
                         if gate and gated and (r["scratch"] or r["vgpr_spill"]):
+                            bad += 1
+                        elif gate and r["scratch"] > SCRATCH_ANY:
+                            # (round 5: two counters carried across a loop made hipcc unroll box_lb_kernel into 512 VGPRs + 3.4 KB of scratch -- ten times
+                            #  its time, on the matcher's critical chain, seen only in the next timeline)
+                            print("%-14s %-70s scratch %d B > %d B allowed for ANY kernel" % (os.path.basename(obj), k[:70], r["scratch"], SCRATCH_ANY))
                             bad += 1
                 if "--resources" in argv and not gate:
                     continue
