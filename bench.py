@@ -173,8 +173,13 @@ def run_job(args, world, rank, local):
     sys.path.insert(0, os.path.join(ROOT, "lidar-global-registration_amd"))
     from lgr_amd import distributed
     costs = [distributed.pair_cost(n, n) for n in sizes]
-    mine = distributed.shard_pairs(n_pairs, world, rank, args.policy, costs)
-    pool = ProcessPoolExecutor(max_workers=max(1, min(6, _usable_cores() // max(1, world) - 1)), mp_context=mp.get_context("spawn"))
+    mine = distributed.rank_order(n_pairs, world, rank, args.policy, costs)   # (the order run_pairs asks for them)
+    # the generator processes inherit this environment: one BLAS / OpenMP thread each.  (Left alone every worker's numpy starts a thread per
+    # visible core -- six workers, ~100 runnable threads on a 16-core lease -- and the library's host threads, which drive ~40 short
+    # synchronisations per alignment, wait for a core: single pairs took two to four times their time, profiles/r5_job_tests156.json's maxima)
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[var] = "1"
+    pool = ProcessPoolExecutor(max_workers=max(1, min(4, _usable_cores() // max(1, world) - 3)), mp_context=mp.get_context("spawn"))
     window = 8
     futs = {}
     nxt = 0

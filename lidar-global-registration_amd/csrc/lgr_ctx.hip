@@ -69,6 +69,7 @@ int lgr_ws(lgr_ctx* ctx, int slot, size_t bytes, void** out) {
             LGR_HIP(ctx, hipMalloc(&b.p, want));
         }
         b.cap = want;
+        if (getenv("LGR_WS_DEBUG")) fprintf(stderr, "[lgr] workspace slot %d of context %p grows to %.1f MB (asked %.1f MB)\n", slot, (void*) ctx, want / 1048576.0, bytes / 1048576.0);
     }
     *out = b.p;
     return LGR_OK;

@@ -940,6 +940,28 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 }
             const double tot = (double) n_rb * mb_pad;
             fprintf(stderr, "[lgr] final pass by criterion: rows only %.4f, columns only %.4f, both %.4f of the tiles\n", by_rows / tot, by_cols / tot, by_both / tot);
+            if (split_used && env_int("LGR_MATCH_DEBUG", 0) >= 2 && h_kept[0] <= (unsigned long long) kept_cap) {
+                // how are the tiles the sweep keeps distributed over the (row block, stage) pairs -- 32 tile slots each?  (Round 5, 900 k points, scene
+                // seed 571: 16 M kept tiles, 78 % of them in pairs that keep more than half of their slots -- blobs of near-duplicate descriptors.
+                // Flagging such stages from the list and giving them to the plain six-step kernel as a whole: 40.8 -> 38.0 ms for that scene, nothing
+                // for the others; what those blobs needed was pass 0 taking every zero lower bound (near_kernel): 26.1 ms, 0.6 M kept tiles.)
+                const size_t nk = (size_t) h_kept[0];
+                std::vector<uint2> hk(nk);
+                if (nk) LGR_HIP(ctx, hipMemcpy(hk.data(), kept, nk * sizeof(uint2), hipMemcpyDeviceToHost));
+                std::vector<unsigned long long> key(nk);
+                for (size_t i = 0; i < nk; ++i) key[i] = ((unsigned long long) (hk[i].x / (BLOCK_ROWS / TILE)) << 32) | (hk[i].y / STAGE_TILES);
+                std::sort(key.begin(), key.end());
+                double hist[6] = {0, 0, 0, 0, 0, 0}, pairs_ = 0;   // kept tiles in pairs holding 1-2, 3-4, 5-8, 9-16, 17-24, 25-32 of them
+                for (size_t i = 0; i < nk;) {
+                    size_t j = i;
+                    while (j < nk && key[j] == key[i]) ++j;
+                    const size_t n = j - i;
+                    hist[n <= 2 ? 0 : n <= 4 ? 1 : n <= 8 ? 2 : n <= 16 ? 3 : n <= 24 ? 4 : 5] += (double) n;
+                    pairs_ += 1; i = j;
+                }
+                fprintf(stderr, "[lgr] kept tiles %zu in %.0f (row block, stage) pairs; tiles by the pair's count 1-2: %.3g, 3-4: %.3g, 5-8: %.3g, 9-16: %.3g, 17-24: %.3g, 25-32: %.3g\n",
+                        nk, pairs_, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+            }
             if (coarse && both && env_int("LGR_MATCH_DEBUG", 0) >= 2) {
                 // What would homogeneous tiles be worth?  (Round 5, bench pair: scheduled pairs 1.57e8 tiles, tile maxima in the present order 1.03e8,
                 // element level 6.8e7 -- rows and columns sorted by U would lose the radial shells, which take 88 M tile slots to 54 M tested, for at

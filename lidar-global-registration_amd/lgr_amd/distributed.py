@@ -41,6 +41,16 @@ def shard_pairs(n_pairs, world, rank, policy="round_robin", costs=None):
     return [p for p, r in enumerate(assign_pairs(n_pairs, world, policy, costs)) if r == rank]
 
 
+def rank_order(n_pairs, world, rank, policy="round_robin", costs=None):
+    """the pairs of `rank` in the order run_pairs aligns them: with predicted costs largest first (the context's workspace -- grown on demand,
+    never shrunk -- then reaches its final size with the first pair instead of being re-allocated at every new record size: up to 80 ms on such
+    a pair in profiles/r5_job_tests156.json), ascending pair id otherwise.  Records are keyed by pair id: the order is invisible to the caller."""
+    mine = shard_pairs(n_pairs, world, rank, policy, costs)
+    if costs is not None:
+        mine.sort(key=lambda q: (-float(costs[q]), q))
+    return mine
+
+
 def pair_cost(m_src, m_tgt):
     """predicted seconds of aligning a pair on one MI355X: the brute-force matcher's M_src * M_tgt term (include/matching.h:594-634; 16 of a
     1M-point pair's 24.5 ms) + a per-point term for the feature stages + a fixed part (RANSAC, launches); fitted to profiles/r5_job_tests156.json.
@@ -96,7 +106,7 @@ def run_pairs(n_pairs, world, rank, align_fn, device=None, policy="round_robin",
     records of all pairs ordered by pair id (numpy [n_pairs, RECORD_FLOATS]).  policy / costs: assign_pairs."""
     import torch
     owner = assign_pairs(n_pairs, world, policy, costs)
-    mine = [p for p, r in enumerate(owner) if r == rank]
+    mine = rank_order(n_pairs, world, rank, policy, costs)
     k = max([owner.count(r) for r in range(world)] + [0])      # shards are padded to the largest one (equal counts per rank for the all-gather)
     local = np.zeros((k, RECORD_FLOATS), np.float32)
     local.view(np.int32)[:, _I_PAIR] = -1

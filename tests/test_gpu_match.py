@@ -438,3 +438,4 @@ def test_match_irregular_rows_give_up(lgr, oracle, matcher_mode):
     x = rng.normal(size=(3000, 33)).astype(np.float32)        # no consensus
     run_both(lgr, oracle, x, rng.normal(size=(2000, 33)).astype(np.float32), 1000)
     assert lgr.match_irregular() == (0, 0, 0)
+

@@ -170,3 +170,23 @@ def test_bench_force_collective_one_rank_group():
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(out) == 1 and out[0]["n_gpus"] == 1 and out[0]["ranks_seen"] == [0] and out[0]["records_ok"] is True
     assert out[0]["collective"] == {"process_group": True, "backend": "gloo"}
+
+
+def test_rank_order_largest_first_and_records_by_pair_id():
+    """run_pairs aligns a rank's pairs in order of decreasing predicted cost (the workspace then grows once), records come back by pair id."""
+    from lgr_amd import distributed
+    sizes = [3, 9, 1, 7, 5, 8, 2]
+    costs = [distributed.pair_cost(1000 * n, 1000 * n) for n in sizes]
+    assert distributed.rank_order(len(sizes), 1, 0, "lpt", costs) == [1, 5, 3, 4, 0, 6, 2]
+    assert distributed.rank_order(len(sizes), 1, 0) == list(range(len(sizes)))
+    seen = []
+
+    def fake(p):
+        seen.append(p)
+        return distributed.pack_record(p, np.eye(4, dtype=np.float32).T.reshape(16), 1, 10 * p, p, 0.0, 0.0)
+    out = distributed.run_pairs(len(sizes), 1, 0, fake, policy="lpt", costs=costs)
+    assert seen == [1, 5, 3, 4, 0, 6, 2]
+    assert [distributed.unpack_record(r)["pair_id"] for r in out] == list(range(len(sizes)))
+    for w in (2, 3):   # the ranks' orders partition the pairs
+        allp = sorted(p for r in range(w) for p in distributed.rank_order(len(sizes), w, r, "lpt", costs))
+        assert allp == list(range(len(sizes)))
