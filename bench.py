@@ -146,6 +146,9 @@ def dry_run(args, world, rank):
         raise SystemExit(3)
 
 
+SEED_SPREAD = (566, 567, 568, 569, 570, 571)   # matcher_extremes.seed_spread: scenes of the bench pair's generator (synthetic.SEED first)
+
+
 def job_sizes(n_pairs, seed=566):
     """points per cloud of the job's pairs: log-uniform in [1e5, 1e6], multiples of 10 000, one draw per pair from default_rng(seed) -- the
     reference's data/tests.yaml lists 156 pairs of WHU-TLS / kizhi / arch / ... scans (clouds not shipped) that its loader voxel-filters
@@ -435,10 +438,20 @@ def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
     pf = features_of(pp)
     res["planar"] = timed(pf[0], pf[1])
     res["planar"]["scene"] = "%d rectangles (ground + 8 buildings), %.0f %% of the points on them, 15 %% clutter blobs, noise 5 mm" % (pp["n_planes"], 100 * pp["plane_frac"])
+    # the same generator with other seeds: how much of the headline is this one scene?  (Round 5: at 900 k points the match stage of seeds
+    # 566 .. 571 took 14.6 / 17.8 / 21.0 / 24.2 / 12.7 / 41.4 ms before pass 0 took every zero lower bound; the bench pair is seed 566.)
+    spread = []
+    for sd in SEED_SPREAD:
+        pr = synthetic.make_pair(int(src.shape[0]), seed=sd)
+        f2 = features_of(pr)
+        t = timed(f2[0], f2[1])
+        spread.append({"seed": sd, "match_stage_ms": t["match_stage_ms"], "match_mfma_ms": t["match_mfma_ms"], "executed_tile_fraction": t["executed_tile_fraction"]})
+        del f2, pr
+    res["seed_spread"] = spread
     res["note"] = ("matcher stage alone (lgr_match_bf2_dev, both directions), second of two runs; this_pair = the bench pair's FPFH rows on the production "
                    "schedule, dense = the same rows with prune = 0, structureless = uniform random 11-bin blocks normalised to 100 on the production schedule "
                    "(lgr_match_options.auto_dense: >= 90 % zero lower bounds -> pass 0 computes everything), structureless_dense = the same random rows with "
-                   "prune = 0, planar = FPFH rows of a planar-dominated pair on the production schedule; irregular_rows = rows per side off the block-sum consensus "
+                   "prune = 0, planar = FPFH rows of a planar-dominated pair on the production schedule; seed_spread = the bench pair's generator with other seeds (the bench pair is the first); irregular_rows = rows per side off the block-sum consensus "
                    "(all-zero FPFH rows of isolated points) that took the exact side scan instead of costing the pair the rotated format")
     return res
 

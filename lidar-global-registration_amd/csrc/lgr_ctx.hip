@@ -60,7 +60,9 @@ int lgr_ws(lgr_ctx* ctx, int slot, size_t bytes, void** out) {
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (b.p) LGR_HIP(ctx, hipFree(b.p));
         b.p = nullptr; b.cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
+        // slack: a half for buffers under 256 MB, a quarter above (a job of pairs of different sizes -- bench.py --job -- re-allocates whenever a pair
+        // needs more than any before it, and a hipFree + hipMalloc of the large buffers costs tens of milliseconds)
+        size_t want = bytes + (bytes < ((size_t) 256 << 20) ? bytes / 2 : bytes / 4) + 256;
         want = (want + 255) & ~(size_t) 255;
         hipError_t e = hipMalloc(&b.p, want);
         if (e != hipSuccess) {
