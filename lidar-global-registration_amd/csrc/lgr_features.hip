@@ -210,11 +210,9 @@ __device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, f
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f dot3e2(v2f ax, v2f ay, v2f az, v2f bx, v2f by, v2f bz) { return (ax * bx + az * bz) + ay * by; }
-__device__ __forceinline__ v2f sel2(bool c0, bool c1, v2f a, v2f b) { return v2f{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
 
 // ---- the three bin indices of a pair through a FILTER with a proven decision band (round 4) ----
-// pcl::computePairFeatures is used here for three INTEGERS only (the bins of f1, f2, f3).  pair_bins_fast2 evaluates the same formulas
+// pcl::computePairFeatures is used here for three INTEGERS only (the bins of f1, f2, f3).  pair_bins_fast evaluates the same formulas
 // with the hardware's approximate reciprocal / reciprocal square root (v_rcp_f32, v_rsq_f32: 1 ulp) instead of two IEEE square roots and
 // seven IEEE divisions, and the bin arithmetic in float instead of double; every operation that is NOT a division or a square root is
 // the very instruction of the canonical sequence (same operands as long as the swap decision is the same), so the two evaluations
@@ -261,49 +259,44 @@ __device__ __forceinline__ bool bin_decided(float t, float margin, int& b) {
     b = (int) fminf(fmaxf(fl, 0.0f), 10.0f);
     return fr > margin && fr < 1.0f - margin;       // (NaN: false)
 }
-// two pairs per lane, like pair_features2.  dec0 / dec1: the pair's three bins were decided (b?_ valid); otherwise the caller runs the
-// canonical evaluation for it.
-__device__ __forceinline__ void pair_bins_fast2(v2f p1x, v2f p1y, v2f p1z, v2f n1x, v2f n1y, v2f n1z, v2f p2x, v2f p2y, v2f p2z, v2f n2x, v2f n2y, v2f n2z,
-                                                int (&b0)[3], int (&b1)[3], bool& dec0, bool& dec1) {
+// One pair per lane (round 5; two per lane on packed operations before: 2 x 16 more operand registers for v_pk_* instructions that issue in the
+// time of two scalar ones).  dec0: the pair's three bins were decided (b0 valid); otherwise the caller runs the canonical evaluation for it.
+__device__ __forceinline__ void pair_bins_fast(float p1x, float p1y, float p1z, float n1x, float n1y, float n1z, float p2x, float p2y, float p2z, float n2x, float n2y, float n2z,
+                                               int (&b0)[3], bool& dec0) {
     constexpr float DA = 1e-6f;
-    v2f dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
-    const v2f f4s = dot3e2(dx, dy, dz, dx, dy, dz);
-    const v2f rs = v2f{__builtin_amdgcn_rsqf(f4s.x), __builtin_amdgcn_rsqf(f4s.y)};
-    const v2f angle1 = dot3e2(n1x, n1y, n1z, dx, dy, dz) * rs;
-    const v2f angle2 = dot3e2(n2x, n2y, n2z, dx, dy, dz) * rs;
-    const v2f a1 = v2f{fabsf(angle1.x), fabsf(angle1.y)}, a2 = v2f{fabsf(angle2.x), fabsf(angle2.y)};
+    float dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    const float f4s = dot3e(dx, dy, dz, dx, dy, dz);
+    const float rs = __builtin_amdgcn_rsqf(f4s);
+    const float angle1 = dot3e(n1x, n1y, n1z, dx, dy, dz) * rs;
+    const float angle2 = dot3e(n2x, n2y, n2z, dx, dy, dz) * rs;
+    const float a1 = fabsf(angle1), a2 = fabsf(angle2);
     // swap <=> acosf(a1) > acosf(a2) (canonical = PCL); certain "no" when a1 > a2 + 2 DA, certain "yes" when a1 < a2 - 2 DA and a2 < 1 - DA
-    const bool s0 = a1.x < a2.x, s1 = a1.y < a2.y;
-    bool c0 = f4s.x > 1e-30f && (s0 ? (a2.x - a1.x > 2.0f * DA && a2.x < 1.0f - DA) : (a1.x - a2.x > 2.0f * DA));
-    bool c1 = f4s.y > 1e-30f && (s1 ? (a2.y - a1.y > 2.0f * DA && a2.y < 1.0f - DA) : (a1.y - a2.y > 2.0f * DA));
-    const v2f ux = sel2(s0, s1, n2x, n1x), uy = sel2(s0, s1, n2y, n1y), uz = sel2(s0, s1, n2z, n1z);
-    const v2f mx = sel2(s0, s1, n1x, n2x), my = sel2(s0, s1, n1y, n2y), mz = sel2(s0, s1, n1z, n2z);
-    dx = sel2(s0, s1, -dx, dx); dy = sel2(s0, s1, -dy, dy); dz = sel2(s0, s1, -dz, dz);
-    const v2f f3 = sel2(s0, s1, -angle2, angle1);
-    v2f vx = dy * uz - dz * uy, vy = dz * ux - dx * uz, vz = dx * uy - dy * ux;
-    const v2f vn2 = dot3e2(vx, vy, vz, vx, vy, vz);
-    const v2f rv = v2f{__builtin_amdgcn_rsqf(vn2.x), __builtin_amdgcn_rsqf(vn2.y)};
-    c0 = c0 && vn2.x > 1e-30f; c1 = c1 && vn2.y > 1e-30f;
+    const bool s0 = a1 < a2;
+    bool c0 = f4s > 1e-30f && (s0 ? (a2 - a1 > 2.0f * DA && a2 < 1.0f - DA) : (a1 - a2 > 2.0f * DA));
+    const float ux = s0 ? n2x : n1x, uy = s0 ? n2y : n1y, uz = s0 ? n2z : n1z;
+    const float mx = s0 ? n1x : n2x, my = s0 ? n1y : n2y, mz = s0 ? n1z : n2z;
+    dx = s0 ? -dx : dx; dy = s0 ? -dy : dy; dz = s0 ? -dz : dz;
+    const float f3 = s0 ? -angle2 : angle1;
+    float vx = dy * uz - dz * uy, vy = dz * ux - dx * uz, vz = dx * uy - dy * ux;
+    const float vn2 = dot3e(vx, vy, vz, vx, vy, vz);
+    const float rv = __builtin_amdgcn_rsqf(vn2);
+    c0 = c0 && vn2 > 1e-30f;
     vx = vx * rv; vy = vy * rv; vz = vz * rv;
-    const v2f wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
-    const v2f f2 = dot3e2(vx, vy, vz, mx, my, mz);
-    const v2f yy = dot3e2(wx, wy, wz, mx, my, mz), xx = dot3e2(ux, uy, uz, mx, my, mz);
-    const v2f rho2 = xx * xx + yy * yy;
-    const v2f f1 = v2f{lgr_atan2f_fast(yy.x, xx.x), lgr_atan2f_fast(yy.y, xx.y)};
-    const v2f irho = v2f{__builtin_amdgcn_rsqf(rho2.x), __builtin_amdgcn_rsqf(rho2.y)};
-    c0 = c0 && rho2.x > 1e-4f; c1 = c1 && rho2.y > 1e-4f;
+    const float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;
+    const float f2 = dot3e(vx, vy, vz, mx, my, mz);
+    const float yy = dot3e(wx, wy, wz, mx, my, mz), xx = dot3e(ux, uy, uz, mx, my, mz);
+    const float rho2 = xx * xx + yy * yy;
+    const float f1 = lgr_atan2f_fast(yy, xx);
+    const float irho = __builtin_amdgcn_rsqf(rho2);
+    c0 = c0 && rho2 > 1e-4f;
     // t = 11 (f1 + pi) / (2 pi_f): scale and offset of the canonical double expression, rounded to float once
     constexpr float S1 = (float) (11.0 * (double) (1.0f / (2.0f * 3.14159274101257324f)));
     constexpr float O1 = (float) (11.0 * 3.14159265358979323846 * (double) (1.0f / (2.0f * 3.14159274101257324f)));
-    const v2f t1 = v2f{__builtin_fmaf(f1.x, S1, O1), __builtin_fmaf(f1.y, S1, O1)};
-    const v2f t2 = v2f{__builtin_fmaf(f2.x, 5.5f, 5.5f), __builtin_fmaf(f2.y, 5.5f, 5.5f)};
-    const v2f t3 = v2f{__builtin_fmaf(f3.x, 5.5f, 5.5f), __builtin_fmaf(f3.y, 5.5f, 5.5f)};
-    const v2f m1 = v2f{__builtin_fmaf(irho.x, 1.751f * 5e-6f, 1.751f * 3e-6f + 2e-6f), __builtin_fmaf(irho.y, 1.751f * 5e-6f, 1.751f * 3e-6f + 2e-6f)};
+    const float t1 = __builtin_fmaf(f1, S1, O1), t2 = __builtin_fmaf(f2, 5.5f, 5.5f), t3 = __builtin_fmaf(f3, 5.5f, 5.5f);
+    const float m1 = __builtin_fmaf(irho, 1.751f * 5e-6f, 1.751f * 3e-6f + 2e-6f);
     constexpr float M2 = 5.5f * 3e-6f + 1e-6f, M3 = 5.5f * DA + 1e-6f;
-    const bool d01 = bin_decided(t1.x, m1.x, b0[0]), d02 = bin_decided(t2.x, M2, b0[1]), d03 = bin_decided(t3.x, M3, b0[2]);
-    const bool d11 = bin_decided(t1.y, m1.y, b1[0]), d12 = bin_decided(t2.y, M2, b1[1]), d13 = bin_decided(t3.y, M3, b1[2]);
+    const bool d01 = bin_decided(t1, m1, b0[0]), d02 = bin_decided(t2, M2, b0[1]), d03 = bin_decided(t3, M3, b0[2]);
     dec0 = d01 && d02 && d03 && c0;
-    dec1 = d11 && d12 && d13 && c1;
 }
 
 __device__ __forceinline__ int bin11(double t) {
@@ -339,10 +332,14 @@ constexpr int ST = 16;          // surface points per wave
 constexpr int SQ = 256;         // pair queue entries: (tile point << 8) | candidate slot
 constexpr int SHP = 33;         // histogram pitch (lanes of one tile point hit bins = banks; the pad of rounds 1-4 bought nothing)
 
+// Five waves per SIMD, as a MINIMUM, and one pair per lane (round 5): with two pairs per lane the allocator took 113 VGPRs and four waves; one pair
+// needs 97, held to 96 it spills nothing, and the FPFH stage alone goes 2.89 -> 2.72 ms per cloud (40 % of the wave cycles were parked behind
+// LDS / memory waits at four waves).  Two pairs per lane held to 96 VGPRs: 2.75 ms with 14 spilled registers; six waves need 80 VGPRs (60 B of
+// scratch) and more LDS than a CU has for 24 of these workgroups.
 #ifndef LGR_SPFH_WAVES
-#define LGR_SPFH_WAVES 4
+#define LGR_SPFH_WAVES 5
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, LGR_SPFH_WAVES))) void spfh_tile_kernel(GridDev g, float r2, const int* __restrict__ order, float* __restrict__ spfh /* [n][HP], sorted positions */) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LGR_SPFH_WAVES, LGR_SPFH_WAVES))) void spfh_tile_kernel(GridDev g, float r2, const int* __restrict__ order, float* __restrict__ spfh /* [n][HP], sorted positions */) {
     __shared__ float4 tp[ST], tn[ST];
     __shared__ float4 cp[64], cn[64];     // live candidates: tested when 64 are buffered (round 5: a chunk's overflow waits in registers, not in a second half of the buffer)
     __shared__ unsigned short queue[SQ];
@@ -373,57 +370,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, LGR_SPFH_
     const double MPI = 3.14159265358979323846;
     int qh = 0, qt = 0;
     // (always_inline: left to its heuristics hipcc turns a lambda of this size into a CALL, with the captures in scratch memory)
-    auto process = [&](int nb) __attribute__((always_inline)) {   // the first nb (<= 128) queued pairs, two per lane: entries l and 64 + l
-        const bool h0 = l < nb, h1 = 64 + l < nb;
-        if (h0) {   // (every lane with a second pair also has a first one)
-            const unsigned e0 = queue[(qh + l) & (SQ - 1)], e1 = h1 ? queue[(qh + 64 + l) & (SQ - 1)] : e0;
-            const int i0 = (int) (e0 >> 8), i1 = (int) (e1 >> 8);
+    auto process = [&](int nb) __attribute__((always_inline)) {   // the first nb (<= 64) queued pairs, one per lane
+        if (l < nb) {
+            const unsigned e0 = queue[(qh + l) & (SQ - 1)];
+            const int i0 = (int) (e0 >> 8);
             const float4 P0 = tp[i0], N0 = tn[i0], Q0 = cp[e0 & 255u], M0 = cn[e0 & 255u];
-            const float4 P1 = tp[i1], N1 = tn[i1], Q1 = cp[e1 & 255u], M1 = cn[e1 & 255u];
-            // the bins through the filter (pair_bins_fast2); the few pairs it does not decide go through the canonical sequence
-            int ba[3], bb[3];
-            bool dec0, dec1, ok0 = true, ok1 = true;
-            pair_bins_fast2(v2f{P0.x, P1.x}, v2f{P0.y, P1.y}, v2f{P0.z, P1.z}, v2f{N0.x, N1.x}, v2f{N0.y, N1.y}, v2f{N0.z, N1.z},
-                            v2f{Q0.x, Q1.x}, v2f{Q0.y, Q1.y}, v2f{Q0.z, Q1.z}, v2f{M0.x, M1.x}, v2f{M0.y, M1.y}, v2f{M0.z, M1.z}, ba, bb, dec0, dec1);
+            // the bins through the filter (pair_bins_fast); the few pairs it does not decide go through the canonical sequence
+            int ba[3];
+            bool dec0, ok0 = true;
+            pair_bins_fast(P0.x, P0.y, P0.z, N0.x, N0.y, N0.z, Q0.x, Q0.y, Q0.z, M0.x, M0.y, M0.z, ba, dec0);
 #ifdef LGR_SPFH_CHECK
-            const bool fdec0 = dec0, fdec1 = dec1 && h1;
-            const int fa0 = ba[0], fa1 = ba[1], fa2 = ba[2], fb0 = bb[0], fb1 = bb[1], fb2 = bb[2];
-            dec0 = dec1 = false;   // evaluate the canonical sequence for EVERY pair and compare
+            const bool fdec0 = dec0;
+            const int fa0 = ba[0], fa1 = ba[1], fa2 = ba[2];
+            dec0 = false;   // evaluate the canonical sequence for EVERY pair and compare
 #endif
-            if (!dec0 || (h1 && !dec1)) {
-                // the canonical sequence, ONE pair at a time in a loop that is not unrolled: it runs for 2e-4 of the pairs, and as a two-pair
-                // evaluation it set the kernel's register count (109 VGPRs, four waves per SIMD)
-#pragma unroll 1
-                for (int hh = 0; hh < 2; ++hh) {
-                    if (hh == 0 ? dec0 : (dec1 || !h1)) continue;
-                    // (operands re-read from LDS: the fast path's 32 operand registers are dead here, the slow sequence -- two acosf, an atan2f -- reuses them)
-                    const int ii = hh ? i1 : i0, cc = (int) ((hh ? e1 : e0) & 255u);
-                    const float Px = tp[ii].x, Py = tp[ii].y, Pz = tp[ii].z, Nx = tn[ii].x, Ny = tn[ii].y, Nz = tn[ii].z;
-                    const float Qx = cp[cc].x, Qy = cp[cc].y, Qz = cp[cc].z, Mx = cn[cc].x, My = cn[cc].y, Mz = cn[cc].z;
-                    float f1, f2, f3;
-                    const bool e = pair_features(Px, Py, Pz, Nx, Ny, Nz, Qx, Qy, Qz, Mx, My, Mz, f1, f2, f3);
-                    const int c0 = bin11(((double) f1 + MPI) * (double) d_pi), c1 = bin11(((double) f2 + 1.0) * 0.5), c2 = bin11(((double) f3 + 1.0) * 0.5);
-                    if (hh) { ok1 = e; bb[0] = c0; bb[1] = c1; bb[2] = c2; }
-                    else { ok0 = e; ba[0] = c0; ba[1] = c1; ba[2] = c2; }
-                }
+            if (!dec0) {
+                // the canonical sequence (two acosf, an atan2f: lgr_libm.cuh) for 2e-4 of the pairs; operands re-read from LDS, the fast path's registers are dead here
+                const int cc = (int) (e0 & 255u);
+                const float Px = tp[i0].x, Py = tp[i0].y, Pz = tp[i0].z, Nx = tn[i0].x, Ny = tn[i0].y, Nz = tn[i0].z;
+                const float Qx = cp[cc].x, Qy = cp[cc].y, Qz = cp[cc].z, Mx = cn[cc].x, My = cn[cc].y, Mz = cn[cc].z;
+                float f1, f2, f3;
+                ok0 = pair_features(Px, Py, Pz, Nx, Ny, Nz, Qx, Qy, Qz, Mx, My, Mz, f1, f2, f3);
+                ba[0] = bin11(((double) f1 + MPI) * (double) d_pi); ba[1] = bin11(((double) f2 + 1.0) * 0.5); ba[2] = bin11(((double) f3 + 1.0) * 0.5);
             }
 #ifdef LGR_SPFH_CHECK
             {
                 const bool bad0 = fdec0 && (!ok0 || fa0 != ba[0] || fa1 != ba[1] || fa2 != ba[2]);
-                const bool bad1 = fdec1 && (!ok1 || fb0 != bb[0] || fb1 != bb[1] || fb2 != bb[2]);
-                const unsigned long long n_pairs = __popcll(__ballot(true)) + __popcll(__ballot(h1));
-                const unsigned long long n_und = __popcll(__ballot(!fdec0)) + __popcll(__ballot(h1 && !fdec1));
-                const unsigned long long n_bad = __popcll(__ballot(bad0)) + __popcll(__ballot(bad1));
+                const unsigned long long n_pairs = __popcll(__ballot(true));
+                const unsigned long long n_und = __popcll(__ballot(!fdec0));
+                const unsigned long long n_bad = __popcll(__ballot(bad0));
                 if (l == 0) { atomicAdd(&g_spfh_check[0], n_pairs); atomicAdd(&g_spfh_check[1], n_und); if (n_bad) atomicAdd(&g_spfh_check[2], n_bad); }
             }
 #endif
             if (ok0) {
                 int* h = &hist[l & 1][i0][0];
                 atomicAdd(h + ba[0], 1); atomicAdd(h + 11 + ba[1], 1); atomicAdd(h + 22 + ba[2], 1);
-            }
-            if (h1 && ok1) {
-                int* h = &hist[l & 1][i1][0];
-                atomicAdd(h + bb[0], 1); atomicAdd(h + 11 + bb[1], 1); atomicAdd(h + 22 + bb[2], 1);
             }
         }
         qh += nb;
@@ -464,13 +445,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, LGR_SPFH_
                     queue[(qt + rank) & (SQ - 1)] = (unsigned short) ((i << 8) | l);
                 }
                 qt += __popcll(em);
-                if (qt - qh >= 128) {
+                if (qt - qh >= 64) {
                     __syncthreads();
-                    process(128);
+                    process(64);
                 }
             }
             __syncthreads();
-            process(qt - qh);
+            while (qt - qh > 0) process(min(qt - qh, 64));
             __syncthreads();
         };
         for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dz - 1); ++zz)
