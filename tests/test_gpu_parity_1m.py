@@ -271,3 +271,44 @@ def test_match_1m_pcl_arithmetic_rows_through_the_existing_matcher(lgr, pcl_feat
         valid = oi >= 0
         np.testing.assert_array_equal(gi[sel], oi)
         np.testing.assert_array_equal(bits(gd[sel])[valid], bits(od)[valid])
+
+
+def test_match_1m_planar_scene_irregular_rows_vs_oracle(lgr, oracle):
+    """Round 5: the planar-dominated 1M pair (85 % of the points on 41 rectangles; the shape of the reference's TLS configs, data/tests.yaml).
+    Its FPFH rows hold all-zero rows of isolated points, which take the matcher's exact side scan instead of costing the pair the rotated
+    operand format (lgr_match_options.irregular_rows).  EVERY irregular row of both sides and 2048 sampled regular queries per direction
+    against the oracle's exhaustive scan over all 1M train rows -- index and distance bits; the lane switched off gives the same tables."""
+    import torch
+    from lgr_amd import synthetic
+    pair = synthetic.make_planar_pair(1_000_000, seed=566)
+    feats = []
+    for side in ("src", "tgt"):
+        cloud = torch.from_numpy(pair[side]).cuda()
+        surf = lgr.downsample(cloud, VOXEL).clone()
+        feats.append(lgr.fpfh(cloud, lgr.normals_knn(surf.clone(), 30, vp=pair["vp_" + side]), float(R)))
+    lgr.sync()
+    on = [x.cpu().numpy() for x in lgr.match_bf2(feats[0], feats[1], BLOCK)]
+    lgr.sync()
+    n_a, n_b, gave_up = lgr.match_irregular()
+    assert gave_up == 0 and n_a > 0 and n_b > 0, (n_a, n_b, gave_up)
+    assert lgr.match_format() == "f16r"
+    h = [f.cpu().numpy() for f in feats]
+    rng = np.random.default_rng(5)
+    for q, t, gi, gd, n_irr in ((h[0], h[1], on[0], on[1], n_a), (h[1], h[0], on[2], on[3], n_b)):
+        fin = np.isfinite(q).all(1)
+        irregular = np.flatnonzero(fin & (np.abs(q.reshape(-1, 3, 11).astype(np.float64).sum(2) - 100.0) > 1e-3).any(1))
+        assert len(irregular) == n_irr
+        sel = np.unique(np.concatenate([irregular, rng.choice(q.shape[0], 2048, replace=False)])).astype(np.int32)
+        oi, od = oracle.match_bf_subset(q, sel, t, BLOCK)
+        ok = oi >= 0
+        assert int((gi[sel] != oi).sum()) == 0
+        assert int((bits(gd[sel])[ok] != bits(od)[ok]).sum()) == 0
+    lgr.set_match_options(irregular_rows=0)
+    try:
+        off = [x.cpu().numpy() for x in lgr.match_bf2(feats[0], feats[1], BLOCK)]
+        lgr.sync()
+        assert lgr.match_format() == "f16" and lgr.match_irregular() == (0, 0, 0)
+    finally:
+        lgr.set_match_options()
+    for a, b in zip(on, off):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
