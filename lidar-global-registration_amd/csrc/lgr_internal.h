@@ -251,7 +251,10 @@ int lgr_plane_setup(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt
 // Gate (RANSAC batches): best_prev = best metric of the earlier batches, record_prev = their record inlier count (INT_MAX when the plane
 // counts are not the records), d_factor (optional) = per-hypothesis factor of the metric (combination: the correspondence metric);
 // a hypothesis whose upper bounds fall below both is abandoned -- it can be neither the best nor a record.  0 / INT_MAX / NULL: no gate.
+// dyn (the device-driven RANSAC schedule, round 5): the number of hypotheses, the counter base and the gate's two values are READ ON THE DEVICE from
+// these words when the launch runs (nh is then only an upper bound for the grid); a null member keeps the host's value.
+struct lgr_plane_dyn { const int* nh; const int* counter_base; const float* best_prev; const int* record_prev; };
 int lgr_plane_eval(lgr_ctx* ctx, const lgr_plane_dev& pd, const float* d_Ts, const int* d_list, int nh, unsigned counter_base, int score_id,
                    int* d_cnt, float* d_metric, float* d_rmse, int2* d_pairs, int* d_n_pairs, float best_prev = 0.f, int record_prev = 0x7fffffff,
-                   const float* d_factor = nullptr);
+                   const float* d_factor = nullptr, const lgr_plane_dyn* dyn = nullptr);
 

@@ -31,7 +31,12 @@ __global__ __launch_bounds__(PB) void plane_kernel(GridDev g, const float* __res
                                                    unsigned counter_base, int score_id, unsigned* __restrict__ visited_all,
                                                    int* __restrict__ claimed_all, int* __restrict__ cnt_out, float* __restrict__ metric_out,
                                                    float* __restrict__ rmse_out, int2* __restrict__ pairs_out, int* __restrict__ n_pairs,
-                                                   float best_prev, int record_prev, const float* __restrict__ factor) {
+                                                   float best_prev, int record_prev, const float* __restrict__ factor, lgr_plane_dyn dyn) {
+    // (device-driven schedule: extents and gate values are the loop's state at the time this launch runs)
+    if (dyn.nh) nh = min(nh, *dyn.nh);
+    if (dyn.counter_base) counter_base = (unsigned) *dyn.counter_base;
+    if (dyn.best_prev) best_prev = *dyn.best_prev;
+    if (dyn.record_prev) record_prev = *dyn.record_prev;
     __shared__ long long s_sc[PB / 64], s_sq[PB / 64];
     __shared__ int s_cnt[PB / 64];
     __shared__ long long g_sc[2][PB / 64];
@@ -197,12 +202,14 @@ int lgr_plane_setup(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt
 }
 
 int lgr_plane_eval(lgr_ctx* ctx, const lgr_plane_dev& pd, const float* d_Ts, const int* d_list, int nh, unsigned counter_base, int score_id,
-                   int* d_cnt, float* d_metric, float* d_rmse, int2* d_pairs, int* d_n_pairs, float best_prev, int record_prev, const float* d_factor) {
+                   int* d_cnt, float* d_metric, float* d_rmse, int2* d_pairs, int* d_n_pairs, float best_prev, int record_prev, const float* d_factor,
+                   const lgr_plane_dyn* dyn) {
     if (nh <= 0) return LGR_OK;
     if (d_pairs) LGR_HIP(ctx, hipMemsetAsync(d_n_pairs, 0, 4, ctx->stream));
     int grid = std::min(nh, pd.n_wg);
+    const lgr_plane_dyn none{nullptr, nullptr, nullptr, nullptr};
     plane_kernel<<<grid, PB, 0, ctx->stream>>>(pd.g, pd.d_src, pd.ns, pd.n_sp, pd.thr, pd.r2, pd.seed, d_Ts, d_list, nh, counter_base, score_id,
-                                               pd.visited, pd.claimed, d_cnt, d_metric, d_rmse, d_pairs, d_n_pairs, best_prev, record_prev, d_factor);
+                                               pd.visited, pd.claimed, d_cnt, d_metric, d_rmse, d_pairs, d_n_pairs, best_prev, record_prev, d_factor, dyn ? *dyn : none);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }

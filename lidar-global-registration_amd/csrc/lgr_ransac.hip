@@ -772,6 +772,7 @@ struct RState {
     float Tn[16];
     float e_metric; int e_ninl; float e_rmse; int pad1;       // evaluation of best_T (the final block, :265-296)
     float e2_metric; int e2_ninl; float e2_rmse; int pad2;    // evaluation of the refit
+    int int_max, pad3[3];                                      // (a constant the plane gate reads where the records are not plane counts)
 };
 
 __device__ inline int est_from_support_dev(int count, int c, float confidence, int nr_samples) {   // = est_from_support below
@@ -928,6 +929,21 @@ __global__ __launch_bounds__(1024) void rs_replay_kernel(RState* __restrict__ S,
         for (int i = 0; i < 16; ++i) S->best_T[i] = Ts[(size_t) best_off * 16 + i];
     S->done = done; S->bound = bound; S->largest = largest; S->num_rejections = num_rej; S->best_iter = best_iter; S->final_metric = final_metric;
     if (done >= bound || done >= max_it) S->stop = 1;
+}
+// closest-plane / combination metrics inside the device-driven schedule (round 5): run_batch's plumbing kernels with their extents read from the
+// RState (fixed grids striding over them)
+__global__ void rs_plane_counts_kernel(const RState* __restrict__ S, const int* __restrict__ cnt, int2* __restrict__ counts) {
+    const int n = S->n_ok;
+    for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) counts[h].x = cnt[h];
+}
+__global__ void rs_plane_pick_kernel(const RState* __restrict__ S, const int* __restrict__ hpos, const int* __restrict__ cnt, const float* __restrict__ cp,
+                                     float* __restrict__ metric, int* __restrict__ ninl) {
+    const int n = S->n_cand;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) { metric[j] = cp[hpos[j]]; ninl[j] = cnt[hpos[j]]; }
+}
+__global__ void rs_plane_mul_kernel(const RState* __restrict__ S, float* __restrict__ metric, const float* __restrict__ cp) {
+    const int n = S->n_cand;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) metric[j] = metric[j] * cp[j];   // metric_cs * metric_cp (src/metric.cpp:248)
 }
 // the evaluation record of a single transform (metric, inliers, rmse as metric_kernel left them) into the RState
 __global__ void rs_store_eval_kernel(const float* __restrict__ ev /* metric, n_inl bits, rmse */, float* __restrict__ dst3) {
@@ -1322,8 +1338,12 @@ static int refit_launch_dev(lgr_ctx* ctx, const Packed& pk, int c, const uint8_t
 // The device-driven schedule (uniformity / correspondences metrics): see RState.  ONE host synchronisation per pair of rounds -- one per
 // alignment whenever the loop ends within two rounds, i.e. for every max_iterations up to 17 batches and whenever a record inlier set
 // brings the bound below that.
+// plane != nullptr (closest_plane / combination, round 5): the same rounds with the plane evaluation in them; the loop only -- the final block
+// (plane pairs sorted by source index for the refit) stays with the caller, which finds the loop's state in *state_out and the best transform
+// on the device at *d_best_out.  initial_metric: the guess's metric (the caller evaluated it), or 0.
 static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const lgr_corr* d_corr, int c, const Packed& pk, const lgr_params* p,
-                                  uint64_t seed, int max_iterations, int batch, uint8_t* d_mask, lgr_result* res) {
+                                  uint64_t seed, int max_iterations, int batch, uint8_t* d_mask, lgr_result* res, const lgr_plane_dev* plane = nullptr,
+                                  float initial_metric = 0.f, RState* state_out = nullptr, float** d_best_out = nullptr) {
     LGR_HIP(ctx, hipFuncSetAttribute((const void*) metric_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
     const int nb_max = (int) std::min<long long>((long long) batch * MAX_ROUND_BATCHES, std::max(max_iterations, 1));
     BatchBuffers b;
@@ -1338,9 +1358,10 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
     memset(hS, 0, sizeof(RState));
     hS->bound = max_iterations; hS->max_iterations = max_iterations; hS->batch = batch; hS->round_cap = MAX_ROUND_BATCHES;
     hS->best_iter = -1; hS->metric_id = p->metric_id; hS->c = c; hS->nr_samples = p->n_samples; hS->confidence = p->confidence;
+    hS->int_max = INT_MAX; hS->final_metric = initial_metric;
     for (int i = 0; i < 16; ++i) hS->best_T[i] = p->has_guess ? p->guess[i] : ((i % 5 == 0) ? 1.f : 0.f);
     LGR_HIP(ctx, hipMemcpyAsync(dS, hS, sizeof(RState), hipMemcpyHostToDevice, ctx->stream));
-    if (p->has_guess) {
+    if (p->has_guess && !plane) {
         // src/sac_prerejective_omp.cpp:134-147: the guess is the hypothesis to beat (final_tn / final_metric)
         uint8_t* d_gm;
         LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASK, (size_t) c + 16, &d_gm));
@@ -1356,6 +1377,15 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
         mask_cap = (int) std::min<size_t>((size_t) nb_max, ((size_t) 2 << 30) / (words * 4));
         if (mask_cap > 0) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASKT, words * (size_t) mask_cap, &maskT));
     }
+    // plane metrics: the plane test's inlier count and metric per evaluated hypothesis (closest_plane: every survivor, indexed like the
+    // survivors' list; combination: every candidate)
+    int* pl_cnt = nullptr;
+    float* pl_cp = nullptr;
+    if (plane) {
+        LGR_TRY(lgr_ws_t(ctx, WS_PLANE_OUT, (size_t) 2 * nb_max + 16, &pl_cnt));
+        pl_cp = (float*) (pl_cnt + nb_max);
+    }
+    const bool closest = plane && p->metric_id == LGR_METRIC_CLOSEST_PLANE;
     const bool need_list = p->metric_id != LGR_METRIC_UNIFORMITY;
     const int g_metric = std::max(1, ctx->n_cu), g_count = 128 * std::max(1, ctx->n_cu);   // one 120 KB workgroup per CU; four times the resident single-wave workgroups (the tail evens out)
     float2* scratch = nullptr;
@@ -1366,7 +1396,22 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
         rs_begin_kernel<<<1, 64, 0, ctx->stream>>>(dS, b.st, first ? 1 : 0);
         rs_hyp_kernel<<<cdiv(nb_up, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, dS, p->edge_thr_coef, b.Ts, b.list, posmap, b.counts);
         count_list_kernel<<<g_count, CB, 0, ctx->stream>>>(b.Ts, b.list, &dS->n_ok, pk.PP, pk.pstats, c, b.counts, maskT, mask_cap);
+        if (closest) {
+            // every survivor on its sparse subset; its plane inliers are "the inliers" (gate: the loop's best metric and record so far)
+            const lgr_plane_dyn dyn{&dS->n_ok, &dS->round_first, &dS->final_metric, &dS->largest};
+            LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list, nb_up, 0u, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr, 0.f, 0, nullptr, &dyn));
+            rs_plane_counts_kernel<<<64, 256, 0, ctx->stream>>>(dS, pl_cnt, b.counts);
+        }
         rs_cand_kernel<<<64, 1024, 0, ctx->stream>>>(dS, b.counts, b.list, b.list2, b.hpos);
+        if (closest) {
+            rs_plane_pick_kernel<<<64, 256, 0, ctx->stream>>>(dS, b.hpos, pl_cnt, pl_cp, b.metric, b.ninl);
+        } else if (plane) {   // combination: correspondences metric with the constant score (include/metric.h:191-192) x plane metric of the candidates
+            metric_kernel<<<g_metric, MB, metric_smem(), ctx->stream>>>(b.Ts, b.list2, 0, pk.P0, pk.P1, pk.sstar, c, LGR_METRIC_CORRESPONDENCES, LGR_SCORE_CONSTANT, b.metric, b.ninl,
+                                                                        nullptr, nullptr, scratch, nullptr, b.hpos, 0, nullptr, &dS->n_cand, &dS->n_ok);
+            const lgr_plane_dyn dyn{&dS->n_cand, &dS->round_first, &dS->final_metric, &dS->int_max};   // (records are correspondence counts here: only the metric gates)
+            LGR_TRY(lgr_plane_eval(ctx, *plane, b.Ts, b.list2, nb_up, 0u, p->score_id, pl_cnt, pl_cp, nullptr, nullptr, nullptr, 0.f, 0x7fffffff, b.metric, &dyn));
+            rs_plane_mul_kernel<<<64, 256, 0, ctx->stream>>>(dS, b.metric, pl_cp);
+        } else
         metric_kernel<<<g_metric, MB, metric_smem(), ctx->stream>>>(b.Ts, b.list2, 0, pk.P0, pk.P1, pk.sstar, c, p->metric_id, p->score_id, b.metric, b.ninl,
                                                                     nullptr, nullptr, scratch, maskT, b.hpos, mask_cap, nullptr, &dS->n_cand, &dS->n_ok);
         rs_replay_kernel<<<1, 1024, 0, ctx->stream>>>(dS, b.list, b.list2, b.metric, b.ninl, b.counts, posmap, b.Ts, b.st);
@@ -1378,15 +1423,22 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
         LGR_TRY(enqueue_round(first));
         first = false;
         LGR_TRY(enqueue_round(false));
-        // :265-296 final re-estimation (enqueued blind: redone when the loop turns out not to have ended)
-        LGR_TRY(evaluate_one_dev(ctx, dS->best_T, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e_metric));
-        LGR_TRY(refit_launch_dev(ctx, pk, c, d_mask, dS->Tn));
-        LGR_TRY(evaluate_one_dev(ctx, dS->Tn, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e2_metric));
+        if (!plane) {
+            // :265-296 final re-estimation (enqueued blind: redone when the loop turns out not to have ended)
+            LGR_TRY(evaluate_one_dev(ctx, dS->best_T, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e_metric));
+            LGR_TRY(refit_launch_dev(ctx, pk, c, d_mask, dS->Tn));
+            LGR_TRY(evaluate_one_dev(ctx, dS->Tn, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e2_metric));
+        }
         LGR_HIP(ctx, hipMemcpyAsync(hS, dS, sizeof(RState), hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ransac_debug) fprintf(stderr, "[lgr] ransac (device schedule) after %d rounds: done %d bound %d largest %d best metric %.4f stop %d\n", hS->rounds, hS->done, hS->bound,
                                   hS->largest, hS->final_metric, hS->stop);
         if (hS->stop) break;
+    }
+    if (plane) {   // the caller's final block takes over
+        *state_out = *hS;
+        *d_best_out = dS->best_T;
+        return LGR_OK;
     }
     int e_ninl, e2_ninl;
     memcpy(&e_ninl, &hS->e_ninl, 4); memcpy(&e2_ninl, &hS->e2_ninl, 4);
@@ -1490,7 +1542,8 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     int bound = max_iterations, done = 0, largest = 0, num_rejections = 0, best_iter = -1;
     float final_metric = 0.f;
     float* d_best;   // device copy of the best transform so far
-    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 64, &d_best));
+    static_assert(sizeof(RState) + 256 <= 256 * sizeof(float), "the device schedule's state fits the slot as requested here (no re-allocation under d_best)");
+    LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MISC, 256, &d_best));
     {
         float I[16];
         for (int i = 0; i < 16; ++i) I[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -1519,78 +1572,18 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
         else LGR_TRY(evaluate_one(ctx, d_best, pk, c, p->metric_id, p->score_id, d_gm, &eg, false));
         final_metric = eg.metric;
     }
-    // Rounds.  The schedule is defined per batch (bound and best hypothesis are updated after every `batch` iterations).
-    // Only ~0.2 % of the samples survive the prerejection, so one batch is a few hundred hypotheses -- far too few to
-    // fill the chip, and every batch costs three host round trips.  Several batches are therefore evaluated by one round
-    // of launches with per-batch statistics, and the host replays the batches in order; batches beyond the point where
-    // the bound stops the loop are discarded, so results are those of the batch-by-batch schedule.  The first round is
-    // one batch (it usually brings the first bound and the candidate gate).
-    const int round_cap = plane_metric ? 1 : MAX_ROUND_BATCHES;   // the plane metrics key their subsets by batch: one at a time
-    BatchBuffers b;
-    LGR_TRY(batch_buffers(ctx, (int) std::min<long long>((long long) batch * round_cap, std::max(max_iterations, 1)), &b));
-    const bool ransac_debug = getenv("LGR_RANSAC_DEBUG") != nullptr;
-    bool first_round = true;
-    while (done < bound) {
-        long long want = (long long) std::min(bound, max_iterations) - done;
-        int n_batches = first_round ? 1 : (int) std::min<long long>(round_cap, (want + batch - 1) / batch);
-        first_round = false;
-        int nb = (int) std::min<long long>((long long) n_batches * batch, max_iterations - done);
-        n_batches = (nb + batch - 1) / batch;
-        int n_ok = 0, n_cand = 0;
-        // Candidate gate.  The reference scores every hypothesis with >= MIN_NR_INLIERS inliers and keeps the best metric
-        // (strict >).  A hypothesis with n inliers cannot reach the best metric m found so far when its metric's upper
-        // bound is below m: uniformity <= ln(n) / ln(10^4) (entropy of n points over 10^4 cells, src/analysis.cpp:95-130),
-        // correspondences <= n / C (scores <= 1, src/metric.cpp:55-81) -- such hypotheses are not scored (0.1 % slack for
-        // the float evaluation).  The record inlier set is unaffected: a new record has more inliers than the best
-        // hypothesis, which itself passes the gate -- and where the metric to beat is a guess's, the gate is capped at the record + 1.
-        int min_inliers = MIN_NR_INLIERS;
-        if (final_metric > 0.f && p->metric_id == LGR_METRIC_UNIFORMITY)
-            min_inliers = std::max(min_inliers, (int) std::floor(std::pow(10000.0, (double) final_metric / 1.001)) - 1);
-        else if (final_metric > 0.f && p->metric_id == LGR_METRIC_CORRESPONDENCES)
-            min_inliers = std::max(min_inliers, (int) std::floor((double) final_metric * (double) c / 1.001) - 1);
-        min_inliers = std::min(min_inliers, std::max(MIN_NR_INLIERS, largest + 1));   // never above the record so far + 1 (a guess sets the metric, not the record)
-        LGR_HIP(ctx, hipMemsetAsync(b.st, 0, sizeof(BatchStats) * n_batches, ctx->stream));
-        LGR_TRY(run_batch(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, done, nb, nullptr, b, &n_ok, &n_cand, plane_metric ? &plane : nullptr, min_inliers,
-                          final_metric, largest));
-        if (ransac_debug) fprintf(stderr, "[lgr] ransac round at %d: %d iterations (%d batches), %d pass the prerejection, %d scored (gate %d inliers), best metric %.4f, largest %d, bound %d\n",
-                                  done, nb, n_batches, n_ok, n_cand, min_inliers, final_metric, largest, bound);
-        BatchStats* hs;
-        LGR_TRY(lgr_pinned(ctx, sizeof(BatchStats) * MAX_ROUND_BATCHES, (void**) &hs));
-        if (n_ok > 0) {
-            if (n_cand > 0) reduce_kernel<<<cdiv(n_cand, 256), 256, 0, ctx->stream>>>(b.list2, n_cand, b.metric, b.ninl, batch, b.st);
-            support_kernel<<<cdiv(n_ok, 256), 256, 0, ctx->stream>>>(b.list, b.counts, n_ok, batch, b.st);
-            LGR_HIP(ctx, hipMemcpyAsync(hs, b.st, sizeof(BatchStats) * n_batches, hipMemcpyDeviceToHost, ctx->stream));
-            LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        } else {
-            memset(hs, 0, sizeof(BatchStats) * n_batches);
-        }
-        // replay the batches of this round in schedule order
-        const int round_first = done;
-        for (int j = 0; j < n_batches && done < bound; ++j) {
-            const BatchStats s = hs[j];
-            const int nbj = std::min(batch, max_iterations - done);
-            num_rejections += nbj - s.n_ok;
-            if (s.best_key) {
-                unsigned mb = (unsigned) (s.best_key >> 32);
-                float m;
-                memcpy(&m, &mb, 4);
-                int off = (int) (0xffffffffu - (unsigned) (s.best_key & 0xffffffffu));
-                if (final_metric < m) {   // src/sac_prerejective_omp.cpp:232-235 / :251-254
-                    final_metric = m; best_iter = round_first + off;
-                    LGR_HIP(ctx, hipMemcpyAsync(d_best, b.Ts + (size_t) off * 16, 64, hipMemcpyDeviceToDevice, ctx->stream));
-                }
-            }
-            if (s.rec_key) {
-                int rec_inl = (int) (s.rec_key >> 32);
-                if (rec_inl > largest) {   // :224-228
-                    largest = rec_inl;
-                    bound = std::min(bound, est_from_support(s.rec_support, c, p->confidence, p->n_samples));
-                }
-            }
-            done += nbj;
-            if (done >= max_iterations) break;
-        }
-        if (done >= max_iterations) break;
+    // The loop itself runs on the device-driven schedule (round 5; rounds 3-4 drove the plane metrics' batches from the host, one batch and three
+    // synchronisations at a time): a round evaluates up to MAX_ROUND_BATCHES batches -- the sparse subset of a hypothesis is keyed by its ITERATION
+    // (Philox counter = round_first + offset), so it does not matter which round or batch evaluates it; the gate uses the loop's state at the
+    // start of the round (a looser gate than batch by batch: it still only abandons what can be neither the best nor a record).
+    {
+        RState hs_end;
+        float* d_best_loop = nullptr;
+        LGR_TRY(ransac_device_schedule(ctx, d_src, d_tgt, d_corr, c, pk, p, seed, max_iterations, batch, nullptr, res, &plane, final_metric, &hs_end, &d_best_loop));
+        done = hs_end.done; bound = hs_end.bound; largest = hs_end.largest; num_rejections = hs_end.num_rejections; best_iter = hs_end.best_iter;
+        final_metric = hs_end.final_metric;
+        // (the schedule's RState shares WS_RANSAC_MISC with d_best: the best transform moves to the front, where the final block expects it)
+        LGR_HIP(ctx, hipMemcpyAsync(d_best, d_best_loop, 64, hipMemcpyDeviceToDevice, ctx->stream));
     }
     // :265-296 final re-estimation
     uint8_t* d_mask = d_final_mask;
