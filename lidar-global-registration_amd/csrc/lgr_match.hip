@@ -632,6 +632,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         ucol16 = (unsigned short*) (kb + (size_t) kept_cap * sizeof(uint2) + 256);
     }
     const unsigned long long* cur_pass_stages = nullptr;   // device: the stage count of the pass being launched (mask_kernel's statistics)
+    // final pass as sweep + listed tiles: the tables are initialised behind the sweep, for the (row block, leaf) pairs the list touches (touched_kernel)
+    std::function<int()> init_touched;   // set by the pass loop for the pass it applies to
     auto launch_mfma = [&](const unsigned* mask, CoarseArgs ca, bool allow_split = true) -> int {
         items_flag_kernel<<<cdiv(n_flags, 256), 256, 0, ctx->stream>>>(mask, n_rb, n_cc, item_rb, n_ir, ccx, iflags);
         size_t sb = 0;
@@ -660,6 +662,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             const int sweep_grid = 8 * (SW_OCC / 2) * std::max(1, ctx->n_cu / 8);
             match_sweep<<<sweep_grid, NTHR, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, c_scale, A.blkcl, ma_pad, mb_pad, rg_rows, mask, n_cc,
                                                               item_rb, ilist, xs_sweep, xcd_ctr, ca, ca.u_colv ? ucol16 : nullptr, kept, kept_count, kept_cap);
+            if (init_touched) LGR_TRY(init_touched());
             const int tiles_grid = 8 * std::max(1, ctx->n_cu);
             if (both) match_tiles<true><<<tiles_grid, 64 * TL_WAVES, 0, ctx->stream>>>((const f16x8*) Aop, (const f16x8*) Bop, bset_stride, out_scale, A.blkcl, ma_pad, mb_pad,
                                                                                        rg_rows, tile_group, rowmin, colmin, kept, kept_count, kept_cap);
@@ -724,6 +727,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         size_t poff = 0;
         auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
         const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
+        const size_t o_touched = pcarve((size_t) n_rb * n_leaves);   // (inside the range cleared below)
         const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_macc = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
         const size_t o_stats = pcarve(sizeof(MaskStats)), o_lbpart = pcarve((size_t) n_rb * sizeof(uint2));
         const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
@@ -737,6 +741,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
         uint8_t* sched = (uint8_t*) (pb + o_sched);
+        uint8_t* touched = (uint8_t*) (pb + o_touched);
+        const uint8_t* sched_final = sched;   // what the final pass left computed: its schedule, or -- sweep + listed tiles -- the pairs the list touched
         unsigned* mask = (unsigned*) (pb + o_mask);
         float* u_rb = (float*) (pb + o_urb);
         float* u_rt = (float*) (pb + o_urt);
@@ -781,10 +787,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
         LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, o_cr - o_done, ctx->stream));   // done, sched, masks, bounds, stats
         auto build_comp = [&]() {
-            comp_rows_kernel<<<cdiv((long long) n_rb * n_groups, 256), 256, 0, ctx->stream>>>(done, sched, group_leaf, n_rb, n_leaves, n_groups, comp_r);
-            if (both) comp_cols_kernel<<<cdiv((long long) n_leaves * n_rg, 256), 256, 0, ctx->stream>>>(done, sched, n_rb, n_leaves, n_rg, rg_rows / BLOCK_ROWS, comp_c);
+            comp_rows_kernel<<<cdiv((long long) n_rb * n_groups, 256), 256, 0, ctx->stream>>>(done, sched_final, group_leaf, n_rb, n_leaves, n_groups, comp_r);
+            if (both) comp_cols_kernel<<<cdiv((long long) n_leaves * n_rg, 256), 256, 0, ctx->stream>>>(done, sched_final, n_rb, n_leaves, n_rg, rg_rows / BLOCK_ROWS, comp_c);
         };
-        chk_done = done; chk_sched = sched; chk_lb = LBsq; chk_ustage = colstage ? u_stage : nullptr;
+        chk_done = done; chk_sched = sched;   // (chk_sched: re-pointed to the touched pairs below when the final pass defers its initialisation) chk_lb = LBsq; chk_ustage = colstage ? u_stage : nullptr;
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
         // ball bounds: on the matrix cores from the packed operands (f16 formats), with packed FMAs from the sorted rows otherwise
@@ -861,13 +867,27 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             }
             // the table initialisation of the pass needs the schedule only: on the third stream, beside mask_kernel (0.27 + 0.28 ms in a row
             // in front of pass 0, 0.30 + 0.37 between the passes); the MFMA launch waits for both
-            const bool init_aside = sB != ctx->stream;
+            // (the final pass as sweep + listed tiles: initialised behind the sweep, for the pairs its list touches -- touched_kernel)
+            const bool defer_init = pass == n_beta && pass > 0 && f16 && rot && coarse && kept != nullptr;
+            const bool init_aside = sB != ctx->stream && !defer_init;
             if (init_aside) {
                 LGR_HIP(ctx, hipEventRecord(ctx->ev[28], ctx->stream));
                 LGR_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev[28], 0));
             }
-            init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, init_aside ? sB : ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
-                                                                                                    (size_t) ma_pad, colmin, (size_t) mb_pad);
+            if (!defer_init) {
+                init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, init_aside ? sB : ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
+                                                                                                        (size_t) ma_pad, colmin, (size_t) mb_pad);
+                init_touched = nullptr;
+            } else {
+                sched_final = touched;
+                init_touched = [&, pass]() -> int {   // (called by launch_mfma between match_sweep and match_tiles, on the context's stream)
+                    LGR_HIP(ctx, hipMemsetAsync(touched, 0, (size_t) n_rb * n_leaves, ctx->stream));
+                    touched_kernel<<<4 * std::max(1, ctx->n_cu), 256, 0, ctx->stream>>>(kept, kept_count, kept_cap, xcd_start + 48, sched, tile_leaf, n_leaves, (size_t) n_rb * n_leaves, touched);
+                    init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(touched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
+                                                                                               (size_t) ma_pad, colmin, (size_t) mb_pad);
+                    return LGR_OK;
+                };
+            }
             if (init_aside) LGR_HIP(ctx, hipEventRecord(ctx->ev[29], sB));
             if (pass == 0 && shell0.rshA) LGR_TRY(join_b());   // (the stage shells come from the column norms, written by the packing)
             mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
@@ -880,6 +900,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             LGR_TRY(launch_mfma(mask, ca));
         }
         build_comp();   // final state for the rerank scans
+        chk_sched = sched_final;
+        init_touched = nullptr;   // (its captures end with this block)
         MaskStats* hs;
         LGR_TRY(lgr_pinned(ctx, 256, (void**) &hs));
         LGR_HIP(ctx, hipMemcpyAsync(hs, mstats, sizeof(MaskStats), hipMemcpyDeviceToHost, ctx->stream));
@@ -896,6 +918,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 32, ctx->stream));
             CoarseArgs ca = ca_on;
             ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb;
+            // (touched_kernel saw the overflow: it marked, and init_tables_kernel initialised, every scheduled pair -- the fused kernel finds its tables ready)
             LGR_TRY(launch_mfma(mask, ca, false));
             LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 24, hipMemcpyDeviceToHost, ctx->stream));
             LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));

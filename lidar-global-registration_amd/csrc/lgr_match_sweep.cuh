@@ -283,6 +283,28 @@ __global__ __launch_bounds__(NTHR, SW_OCC) void match_sweep(const f16x8* __restr
     }
 }
 
+// Which (row block, leaf) pairs of the final pass does the list touch?  (Round 5.)  The sweep writes no table; match_tiles writes the minima of
+// the listed tiles only -- 0.7 M of the 51 M tested on the bench pair.  Initialising the table entries of EVERY scheduled pair ahead of the pass
+// (2 GB of +inf, 0.7 ms between the passes) and scanning them all again in the rerank is work for entries that stay +inf: only the pairs that
+// hold a listed tile are marked (with their schedule byte), initialised behind the sweep and reported as computed.  A scheduled pair without
+// a listed tile has had every tile rejected -- none of its elements can be a nearest neighbour or a tie of its row or column -- and "not
+// computed" says the same as +inf.  When the plain kernel takes the pass (pass_select_kernel) or the list overflows (the fused kernel repeats
+// the pass), every scheduled pair is marked.
+__global__ void touched_kernel(const uint2* __restrict__ kept, const unsigned long long* __restrict__ kept_count, unsigned kept_cap, const int* __restrict__ xs_plain /* [9] */,
+                               const uint8_t* __restrict__ sched, const int* __restrict__ tile_leaf, int n_leaves, size_t n_pairs, uint8_t* __restrict__ touched /* zeroed */) {
+    const size_t i0 = (size_t) blockIdx.x * blockDim.x + threadIdx.x, step = (size_t) gridDim.x * blockDim.x;
+    if (xs_plain[8] > 0 || *kept_count > (unsigned long long) kept_cap) {
+        for (size_t i = i0; i < n_pairs; i += step) touched[i] = sched[i];
+        return;
+    }
+    const size_t n = (size_t) *kept_count;
+    for (size_t e = i0; e < n; e += step) {
+        const uint2 ent = kept[e];
+        const size_t idx = (size_t) (ent.x / (BLOCK_ROWS / TILE)) * n_leaves + tile_leaf[ent.y];
+        touched[idx] = sched[idx];   // (every writer of a byte writes the same value)
+    }
+}
+
 // the listed tiles in full: one wave per tile, TL_RUN consecutive list entries per wave visit
 constexpr int TL_WAVES = 4, TL_RUN = 4;
 template <bool COLDIR>
