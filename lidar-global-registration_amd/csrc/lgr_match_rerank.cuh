@@ -689,8 +689,12 @@ __global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, c
         todo = todo && !act;
         const bool wave_on = __ballot(act) != 0ull;
         f16x8 qf[KS];
-        float thr_r[16], eps_r[16];
-        int q_r[16];
+        // Pre-test of a tile (round 5): about one pair per query passes in the whole launch, so nearly every 32 x 32 tile ends with nothing to emit --
+        // but the exact test below is sixteen multiply / subtract / compare / ballot / branch groups per tile, the bulk of the kernel's vector
+        // instructions.  bound = (thr + eps) / out_scale, inflated by 1e-6 (its own roundings and the exact test's are worth 3e-7): whatever the
+        // exact test passes has acc <= bound, so a tile whose smallest acc - bound is positive in every lane is left at once.
+        float bnd_r[16];
+        float bnd_lane = 0.f;
         if (wave_on) {
             if (ROWDIR) {   // thresholds by accumulator row: inactive rows can never pass
                 if (half == 0) { thr_s[wave][c] = act ? my_thr : -__uint_as_float(0x7f800000u); eps_s[wave][c] = act ? my_e : 0.f; q_s[wave][c] = my_q; }
@@ -700,13 +704,17 @@ __global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, c
             const size_t o = ((size_t) (my_q >> 5) * KS) * 64 + (my_q & 31) + 32 * half;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) qf[kk] = src[o + (size_t) kk * 64];
+            auto inflate = [&](float t) {   // (thr + eps) / out_scale, rounded up; -inf stays -inf, NaN keeps the tile
+                const float b = t / ra.out_scale;
+                return b >= 0.f ? b * 1.000001f + 1e-30f : (b < 0.f ? b * 0.999999f + 1e-30f : __uint_as_float(0x7f800000u));
+            };
             if (ROWDIR) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    thr_r[r] = thr_s[wave][row]; eps_r[r] = eps_s[wave][row]; q_r[r] = q_s[wave][row];
+                    bnd_r[r] = inflate(thr_s[wave][row] + eps_s[wave][row]);
                 }
-            }
+            } else bnd_lane = act ? inflate(my_thr + my_e) : -__uint_as_float(0x7f800000u);
         }
         const int j0 = starts ? starts[g] : (int) g * group_size, j1 = starts ? starts[g + 1] : min(t_pad, j0 + group_size);
         const f16x8* tsrc = ROWDIR ? ra.Bp + (size_t) p * ra.bset_stride : ra.Ap;
@@ -732,16 +740,30 @@ __global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, c
                 acc = ROWDIR ? mfma_step(qf[kk], tf, acc) : mfma_step(tf, qf[kk], acc);
             }
             // ROWDIR: acc[r] = (query row (r&3) + 8 (r>>2) + 4 half, train column c); COLDIR: (train row ..., query column c)
+            {
+                float dmin;
+                if (ROWDIR) {
+                    dmin = acc[0] - bnd_r[0];
+#pragma unroll
+                    for (int r = 1; r < 16; r += 3) dmin = fminf(fminf(dmin, acc[r] - bnd_r[r]), fminf(acc[r + 1] - bnd_r[r + 1], acc[r + 2] - bnd_r[r + 2]));
+                } else {
+                    dmin = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; r += 3) dmin = fminf(fminf(dmin, acc[r]), fminf(acc[r + 1], acc[r + 2]));
+                    dmin = dmin - bnd_lane;
+                }
+                if (__ballot(!(dmin > 0.f)) == 0ull) continue;   // (NaN keeps the tile)
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[r] * ra.out_scale;
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const bool pass = ROWDIR ? (v - eps_r[r] <= thr_r[r]) : (act && v - my_e <= my_thr);
+                const bool pass = ROWDIR ? (v - eps_s[wave][row] <= thr_s[wave][row]) : (act && v - my_e <= my_thr);
                 const unsigned long long bal = __ballot(pass);
                 if (bal != 0ull) {   // wave uniform
                     if (pass) {
                         const int slot = n_buf + __popcll(bal & ((1ull << lane) - 1ull));
-                        buf_q[wave][slot] = ROWDIR ? (unsigned) q_r[r] : (unsigned) my_q;
+                        buf_q[wave][slot] = ROWDIR ? (unsigned) q_s[wave][row] : (unsigned) my_q;
                         buf_t[wave][slot] = ROWDIR ? (unsigned) (t0 + c) : (unsigned) (t0 + row);
                     }
                     n_buf += __popcll(bal);
