@@ -619,8 +619,11 @@ struct RefilterArgs {
     int pair_cap;         // >= 0: upper limit of the pair buffer (env LGR_MATCH_PAIR_CAP, tests)
 };
 constexpr int RF_THREADS = 256;
+#ifndef RF_OCC
+#define RF_OCC 4   // waves per SIMD of rerank_refilter (round 5: the allocator took 154 VGPRs and two; the kernel waits on barriers and tile loads 64 % of its wave cycles)
+#endif
 template <bool ROWDIR, int KS>
-__global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, const unsigned* __restrict__ item_g, const unsigned* __restrict__ item_q, unsigned n_items,
+__global__ __launch_bounds__(RF_THREADS) __attribute__((amdgpu_waves_per_eu(RF_OCC, RF_OCC))) void rerank_refilter(RefilterArgs ra, const unsigned* __restrict__ item_g, const unsigned* __restrict__ item_q, unsigned n_items,
                                                               int n_groups, int q_pad, int t_pad, int group_size, const int* __restrict__ starts,
                                                               const float* __restrict__ nQ, const int* __restrict__ blkclQ, const float* __restrict__ nQ_sets,
                                                               const float* __restrict__ gmax, const int* __restrict__ cl_of_group, EpsExtra ex,
@@ -649,7 +652,13 @@ __global__ __launch_bounds__(RF_THREADS) void rerank_refilter(RefilterArgs ra, c
     // only joins the barriers.
     __shared__ __attribute__((aligned(16))) f16x8 tile_s[KS * 64];
     __shared__ unsigned long long runkey_s[RF_THREADS / 64];
-    const unsigned base = (blockIdx.x * (RF_THREADS / 64) + wave) * 32u;
+    // XCD-aware block order (round 5): the items are sorted by group, a group's ~700 items are five or six consecutive blocks -- which the
+    // hardware spreads over as many XCDs, each L2 fetching the group's 192 KB of fragments for itself (2.2 GB of HBM-side traffic per launch at
+    // 3.2 TB/s: the kernel's bound).  XCD x takes the contiguous block range [x per, (x + 1) per): a group's blocks run back to back on one L2.
+    const int n_blk = (int) ((n_items + 32u * (RF_THREADS / 64) - 1u) / (32u * (RF_THREADS / 64)));
+    const int blk = (int) (blockIdx.x & 7u) * ((n_blk + 7) >> 3) + (int) (blockIdx.x >> 3);
+    if (blk >= n_blk) return;
+    const unsigned base = ((unsigned) blk * (RF_THREADS / 64) + wave) * 32u;
     // lane c (both halves) owns item base + c
     const bool have = base + c < n_items;
     const unsigned my_g = have ? item_g[base + c] : 0xffffffffu;
@@ -1032,7 +1041,7 @@ int run_rerank(lgr_ctx* ctx, EpsExtra ex, CompView comp, const float* table, int
             LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PAIRS, (size_t) 2 * cap + 64, &pb));
             unsigned *n_pairs = pb, *pair_q = pb + 16, *pair_t = pb + 16 + cap;
             LGR_HIP(ctx, hipMemsetAsync(n_pairs, 0, 4, ctx->stream));
-            const int rf_grid = cdiv(n_items, 32 * (RF_THREADS / 64));
+            const int rf_grid = ((cdiv(n_items, 32 * (RF_THREADS / 64)) + 7) >> 3) << 3;   // (a multiple of 8: the kernel's XCD-aware block order)
 #define LGR_RF_ARGS ra, item_g2, item_q2, n_items, n_groups, q_pad, ts.n_pad, group_size, starts, nQ, qs.blkcl, nQ_sets, gmax, cl_of_group, ex, thr, cap, n_pairs, pair_q, pair_t
             if (ra.ks == 6) rerank_refilter<ROWDIR, 6><<<rf_grid, RF_THREADS, 0, ctx->stream>>>(LGR_RF_ARGS);
             else rerank_refilter<ROWDIR, 7><<<rf_grid, RF_THREADS, 0, ctx->stream>>>(LGR_RF_ARGS);
