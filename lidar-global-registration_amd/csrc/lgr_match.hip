@@ -549,6 +549,42 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         }
         return LGR_OK;
     };
+    const int n_cc = cdiv(mb_pad, CHUNK_COLS);
+    // ---- (3b ahead of time) the skipping bookkeeping's workspace, cleared on the third stream, and the leaf centres packed as train rows for the
+    // ball bounds on the matrix cores -- both need nothing of the operand packing below and used to sit on the critical chain behind it
+    // (a 12 MB memset and two short launches: 0.36 ms between pack16 and lb_mfma_kernel in the round-5 timeline)
+    char* pb = nullptr;
+    size_t poff = 0;
+    auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
+    const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
+    const size_t o_touched = pcarve((size_t) n_rb * n_leaves);   // (inside the range cleared below)
+    const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_macc = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
+    const size_t o_stats = pcarve(sizeof(MaskStats)), o_lbpart = pcarve((size_t) n_rb * sizeof(uint2));
+    const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
+    const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
+    const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
+    const size_t o_urow = pcarve((size_t) ma_pad * 4), o_ucolv = pcarve((size_t) mb_pad * 4);
+    const size_t o_ssh = pcarve((size_t) KCL * n_stage_total * 8), o_rsh = pcarve((size_t) n_rb * 8);
+    const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
+    const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
+    if (prune) LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
+    const int n_cpad = pad_to(n_leaves, TILE);
+    const size_t cset_stride = (size_t) (n_cpad / TILE) * KS * 64;
+    bool early_b = false;   // ev[27] on sB: workspace cleared (+ centres packed, f16 formats)
+    if (prune) {
+        if (sB != ctx->stream) {
+            LGR_HIP(ctx, hipEventRecord(ctx->ev[31], ctx->stream));
+            LGR_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev[31], 0));
+        }
+        LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, o_cr - o_done, sB));   // done, sched, touched, masks, bounds, stats
+        if (f16) {
+            int* cperm = (int*) (pb + o_cperm);
+            centre_perm_kernel<<<cdiv(n_cpad, 256), 256, 0, sB>>>(n_leaves, n_cpad, cperm);
+            if (rot) pack16_kernel<true><<<cdiv(n_cpad, 256), 256, 0, sB>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) (pb + o_cop), (float*) (pb + o_cnrm), nullptr);
+            else pack16_kernel<false><<<cdiv(n_cpad, 256), 256, 0, sB>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) (pb + o_cop), (float*) (pb + o_cnrm), nullptr);
+        }
+        if (sB != ctx->stream) { LGR_HIP(ctx, hipEventRecord(ctx->ev[27], sB)); early_b = true; }
+    }
     if (!f16) {
         pack_kernel<<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, (float*) Aop, nAp, d_max + 2);
         pack_kernel<<<dim3(cdiv(mb_pad, 256), KCL), 256, 0, ctx->stream>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, (float*) Bop, nBp, d_max + 2);
@@ -558,17 +594,24 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         force_dense = h_ovf[0] != 0u;
     } else {
-        if (rot) {
-            pack16_kernel<true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
-            LGR_TRY(fork_b());
-            pack16_kernel<true><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, shellB);
-        } else {
-            pack16_kernel<false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
-            LGR_TRY(fork_b());
-            pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, shellB);
-        }
+        if (rot) pack16_kernel<true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
+        else pack16_kernel<false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
     }
-    group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
+    // the column operands (f16 formats: 3 GB at 1M, HBM-write bound) and their group maxima, on the third stream behind whatever the main stream
+    // holds when this is called: the skipping schedule calls it behind lb_mfma_kernel (round 5: side by side the two share the machine and the ball
+    // bounds -- on the critical chain -- took 0.85 ms instead of 0.3), the dense schedule right here
+    bool b_packed = !f16;
+    auto pack_b = [&]() -> int {
+        if (b_packed) return LGR_OK;
+        b_packed = true;
+        LGR_TRY(fork_b());
+        if (rot) pack16_kernel<true><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, shellB);
+        else pack16_kernel<false><<<cdiv(mb_pad, 256), 256, 0, sB>>>(d_b, B.perm, mb_pad, 1, cen, nullptr, sc, (_Float16*) Bop, nBp, shellB);
+        group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
+        return LGR_OK;
+    };
+    if (!f16) group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
+    else if (!prune) LGR_TRY(pack_b());
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
     bool b_joined = sB == ctx->stream, b_recorded = false;
     // (the event is recorded behind the last PRODUCER on sB -- record_b, called where the set-up has been enqueued -- not where the first reader
@@ -607,7 +650,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     // rest is filled with 0 -- the most harmful value a stale entry could have -- to show that nothing reads it)
     if (!prune) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
     else if (mo.poison_tables) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0, tab_floats, ctx->stream));
-    const int n_cc = cdiv(mb_pad, CHUNK_COLS);
     // work items of the persistent MFMA kernel: one row group (the owner of its column minima) x one column chunk
     const int item_rb = both ? std::min(rg_rows / BLOCK_ROWS, 16) : 4;
     const int n_ir = cdiv(n_rb, item_rb), ccx = cdiv(n_cc, 8), n_flags = 8 * ccx * n_ir;
@@ -723,21 +765,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         g_last_stats.stages_done = g_last_stats.stages_unique = g_last_stats.stages_all;
     } else {
         // section 3b: lower bounds, pass 1 (nearest tiles), upper bounds, pass 2 (everything the bounds cannot exclude)
-        char* pb;
-        size_t poff = 0;
-        auto pcarve = [&](size_t bytes) { size_t o = poff; poff += (bytes + 255) & ~(size_t) 255; return o; };
-        const size_t o_lb = pcarve((size_t) n_rb * n_leaves * 4), o_done = pcarve((size_t) n_rb * n_leaves), o_sched = pcarve((size_t) n_rb * n_leaves);
-        const size_t o_touched = pcarve((size_t) n_rb * n_leaves);   // (inside the range cleared below)
-        const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_macc = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
-        const size_t o_stats = pcarve(sizeof(MaskStats)), o_lbpart = pcarve((size_t) n_rb * sizeof(uint2));
-        const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
-        const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
-        const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
-        const size_t o_urow = pcarve((size_t) ma_pad * 4), o_ucolv = pcarve((size_t) mb_pad * 4);
-        const size_t o_ssh = pcarve((size_t) KCL * n_stage_total * 8), o_rsh = pcarve((size_t) n_rb * 8);
-        const size_t o_cperm = pcarve((size_t) (n_leaves + TILE) * 4), o_cnrm = pcarve((size_t) KCL * (n_leaves + TILE) * 4);
-        const size_t o_cop = pcarve((size_t) KCL * ((n_leaves + TILE) / TILE) * 7 * 64 * sizeof(f16x8));   // the leaf centres as packed train rows
-        LGR_TRY(lgr_ws_t(ctx, WS_MATCH_PRUNE, poff, &pb));
         float* LBsq = (float*) (pb + o_lb);
         uint8_t* done = (uint8_t*) (pb + o_done);
         uint8_t* sched = (uint8_t*) (pb + o_sched);
@@ -752,6 +779,26 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         MaskStats* mstats = (MaskStats*) (pb + o_stats);
         unsigned* u_stage = (unsigned*) (pb + o_ust);
         unsigned* u_ct = (unsigned*) (pb + o_uct);
+        // ball bounds: on the matrix cores from the packed operands (f16 formats; the leaf centres were packed as train rows ahead of the operand
+        // packing, on the third stream), with packed FMAs from the sorted rows otherwise
+        if (early_b) LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[27], 0));   // the cleared workspace, the packed centres
+        auto launch_lb = [&](lgr_ctx* cx) -> int {
+            if (!f16) {
+                lb_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
+            } else {
+                float* nC = (float*) (pb + o_cnrm);
+                f16x8* Cop = (f16x8*) (pb + o_cop);
+                if (rot) lb_mfma_kernel<OpFmt<FMT_F16R>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
+                                                                                                  B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
+                else lb_mfma_kernel<OpFmt<FMT_F16>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
+                                                                                              B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
+            }
+            LGR_HIP(cx, hipGetLastError());
+            return (int) LGR_OK;
+        };
+        if (!f16) LGR_TRY(join_sorted());   // lb_kernel reads sortedA
+        LGR_TRY(launch_lb(ctx));
+        LGR_TRY(pack_b());   // (f16 formats: the column operands behind the ball bounds; everything below that reads them or their norms joins sB)
         const bool colstage = both && mo.column_stage != 0;
         // coarse rejection inside match_mfma (rotated format, passes with upper bounds): thresholds from u_rb / u_stage
         const bool coarse = f16 && rot && mo.coarse_rejection != 0;
@@ -785,7 +832,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         shell0.u_rb = nullptr;
         uint8_t* comp_r = (uint8_t*) (pb + o_cr);
         uint8_t* comp_c = (uint8_t*) (pb + o_cc);
-        LGR_HIP(ctx, hipMemsetAsync(pb + o_done, 0, o_cr - o_done, ctx->stream));   // done, sched, masks, bounds, stats
         auto build_comp = [&]() {
             comp_rows_kernel<<<cdiv((long long) n_rb * n_groups, 256), 256, 0, ctx->stream>>>(done, sched_final, group_leaf, n_rb, n_leaves, n_groups, comp_r);
             if (both) comp_cols_kernel<<<cdiv((long long) n_leaves * n_rg, 256), 256, 0, ctx->stream>>>(done, sched_final, n_rb, n_leaves, n_rg, rg_rows / BLOCK_ROWS, comp_c);
@@ -793,32 +839,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         chk_done = done; chk_sched = sched;   // (chk_sched: re-pointed to the touched pairs below when the final pass defers its initialisation) chk_lb = LBsq; chk_ustage = colstage ? u_stage : nullptr;
         comp_rows = CompView{comp_r, n_groups, nullptr};
         comp_cols = CompView{comp_c, n_rg, tile_leaf};
-        // ball bounds: on the matrix cores from the packed operands (f16 formats), with packed FMAs from the sorted rows otherwise
-        const int n_cpad = pad_to(n_leaves, TILE);
-        const size_t cset_stride = (size_t) (n_cpad / TILE) * KS * 64;
-        auto launch_lb = [&](lgr_ctx* cx) -> int {
-            if (!f16) {
-                lb_kernel<<<n_rb, 256, 0, cx->stream>>>(sortedA, A.perm, cen2, B.r2max, B.leaf_count, n_leaves, LBsq);
-            } else {
-                int* cperm = (int*) (pb + o_cperm);
-                float* nC = (float*) (pb + o_cnrm);
-                f16x8* Cop = (f16x8*) (pb + o_cop);
-                centre_perm_kernel<<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(n_leaves, n_cpad, cperm);
-                if (rot) {
-                    pack16_kernel<true><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
-                    lb_mfma_kernel<OpFmt<FMT_F16R>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
-                                                                                             B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
-                } else {
-                    pack16_kernel<false><<<cdiv(n_cpad, 256), 256, 0, cx->stream>>>(cen2, cperm, n_cpad, 1, cen, nullptr, sc, (_Float16*) Cop, nC, nullptr);
-                    lb_mfma_kernel<OpFmt<FMT_F16>::KS><<<n_rb, LBM_THREADS, 0, cx->stream>>>((const f16x8*) Aop, Cop, cset_stride, out_scale, A.blkcl, nAp, nC, ex,
-                                                                                            B.r2max, B.leaf_count, n_leaves, n_cpad, LBsq);
-                }
-            }
-            LGR_HIP(cx, hipGetLastError());
-            return (int) LGR_OK;
-        };
-        if (!f16) LGR_TRY(join_sorted());   // lb_kernel reads sortedA
-        LGR_TRY(launch_lb(ctx));
         // do the bounds separate anything?  (zero / finite lower bounds: counted by box_lb_kernel where it writes the final bounds, by lb_stats_kernel
         // without boxes; near_kernel: when nearly every lower bound is zero, pass 0 takes everything)
         unsigned long long* lbstat = &mstats->stages[5];   // [5] zero, [6] finite lower bounds (MaskStats slots the passes do not use)
@@ -880,7 +900,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 init_touched = nullptr;
             } else {
                 sched_final = touched;
-                init_touched = [&, pass]() -> int {   // (called by launch_mfma between match_sweep and match_tiles, on the context's stream)
+                init_touched = [&]() -> int {   // (called by launch_mfma between match_sweep and match_tiles, on the context's stream)
                     LGR_HIP(ctx, hipMemsetAsync(touched, 0, (size_t) n_rb * n_leaves, ctx->stream));
                     touched_kernel<<<4 * std::max(1, ctx->n_cu), 256, 0, ctx->stream>>>(kept, kept_count, kept_cap, xcd_start + 48, sched, tile_leaf, n_leaves, (size_t) n_rb * n_leaves, touched);
                     init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(touched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,

@@ -79,14 +79,17 @@ __global__ __launch_bounds__(256) void lb_kernel(const float* __restrict__ Asort
 // matrix cores and keeps the row minimum -- 6 (7) MFMA steps per 32 x 32 (row, centre) tile instead of 33 packed FMAs per pair.
 // The filtered value is within eps(x, y) of |a - c|^2 (x = largest |a'| of the block, y = |c'|: the matcher's own proven bound),
 // so  dmin - eps  is a valid lower bound of the smallest distance; eps is ~1e-5 (x + y)^2, far below what the bound is used for.
-constexpr int LBM_THREADS = 512, LBM_CHUNK = 8;   // 8 waves = the 8 row tiles of a block; centre tiles staged through LDS 8 at a time
+constexpr int LBM_THREADS = 512, LBM_CHUNK = 4;   // 8 waves = the 8 row tiles of a block; centre tiles go through LDS 4 at a time, double buffered
 template <int KS>
 __global__ __launch_bounds__(LBM_THREADS) void lb_mfma_kernel(const f16x8* __restrict__ Ap, const f16x8* __restrict__ Cp, size_t cset_stride /* fragments */,
                                                               float out_scale, const int* __restrict__ blkcl, const float* __restrict__ nA,
                                                               const float* __restrict__ nC /* [KCL][n_cpad] */, EpsExtra ex,
                                                               const unsigned* __restrict__ r2max, const int* __restrict__ leaf_count, int n_leaves, int n_cpad,
                                                               float* __restrict__ LBsq) {
-    __shared__ __attribute__((aligned(16))) f16x8 cs[LBM_CHUNK * KS * 64];
+    // (round 5: the chunks arrive by LDS-DMA, the next one while the current one is multiplied -- staged through registers, every 16-byte piece
+    //  of a chunk waited for its own memory round trip, six in a row per chunk: 0.62 ms for 0.09 ms worth of MFMAs, on the matcher's critical chain)
+    constexpr int CH_BLOCKS = LBM_CHUNK * KS;   // 1 KB blocks per chunk
+    __shared__ __attribute__((aligned(16))) f16x8 cs[2][LBM_CHUNK * KS * 64];
     __shared__ int dmin_s[MAXLEAF + TILE];
     __shared__ float xw[LBM_THREADS / 64];
     const int rb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -105,16 +108,28 @@ __global__ __launch_bounds__(LBM_THREADS) void lb_mfma_kernel(const f16x8* __res
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) a[kk] = Ap[((size_t) row_tile * KS + kk) * 64 + lane];
     const f16x8* Cset = Cp + (size_t) p * cset_stride;
-    const int n_ct = n_cpad / TILE;
-    for (int ct0 = 0; ct0 < n_ct; ct0 += LBM_CHUNK) {
-        const int nt = min(LBM_CHUNK, n_ct - ct0);
-        __syncthreads();   // everybody is done with the previous chunk (and, the first time, dmin_s / xw are written)
-        for (int e = tid; e < nt * KS * 64; e += LBM_THREADS) cs[e] = Cset[(size_t) ct0 * KS * 64 + e];
-        __syncthreads();
-        for (int t = 0; t < nt; ++t) {
+    const int n_ct = n_cpad / TILE, n_ch = (n_ct + LBM_CHUNK - 1) / LBM_CHUNK;
+    auto issue = [&](int ch) {   // wave w copies the 1 KB blocks w, w + 8, ... of chunk ch
+        const int nblk = min(LBM_CHUNK, n_ct - ch * LBM_CHUNK) * KS;
+        const char* src = reinterpret_cast<const char*>(Cset + (size_t) ch * LBM_CHUNK * KS * 64);
+        char* dst = reinterpret_cast<char*>(&cs[ch & 1][0]);
+        for (int blk = wave; blk < nblk; blk += LBM_THREADS / 64)
+            __builtin_amdgcn_global_load_lds((const void*) (src + blk * 1024 + lane * 16), (__attribute__((address_space(3))) void*) (dst + blk * 1024), 16, 0, 0);
+    };
+    static_assert(CH_BLOCKS * 1024 == (int) sizeof(cs) / 2, "a chunk image is CH_BLOCKS blocks of 1 KB");
+    issue(0);
+    for (int ch = 0; ch < n_ch; ++ch) {
+        const int ct0 = ch * LBM_CHUNK, nt = min(LBM_CHUNK, n_ct - ct0);
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // this wave's pieces of chunk ch (the only DMAs in flight) -- and, the first time, a / nA
+        __syncthreads();   // every wave's pieces are in LDS; everybody is done with chunk ch - 1, whose buffer the next DMA takes (first time: dmin_s / xw)
+        if (ch + 1 < n_ch) issue(ch + 1);
+        const f16x8* cb = &cs[ch & 1][0];
+#pragma unroll
+        for (int t = 0; t < LBM_CHUNK; ++t) {
+            if (t >= nt) break;   // (uniform)
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) acc = mfma_step(a[kk], cs[(t * KS + kk) * 64 + lane], acc);
+            for (int kk = 0; kk < KS; ++kk) acc = mfma_step(a[kk], cb[(t * KS + kk) * 64 + lane], acc);
             // minimum over the wave's 32 rows, on the bit patterns (a negative value -- a distance within eps of zero -- stays
             // negative under the signed-integer order, whichever negative it is; it ends as a bound of 0 below)
             int m = min(__float_as_int(acc[0]), __float_as_int(acc[1]));

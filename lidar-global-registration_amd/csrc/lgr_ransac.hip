@@ -1540,6 +1540,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     int max_iterations = std::min(comb_or_max(c, p->n_samples), p->max_iterations);
     int batch = std::max(1, p->ransac_batch);
     int bound = max_iterations, done = 0, largest = 0, num_rejections = 0, best_iter = -1;
+    (void) largest;
     float final_metric = 0.f;
     float* d_best;   // device copy of the best transform so far
     static_assert(sizeof(RState) + 256 <= 256 * sizeof(float), "the device schedule's state fits the slot as requested here (no re-allocation under d_best)");
