@@ -597,9 +597,10 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         if (rot) pack16_kernel<true><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
         else pack16_kernel<false><<<cdiv(ma_pad, 256), 256, 0, ctx->stream>>>(d_a, A.perm, ma_pad, 0, cen, A.blkcl, sc, (_Float16*) Aop, nAp, shellA);
     }
-    // the column operands (f16 formats: 3 GB at 1M, HBM-write bound) and their group maxima, on the third stream behind whatever the main stream
-    // holds when this is called: the skipping schedule calls it behind lb_mfma_kernel (round 5: side by side the two share the machine and the ball
-    // bounds -- on the critical chain -- took 0.85 ms instead of 0.3), the dense schedule right here
+    // the column operands (f16 formats: 3 GB at 1M, HBM-write bound) and their group maxima, on the third stream behind the row operands.  (Round 5
+    // measured the alternatives: behind lb_mfma_kernel -- which then runs alone in 0.18 ms instead of 0.85 -- box_lb_kernel crawls beside the
+    // packing instead (0.07 -> 0.92 ms); behind the near kernels, with pass 0's stage selection from assign_kernel's distances so that
+    // mask_kernel need not wait for the column norms: mask_kernel crawls (0.4 -> 1.04 ms) and pass 0 starts 0.1 ms later than with this order.)
     bool b_packed = !f16;
     auto pack_b = [&]() -> int {
         if (b_packed) return LGR_OK;
@@ -611,7 +612,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         return LGR_OK;
     };
     if (!f16) group_max_kernel<<<dim3(n_groups, KCL), 256, 0, sB>>>(nBp, mb_pad, 0, group_start, gmaxB);
-    else if (!prune) LGR_TRY(pack_b());
+    else LGR_TRY(pack_b());   // (right behind the row operands: 1 ms of HBM writes that everything up to pass 0 crawls beside -- started later, pass 0 starts later)
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
     bool b_joined = sB == ctx->stream, b_recorded = false;
     // (the event is recorded behind the last PRODUCER on sB -- record_b, called where the set-up has been enqueued -- not where the first reader
@@ -798,7 +799,6 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
         };
         if (!f16) LGR_TRY(join_sorted());   // lb_kernel reads sortedA
         LGR_TRY(launch_lb(ctx));
-        LGR_TRY(pack_b());   // (f16 formats: the column operands behind the ball bounds; everything below that reads them or their norms joins sB)
         const bool colstage = both && mo.column_stage != 0;
         // coarse rejection inside match_mfma (rotated format, passes with upper bounds): thresholds from u_rb / u_stage
         const bool coarse = f16 && rot && mo.coarse_rejection != 0;
