@@ -274,8 +274,8 @@ constexpr int ASSIGN_THREADS = 1024;   // the sub-centres (up to 135 KB of LDS) 
 // nstat (the operand statistics the f16 packing needs before it can choose its scale; they used to cost a pass of their own over
 // both sets): [0] largest finite |x - c|^2 (float bits) over the centres the row will be packed against -- its own cluster's
 // (role 0, query side) or all KCL (role 1, train side: one operand copy per column set) --, [1] the largest energy of the three
-// coordinates the rotated 30-D format drops (u_j = block sum of x - c over sqrt(11); summed in double, rounded up: the same
-// expression as the packing kernel's), [2] set when such a |x - c|^2 overflows float, [3] the number of irregular rows (all of them, listed or not).
+// coordinates the rotated 30-D format drops (u_j = block sum of x - c over sqrt(11); an upper bound from the row's and the centre's
+// block sums, see the loop), [2] set when such a |x - c|^2 overflows float, [3] the number of irregular rows (all of them, listed or not).
 __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __restrict__ X, int m, const float* __restrict__ cen, const float* __restrict__ cen2, int sub,
                                                                 unsigned* __restrict__ keys, int* __restrict__ vals, uint8_t* __restrict__ valid,
                                                                 int* __restrict__ counts /* [MAXLEAF+1] */, unsigned* __restrict__ rmax /* [MAXLEAF] */,
@@ -290,6 +290,14 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
     unsigned* lr = (unsigned*) (lc + MAXLEAF + 1);
     for (int e = threadIdx.x; e < KCL * sub * 33; e += blockDim.x) c2s[(e / (sub * 33)) * pitch + e % (sub * 33)] = cen2[e];
     for (int i = threadIdx.x; i <= MAXLEAF; i += blockDim.x) { lc[i] = 0; if (i < MAXLEAF) lr[i] = 0u; }
+    // the three block sums of every centre, in double (the dropped-energy statistic below)
+    __shared__ double cs_s[KCL][3];
+    if (threadIdx.x < KCL * 3) {
+        const int cc = threadIdx.x / 3, j = threadIdx.x % 3;
+        double t = 0.0;
+        for (int k = 0; k < 11; ++k) t += (double) cen[cc * 33 + 11 * j + k];
+        cs_s[cc][j] = t;
+    }
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     float st_n2 = 0.f, st_drop = 0.f;
@@ -301,10 +309,10 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
         // irregular rows (see km_consensus): finite, but off the consensus of the block sums -- listed for the exact side scan, kept out of
         // the clustering statistics and the operands (valid = 2: a train row for the exact scans, not a row of the filter)
         bool irr = false;
+        double bx0 = 0.0, bx1 = 0.0, bx2 = 0.0;   // the row's own block sums (exact sums of floats, rounded once)
+        if (ok) block_sums(v, bx0, bx1, bx2);
         if (ok && irr_ref && irr_ref->enabled) {
-            double s0, s1, s2;
-            block_sums(v, s0, s1, s2);
-            irr = !sums_agree(s0, s1, s2, irr_ref->s[0], irr_ref->s[1], irr_ref->s[2], irr_ref->tol);
+            irr = !sums_agree(bx0, bx1, bx2, irr_ref->s[0], irr_ref->s[1], irr_ref->s[2], irr_ref->tol);
             if (irr) {
                 const unsigned pos = atomicAdd(&nstat[3], 1u);
                 if (pos < (unsigned) IRR_CAP) irr_list[pos] = i;
@@ -321,13 +329,17 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float* __r
 #pragma unroll 1
             for (int cc = 0; cc < KCL; ++cc) {
                 float d = 0.f;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int k = 0; k < 33; ++k) {
                     const float t = v[k] - cen[cc * 33 + k];
                     d = d + t * t;
-                    if (k < 11) s0 += (double) t; else if (k < 22) s1 += (double) t; else s2 += (double) t;
                 }
+                // Dropped energy: the packing kernel drops u_j = (sum over block j of t_k) / sqrt 11 with t_k = fl(v_k - c_k).  The block sums of the
+                // ROUNDED differences differ from (row's block sum - centre's block sum) by at most 11 roundings of size 2^-24 |t_k|, |t_k| <= sqrt d:
+                // the statistic is evaluated from the two block sums with that margin on every |s_j| (round 5: the sums of the t_k themselves, in
+                // double, were 528 conversions and double additions per row -- a quarter of this kernel).
+                const double mg = 6.6e-7 * (double) sqrtf(d);   // 11 x 2^-24 x 1.006
+                const double s0 = fabs(bx0 - cs_s[cc][0]) + mg, s1 = fabs(bx1 - cs_s[cc][1]) + mg, s2 = fabs(bx2 - cs_s[cc][2]) + mg;
                 const float dr = (float) (((s0 * s0 + s1 * s1) + s2 * s2) * (1.0001 / 11.0)) * 1.000001f + 1e-20f * d;
                 if (d < r2) { r2 = d; c = cc; own_drop = dr; }
                 if (role == 1) {
