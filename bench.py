@@ -377,7 +377,7 @@ def stage_rooflines(ctx, capi, torch, pair, src, tgt, params, n_steps_res):
 def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
     """What the headline depends on (outside the timed region).  The matcher's cost is a property of the descriptor
     distribution: its exact bound-based skipping computes ~10 % of the (row block, stage) tiles of THIS scene's FPFH rows.  Two more
-    measurements of the matcher stage (lgr_match_bf2_dev alone, second of two runs, host wall between stream synchronisations):
+    measurements of the matcher stage (lgr_match_bf2_dev alone, the faster of two runs after a warm-up call, host wall between stream synchronisations):
       dense          the same pair's rows with lgr_match_options.prune = 0: every tile computed on the f16 MFMA path, no bounds, no masks
       structureless  the production schedule on rows no bound can separate: M x 33 rows of three 11-bin blocks, bins i.i.d. uniform,
                      each block normalised to sum 100 (the FPFH shape with no structure: the worst case for every bound)
@@ -392,13 +392,17 @@ def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
     ctx.sync(); torch.cuda.synchronize()
 
     def timed(a, b):
+        # one warm-up call, then the faster of two (round 5: about one call in a hundred stalls on the host for ~35 ms on these boxes -- no gap inside
+        # the call's kernel timeline, python's collector switched off or not --, and a single sample of a 15 ms stage carried that into the report)
         out = {}
-        for _ in range(2):
+        for it in range(3):
             ctx.sync(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             ctx.match_bf2(a, b, params.bf_block_size)
             ctx.sync(); torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            if it == 2 and 1e3 * dt >= out["match_stage_ms"]:
+                continue
             z, f = ctx.match_lbstats()
             out = {"match_stage_ms": 1e3 * dt, "match_mfma_ms": ctx.match_kernel_ms(), "executed_tile_fraction": ctx.match_work(),
                    "issued_tile_fraction": ctx.match_issued(), "operand_format": ctx.match_format(), "zero_lower_bound_fraction": (z / f) if f > 0 else None, "irregular_rows": list(ctx.match_irregular()[:2])}
@@ -448,7 +452,7 @@ def matcher_extremes(ctx, capi, torch, pair, src, tgt, params):
         spread.append({"seed": sd, "match_stage_ms": t["match_stage_ms"], "match_mfma_ms": t["match_mfma_ms"], "executed_tile_fraction": t["executed_tile_fraction"]})
         del f2, pr
     res["seed_spread"] = spread
-    res["note"] = ("matcher stage alone (lgr_match_bf2_dev, both directions), second of two runs; this_pair = the bench pair's FPFH rows on the production "
+    res["note"] = ("matcher stage alone (lgr_match_bf2_dev, both directions), the faster of two runs after a warm-up call; this_pair = the bench pair's FPFH rows on the production "
                    "schedule, dense = the same rows with prune = 0, structureless = uniform random 11-bin blocks normalised to 100 on the production schedule "
                    "(lgr_match_options.auto_dense: >= 90 % zero lower bounds -> pass 0 computes everything), structureless_dense = the same random rows with "
                    "prune = 0, planar = FPFH rows of a planar-dominated pair on the production schedule; seed_spread = the bench pair's generator with other seeds (the bench pair is the first); irregular_rows = rows per side off the block-sum consensus "

@@ -127,7 +127,7 @@ typedef struct {
                                    * cause is not established.  Do not enable it where bit-reproducibility is a requirement.  One process per
                                    * GPU (the multi-GPU layout) never has two contexts on a device. */
     int32_t arithmetic;           /* LGR_ARITH_FAST (0, default) / LGR_ARITH_PCL (1): see below */
-    int32_t pcl_neighbour_cap;    /* LGR_ARITH_PCL: neighbours of a key point sorted at once; 0 default (1024), 64 (tests: drives the shell path).  Never changes results */
+    int32_t pcl_neighbour_cap;    /* LGR_ARITH_PCL: neighbours of a key point sorted at once; 0 default (512), 1024, 64 (tests: drives the shell path).  Never changes results */
     int32_t reserved[4];
 } lgr_ctx_options;
 /* Arithmetic of the third-party pieces (normals, pair features, FPFH weighting: PCL 1.12.1 behind include/common.h:322-332 and

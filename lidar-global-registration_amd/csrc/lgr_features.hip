@@ -1287,7 +1287,8 @@ extern "C" int lgr_fpfh_dev(lgr_ctx* ctx, const float* d_kps, int m, const float
     if (ctx->opt.arithmetic == LGR_ARITH_PCL) {
         // PCL's own weighting order and rounding steps (fpfh_pcl_kernel); pcl_neighbour_cap: neighbours sorted at once (tests shrink it to drive the shells)
         if (ctx->opt.pcl_neighbour_cap == 64) fpfh_pcl_kernel<64><<<lgr_xcd_grid(m), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
-        else fpfh_pcl_kernel<1024><<<lgr_xcd_grid(m), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
+        else if (ctx->opt.pcl_neighbour_cap == 1024) fpfh_pcl_kernel<1024><<<lgr_xcd_grid(m), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
+        else fpfh_pcl_kernel<512><<<lgr_xcd_grid(m), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);   // (default: 6 KB of LDS per wave; ~260 neighbours on average, more go in shells)
     } else {
         fpfh_mfma_kernel<<<lgr_xcd_grid(cdiv(m, FT)), 64, 0, ctx->stream>>>(g, d_kps, kvals2, m, r2, spfh, d_out);
     }

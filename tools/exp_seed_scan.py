@@ -3,12 +3,15 @@ python tools/exp_seed_scan.py N seed [seed ...]  -> per seed the matcher stage a
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "lidar-global-registration_amd")]
+import gc
 import numpy as np
 import torch
 from lgr_amd import capi, synthetic
 
 n = int(sys.argv[1]); seeds = [int(x) for x in sys.argv[2:]]
 ctx = capi.Context(0)
+if os.environ.get("NOGC"):
+    gc.disable()
 if os.environ.get("MATCH_OPTS"):   # e.g. MATCH_OPTS="near=48,shell_bound=0"
     ctx.set_match_options(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["MATCH_OPTS"].split(","))})
 r = 0.25
