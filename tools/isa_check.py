@@ -60,7 +60,15 @@ def check_hazard():
         ins = funcs[name]
         first = next((i for i, x in enumerate(ins) if x[1].startswith("v_accvgpr_read")), None)
         if first is None:
-            raise SystemExit("isa_check: %s has no v_accvgpr_read -- the check no longer matches the kernel" % name)
+            # with a small register budget the accumulators live in architectural VGPRs and the epilogue reads them
+            # directly: the read is then the first instruction behind the s_nop run that follows the last v_mfma
+            last_mfma = max((i for i, x in enumerate(ins) if x[1].startswith("v_mfma")), default=None)
+            if last_mfma is None:
+                raise SystemExit("isa_check: %s has no v_mfma -- the check no longer matches the kernel" % name)
+            nop = next((i for i in range(last_mfma + 1, len(ins)) if ins[i][1] == "s_nop" and int(ins[i][2], 0) >= 7), None)
+            if nop is None:
+                raise SystemExit("isa_check: %s has no s_nop run behind its last v_mfma -- the epilogue padding was dropped" % name)
+            first = next(i for i in range(nop, len(ins)) if ins[i][1] != "s_nop")
         if not any(x[1].startswith("v_mfma") for x in ins[:first]):
             raise SystemExit("isa_check: no v_mfma in front of the first accumulator read of " + name)
         waits = 0
