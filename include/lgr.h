@@ -46,7 +46,7 @@ enum {
     LGR_ERR_NO_DEVICE = -2,
     LGR_ERR_OOM = -3,
     LGR_ERR_HIP = -4,          /* a HIP runtime call failed; see lgr_last_error */
-    LGR_ERR_UNSUPPORTED = -5,  /* e.g. n_samples != 3, randomness != 1, alignment teaser (throws in the reference) */
+    LGR_ERR_UNSUPPORTED = -5,  /* e.g. n_samples outside 3..8, randomness != 1, alignment teaser (throws in the reference) */
     LGR_ERR_VOXEL_TOO_SMALL = -6
 };
 
@@ -71,7 +71,8 @@ typedef struct {
     int32_t bf_block_size;       /* ALIGNMENT_BLOCK_SIZE (lgr_default_params: 10000); every shipped YAML sets 200000 (data/test.yaml:12) */
     int32_t cluster_k;           /* 40 */
     int32_t randomness;          /* 1 (only 1, as data/test.yaml:14 says) */
-    int32_t n_samples;           /* 3 */
+    int32_t n_samples;           /* 3 (every shipped config); 3..8 accepted: sampler, polygon test and Umeyama are generic in it,
+                                    src/sac_prerejective_omp.cpp:33-77,105-108,220 */
     int32_t alignment_id, matching_id, metric_id, score_id;
     int32_t max_iterations;
     int32_t normals_available;
@@ -334,12 +335,14 @@ int lgr_ransac(lgr_ctx*, const float* src, int ns, const float* tgt, int nt, con
                const lgr_params*, lgr_result*, uint8_t* final_mask);
 int lgr_ransac_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                    const lgr_params*, lgr_result* /* host */, uint8_t* d_final_mask);
-/* replay mode (SURVEY section 7 "RANSAC RNG"): evaluate n caller-supplied sample triples (correspondence indices) */
+/* replay mode (SURVEY section 7 "RANSAC RNG"): evaluate n caller-supplied sample tuples (params.n_samples correspondence indices each) */
 int lgr_ransac_replay_dev(lgr_ctx*, const float* d_src, int ns, const float* d_tgt, int nt, const lgr_corr* d_corr, int c,
                           const lgr_params*, const int32_t* d_triples, int n,
                           uint8_t* d_ok, float* d_T16, int32_t* d_n_inliers, float* d_metric);
 /* the on-device sampler alone: triples of iterations [first, first+n) (Philox4x32-10 + selectCorrespondences :33-77) */
 int lgr_ransac_samples_dev(lgr_ctx*, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples);
+/* ... for any n_samples in 3..8: draw j of an iteration is word j % 4 of Philox(key = seed, counter = (iteration, j / 4, 0, 0)) >> 1 */
+int lgr_ransac_samples_n_dev(lgr_ctx*, uint64_t seed, int first, int n, int n_corr, int n_samples, int32_t* d_tuples);
 /* one Philox4x32-10 block from the device's generator (the sampler above uses counter = (iteration, 0, 0, 0), key = seed; the closest-plane
  * metric's subsets the full counter): key = (k0 | k1 << 32).  For Random123's known-answer vectors. */
 int lgr_selfcheck_philox(lgr_ctx*, uint64_t key, const uint32_t counter4[4], uint32_t out4[4]);

@@ -583,7 +583,7 @@ extern "C" int lgr_align_dev(lgr_ctx* ctx, const float* d_src, int ns, const flo
     LGR_CHECK(ctx, (d_src || ns == 0) && (d_tgt || nt == 0) && p && res && ns >= 0 && nt >= 0, LGR_ERR_INVALID_ARG);
     // alignTeaser throws in the reference (src/alignment.cpp:40)
     LGR_CHECK(ctx, p->alignment_id == LGR_ALIGN_RANSAC || p->alignment_id == LGR_ALIGN_GROR, LGR_ERR_UNSUPPORTED);
-    LGR_CHECK(ctx, p->n_samples == 3, LGR_ERR_UNSUPPORTED);
+    LGR_CHECK(ctx, p->n_samples >= 3 && p->n_samples <= 8, LGR_ERR_UNSUPPORTED);   // (lgr_ransac.hip instantiates its kernels for 3..8)
     if (ns < 2 || nt < 2) {
         // a cloud without two points gives no correspondences; the reference then leaves the identity, not converged
         // (selectCorrespondences refuses fewer than n_samples, src/sac_prerejective_omp.cpp:36-42)

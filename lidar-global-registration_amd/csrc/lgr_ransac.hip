@@ -33,11 +33,12 @@ constexpr double MIN_INLIER_RATE = 0.15;   // :10
 // ---------------------------------------------------------------------------------------------------- sampling
 __device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned iter, unsigned out[4]) { lgr_philox4(seed, iter, 0u, 0u, 0u, out); }
 
-// src/sac_prerejective_omp.cpp:33-77 selectCorrespondences, nr_samples = 3 (control flow kept literally)
-__device__ __forceinline__ void select3(const int r[3], int n_corr, int sample[3]) {
-    // The reference's loops (for i < 3: draw, for j < i: bump / wrap / insert-and-break) written out for i = 0, 1, 2 on three scalars:
-    // with run-time indices sample[] lived in scratch memory.  `step` is one pass of the j loop's body at position j for the value x
-    // being placed: returns true for `continue` (x was bumped and stays the candidate for the next j), false for "insert x at j".
+// src/sac_prerejective_omp.cpp:33-77 selectCorrespondences (control flow kept literally), NS = AlignmentParameters::n_samples
+// The reference's loops (for i < NS: draw, for j < i: bump / wrap / insert-and-break) unrolled at compile time so that sample[] stays in
+// registers (with run-time indices it lived in scratch memory).  `step` is one pass of the j loop's body at position j for the value x
+// being placed: returns true for `continue` (x was bumped and stays the candidate for the next j), false for "insert x at j".
+template <int NS>
+__device__ __forceinline__ void select_n(const int (&r)[NS], int n_corr, int (&sample)[NS]) {
     auto step = [&](int& x, int sj) {
         if (x >= sj) {
             if (x < n_corr - 1) { x++; return true; }
@@ -46,35 +47,56 @@ __device__ __forceinline__ void select3(const int r[3], int n_corr, int sample[3
         }
         return false;
     };
-    int s0 = r[0] % n_corr, s1, s2;
-    int x = r[1] % n_corr;
-    if (step(x, s0)) { s1 = x; } else { s1 = s0; s0 = x; }
-    x = r[2] % n_corr;
-    if (!step(x, s0)) { s2 = s1; s1 = s0; s0 = x; }
-    else if (step(x, s1)) { s2 = x; }
-    else { s2 = s1; s1 = x; }
-    sample[0] = s0; sample[1] = s1; sample[2] = s2;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        int x = r[i] % n_corr;
+        bool placed = false;
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            if (!placed && !step(x, sample[j])) {
+#pragma unroll
+                for (int k = i; k > j; --k) sample[k] = sample[k - 1];
+                sample[j] = x;
+                placed = true;
+            }
+        }
+        if (!placed) sample[i] = x;
+    }
 }
 
-__global__ void samples_kernel(unsigned long long seed, int first, int n, int n_corr, int32_t* __restrict__ triples) {
+// the raw draws of iteration `iter`: draw j = word j % 4 of Philox(seed; counter (iter, j / 4, 0, 0)), top 31 bits
+template <int NS>
+__device__ __forceinline__ void draws_n(unsigned long long seed, unsigned iter, int (&r)[NS]) {
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        if ((j & 3) == 0) lgr_philox4(seed, iter, (unsigned) (j >> 2), 0u, 0u, w);
+        r[j] = (int) (w[j & 3] >> 1);
+    }
+}
+
+template <int NS>
+__global__ void samples_kernel(unsigned long long seed, int first, int n, int n_corr, int32_t* __restrict__ tuples) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
-    unsigned w[4];
-    philox4x32(seed, (unsigned) (first + b), w);
-    int r[3] = {(int) (w[0] >> 1), (int) (w[1] >> 1), (int) (w[2] >> 1)}, s[3];
-    select3(r, n_corr, s);
-    triples[3 * b] = s[0]; triples[3 * b + 1] = s[1]; triples[3 * b + 2] = s[2];
+    int r[NS], s[NS];
+    draws_n<NS>(seed, (unsigned) (first + b), r);
+    select_n<NS>(r, n_corr, s);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) tuples[(size_t) NS * b + j] = s[j];
 }
 
 // ---------------------------------------------------------------------------------------------------- hypotheses
 struct P3 { float x, y, z; };
 __device__ __forceinline__ P3 ldp(const float* pts, int i) { const float* p = pts + (size_t) i * 12; return P3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ float p3c(const P3& p, int a) { return a == 0 ? p.x : (a == 1 ? p.y : p.z); }
 
-// pcl::registration::CorrespondenceRejectorPoly::thresholdPolygon
-__device__ __forceinline__ bool poly_ok(const P3 s[3], const P3 t[3], float thr2) {
+// pcl::registration::CorrespondenceRejectorPoly::thresholdPolygon: every edge i -> (i + 1) % NS
+template <int NS>
+__device__ __forceinline__ bool poly_ok(const P3 (&s)[NS], const P3 (&t)[NS], float thr2) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        int j = (i + 1) % 3;
+    for (int i = 0; i < NS; ++i) {
+        const int j = (i + 1) % NS;
         float dx = s[i].x - s[j].x, dy = s[i].y - s[j].y, dz = s[i].z - s[j].z;
         float ds = dx * dx + dy * dy + dz * dz;
         dx = t[i].x - t[j].x; dy = t[i].y - t[j].y; dz = t[i].z - t[j].z;
@@ -85,25 +107,31 @@ __device__ __forceinline__ bool poly_ok(const P3 s[3], const P3 t[3], float thr2
     return true;
 }
 
-// pcl::umeyama (no scaling) on 3 pairs; T column-major
-__device__ __forceinline__ void umeyama3(const P3 s[3], const P3 d[3], float* T) {
-    const float one_over_n = 1.0f / 3.0f;
-    float sv[3][3] = {{s[0].x, s[1].x, s[2].x}, {s[0].y, s[1].y, s[2].y}, {s[0].z, s[1].z, s[2].z}};
-    float dv[3][3] = {{d[0].x, d[1].x, d[2].x}, {d[0].y, d[1].y, d[2].y}, {d[0].z, d[1].z, d[2].z}};
-    float sm[3], dm[3], S[3][3], D[3][3];
+// pcl::umeyama (no scaling) on NS pairs; T column-major.  Means and the entries of sigma are left-to-right sums over the points.
+template <int NS>
+__device__ __forceinline__ void umeyama_n(const P3 (&s)[NS], const P3 (&d)[NS], float* T) {
+    const float one_over_n = 1.0f / (float) NS;
+    float sm[3], dm[3], S[3][NS], D[3][NS];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        sm[a] = ((sv[a][0] + sv[a][1]) + sv[a][2]) * one_over_n;
-        dm[a] = ((dv[a][0] + dv[a][1]) + dv[a][2]) * one_over_n;
+        float ss = p3c(s[0], a), ds = p3c(d[0], a);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { S[a][j] = sv[a][j] - sm[a]; D[a][j] = dv[a][j] - dm[a]; }
+        for (int j = 1; j < NS; ++j) { ss += p3c(s[j], a); ds += p3c(d[j], a); }
+        sm[a] = ss * one_over_n;
+        dm[a] = ds * one_over_n;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { S[a][j] = p3c(s[j], a) - sm[a]; D[a][j] = p3c(d[j], a) - dm[a]; }
     }
     float sigma[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            sigma[3 * i + j] = one_over_n * ((D[i][0] * S[j][0] + D[i][1] * S[j][1]) + D[i][2] * S[j][2]);
+        for (int j = 0; j < 3; ++j) {
+            float acc = D[i][0] * S[j][0];
+#pragma unroll
+            for (int k = 1; k < NS; ++k) acc += D[i][k] * S[j][k];
+            sigma[3 * i + j] = one_over_n * acc;
+        }
     float U[9], Sg[3], V[9];
     lgr_svd3(sigma, U, Sg, V);
     float sgn = (lgr_det3(U) * lgr_det3(V) < 0.f) ? -1.f : 1.f;
@@ -127,26 +155,28 @@ __device__ __forceinline__ void umeyama3(const P3 s[3], const P3 d[3], float* T)
     T[15] = 1.f;
 }
 
-// one thread per iteration of the batch: sample (or replay a given triple) -> prerejection -> 3-point transform
+// one thread per iteration of the batch: sample (or replay a given tuple) -> prerejection -> NS-point transform
+template <int NS>
 __global__ void hypotheses_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr,
-                                  int c, unsigned long long seed, int first, int n, const int32_t* __restrict__ triples,
+                                  int c, unsigned long long seed, int first, int n, const int32_t* __restrict__ tuples,
                                   float edge_thr, float* __restrict__ Ts, int* __restrict__ ok) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
-    int smp[3];
-    if (triples) { smp[0] = triples[3 * b]; smp[1] = triples[3 * b + 1]; smp[2] = triples[3 * b + 2]; }
-    else {
-        unsigned w[4];
-        philox4x32(seed, (unsigned) (first + b), w);
-        int r[3] = {(int) (w[0] >> 1), (int) (w[1] >> 1), (int) (w[2] >> 1)};
-        select3(r, c, smp);
-    }
-    P3 s[3], t[3];
+    int smp[NS];
+    if (tuples) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { lgr_corr cr = corr[smp[j]]; s[j] = ldp(src, cr.index_query); t[j] = ldp(tgt, cr.index_match); }   // buildIndices :17-31
-    bool good = poly_ok(s, t, edge_thr * edge_thr);
+        for (int j = 0; j < NS; ++j) smp[j] = tuples[(size_t) NS * b + j];
+    } else {
+        int r[NS];
+        draws_n<NS>(seed, (unsigned) (first + b), r);
+        select_n<NS>(r, c, smp);
+    }
+    P3 s[NS], t[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) { lgr_corr cr = corr[smp[j]]; s[j] = ldp(src, cr.index_query); t[j] = ldp(tgt, cr.index_match); }   // buildIndices :17-31
+    bool good = poly_ok<NS>(s, t, edge_thr * edge_thr);
     float T[16];
-    if (good) umeyama3(s, t, T);
+    if (good) umeyama_n<NS>(s, t, T);
     else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -156,6 +186,18 @@ __global__ void hypotheses_kernel(const float* __restrict__ src, const float* __
     o[2] = make_float4(T[8], T[9], T[10], T[11]); o[3] = make_float4(T[12], T[13], T[14], T[15]);
     ok[b] = good ? 1 : 0;
 }
+
+// n_samples the kernels are instantiated for (the reference's sampler, polygon test and Umeyama are generic in it; every shipped config uses 3)
+constexpr int LGR_MIN_SAMPLES = 3, LGR_MAX_SAMPLES = 8;
+#define LGR_NS_DISPATCH(ns, CALL)                                                                                      \
+    switch (ns) {                                                                                                      \
+        case 3: { constexpr int NS = 3; CALL; break; }                                                                 \
+        case 4: { constexpr int NS = 4; CALL; break; }                                                                 \
+        case 5: { constexpr int NS = 5; CALL; break; }                                                                 \
+        case 6: { constexpr int NS = 6; CALL; break; }                                                                 \
+        case 7: { constexpr int NS = 7; CALL; break; }                                                                 \
+        default: { constexpr int NS = 8; CALL; break; }                                                                \
+    }
 
 // ---------------------------------------------------------------------------------------------------- packing
 // pack[i] = {sx, sy, sz, thr | tx, ty, tz, bins}; sstar[i] = smallest float s with sqrt_rn(s) >= thr, so that the
@@ -806,6 +848,7 @@ __global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__
     S->rounds += 1;
 }
 
+template <int NS>
 __global__ void rs_hyp_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
                               unsigned long long seed, RState* __restrict__ S, float edge_thr, float* __restrict__ Ts, int* __restrict__ list,
                               int* __restrict__ posmap, int2* __restrict__ counts) {
@@ -815,17 +858,16 @@ __global__ void rs_hyp_kernel(const float* __restrict__ src, const float* __rest
     bool good = false;
     if (b < nb) {
         counts[b] = make_int2(0, 0);   // (list positions are < the survivors' number <= nb)
-        unsigned w[4];
-        philox4x32(seed, (unsigned) (S->round_first + b), w);
-        int r[3] = {(int) (w[0] >> 1), (int) (w[1] >> 1), (int) (w[2] >> 1)}, smp[3];
-        select3(r, c, smp);
-        P3 s[3], t[3];
+        int r[NS], smp[NS];
+        draws_n<NS>(seed, (unsigned) (S->round_first + b), r);
+        select_n<NS>(r, c, smp);
+        P3 s[NS], t[NS];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { lgr_corr cr = corr[smp[j]]; s[j] = ldp(src, cr.index_query); t[j] = ldp(tgt, cr.index_match); }
-        good = poly_ok(s, t, edge_thr * edge_thr);
+        for (int j = 0; j < NS; ++j) { lgr_corr cr = corr[smp[j]]; s[j] = ldp(src, cr.index_query); t[j] = ldp(tgt, cr.index_match); }
+        good = poly_ok<NS>(s, t, edge_thr * edge_thr);
         if (good) {
             float T[16];
-            umeyama3(s, t, T);
+            umeyama_n<NS>(s, t, T);
             float4* o = reinterpret_cast<float4*>(Ts + (size_t) b * 16);
             o[0] = make_float4(T[0], T[1], T[2], T[3]); o[1] = make_float4(T[4], T[5], T[6], T[7]);
             o[2] = make_float4(T[8], T[9], T[10], T[11]); o[3] = make_float4(T[12], T[13], T[14], T[15]);
@@ -1162,15 +1204,19 @@ extern "C" int lgr_evaluate_plane_dev(lgr_ctx* ctx, const float* d_src, int ns, 
     return LGR_OK;
 }
 
-extern "C" int lgr_ransac_samples_dev(lgr_ctx* ctx, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples) {
+extern "C" int lgr_ransac_samples_n_dev(lgr_ctx* ctx, uint64_t seed, int first, int n, int n_corr, int n_samples, int32_t* d_tuples) {
     lgr_turn turn__(ctx);   // contexts of one device take turns (lgr_internal.h)
     if (!ctx) return LGR_ERR_INVALID_ARG;
-    LGR_CHECK(ctx, n >= 0 && n_corr >= 3 && (d_triples || n == 0) && first >= 0, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, n_samples >= LGR_MIN_SAMPLES && n_samples <= LGR_MAX_SAMPLES, LGR_ERR_UNSUPPORTED);
+    LGR_CHECK(ctx, n >= 0 && n_corr >= n_samples && (d_tuples || n == 0) && first >= 0, LGR_ERR_INVALID_ARG);
     if (n == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
-    samples_kernel<<<cdiv(n, 256), 256, 0, ctx->stream>>>(seed, first, n, n_corr, d_triples);
+    LGR_NS_DISPATCH(n_samples, (samples_kernel<NS><<<cdiv(n, 256), 256, 0, ctx->stream>>>(seed, first, n, n_corr, d_tuples)));
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
+}
+extern "C" int lgr_ransac_samples_dev(lgr_ctx* ctx, uint64_t seed, int first, int n, int n_corr, int32_t* d_triples) {
+    return lgr_ransac_samples_n_dev(ctx, seed, first, n, n_corr, 3, d_triples);
 }
 
 // lgr.h: one Philox4x32-10 block through the device's generator (known-answer tests)
@@ -1234,8 +1280,8 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
                      const lgr_params* p, uint64_t seed, int first, int nb, const int32_t* d_triples, BatchBuffers& b,
                      int* n_ok, int* n_cand, const lgr_plane_dev* plane = nullptr, int min_inliers = MIN_NR_INLIERS,
                      float best_prev = 0.f, int record_prev = 0) {
-    hypotheses_kernel<<<cdiv(nb, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, first, nb, d_triples,
-                                                              p->edge_thr_coef, b.Ts, b.ok);
+    LGR_NS_DISPATCH(p->n_samples, (hypotheses_kernel<NS><<<cdiv(nb, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, first, nb, d_triples,
+                                                                                                  p->edge_thr_coef, b.Ts, b.ok)));
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, b.ok, b.pos, 0, (size_t) nb, rocprim::plus<int>(), ctx->stream));
     void* tmp;
@@ -1394,7 +1440,8 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
     auto enqueue_round = [&](bool first) -> int {
         const int nb_up = first ? std::min(batch, nb_max) : nb_max;
         rs_begin_kernel<<<1, 64, 0, ctx->stream>>>(dS, b.st, first ? 1 : 0);
-        rs_hyp_kernel<<<cdiv(nb_up, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, dS, p->edge_thr_coef, b.Ts, b.list, posmap, b.counts);
+        LGR_NS_DISPATCH(p->n_samples, (rs_hyp_kernel<NS><<<cdiv(nb_up, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, dS, p->edge_thr_coef, b.Ts, b.list,
+                                                                                                     posmap, b.counts)));
         count_list_kernel<<<g_count, CB, 0, ctx->stream>>>(b.Ts, b.list, &dS->n_ok, pk.PP, pk.pstats, c, b.counts, maskT, mask_cap);
         if (closest) {
             // every survivor on its sparse subset; its plane inliers are "the inliers" (gate: the loop's best metric and record so far)
@@ -1458,7 +1505,7 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
 
 static int check_params(lgr_ctx* ctx, const lgr_params* p) {
     LGR_CHECK(ctx, p != nullptr, LGR_ERR_INVALID_ARG);
-    LGR_CHECK(ctx, p->n_samples == 3, LGR_ERR_UNSUPPORTED);
+    LGR_CHECK(ctx, p->n_samples >= LGR_MIN_SAMPLES && p->n_samples <= LGR_MAX_SAMPLES, LGR_ERR_UNSUPPORTED);   // (fewer than 3 pairs leave Umeyama's rotation open)
     LGR_CHECK(ctx, p->metric_id == LGR_METRIC_UNIFORMITY || p->metric_id == LGR_METRIC_CORRESPONDENCES ||
                        p->metric_id == LGR_METRIC_CLOSEST_PLANE || p->metric_id == LGR_METRIC_COMBINATION,
               LGR_ERR_UNSUPPORTED);   // weighted_closest_plane (src/weights.cpp) is not built
@@ -1473,7 +1520,7 @@ extern "C" int lgr_ransac_replay_dev(lgr_ctx* ctx, const float* d_src, int ns, c
     if (!ctx) return LGR_ERR_INVALID_ARG;
     LGR_TRY(check_params(ctx, p));
     LGR_CHECK(ctx, p->metric_id == LGR_METRIC_UNIFORMITY || p->metric_id == LGR_METRIC_CORRESPONDENCES, LGR_ERR_UNSUPPORTED);   // plane metrics: lgr_evaluate_plane_dev
-    LGR_CHECK(ctx, d_src && d_tgt && d_corr && d_triples && d_ok && d_T16 && d_n_inliers && d_metric && c >= 3 && n >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, d_src && d_tgt && d_corr && d_triples && d_ok && d_T16 && d_n_inliers && d_metric && c >= p->n_samples && n >= 0 && ns > 0 && nt > 0, LGR_ERR_INVALID_ARG);
     if (n == 0) return LGR_OK;
     LGR_HIP(ctx, hipSetDevice(ctx->device));
     Packed pk;
@@ -1482,7 +1529,7 @@ extern "C" int lgr_ransac_replay_dev(lgr_ctx* ctx, const float* d_src, int ns, c
     LGR_TRY(batch_buffers(ctx, n, &b));
     int n_ok = 0;
     // every prerejection survivor gets its metric here (no MIN_NR_INLIERS gate): replay reports per hypothesis
-    hypotheses_kernel<<<cdiv(n, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0, 0, n, d_triples, p->edge_thr_coef, b.Ts, b.ok);
+    LGR_NS_DISPATCH(p->n_samples, (hypotheses_kernel<NS><<<cdiv(n, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, 0, 0, n, d_triples, p->edge_thr_coef, b.Ts, b.ok)));
     size_t tb = 0;
     LGR_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, b.ok, b.pos, 0, (size_t) n, rocprim::plus<int>(), ctx->stream));
     void* tmp;
@@ -1533,7 +1580,7 @@ extern "C" int lgr_ransac_dev(lgr_ctx* ctx, const float* d_src, int ns, const fl
     memset(res, 0, sizeof(*res));
     for (int i = 0; i < 16; ++i) res->transformation[i] = (i % 5 == 0) ? 1.f : 0.f;
     res->n_correspondences = c;
-    if (c < 3) return LGR_OK;   // selectCorrespondences refuses (src/sac_prerejective_omp.cpp:36-42); identity, not converged
+    if (c < p->n_samples) return LGR_OK;   // selectCorrespondences refuses (src/sac_prerejective_omp.cpp:36-42); identity, not converged
     uint64_t seed = p->fix_seed ? 566ull : p->seed;
     Packed pk;
     LGR_TRY(pack(ctx, d_src, ns, d_tgt, nt, d_corr, c, &pk));
@@ -1653,7 +1700,7 @@ extern "C" int lgr_ransac(lgr_ctx* ctx, const float* src, int ns, const float* t
     LGR_HIP(ctx, hipMemcpyAsync(dt, tgt, (size_t) nt * 48, hipMemcpyHostToDevice, ctx->stream));
     if (c) LGR_HIP(ctx, hipMemcpyAsync(dc, corr, (size_t) c * 16, hipMemcpyHostToDevice, ctx->stream));
     LGR_TRY(lgr_ransac_dev(ctx, ds, ns, dt, nt, dc, c, p, res, dm));
-    if (final_mask && c >= 3) {
+    if (final_mask && c >= p->n_samples) {
         LGR_HIP(ctx, hipMemcpyAsync(final_mask, dm, (size_t) c, hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     } else if (final_mask && c > 0) memset(final_mask, 0, c);

@@ -475,9 +475,9 @@ class Context:
             return self.torch.from_numpy(np.ascontiguousarray(corr).view(np.int32).reshape(-1, 4)).to(self._dev())
         return corr
 
-    def ransac_samples(self, seed, first, n, n_corr):
-        out = self.empty((n, 3), self.torch.int32)
-        self.check(_lib.lgr_ransac_samples_dev(self.h, C.c_uint64(seed), int(first), int(n), int(n_corr), _ptr(out)))
+    def ransac_samples(self, seed, first, n, n_corr, n_samples=3):
+        out = self.empty((n, n_samples), self.torch.int32)
+        self.check(_lib.lgr_ransac_samples_n_dev(self.h, C.c_uint64(seed), int(first), int(n), int(n_corr), int(n_samples), _ptr(out)))
         return out
 
     def evaluate(self, src, tgt, corr, T, metric_id=METRIC_UNIFORMITY, score_id=SCORE_MSE):
@@ -517,6 +517,7 @@ class Context:
         torch = self.torch
         corr = self._corr_dev(corr)
         n = triples.shape[0]
+        assert triples.shape[1] == params.n_samples, "one row of params.n_samples correspondence indices per hypothesis"
         ok = self.empty((n,), torch.uint8); Ts = self.empty((n, 16), torch.float32)
         ninl = self.empty((n,), torch.int32); met = self.empty((n,), torch.float32)
         self.check(_lib.lgr_ransac_replay_dev(self.h, _ptr(src), src.shape[0], _ptr(tgt), tgt.shape[0], _ptr(corr), corr.shape[0],

@@ -176,10 +176,15 @@ void orc_philox(uint64_t seed, uint32_t iter, uint32_t out[4]);
 void orc_philox_full(uint64_t key, const uint32_t counter4[4], uint32_t out[4]);   /* key = k0 | k1 << 32 */
 /* src/sac_prerejective_omp.cpp:33-77 given the three raw draws r[3] (already non-negative) */
 void orc_select3(const int r[3], int n_corr, int sample[3]);
+#define ORC_MAX_SAMPLES 8   /* n_samples this restatement's local arrays hold (the reference's code is generic in it; 3 everywhere it ships) */
+void orc_select_n(const int* r, int nr_samples, int n_corr, int* sample);
+void orc_philox_draws(uint64_t seed, uint32_t iter, int nr_samples, int* r);
 /* pcl CorrespondenceRejectorPoly::thresholdPolygon (call site src/sac_prerejective_omp.cpp:214) */
 int orc_poly_ok(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float edge_thr);
+int orc_poly_ok_n(const float* src, const float* tgt, const int* sidx, const int* tidx, int n, float edge_thr);
 /* pcl TransformationEstimationSVD (umeyama, no scaling) on 3 pairs (call site :220) */
 void orc_umeyama3(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float T[16]);
+void orc_umeyama_n(const float* src, const float* tgt, const int* sidx, const int* tidx, int n, float T[16]);
 /* src/metric.cpp:125-179 : inlier mask (n_corr bytes), rmse, metric for transform T */
 int orc_evaluate(const float* src, int ns, const float* tgt, int nt, const lgr_orc_corr* corr, int c,
                  const float T[16], int metric_id, int score_id,

@@ -381,6 +381,34 @@ def select3(r, n_corr):
     return list(s)
 
 
+def select_n(r, n_corr):
+    n = len(r)
+    rr = (C.c_int * n)(*[int(x) for x in r])
+    s = (C.c_int * n)()
+    lib().orc_select_n(rr, n, int(n_corr), s)
+    return list(s)
+
+
+def philox_draws(seed, it, n_samples):
+    r = (C.c_int * n_samples)()
+    lib().orc_philox_draws(C.c_uint64(seed), C.c_uint32(it), int(n_samples), r)
+    return list(r)
+
+
+def poly_ok_n(src, tgt, sidx, tidx, edge_thr=0.95):
+    src, tgt = _pts(src), _pts(tgt)
+    n = len(sidx)
+    return bool(lib().orc_poly_ok_n(_p(src), _p(tgt), (C.c_int * n)(*sidx), (C.c_int * n)(*tidx), n, C.c_float(edge_thr)))
+
+
+def umeyama_n(src, tgt, sidx, tidx):
+    src, tgt = _pts(src), _pts(tgt)
+    n = len(sidx)
+    T = np.zeros(16, np.float32)
+    lib().orc_umeyama_n(_p(src), _p(tgt), (C.c_int * n)(*sidx), (C.c_int * n)(*tidx), n, _p(T))
+    return T.reshape(4, 4).T.copy()
+
+
 def poly_ok(src, tgt, sidx, tidx, edge_thr=0.95):
     src, tgt = _pts(src), _pts(tgt)
     return bool(lib().orc_poly_ok(_p(src), _p(tgt), (C.c_int * 3)(*sidx), (C.c_int * 3)(*tidx), C.c_float(edge_thr)))

@@ -87,11 +87,12 @@ extern "C" int orc_rng_stream(int rng_mode, uint64_t seed, int n, int* out) {
     return 0;
 }
 
-// src/sac_prerejective_omp.cpp:33-77 selectCorrespondences with nr_samples = 3; r[i] are the raw RNG outputs
-// (control flow copied literally, including the wrap-around branch).
-extern "C" void orc_select3(const int r[3], int n_corr, int sample[3]) {
+// src/sac_prerejective_omp.cpp:33-77 selectCorrespondences; r[i] are the raw RNG outputs, one per sample
+// (control flow copied literally, including the wrap-around branch).  nr_samples is the reference's
+// AlignmentParameters::n_samples (3 in every shipped config; ORC_MAX_SAMPLES bounds the local arrays of this restatement).
+extern "C" void orc_select_n(const int* r, int nr_samples, int n_corr, int* sample) {
     int temp_sample;
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < nr_samples; i++) {
         sample[i] = r[i] % n_corr;
         for (int j = 0; j < i; j++) {
             if (sample[i] >= sample[j]) {
@@ -112,14 +113,27 @@ extern "C" void orc_select3(const int r[3], int n_corr, int sample[3]) {
         }
     }
 }
+extern "C" void orc_select3(const int r[3], int n_corr, int sample[3]) { orc_select_n(r, 3, n_corr, sample); }
+
+// The raw draws of Philox iteration `iter`: draw j is word j % 4 of philox4x32-10(key = seed, counter = (iter, j / 4, 0, 0)), top 31 bits
+// (for n_samples <= 4 -- every shipped config -- that is the one block orc_philox returns).
+extern "C" void orc_philox_draws(uint64_t seed, uint32_t iter, int nr_samples, int* r) {
+    uint32_t w[4];
+    for (int j = 0; j < nr_samples; ++j) {
+        if ((j & 3) == 0) philox4(seed, iter, (uint32_t) (j >> 2), 0, 0, w);
+        r[j] = (int) (w[j & 3] >> 1);
+    }
+}
 
 // pcl::registration::CorrespondenceRejectorPoly::thresholdPolygon, cardinality 3 [3P PCL 1.12.1
 // registration/correspondence_rejection_poly.h]; call site src/sac_prerejective_omp.cpp:105-108,214; SURVEY.md A.4.
 // computeSquaredDistance = dx*dx + dy*dy + dz*dz (left to right).
-extern "C" int orc_poly_ok(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float edge_thr) {
+// cardinality 2 tests its one edge, any other cardinality every edge i -> (i + 1) % n.
+extern "C" int orc_poly_ok_n(const float* src, const float* tgt, const int* sidx, const int* tidx, int n, float edge_thr) {
     float thr2 = edge_thr * edge_thr;
-    for (int i = 0; i < 3; ++i) {
-        int j = (i + 1) % 3;
+    const int edges = n == 2 ? 1 : n;
+    for (int i = 0; i < edges; ++i) {
+        int j = (i + 1) % n;
         const float *a = src + 12 * (size_t) sidx[i], *b = src + 12 * (size_t) sidx[j];
         const float *c = tgt + 12 * (size_t) tidx[i], *d = tgt + 12 * (size_t) tidx[j];
         float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
@@ -131,27 +145,35 @@ extern "C" int orc_poly_ok(const float* src, const float* tgt, const int sidx[3]
     }
     return 1;
 }
+extern "C" int orc_poly_ok(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float edge_thr) {
+    return orc_poly_ok_n(src, tgt, sidx, tidx, 3, edge_thr);
+}
 
 // pcl::registration::TransformationEstimationSVD::estimateRigidTransformation -> pcl::umeyama(src, tgt, false)
 // [3P PCL 1.12.1 common/impl/eigen.hpp == Eigen/src/Geometry/Umeyama.h]; call site :220; SURVEY.md A.5.
 //   means; demean; sigma = (1/n) * dst_demean * src_demean^T; SVD; S = (1,1,+-1) by det(U)*det(V); R = U S V^T;
 //   t = dst_mean - R*src_mean.  The SVD is the canonical one-sided Jacobi (orc_math.h) instead of Eigen::JacobiSVD
 //   (DEVIATION at rounding level; R is unique whenever sigma has rank >= 2).
-extern "C" void orc_umeyama3(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float T[16]) {
-    const float one_over_n = 1.0f / 3.0f;
-    float sm[3], dm[3], S[3][3], D[3][3];
+//   For n points the means and the entries of sigma are left-to-right sums over the points (Eigen's coefficient-based evaluation of a
+//   3 x n by n x 3 product; a vectorised build of Eigen may associate the inner sums differently for n >= 4: parity unpinned there, the
+//   reference holds no fixture for any n, and n = 3 has a single association).
+extern "C" void orc_umeyama_n(const float* src, const float* tgt, const int* sidx, const int* tidx, int n, float T[16]) {
+    const float one_over_n = 1.0f / (float) n;
+    float sm[3], dm[3], S[3][ORC_MAX_SAMPLES], D[3][ORC_MAX_SAMPLES];
     for (int a = 0; a < 3; ++a) {
-        float s0 = src[12 * (size_t) sidx[0] + a], s1 = src[12 * (size_t) sidx[1] + a], s2 = src[12 * (size_t) sidx[2] + a];
-        float d0 = tgt[12 * (size_t) tidx[0] + a], d1 = tgt[12 * (size_t) tidx[1] + a], d2 = tgt[12 * (size_t) tidx[2] + a];
-        sm[a] = ((s0 + s1) + s2) * one_over_n;
-        dm[a] = ((d0 + d1) + d2) * one_over_n;
-        S[a][0] = s0 - sm[a]; S[a][1] = s1 - sm[a]; S[a][2] = s2 - sm[a];
-        D[a][0] = d0 - dm[a]; D[a][1] = d1 - dm[a]; D[a][2] = d2 - dm[a];
+        float ss = src[12 * (size_t) sidx[0] + a], ds = tgt[12 * (size_t) tidx[0] + a];
+        for (int j = 1; j < n; ++j) { ss += src[12 * (size_t) sidx[j] + a]; ds += tgt[12 * (size_t) tidx[j] + a]; }
+        sm[a] = ss * one_over_n;
+        dm[a] = ds * one_over_n;
+        for (int j = 0; j < n; ++j) { S[a][j] = src[12 * (size_t) sidx[j] + a] - sm[a]; D[a][j] = tgt[12 * (size_t) tidx[j] + a] - dm[a]; }
     }
     float sigma[9];
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            sigma[3 * i + j] = one_over_n * ((D[i][0] * S[j][0] + D[i][1] * S[j][1]) + D[i][2] * S[j][2]);
+        for (int j = 0; j < 3; ++j) {
+            float acc = D[i][0] * S[j][0];
+            for (int k = 1; k < n; ++k) acc += D[i][k] * S[j][k];
+            sigma[3 * i + j] = one_over_n * acc;
+        }
     float U[9], Sg[3], V[9];
     c_svd3(sigma, U, Sg, V);
     float sgn = (c_det3(U) * c_det3(V) < 0.f) ? -1.f : 1.f;
@@ -167,6 +189,9 @@ extern "C" void orc_umeyama3(const float* src, const float* tgt, const int sidx[
         T[12 + i] = t[i];
     }
     T[15] = 1.f;
+}
+extern "C" void orc_umeyama3(const float* src, const float* tgt, const int sidx[3], const int tidx[3], float T[16]) {
+    orc_umeyama_n(src, tgt, sidx, tidx, 3, T);
 }
 
 namespace {
@@ -418,12 +443,12 @@ extern "C" int orc_comb_or_max(int n, int k) { return comb_or_max(n, k); }   // 
 namespace {
 
 struct Hyp { bool ok; float T[16]; };
-inline Hyp make_hyp(const float* src, const float* tgt, const lgr_orc_corr* corr, const int sample[3], float edge_thr) {
+inline Hyp make_hyp(const float* src, const float* tgt, const lgr_orc_corr* corr, const int* sample, float edge_thr, int n = 3) {
     Hyp h;
-    int sidx[3], tidx[3];
-    for (int j = 0; j < 3; ++j) { sidx[j] = corr[sample[j]].query; tidx[j] = corr[sample[j]].match; }  // buildIndices :17-31
-    h.ok = orc_poly_ok(src, tgt, sidx, tidx, edge_thr) != 0;
-    if (h.ok) orc_umeyama3(src, tgt, sidx, tidx, h.T);
+    int sidx[ORC_MAX_SAMPLES], tidx[ORC_MAX_SAMPLES];
+    for (int j = 0; j < n; ++j) { sidx[j] = corr[sample[j]].query; tidx[j] = corr[sample[j]].match; }  // buildIndices :17-31
+    h.ok = orc_poly_ok_n(src, tgt, sidx, tidx, n, edge_thr) != 0;
+    if (h.ok) orc_umeyama_n(src, tgt, sidx, tidx, n, h.T);
     else { for (int i = 0; i < 16; ++i) h.T[i] = (i % 5 == 0) ? 1.f : 0.f; }
     return h;
 }
@@ -477,7 +502,7 @@ extern "C" int orc_replay(const float* src, int ns, const float* tgt, int nt, co
         std::vector<int> hist(30000);
 #pragma omp for schedule(dynamic, 8)
         for (int i = 0; i < n; ++i) {
-            Hyp h = make_hyp(src, tgt, corr, triples + 3 * (size_t) i, p->edge_thr_coef);
+            Hyp h = make_hyp(src, tgt, corr, triples + (size_t) p->n_samples * i, p->edge_thr_coef, p->n_samples);
             ok[i] = h.ok;
             std::memcpy(Ts + 16 * (size_t) i, h.T, 64);
             if (h.ok) {
@@ -501,9 +526,10 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
                           const lgr_orc_params* p, lgr_orc_result* res, uint8_t* final_mask) {
     (void) nt;
     std::memset(res, 0, sizeof(*res));
-    if (p->n_samples != 3) return -1;
+    if (p->n_samples < 3 || p->n_samples > ORC_MAX_SAMPLES) return -1;
+    const int nsmp = p->n_samples;
     for (int i = 0; i < 16; ++i) res->T[i] = (i % 5 == 0) ? 1.f : 0.f;
-    if (c < 3) { res->converged = 0; return 0; }
+    if (c < nsmp) { res->converged = 0; return 0; }   // selectCorrespondences refuses (:36-42)
     float mn[3], mx[3];
     orc_bbox(src, ns, mn, mx);
     const bool plane = p->metric_id == ORC_METRIC_CLOSEST_PLANE || p->metric_id == ORC_METRIC_COMBINATION;
@@ -545,11 +571,10 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
                 std::vector<uint32_t> visited;
 #pragma omp for schedule(dynamic, 8)
                 for (int b = 0; b < nb; ++b) {
-                    uint32_t w[4];
-                    orc_philox(p->seed, (uint32_t) (done + b), w);
-                    int r[3] = {(int) (w[0] >> 1), (int) (w[1] >> 1), (int) (w[2] >> 1)}, sample[3];
-                    orc_select3(r, c, sample);
-                    Hyp h = make_hyp(src, tgt, corr, sample, p->edge_thr_coef);
+                    int r[ORC_MAX_SAMPLES], sample[ORC_MAX_SAMPLES];
+                    orc_philox_draws(p->seed, (uint32_t) (done + b), nsmp, r);
+                    orc_select_n(r, nsmp, c, sample);
+                    Hyp h = make_hyp(src, tgt, corr, sample, p->edge_thr_coef, nsmp);
                     ok[b] = h.ok;
                     std::memcpy(&Ts[(size_t) b * 16], h.T, 64);
                     if (!h.ok) continue;
@@ -591,9 +616,10 @@ extern "C" int orc_ransac(const float* src, int ns, const float* tgt, int nt, co
             for (int i = lo; i < lo + cnt; ++i) {
                 if ((long long) L.its * T >= L.iters_local) continue;
                 ++L.its;
-                int rr[3] = {rng(), rng(), rng()}, sample[3];
-                orc_select3(rr, c, sample);
-                Hyp h = make_hyp(src, tgt, corr, sample, p->edge_thr_coef);
+                int rr[ORC_MAX_SAMPLES], sample[ORC_MAX_SAMPLES];
+                for (int j = 0; j < nsmp; ++j) rr[j] = rng();
+                orc_select_n(rr, nsmp, c, sample);
+                Hyp h = make_hyp(src, tgt, corr, sample, p->edge_thr_coef, nsmp);
                 if (!h.ok) { ++L.rej; continue; }
                 Eval e = evaluate(src, tgt, corr, c, h.T, p->metric_id, p->score_id, mn, mx, nullptr, hist, &pc, (uint32_t) i, &visited);
                 if (e.n_inl < MIN_NR_INLIERS) continue;

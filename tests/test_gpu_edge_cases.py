@@ -112,7 +112,7 @@ def test_invalid_arguments_return_status_not_crash(lgr, pair):
     assert lib.lgr_align_dev(lgr.h, ps, 10, pt, 10, None, C.byref(res)) == ERR_INVALID_ARG              # null params
     assert lib.lgr_align_dev(lgr.h, ps, 10, pt, 10, C.byref(p), None) == ERR_INVALID_ARG                # null result
     assert b"" != lib.lgr_last_error(lgr.h)
-    bad = base_params(capi, pair); bad.n_samples = 4                                                          # the reference's polygon test is 3-point
+    bad = base_params(capi, pair); bad.n_samples = 9                                                          # kernels are instantiated for 3..8 samples
     assert lib.lgr_align_dev(lgr.h, ps, src.shape[0], pt, tgt.shape[0], C.byref(bad), C.byref(res)) == ERR_UNSUPPORTED
     bad = base_params(capi, pair); bad.alignment_id = 2                                                        # "teaser": alignTeaser throws in the reference
     assert lib.lgr_align_dev(lgr.h, ps, src.shape[0], pt, tgt.shape[0], C.byref(bad), C.byref(res)) == ERR_UNSUPPORTED

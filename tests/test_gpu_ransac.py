@@ -240,3 +240,70 @@ def test_choose_best_hypothesis(lgr, oracle, problem):
     assert bi == -1 and np.array_equal(Tb, np.eye(4, dtype=np.float32))
     bi, Tb, _ = lgr.choose_best_hypothesis(src, tgt, problem["corr"], [])
     assert bi == -1
+
+
+# ---- n_samples other than 3 (src/sac_prerejective_omp.cpp:33-77,105-108,220 are generic in it; every shipped config uses 3) ---------------
+@pytest.mark.parametrize("n_samples", [4, 5, 8])
+def test_sampler_matches_oracle_n_samples(lgr, oracle, n_samples):
+    n, n_corr = 2000, 1000
+    got = lgr.ransac_samples(566, 11, n, n_corr, n_samples=n_samples).cpu().numpy()
+    for i in range(n):
+        assert got[i].tolist() == oracle.select_n(oracle.philox_draws(566, 11 + i, n_samples), n_corr), i
+    # the wrap-around branch: with as many correspondences as samples most draws collide
+    got = lgr.ransac_samples(3, 0, 256, n_samples, n_samples=n_samples).cpu().numpy()
+    for i in range(256):
+        assert got[i].tolist() == oracle.select_n(oracle.philox_draws(3, i, n_samples), n_samples), i
+
+
+def test_sampler_n_samples_3_is_the_triple_sampler(lgr):
+    a = lgr.ransac_samples(566, 5, 4096, 777).cpu().numpy()
+    b = lgr.ransac_samples(566, 5, 4096, 777, n_samples=3).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("n_samples", [4, 6])
+@pytest.mark.parametrize("metric", [1, 0])
+def test_replay_n_samples(lgr, oracle, problem, n_samples, metric):
+    from lgr_amd import capi
+    p_o, p_g = params_pair(oracle, capi, metric_id=metric, score_id=2, n_samples=n_samples)
+    corr = problem["corr"]
+    c, n = corr.shape[0], 6000
+    tup = lgr.ransac_samples(566, 0, n, c, n_samples=n_samples).cpu().numpy()
+    # half of the rows drawn among the inliers only, so that whole tuples get through the polygon test
+    ocorr = to_orc_corr(oracle, corr)
+    omask, _, _, _ = oracle.evaluate(problem["src"], problem["tgt"], ocorr, problem["T_gt"].astype(np.float32), 0, 2)
+    inl = np.flatnonzero(omask)
+    rng = np.random.default_rng(1)
+    tup[: n // 2] = np.sort(np.stack([rng.choice(inl, n_samples, replace=False) for _ in range(n // 2)]), axis=1).astype(np.int32)
+    ok, Ts, ninl, met = lgr.ransac_replay(cuda(problem["src"]), cuda(problem["tgt"]), corr, p_g, cuda(tup))
+    ook, oTs, oninl, omet = oracle.replay(problem["src"], problem["tgt"], ocorr, p_o, tup)
+    np.testing.assert_array_equal(ok, ook)
+    assert ok.sum() > n // 8
+    np.testing.assert_array_equal(bits(Ts), bits(oTs))
+    np.testing.assert_array_equal(ninl, oninl)
+    np.testing.assert_array_equal(bits(met), bits(omet))
+    good = (ninl > 0.3 * c)
+    assert good.sum() > 100 and np.abs(Ts[good].reshape(-1, 4, 4).transpose(0, 2, 1) - problem["T_gt"]).max() < 0.05
+
+
+@pytest.mark.parametrize("n_samples,metric,batch,iters", [(4, 1, 4096, 40000), (5, 0, 1000, 60000)])
+def test_ransac_whole_loop_n_samples(lgr, oracle, problem, n_samples, metric, batch, iters):
+    from lgr_amd import capi
+    p_o, p_g = params_pair(oracle, capi, metric_id=metric, score_id=2, max_iterations=iters, ransac_batch=batch, n_samples=n_samples)
+    corr = problem["corr"]
+    res, mask = lgr.ransac(cuda(problem["src"]), cuda(problem["tgt"]), corr, p_g)
+    ores, omask = oracle.ransac(problem["src"], problem["tgt"], to_orc_corr(oracle, corr), p_o)
+    assert res.iterations == ores.iterations and res.best_iteration == ores.best_iteration
+    assert res.num_rejections == ores.num_rejections and res.estimated_iters == ores.estimated_iters
+    assert res.converged == ores.converged == 1
+    assert res.n_inliers == ores.n_inliers
+    np.testing.assert_array_equal(mask, omask)
+    np.testing.assert_array_equal(bits(res.matrix()), bits(ores.matrix()))
+    assert np.abs(res.matrix() - problem["T_gt"]).max() < 1e-3
+
+
+def test_n_samples_outside_the_built_range_is_unsupported(lgr, problem):
+    from lgr_amd import capi
+    for ns in (2, 9):
+        with pytest.raises(capi.LgrError, match="rc=-5"):
+            lgr.ransac(cuda(problem["src"]), cuda(problem["tgt"]), problem["corr"], capi.default_params(n_samples=ns))

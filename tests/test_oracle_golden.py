@@ -48,8 +48,12 @@ def test_uniform_rand_int_generator_streams(oracle):
 
 
 def _select3_py(r, n):
-    s = [0, 0, 0]
-    for i in range(3):
+    return _select_py(r, n)
+
+
+def _select_py(r, n):
+    s = [0] * len(r)
+    for i in range(len(r)):
         s[i] = r[i] % n
         j = 0
         while j < i:
@@ -79,6 +83,21 @@ def test_select_correspondences_control_flow(oracle):
     C = 100
     assert oracle.select3([3, C - 3, C - 2], C) == [3, 0, C - 2]
     assert oracle.select3([5, 9, 2], 1000) == [2, 5, 10]        # common case: ascending; 9 >= 5 is bumped to 10
+    # the same loops for any n_samples (the reference is generic in it; 3 everywhere it ships)
+    for ns in (3, 4, 5, 8):
+        for n in (ns, ns + 1, 10, 1000):
+            for _ in range(200):
+                r = rng.integers(0, 2 ** 31 - 1, ns).tolist()
+                got = oracle.select_n(r, n)
+                assert got == _select_py(r, n)
+                if ns == 3:
+                    assert got == oracle.select3(r, n)
+    # Philox draws: draw j is word j % 4 of the block with counter (iteration, j / 4, 0, 0), top 31 bits
+    for it in (0, 7, 123456):
+        d = oracle.philox_draws(566, it, 8)
+        assert d[:4] == [w >> 1 for w in oracle.philox(566, it)]
+        assert d[4:] == [w >> 1 for w in oracle.philox_full(566, [it, 1, 0, 0])]
+        assert oracle.philox_draws(566, it, 3) == d[:3]
 
 
 def test_combination_and_estimate_formulas(oracle):

@@ -148,6 +148,16 @@ def test_poly_umeyama_refit(oracle):
     assert np.abs(Tu - T).max() < 2e-4
     R = Tu[:3, :3]
     assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5 and np.linalg.det(R) > 0.999
+    # n points: n = 3 is the 3-point routine bit for bit; more points recover the same motion; the polygon test walks every edge i -> i + 1
+    idx = [4, 9, 17, 23, 31, 40]
+    assert np.array_equal(oracle.umeyama_n(src, tgt, idx[:3], idx[:3]).view(np.uint32), Tu.view(np.uint32))
+    for n in (4, 5, 6):
+        Tn = oracle.umeyama_n(src, tgt, idx[:n], idx[:n])
+        assert np.abs(Tn - T).max() < 2e-4
+        assert oracle.poly_ok_n(src, tgt, idx[:n], idx[:n])
+        bad = list(idx[:n]); bad[-1] = 45
+        assert not oracle.poly_ok_n(src, tgt, idx[:n], bad)        # the last two edges (n-2 -> n-1, n-1 -> 0) are broken
+    assert oracle.poly_ok_n(src, tgt, [0, 1, 2], [0, 1, 2]) == oracle.poly_ok(src, tgt, [0, 1, 2], [0, 1, 2])
     corr = np.zeros(50, oracle.CORR_DTYPE); corr["query"] = np.arange(50); corr["match"] = np.arange(50); corr["threshold"] = 0.1
     Tr = oracle.refit(src, tgt, corr, np.ones(50, np.uint8))
     assert np.abs(Tr - T).max() < 1e-4
@@ -191,6 +201,27 @@ def test_ransac_recovers_ground_truth(oracle, mode):
     assert np.abs(res.matrix() - pr["T_gt"]).max() < 2e-3
     assert res.iterations < 20000                                   # the adaptive bound (src/metric.cpp:103-123) fired
     assert mask.sum() == res.n_inliers
+
+
+@pytest.mark.parametrize("mode,n_samples", [("philox", 4), ("mt_lemire", 5)])
+def test_ransac_recovers_ground_truth_with_more_samples(oracle, mode, n_samples):
+    """AlignmentParameters::n_samples other than 3: sampler, polygon test and Umeyama take n correspondences (src/sac_prerejective_omp.cpp:33-77,
+    105-108, 220); the adaptive bound's exponent is n_samples (src/metric.cpp:116-122)"""
+    pr = synthetic.make_correspondence_problem(n_pts=5000, c=1500, inlier_frac=0.5, seed=13)
+    corr = np.zeros(len(pr["corr"]), oracle.CORR_DTYPE)
+    for a, b in (("query", "index_query"), ("match", "index_match"), ("distance", "distance"), ("threshold", "threshold")):
+        corr[a] = pr["corr"][b]
+    rng_mode = dict(philox=oracle.RNG_PHILOX, mt_lemire=oracle.RNG_MT19937_LEMIRE)[mode]
+    p = oracle.default_params(rng_mode=rng_mode, max_iterations=40000, batch_size=2048, n_threads=4, n_samples=n_samples)
+    res, mask = oracle.ransac(pr["src"], pr["tgt"], corr, p)
+    assert res.converged == 1 and abs(res.n_inliers - 750) < 40
+    assert np.abs(res.matrix() - pr["T_gt"]).max() < 2e-3
+    p3 = oracle.default_params(rng_mode=rng_mode, max_iterations=40000, batch_size=2048, n_threads=4)
+    res3, _ = oracle.ransac(pr["src"], pr["tgt"], corr, p3)
+    assert res.estimated_iters > res3.estimated_iters               # (inlier fraction / 4) ** n_samples in the bound
+    for bad in (2, 9):
+        with pytest.raises(Exception):
+            oracle.ransac(pr["src"], pr["tgt"], corr, oracle.default_params(n_samples=bad))
 
 
 def test_update_hypotheses(oracle):
