@@ -74,6 +74,8 @@ def parse():
                          "8-rank makespan each sharding policy would have from the measured per-pair times")
     ap.add_argument("--job-pairs", type=int, default=156)
     ap.add_argument("--policy", default="lpt", choices=["round_robin", "lpt"], help="sharding policy of --job when N > 1")
+    ap.add_argument("--ransac-schedule", default="default", choices=["default", "chain", "resident"],
+                    help="lgr_ctx_options.ransac_schedule: how the RANSAC loop is driven (never changes results; include/lgr.h)")
     ap.add_argument("--arithmetic", default="fast", choices=["fast", "pcl"],
                     help="lgr_ctx_options.arithmetic: fast (default) or PCL's own FPFH weighting order and rounding steps (include/lgr.h)")
     ap.add_argument("--match-opt", action="append", default=[], metavar="FIELD=VALUE",
@@ -204,7 +206,8 @@ def run_job(args, world, rank, local):
     torch.cuda.set_device(local)
     from lgr_amd import capi
     ctx = capi.Context(local)
-    ctx.set_options(helper_contexts=0 if args.single_context else 1, arithmetic=capi.ARITH_PCL if args.arithmetic == "pcl" else capi.ARITH_FAST)
+    ctx.set_options(helper_contexts=0 if args.single_context else 1, arithmetic=capi.ARITH_PCL if args.arithmetic == "pcl" else capi.ARITH_FAST,
+                    ransac_schedule={"default": 0, "chain": 1, "resident": 2}[args.ransac_schedule])
     per = {}
 
     def align_fn(pid):
@@ -563,7 +566,8 @@ def main():
     torch.cuda.set_device(local)
     from lgr_amd import capi, synthetic, distributed
     ctx = capi.Context(local)
-    ctx.set_options(helper_contexts=0 if args.single_context else 1, arithmetic=capi.ARITH_PCL if args.arithmetic == "pcl" else capi.ARITH_FAST)
+    ctx.set_options(helper_contexts=0 if args.single_context else 1, arithmetic=capi.ARITH_PCL if args.arithmetic == "pcl" else capi.ARITH_FAST,
+                    ransac_schedule={"default": 0, "chain": 1, "resident": 2}[args.ransac_schedule])
     if args.match_opt:
         ctx.set_match_options(**{k: int(v) for k, v in (kv.split("=", 1) for kv in args.match_opt)})
 

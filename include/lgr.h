@@ -129,8 +129,13 @@ typedef struct {
                                    * GPU (the multi-GPU layout) never has two contexts on a device. */
     int32_t arithmetic;           /* LGR_ARITH_FAST (0, default) / LGR_ARITH_PCL (1): see below */
     int32_t pcl_neighbour_cap;    /* LGR_ARITH_PCL: neighbours of a key point sorted at once; 0 default (512), 1024, 64 (tests: drives the shell path).  Never changes results */
-    int32_t reserved[4];
+    int32_t ransac_schedule;      /* how the RANSAC loop (uniformity / correspondences metrics) is driven; never changes results.
+                                   * LGR_RANSAC_SCHEDULE_DEFAULT (0) = LGR_RANSAC_SCHEDULE_CHAIN (1): device-driven chain of launches, six per round;
+                                   * LGR_RANSAC_SCHEDULE_RESIDENT (2): ONE resident kernel for the whole loop (a workgroup per CU, phases handed over
+                                   * at grid barriers).  The plane metrics always use the chain. */
+    int32_t reserved[3];
 } lgr_ctx_options;
+enum { LGR_RANSAC_SCHEDULE_DEFAULT = 0, LGR_RANSAC_SCHEDULE_CHAIN = 1, LGR_RANSAC_SCHEDULE_RESIDENT = 2 };
 /* Arithmetic of the third-party pieces (normals, pair features, FPFH weighting: PCL 1.12.1 behind include/common.h:322-332 and
  * src/common.cpp:644-655).  In BOTH modes the normals are pcl::eigen33's closed form and the pair features use the acosf swap test and the
  * atan2f of the named libm (GNU libc 2.35's float routines restated op for op: csrc/lgr_libm.cuh, pinned against the running libm by

@@ -243,6 +243,7 @@ extern "C" int lgr_ctx_set_options(lgr_ctx* ctx, const lgr_ctx_options* opt) {
     if (opt) o = *opt;
     LGR_CHECK(ctx, (o.helper_contexts == 0 || o.helper_contexts == 1) && (o.concurrent_contexts == 0 || o.concurrent_contexts == 1), LGR_ERR_INVALID_ARG);
     LGR_CHECK(ctx, (o.arithmetic == LGR_ARITH_FAST || o.arithmetic == LGR_ARITH_PCL) && (o.pcl_neighbour_cap == 0 || o.pcl_neighbour_cap == 64 || o.pcl_neighbour_cap == 1024), LGR_ERR_INVALID_ARG);
+    LGR_CHECK(ctx, o.ransac_schedule >= 0 && o.ransac_schedule <= 2, LGR_ERR_INVALID_ARG);
     if (o.helper_contexts != ctx->opt.helper_contexts) {
         // the internal contexts are bound to a stream when they are created: drop them (workspaces included), they come back on
         // first use with the stream the new setting asks for

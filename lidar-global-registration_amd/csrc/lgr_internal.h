@@ -62,7 +62,7 @@ struct lgr_ctx {
     hipEvent_t aux2_ev = nullptr;
     hipStream_t stream3 = nullptr;  // matcher: the column operands are packed on it while the bounds of pass 0 are computed on `stream` (lgr_ctx_stream3)
     hipEvent_t ev3 = nullptr;
-    lgr_ctx_options opt{1, 0, LGR_ARITH_FAST, 0, {0, 0, 0, 0}};   // lgr_ctx_default_options
+    lgr_ctx_options opt{1, 0, LGR_ARITH_FAST, 0, 0, {0, 0, 0}};   // lgr_ctx_default_options
     lgr_helper* helper = nullptr;               // of an internal context: the host thread that drives it (opt.helper_contexts)
     lgr_match_stats mstats{};                   // lgr_match_last_*: the last match call of THIS context
     double mcheck[2] = {-1, -1};

@@ -288,10 +288,10 @@ struct CPair { v2f_c sx, sy, sz, qx, qy, qz, ss, rs; };
 static_assert(sizeof(CPair) == CP_FLOATS * 4, "pack_kernel writes this layout");
 
 __device__ __forceinline__ void count_item(const int bx /* block of CB hypotheses */, const int by /* chunk of cch correspondences */,
-                                           const float* __restrict__ Ts, const int* __restrict__ list, int nh,
-                                           const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* __restrict__ counts,
-                                           unsigned* __restrict__ maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */, int cch) {
-    const int h = bx * CB + threadIdx.x;
+                                           const float* Ts, const int* list, int nh,
+                                           const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* counts,
+                                           unsigned* maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */, int cch, const int lane) {
+    const int h = bx * CB + lane;
     const bool act = h < nh;
     float T[16];
     {
@@ -370,7 +370,7 @@ __host__ __device__ inline int count_chunk(int nh, int c) {
 __global__ __launch_bounds__(CB) void count_kernel(const float* __restrict__ Ts, const int* __restrict__ list, int nh,
                                                     const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* __restrict__ counts,
                                                     unsigned* __restrict__ maskT, int cch) {
-    count_item(blockIdx.x, blockIdx.y, Ts, list, nh, PP, pstats, c, counts, maskT, cch);
+    count_item(blockIdx.x, blockIdx.y, Ts, list, nh, PP, pstats, c, counts, maskT, cch, threadIdx.x);
 }
 // the same over a work list whose size only the device knows (device-driven schedule, lgr_ransac_dev): nh = *nh_dev hypotheses, a fixed
 // grid of single-wave workgroups strides over the (hypothesis block, chunk) items, hypothesis blocks fastest (neighbouring workgroups
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(CB) void count_list_kernel(const float* __restrict_
     const long long items = (long long) hb_n * ((c + cch - 1) / cch);
     unsigned* const mt = nh <= mask_cap ? maskT : nullptr;
     for (long long it = blockIdx.x; it < items; it += gridDim.x)
-        count_item((int) (it % hb_n), (int) (it / hb_n), Ts, list, nh, PP, pstats, c, counts, mt, cch);
+        count_item((int) (it % hb_n), (int) (it / hb_n), Ts, list, nh, PP, pstats, c, counts, mt, cch, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------- phase 2
@@ -440,32 +440,26 @@ __global__ __launch_bounds__(256) void inlier_hist_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&ghist[30000], __popcll(m));
 }
 
-__global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts, const int* __restrict__ list2, int nh2,
-                                                     const float4* __restrict__ P0, const float4* __restrict__ P1,
-                                                     const float* __restrict__ sstar, int c, int metric_id, int score_id,
-                                                     float* __restrict__ metric_out, int* __restrict__ ninl_out,
-                                                     float* __restrict__ rmse_out, uint8_t* __restrict__ mask,
-                                                     float2* __restrict__ scratch /* [gridDim.x][c] inlier (dist, thr) lists */,
-                                                     const unsigned* __restrict__ maskT /* count_kernel's inlier bits [words][mask_nh], or nullptr */,
-                                                     const int* __restrict__ hpos /* candidate -> column of maskT */, int mask_nh,
-                                                     const int* __restrict__ ghist = nullptr /* [30000 + 1]: the uniformity histogram and the inlier count of the ONE
-                                                        hypothesis, already counted by inlier_hist_kernel (single-transform evaluations) */,
-                                                     const int* __restrict__ nh2_dev = nullptr /* device-driven schedule: the number of candidates lives on the
-                                                        device and the grid strides over them; maskT is used when mask_nh_dev[0] <= mask_nh */,
-                                                     const int* __restrict__ mask_nh_dev = nullptr) {
+// (the body: one workgroup of MB threads = workgroup `wg` of `n_wg`; the resident RANSAC kernel runs it as one of its phases.  No __restrict__
+// on what another phase of that kernel writes.)
+__device__ __forceinline__ void metric_body(const int tid, const int wg, const int n_wg, const float* Ts, const int* list2, int nh2,
+                                            const float4* __restrict__ P0, const float4* __restrict__ P1,
+                                            const float* __restrict__ sstar, int c, int metric_id, int score_id,
+                                            float* metric_out, int* ninl_out, float* rmse_out, uint8_t* mask,
+                                            float2* scratch, const unsigned* maskT, const int* hpos, int mask_nh,
+                                            const int* ghist, const int* nh2_dev, const int* mask_nh_dev) {
     extern __shared__ int hist[];   // 30000 ints (uniformity) + 64 ints scan scratch
     __shared__ float T[16];
     __shared__ int s_count;
     __shared__ int s_nnz[3];
     __shared__ float ent[3];
-    const int tid = threadIdx.x;
     if (nh2_dev) {
         nh2 = *nh2_dev;
         const int cols = *mask_nh_dev;   // hypotheses count_list_kernel wrote mask columns for (its stride)
         if (cols > mask_nh) maskT = nullptr;
         mask_nh = cols;
     }
-  for (int hb = blockIdx.x; hb < nh2; hb += gridDim.x) {
+  for (int hb = wg; hb < nh2; hb += n_wg) {
     __syncthreads();   // the previous candidate of this workgroup is finished with the shared arrays
     int hyp = list2 ? list2[hb] : hb;
     if (tid < 16) T[tid] = Ts[(size_t) hyp * 16 + tid];
@@ -473,7 +467,7 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
     if (uni) for (int i = tid; i < 30000; i += MB) hist[i] = 0;
     if (tid == 0) s_count = 0;
     int* scan = hist + 30000;
-    float2* lst = scratch ? scratch + (size_t) blockIdx.x * c : nullptr;   // one list per workgroup
+    float2* lst = scratch ? scratch + (size_t) wg * c : nullptr;   // one list per workgroup
     __syncthreads();
     const bool from_hist = ghist && uni && !lst;
     if (from_hist) {
@@ -600,6 +594,22 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
         if (rmse_out) rmse_out[hb] = n_inl ? __builtin_sqrtf(rm / (float) n_inl) : 3.4028234663852886e38f;
     }
   }
+}
+__global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts, const int* __restrict__ list2, int nh2,
+                                                     const float4* __restrict__ P0, const float4* __restrict__ P1,
+                                                     const float* __restrict__ sstar, int c, int metric_id, int score_id,
+                                                     float* __restrict__ metric_out, int* __restrict__ ninl_out,
+                                                     float* __restrict__ rmse_out, uint8_t* __restrict__ mask,
+                                                     float2* __restrict__ scratch /* [gridDim.x][c] inlier (dist, thr) lists */,
+                                                     const unsigned* __restrict__ maskT /* count_kernel's inlier bits [words][mask_nh], or nullptr */,
+                                                     const int* __restrict__ hpos /* candidate -> column of maskT */, int mask_nh,
+                                                     const int* __restrict__ ghist = nullptr /* [30000 + 1]: the uniformity histogram and the inlier count of the ONE
+                                                        hypothesis, already counted by inlier_hist_kernel (single-transform evaluations) */,
+                                                     const int* __restrict__ nh2_dev = nullptr /* device-driven schedule: the number of candidates lives on the
+                                                        device and the grid strides over them; maskT is used when mask_nh_dev[0] <= mask_nh */,
+                                                     const int* __restrict__ mask_nh_dev = nullptr) {
+    metric_body(threadIdx.x, blockIdx.x, gridDim.x, Ts, list2, nh2, P0, P1, sstar, c, metric_id, score_id, metric_out, ninl_out, rmse_out, mask, scratch, maskT, hpos, mask_nh,
+                ghist, nh2_dev, mask_nh_dev);
 }
 
 // ---------------------------------------------------------------------------------------------------- batch reduce
@@ -809,15 +819,18 @@ struct RState {
     int rounds;
     int metric_id, c, nr_samples;
     float confidence;
-    int pad0[3];
+    unsigned bar_count, bar_gen; int abort;                   // the resident kernel's grid barrier (arrivals, generation) and its time-out flag
     float best_T[16];
     float Tn[16];
     float e_metric; int e_ninl; float e_rmse; int pad1;       // evaluation of best_T (the final block, :265-296)
     float e2_metric; int e2_ninl; float e2_rmse; int pad2;    // evaluation of the refit
-    int int_max, pad3[3];                                      // (a constant the plane gate reads where the records are not plane counts)
+    int int_max, tot_ok, tot_cand, pad3;                       // (int_max: a constant the plane gate reads where the records are not plane counts; tot_*: survivors / candidates over all rounds, for LGR_RANSAC_DEBUG)
+    unsigned long long phase_ticks[8];                         // resident kernel: 100 MHz ticks workgroup 0 spent per phase incl. its barrier (begin/replay, hyp, count, cand, metric)
+    unsigned long long busy_max[8], busy_sum[8];               // ... and the workgroups' own work per phase (without the barrier): maximum and sum over the workgroups
 };
 
-__device__ inline int est_from_support_dev(int count, int c, float confidence, int nr_samples) {   // = est_from_support below
+__device__ __noinline__ int est_from_support_dev(int count, int c, float confidence, int nr_samples) {   // = est_from_support below
+    // (a real call: inlined, its double-precision log / pow bring ~100 registers of constants that the resident kernel's loop would carry)
     float frac = (float) count / (float) c;
     frac /= 4.f;
     if (frac <= 0.0 || log(1.0 - pow((double) frac, (double) nr_samples)) >= 0.0) return INT_MAX;
@@ -825,7 +838,13 @@ __device__ inline int est_from_support_dev(int count, int c, float confidence, i
     return (int) fmin((double) INT_MAX, iterations);
 }
 
-__global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__ st, int first_round) {
+__device__ __noinline__ int rs_gate_dev(float final_metric, int metric_id, int c) {   // (a real call for the same reason as est_from_support_dev)
+    int mi = MIN_NR_INLIERS;
+    if (final_metric > 0.f && metric_id == LGR_METRIC_UNIFORMITY) mi = max(mi, (int) floor(pow(10000.0, (double) final_metric / 1.001)) - 1);
+    else if (final_metric > 0.f && metric_id == LGR_METRIC_CORRESPONDENCES) mi = max(mi, (int) floor((double) final_metric * (double) c / 1.001) - 1);
+    return mi;
+}
+__device__ __forceinline__ void rs_begin_body(RState* S, BatchStats* st, int first_round) {
     if (threadIdx.x < MAX_ROUND_BATCHES) { BatchStats z{}; st[threadIdx.x] = z; }
     if (threadIdx.x != 0) return;
     S->n_ok = 0; S->n_cand = 0; S->round_nb = 0; S->round_batches = 0;
@@ -836,9 +855,7 @@ __global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__
     const int nb = (int) min((long long) n_batches * S->batch, (long long) S->max_iterations - S->done);
     n_batches = (nb + S->batch - 1) / S->batch;
     // candidate gate (see lgr_ransac_dev): a hypothesis whose metric cannot reach the best one so far is not scored
-    int mi = MIN_NR_INLIERS;
-    if (S->final_metric > 0.f && S->metric_id == LGR_METRIC_UNIFORMITY) mi = max(mi, (int) floor(pow(10000.0, (double) S->final_metric / 1.001)) - 1);
-    else if (S->final_metric > 0.f && S->metric_id == LGR_METRIC_CORRESPONDENCES) mi = max(mi, (int) floor((double) S->final_metric * (double) S->c / 1.001) - 1);
+    int mi = rs_gate_dev(S->final_metric, S->metric_id, S->c);
     // ... and it must not hide a RECORD inlier set (:224-228 feed the adaptive bound from every hypothesis with >= MIN_NR_INLIERS): only counts
     // up to the record so far are safe to drop.  When the best metric is a loop hypothesis's, its own count already is >= the gate and <= the
     // record, so this changes nothing; a GUESS (:134-147) sets the metric to beat without ever entering the record.
@@ -847,14 +864,13 @@ __global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__
     S->round_first = S->done; S->round_nb = nb; S->round_batches = n_batches;
     S->rounds += 1;
 }
+__global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__ st, int first_round) { rs_begin_body(S, st, first_round); }
 
+// iteration `b` of the round (b - lane is wave-uniform; a wave wholly behind the round's end does nothing)
 template <int NS>
-__global__ void rs_hyp_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
-                              unsigned long long seed, RState* __restrict__ S, float edge_thr, float* __restrict__ Ts, int* __restrict__ list,
-                              int* __restrict__ posmap, int2* __restrict__ counts) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rs_hyp_item(const int b, const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
+                                            unsigned long long seed, RState* S, float edge_thr, float* Ts, int* list, int* posmap, int2* counts) {
     const int nb = S->round_nb;
-    if (b - (int) threadIdx.x >= nb) return;   // (whole workgroup; S->stop leaves round_nb = 0)
     bool good = false;
     if (b < nb) {
         counts[b] = make_int2(0, 0);   // (list positions are < the survivors' number <= nb)
@@ -885,36 +901,43 @@ __global__ void rs_hyp_kernel(const float* __restrict__ src, const float* __rest
         posmap[b] = pos;
     }
 }
+template <int NS>
+__global__ void rs_hyp_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
+                              unsigned long long seed, RState* __restrict__ S, float edge_thr, float* __restrict__ Ts, int* __restrict__ list,
+                              int* __restrict__ posmap, int2* __restrict__ counts) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b - (int) threadIdx.x >= S->round_nb) return;   // (whole workgroup; S->stop leaves round_nb = 0)
+    rs_hyp_item<NS>(b, src, tgt, corr, c, seed, S, edge_thr, Ts, list, posmap, counts);
+}
 
 // candidates = survivors with enough inliers for the gate.  Up to 2^17 survivors ONE workgroup compacts them in list order (an ordered
 // block scan per 1024 survivors): the metric kernel walks the inlier-mask column hpos[candidate] of every candidate, a 4-byte read per
 // 128 KB row -- neighbouring workgroups then share the cache lines of neighbouring columns (with the candidates in arrival order of an
 // atomic append the same launch took 1.9 instead of 0.5 ms at 9.5 k candidates).  Beyond that all workgroups append unordered.
-__global__ __launch_bounds__(1024) void rs_cand_kernel(RState* __restrict__ S, const int2* __restrict__ counts, const int* __restrict__ list,
-                                                       int* __restrict__ list2, int* __restrict__ hpos) {
+__device__ __forceinline__ void rs_cand_body(const int tid, const int wg, const int n_wg, RState* S, const int2* counts, const int* list, int* list2, int* hpos) {
     __shared__ int scan[1024 / 64 + 2];
     const int n_ok = S->n_ok, mi = S->min_inliers;
     if (n_ok <= (1 << 17)) {
-        if (blockIdx.x != 0) return;
+        if (wg != 0) return;
         int total = 0;
         for (int h0 = 0; h0 < n_ok; h0 += 1024) {
-            const int h = h0 + threadIdx.x;
+            const int h = h0 + tid;
             const bool cand = h < n_ok && counts[h].x >= mi;
             int tot;
-            const int pos = total + block_excl_scan_1024(cand ? 1 : 0, scan, threadIdx.x, &tot);
+            const int pos = total + block_excl_scan_1024(cand ? 1 : 0, scan, tid, &tot);
             if (cand) { list2[pos] = list[h]; hpos[pos] = h; }
             total += tot;
         }
-        if (threadIdx.x == 0) S->n_cand = total;
+        if (tid == 0) S->n_cand = total;
         return;
     }
-    for (int h0 = blockIdx.x * blockDim.x; h0 < n_ok; h0 += gridDim.x * blockDim.x) {
-        const int h = h0 + threadIdx.x;
+    for (int h0 = wg * 1024; h0 < n_ok; h0 += n_wg * 1024) {
+        const int h = h0 + tid;
         const bool cand = h < n_ok && counts[h].x >= mi;
         const unsigned long long m = __ballot(cand);
         if (m == 0ull) continue;
         int base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(&S->n_cand, __popcll(m));
+        if ((tid & 63) == 0) base = atomicAdd(&S->n_cand, __popcll(m));
         base = __shfl(base, 0);
         if (cand) {
             const int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u));
@@ -924,13 +947,17 @@ __global__ __launch_bounds__(1024) void rs_cand_kernel(RState* __restrict__ S, c
     }
 }
 
-__global__ __launch_bounds__(1024) void rs_replay_kernel(RState* __restrict__ S, const int* __restrict__ list, const int* __restrict__ list2,
-                                                          const float* __restrict__ metric, const int* __restrict__ ninl, const int2* __restrict__ counts,
-                                                          const int* __restrict__ posmap, const float* __restrict__ Ts, BatchStats* __restrict__ st_out) {
+__global__ __launch_bounds__(1024) void rs_cand_kernel(RState* __restrict__ S, const int2* __restrict__ counts, const int* __restrict__ list,
+                                                       int* __restrict__ list2, int* __restrict__ hpos) {
+    rs_cand_body(threadIdx.x, blockIdx.x, gridDim.x, S, counts, list, list2, hpos);
+}
+
+__device__ __forceinline__ void rs_replay_body(const int tid, RState* S, const int* list, const int* list2, const float* metric, const int* ninl, const int2* counts,
+                                               const int* posmap, const float* Ts, BatchStats* st_out) {
     __shared__ unsigned long long best_key[MAX_ROUND_BATCHES], rec_key[MAX_ROUND_BATCHES];
     __shared__ int n_ok_b[MAX_ROUND_BATCHES];
-    const int tid = threadIdx.x;
     if (S->stop || S->round_nb == 0) return;
+    if (tid == 0) { S->tot_ok += S->n_ok; S->tot_cand += S->n_cand; }
     if (tid < MAX_ROUND_BATCHES) { best_key[tid] = 0ull; rec_key[tid] = 0ull; n_ok_b[tid] = 0; }
     __syncthreads();
     const int batch = S->batch, n_ok = S->n_ok, n_cand = S->n_cand;
@@ -971,6 +998,136 @@ __global__ __launch_bounds__(1024) void rs_replay_kernel(RState* __restrict__ S,
         for (int i = 0; i < 16; ++i) S->best_T[i] = Ts[(size_t) best_off * 16 + i];
     S->done = done; S->bound = bound; S->largest = largest; S->num_rejections = num_rej; S->best_iter = best_iter; S->final_metric = final_metric;
     if (done >= bound || done >= max_it) S->stop = 1;
+}
+__global__ __launch_bounds__(1024) void rs_replay_kernel(RState* __restrict__ S, const int* __restrict__ list, const int* __restrict__ list2,
+                                                          const float* __restrict__ metric, const int* __restrict__ ninl, const int2* __restrict__ counts,
+                                                          const int* __restrict__ posmap, const float* __restrict__ Ts, BatchStats* __restrict__ st_out) {
+    rs_replay_body(threadIdx.x, S, list, list2, metric, ninl, counts, posmap, Ts, st_out);
+}
+
+// ---------------------------------------------------------------------------------------------------- the resident loop
+// north_star's "persistent-thread RANSAC": the phases of a round above as ONE kernel whose workgroups stay resident for the whole loop and hand
+// over at grid barriers.  One workgroup of 1024 threads per CU (the metric phase's shape: 117 KB of LDS for the uniformity histogram); the
+// hypothesis phase strides threads over the round's iterations, the counting phase strides WAVES over the (hypothesis block, chunk) items,
+// the candidate / replay phases run in workgroup 0, the metric phase strides workgroups over the candidates.  The state (RState) and every
+// list live in global memory exactly as in the launch chain, so the results are the chain's bit for bit.
+//   * barrier: arrivals counted with a device-scope atomic, the last arrival bumps a generation word the others poll with device-scope loads;
+//     a release fence before arriving and an acquire fence after leaving carry the phase's plain stores across the XCDs' L2s.
+//   * every wave reaches the end of the kernel: the loop runs at most `max_rounds` rounds (the host's bound: every round consumes at least one
+//     batch), and a workgroup that polls longer than RS_BARRIER_TICKS of the 100 MHz wall clock sets `abort`, on which every workgroup leaves
+//     at its next poll (the host then reports LGR_ERR_HIP; it cannot happen unless a workgroup of the grid never becomes resident).
+constexpr unsigned long long RS_BARRIER_TICKS = 200000000ull;   // 2 s
+__device__ __forceinline__ bool rs_grid_barrier(RState* S, const unsigned n_wg) {
+    __shared__ int s_go;   // the workgroup's one reading of `abort` (every wave takes the same way out)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();   // release: this workgroup's stores of the phase (the barrier above ordered the other waves' before this one)
+        const unsigned gen = __hip_atomic_load(&S->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&S->bar_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == n_wg - 1u) {
+            __hip_atomic_store(&S->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&S->bar_gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&S->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(8);
+                if (__hip_atomic_load(&S->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (wall_clock64() - t0 > RS_BARRIER_TICKS) { __hip_atomic_store(&S->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __threadfence();   // acquire: the other workgroups' stores
+        s_go = __hip_atomic_load(&S->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    }
+    __syncthreads();
+    return s_go != 0;
+}
+
+// what the loop WRITES (and reads back in a later phase) travels in this struct; what it only reads are kernel arguments of their own with
+// const __restrict__: only those may go through scalar loads (count_item's wave-uniform pair records) -- a pointer out of a struct carries
+// no such promise, and the counting phase then fetched every record once per LANE (measured: twice the time, 80 spilled registers)
+struct ResidentArgs {
+    int c; int n_samples;
+    unsigned long long seed; float edge_thr;
+    RState* S; BatchStats* st;
+    float* Ts; int* list; int* posmap; int2* counts; int* list2; int* hpos; float* metric; int* ninl;
+    unsigned* maskT; int mask_cap; float2* scratch;
+    int metric_id, score_id, max_rounds;
+};
+
+__global__ __launch_bounds__(MB) void rs_resident_kernel(const ResidentArgs a, const float* __restrict__ in_src, const float* __restrict__ in_tgt,
+                                                         const lgr_corr* __restrict__ in_corr, const CPair* __restrict__ in_PP,
+                                                         const unsigned* __restrict__ in_pstats, const float4* __restrict__ in_P0,
+                                                         const float4* __restrict__ in_P1, const float* __restrict__ in_sstar) {
+    const int wg = blockIdx.x, n_wg = gridDim.x, tid = threadIdx.x;
+    RState* const S = a.S;
+    if (wg == 0) rs_begin_body(S, a.st, 1);
+    unsigned long long t_prev = wall_clock64();
+    auto stamp = [&](int phase) {   // (workgroup 0's view of where the loop's time goes: LGR_RANSAC_DEBUG prints it)
+        if (wg == 0 && tid == 0) { const unsigned long long t = wall_clock64(); S->phase_ticks[phase] += t - t_prev; t_prev = t; }
+    };
+    unsigned long long busy[5] = {0, 0, 0, 0, 0}, t_in = t_prev;
+    auto work_begin = [&]() { if (tid == 0) t_in = wall_clock64(); };
+    auto work_end = [&](int phase) { if (tid == 0) busy[phase] += wall_clock64() - t_in; };
+    for (int round = 0; round < a.max_rounds; ++round) {
+        if (!rs_grid_barrier(S, n_wg)) return;
+        stamp(0);
+        if (S->stop) {
+            if (tid == 0)
+                for (int k = 1; k < 5; ++k) { atomicMax(&S->busy_max[k], busy[k]); atomicAdd(&S->busy_sum[k], busy[k]); }
+            return;
+        }
+        work_begin();   // (written by workgroup 0 in front of the barrier: every workgroup reads the same value)
+        // ---- sample -> prerejection -> transform
+        {
+            const int nb = S->round_nb;
+            int tid_h = tid;
+            asm volatile("" : "+v"(tid_h));   // (opaque per round and phase: per-thread values are recomputed in the phase that uses them instead of being carried -- spilled -- through the others)
+            for (int b0 = wg * MB + (tid_h & ~63); b0 < nb; b0 += n_wg * MB) {
+                const int b = b0 + (tid_h & 63);
+                LGR_NS_DISPATCH(a.n_samples, (rs_hyp_item<NS>(b, in_src, in_tgt, in_corr, a.c, a.seed, S, a.edge_thr, a.Ts, a.list, a.posmap, a.counts)));
+            }
+        }
+        work_end(1);
+        if (!rs_grid_barrier(S, n_wg)) return;
+        stamp(1);
+        work_begin();
+        // ---- inlier counts of the survivors
+        {
+            const int nh = S->n_ok;
+            if (nh > 0) {
+                const int hb_n = (nh + CB - 1) / CB, cch = count_chunk(nh, a.c);
+                const long long items = (long long) hb_n * ((a.c + cch - 1) / cch);
+                unsigned* const mt = nh <= a.mask_cap ? a.maskT : nullptr;
+                int tid_c = tid;
+                asm volatile("" : "+v"(tid_c));
+                const int wave = __builtin_amdgcn_readfirstlane(tid_c >> 6);   // (uniform for the compiler too: the item's correspondences come through scalar loads)
+                for (long long it = (long long) wg * (MB / 64) + wave; it < items; it += (long long) n_wg * (MB / 64))
+                    count_item((int) (it % hb_n), (int) (it / hb_n), a.Ts, a.list, nh, in_PP, in_pstats, a.c, a.counts, mt, cch, tid_c & 63);
+            }
+        }
+        work_end(2);
+        if (!rs_grid_barrier(S, n_wg)) return;
+        stamp(2);
+        work_begin();
+        int tid_m = tid;
+        asm volatile("" : "+v"(tid_m));
+        rs_cand_body(tid_m, wg, n_wg, S, a.counts, a.list, a.list2, a.hpos);
+        work_end(3);
+        if (!rs_grid_barrier(S, n_wg)) return;
+        stamp(3);
+        work_begin();
+        asm volatile("" : "+v"(tid_m));
+        metric_body(tid_m, wg, n_wg, a.Ts, a.list2, 0, in_P0, in_P1, in_sstar, a.c, a.metric_id, a.score_id, a.metric, a.ninl, nullptr, nullptr, a.scratch, a.maskT, a.hpos,
+                    a.mask_cap, nullptr, &S->n_cand, &S->n_ok);
+        work_end(4);
+        if (!rs_grid_barrier(S, n_wg)) return;
+        stamp(4);
+        if (wg == 0) {
+            asm volatile("" : "+v"(tid_m));
+            rs_replay_body(tid_m, S, a.list, a.list2, a.metric, a.ninl, a.counts, a.posmap, a.Ts, a.st);
+            __syncthreads();
+            rs_begin_body(S, a.st, 0);   // the next round's range (or `stop`)
+        }
+    }
 }
 // closest-plane / combination metrics inside the device-driven schedule (round 5): run_batch's plumbing kernels with their extents read from the
 // RState (fixed grids striding over them)
@@ -1465,8 +1622,41 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
         LGR_HIP(ctx, hipGetLastError());
         return LGR_OK;
     };
+    // 0 (default) and 1: the launch chain; 2: the resident kernel (one launch for the whole loop; not for the plane metrics)
+    const bool resident = ctx->opt.ransac_schedule == 2 && !plane;
+    if (resident) {
+        LGR_HIP(ctx, hipFuncSetAttribute((const void*) rs_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) metric_smem()));
+        int per_cu = 0;
+        LGR_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*) rs_resident_kernel, MB, metric_smem()));
+        LGR_CHECK(ctx, per_cu >= 1 && g_metric >= 1, LGR_ERR_HIP);   // (the grid must fit the device at once: one workgroup per CU)
+        ResidentArgs ra{};
+        ra.c = c; ra.n_samples = p->n_samples; ra.seed = seed; ra.edge_thr = p->edge_thr_coef;
+        ra.S = dS; ra.st = b.st; ra.Ts = b.Ts; ra.list = b.list; ra.posmap = posmap; ra.counts = b.counts; ra.list2 = b.list2; ra.hpos = b.hpos;
+        ra.metric = b.metric; ra.ninl = b.ninl;
+        ra.maskT = maskT; ra.mask_cap = mask_cap; ra.scratch = scratch; ra.metric_id = p->metric_id; ra.score_id = p->score_id;
+        ra.max_rounds = (int) std::min<long long>(((long long) max_iterations + batch - 1) / batch + 2, INT_MAX);
+        rs_resident_kernel<<<g_metric, MB, metric_smem(), ctx->stream>>>(ra, d_src, d_tgt, d_corr, pk.PP, pk.pstats, pk.P0, pk.P1, pk.sstar);
+        LGR_HIP(ctx, hipGetLastError());
+        LGR_TRY(evaluate_one_dev(ctx, dS->best_T, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e_metric));
+        LGR_TRY(refit_launch_dev(ctx, pk, c, d_mask, dS->Tn));
+        LGR_TRY(evaluate_one_dev(ctx, dS->Tn, pk, c, p->metric_id, p->score_id, d_mask, d_ev, &dS->e2_metric));
+        LGR_HIP(ctx, hipMemcpyAsync(hS, dS, sizeof(RState), hipMemcpyDeviceToHost, ctx->stream));
+        LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ransac_debug) fprintf(stderr, "[lgr] ransac (resident kernel, %d workgroups) after %d rounds: done %d bound %d largest %d best metric %.4f stop %d abort %d\n", g_metric,
+                                  hS->rounds, hS->done, hS->bound, hS->largest, hS->final_metric, hS->stop, hS->abort);
+        if (ransac_debug) fprintf(stderr, "[lgr]   %d survivors, %d candidates in all\n", hS->tot_ok, hS->tot_cand);
+        if (ransac_debug) fprintf(stderr, "[lgr]   workgroup 0, us per phase incl. barrier: begin/replay %.1f hyp %.1f count %.1f cand %.1f metric %.1f\n", hS->phase_ticks[0] * 0.01,
+                                  hS->phase_ticks[1] * 0.01, hS->phase_ticks[2] * 0.01, hS->phase_ticks[3] * 0.01, hS->phase_ticks[4] * 0.01);
+        if (ransac_debug) fprintf(stderr, "[lgr]   own work per workgroup, us, max / mean: hyp %.1f / %.1f count %.1f / %.1f cand %.1f / %.1f metric %.1f / %.1f\n",
+                                  hS->busy_max[1] * 0.01, hS->busy_sum[1] * 0.01 / g_metric, hS->busy_max[2] * 0.01, hS->busy_sum[2] * 0.01 / g_metric,
+                                  hS->busy_max[3] * 0.01, hS->busy_sum[3] * 0.01 / g_metric, hS->busy_max[4] * 0.01, hS->busy_sum[4] * 0.01 / g_metric);
+        if (hS->abort || !hS->stop) {
+            ctx->err = "resident RANSAC kernel: a grid barrier timed out (a workgroup of the grid did not become resident) or the loop did not end";
+            return LGR_ERR_HIP;
+        }
+    }
     bool first = true;
-    for (;;) {
+    while (!resident) {
         LGR_TRY(enqueue_round(first));
         first = false;
         LGR_TRY(enqueue_round(false));
@@ -1478,8 +1668,8 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
         }
         LGR_HIP(ctx, hipMemcpyAsync(hS, dS, sizeof(RState), hipMemcpyDeviceToHost, ctx->stream));
         LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ransac_debug) fprintf(stderr, "[lgr] ransac (device schedule) after %d rounds: done %d bound %d largest %d best metric %.4f stop %d\n", hS->rounds, hS->done, hS->bound,
-                                  hS->largest, hS->final_metric, hS->stop);
+        if (ransac_debug) fprintf(stderr, "[lgr] ransac (device schedule) after %d rounds: done %d bound %d largest %d best metric %.4f stop %d (%d survivors, %d candidates in all)\n",
+                                  hS->rounds, hS->done, hS->bound, hS->largest, hS->final_metric, hS->stop, hS->tot_ok, hS->tot_cand);
         if (hS->stop) break;
     }
     if (plane) {   // the caller's final block takes over

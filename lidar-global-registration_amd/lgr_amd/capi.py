@@ -66,9 +66,10 @@ class MatchOptions(C.Structure):
 class CtxOptions(C.Structure):
     """lgr_ctx_options (include/lgr.h): how the context uses host threads and streams, never what it returns."""
     _fields_ = [("helper_contexts", C.c_int32), ("concurrent_contexts", C.c_int32), ("arithmetic", C.c_int32), ("pcl_neighbour_cap", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("ransac_schedule", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
+RANSAC_SCHEDULE_DEFAULT, RANSAC_SCHEDULE_CHAIN, RANSAC_SCHEDULE_RESIDENT = 0, 1, 2   # lgr_ctx_options.ransac_schedule
 ARITH_FAST, ARITH_PCL = 0, 1   # lgr_ctx_options.arithmetic (include/lgr.h): the FPFH weighting as one fused chain in grid order / exactly as PCL writes it
 LIBM_ACOSF, LIBM_ATANF, LIBM_ATAN2F, LIBM_SINF, LIBM_COSF = 0, 1, 2, 3, 4
 

@@ -307,3 +307,82 @@ def test_n_samples_outside_the_built_range_is_unsupported(lgr, problem):
     for ns in (2, 9):
         with pytest.raises(capi.LgrError, match="rc=-5"):
             lgr.ransac(cuda(problem["src"]), cuda(problem["tgt"]), problem["corr"], capi.default_params(n_samples=ns))
+
+
+# ---- the resident kernel (lgr_ctx_options.ransac_schedule = 2): ONE launch for the whole loop; results are the launch chain's and the oracle's --------
+@pytest.fixture()
+def resident(lgr):
+    from lgr_amd import capi
+    lgr.set_options(ransac_schedule=capi.RANSAC_SCHEDULE_RESIDENT)
+    yield lgr
+    lgr.set_options()
+
+
+def _same_result(a, b, ma, mb):
+    for f in ("iterations", "best_iteration", "num_rejections", "estimated_iters", "converged", "n_inliers"):
+        assert getattr(a, f) == getattr(b, f), f
+    np.testing.assert_array_equal(bits(a.matrix()), bits(b.matrix()))
+    assert np.float32(a.metric).view(np.uint32) == np.float32(b.metric).view(np.uint32)
+    np.testing.assert_array_equal(ma, mb)
+
+
+@pytest.mark.parametrize("metric,batch,iters,n_samples", [(1, 4096, 20000, 3), (0, 16384, 50000, 3), (1, 1000, 3000, 3), (1, 256, 20000, 3), (0, 300, 30000, 3),
+                                                          (0, 64, 12000, 3), (1, 65536, 1000000, 3), (1, 4096, 40000, 4), (0, 1000, 60000, 5), (1, 7, 1, 3)])
+def test_resident_kernel_whole_loop(lgr, oracle, problem, metric, batch, iters, n_samples):
+    from lgr_amd import capi
+    p_o, p_g = params_pair(oracle, capi, metric_id=metric, score_id=2, max_iterations=iters, ransac_batch=batch, n_samples=n_samples)
+    corr = problem["corr"]
+    src, tgt = cuda(problem["src"]), cuda(problem["tgt"])
+    chain, cmask = lgr.ransac(src, tgt, corr, p_g)
+    try:
+        lgr.set_options(ransac_schedule=capi.RANSAC_SCHEDULE_RESIDENT)
+        res, mask = lgr.ransac(src, tgt, corr, p_g)
+        res2, mask2 = lgr.ransac(src, tgt, corr, p_g)     # (the barrier words start from the host's record every time)
+    finally:
+        lgr.set_options()
+    _same_result(res, chain, mask, cmask)
+    _same_result(res2, chain, mask2, cmask)
+    ores, omask = oracle.ransac(problem["src"], problem["tgt"], to_orc_corr(oracle, corr), p_o)
+    _same_result(res, ores, mask, omask)
+    if iters > 1:
+        assert res.converged == 1 and np.abs(res.matrix() - problem["T_gt"]).max() < 1e-3
+
+
+def test_resident_kernel_guess_and_degenerate(resident, oracle, problem):
+    from lgr_amd import capi
+    lgr = resident
+    corr = problem["corr"]
+    src, tgt = cuda(problem["src"]), cuda(problem["tgt"])
+    # a good guess (the gate of ADVICE r4): iterations / estimated_iters still the oracle's
+    p_o, p_g = params_pair(oracle, capi, metric_id=1, score_id=2, max_iterations=20000, ransac_batch=1000, guess=problem["T_gt"].astype(np.float32))
+    res, mask = lgr.ransac(src, tgt, corr, p_g)
+    ores, omask = oracle.ransac(problem["src"], problem["tgt"], to_orc_corr(oracle, corr), p_o)
+    _same_result(res, ores, mask, omask)
+    # nothing reaches MIN_NR_INLIERS: the loop runs to max_iterations and ends not converged
+    p_o, p_g = params_pair(oracle, capi, metric_id=1, max_iterations=2000)
+    rng = np.random.default_rng(0)
+    bad = corr.copy()
+    bad["index_match"] = rng.integers(0, problem["tgt"].shape[0], bad.shape[0])
+    res, mask = lgr.ransac(src, tgt, bad, p_g)
+    ores, omask = oracle.ransac(problem["src"], problem["tgt"], to_orc_corr(oracle, bad), p_o)
+    assert res.converged == ores.converged == 0 and res.iterations == ores.iterations and res.num_rejections == ores.num_rejections
+    # fewer correspondences than samples: refused before any launch
+    res, mask = lgr.ransac(src, tgt, corr[:2], p_g)
+    assert res.converged == 0 and np.array_equal(res.matrix(), np.eye(4, dtype=np.float32))
+    # exactly n_samples correspondences: C(3, 3) = 1 iteration
+    p_o, p_g = params_pair(oracle, capi, metric_id=0, max_iterations=2000)
+    res, mask = lgr.ransac(src, tgt, corr[:3], p_g)
+    ores, omask = oracle.ransac(problem["src"], problem["tgt"], to_orc_corr(oracle, corr[:3]), p_o)
+    assert res.iterations == ores.iterations == 1 and res.converged == ores.converged
+
+
+def test_resident_kernel_plane_metrics_keep_the_chain(resident, problem):
+    """the plane metrics' loop has launches of its own between the phases: the option is ignored for them (same result as without it)"""
+    from lgr_amd import capi
+    lgr = resident
+    p = capi.default_params(metric_id=capi.METRIC_COMBINATION if hasattr(capi, "METRIC_COMBINATION") else 3, score_id=0, max_iterations=3000, ransac_batch=1000)
+    src, tgt = cuda(problem["src"]), cuda(problem["tgt"])
+    a, ma = lgr.ransac(src, tgt, problem["corr"], p)
+    lgr.set_options()
+    b, mb = lgr.ransac(src, tgt, problem["corr"], p)
+    _same_result(a, b, ma, mb)

@@ -7,6 +7,8 @@ import numpy as np, torch
 from lgr_amd import capi, synthetic
 
 ctx = capi.Context(0)
+if os.environ.get("LGR_RANSAC_SCHEDULE"):   # 1 chain / 2 resident kernel (lgr_ctx_options.ransac_schedule)
+    ctx.set_options(ransac_schedule=int(os.environ["LGR_RANSAC_SCHEDULE"]))
 
 
 def timed(f, n=3):
