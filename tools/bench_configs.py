@@ -11,13 +11,16 @@ if os.environ.get("LGR_RANSAC_SCHEDULE"):   # 1 chain / 2 resident kernel (lgr_c
     ctx.set_options(ransac_schedule=int(os.environ["LGR_RANSAC_SCHEDULE"]))
 
 
-def timed(f, n=3):
+def timed(f, n=5):
+    """median of n individually timed calls after a warm-up (a sporadic host stall of tens of ms -- allocator, GC -- lands in one call, not in the figure)"""
     f(); ctx.sync(); torch.cuda.synchronize()
-    t = time.perf_counter()
+    ts = []
     for _ in range(n):
+        t = time.perf_counter()
         r = f()
-    ctx.sync(); torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n * 1e3, r
+        ctx.sync(); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) * 1e3)
+    return sorted(ts)[len(ts) // 2], r
 
 
 which = sys.argv[1:] or ["ransac", "gror", "features5m"]
@@ -63,7 +66,7 @@ if "iss1m" in which:
         print(f"ISS on 1M points, radius {r}: {idx.shape[0]} key points, {ms:.1f} ms", flush=True)
     p = capi.default_params(matching_id=0, metric_id=capi.METRIC_UNIFORMITY, feature_radius=0.25, bf_block_size=200000, max_iterations=1000000,
                             distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"], keypoint_id=1, iss_radius_src=0.05, iss_radius_tgt=0.05)
-    ms, res = timed(lambda: ctx.align(s, t, p), n=2)
+    ms, res = timed(lambda: ctx.align(s, t, p), n=5)
     print(f"1M-point pair with ISS key points (r = 0.05): {ms:.1f} ms, correspondences {res.n_correspondences}, inliers {res.n_inliers}, "
           f"converged {res.converged}, err {np.abs(res.matrix() - pair['T_gt']).max():.2e}", flush=True)
 if "plane1m" in which:
@@ -73,6 +76,6 @@ if "plane1m" in which:
     for mid, name in ((3, "combination"), (2, "closest_plane")):
         p = capi.default_params(matching_id=0, metric_id=mid, feature_radius=0.25, bf_block_size=200000, max_iterations=200000,
                                 distance_thr=0.1, vp_src=pair["vp_src"], vp_tgt=pair["vp_tgt"], keypoint_id=1, iss_radius_src=0.05, iss_radius_tgt=0.05)
-        ms, res = timed(lambda: ctx.align(s, t, p), n=1)
+        ms, res = timed(lambda: ctx.align(s, t, p), n=5)
         print(f"1M-point pair, ISS key points, metric {name}: {ms:.1f} ms (RANSAC {list(res.stage_ms)[5]:.1f} ms, {res.iterations} iterations), "
               f"inliers {res.n_inliers}, metric {res.metric:.4f}, err {np.abs(res.matrix() - pair['T_gt']).max():.2e}", flush=True)

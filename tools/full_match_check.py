@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=50_000)
     ap.add_argument("--block", type=int, default=200_000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "full_match_check.json"))
+    ap.add_argument("--seed", type=int, default=None, help="generator seed (default: the bench pair's)")
+    ap.add_argument("--scene", default="bench", choices=["bench", "planar"], help="bench: height field + boxes; planar: the planar-dominated scene of matcher_extremes")
     a = ap.parse_args()
     import torch
     import oracle as o
@@ -44,7 +46,8 @@ def main():
         pass
     o.set_num_threads(cores)
     ctx = capi.Context(0)
-    pair = synthetic.make_pair(a.points, seed=synthetic.SEED)
+    seed = synthetic.SEED if a.seed is None else a.seed
+    pair = synthetic.make_planar_pair(a.points, seed=seed) if a.scene == "planar" else synthetic.make_pair(a.points, seed=seed)
     voxel = float(np.sqrt(np.float32(np.pi * 0.25 * 0.25 / 352.0)))
     feats = []
     for side in ("src", "tgt"):
@@ -55,7 +58,8 @@ def main():
     ctx.sync()
     work, fmt, stats = ctx.match_work(), ctx.match_format(), ctx.match_stats()
     fh = [f.cpu().numpy() for f in feats]
-    out = {"workload": "BASELINE configs[1] pair, seed %d, %d points per cloud" % (synthetic.SEED, a.points), "bf_block_size": a.block,
+    out = {"workload": "%s, seed %d, %d points per cloud" % ("BASELINE configs[1] pair" if a.scene == "bench" else "planar-dominated scene", seed, a.points), "bf_block_size": a.block,
+           "irregular_rows": list(ctx.match_irregular()),
            "executed_tile_fraction": work, "operand_format": fmt, "dense_fallbacks": [int(stats["dense_ab"]), int(stats["dense_ba"])],
            "cores": cores, "directions": {}}
     t_all = time.time()
