@@ -983,6 +983,21 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 }
             const double tot = (double) n_rb * mb_pad;
             fprintf(stderr, "[lgr] final pass by criterion: rows only %.4f, columns only %.4f, both %.4f of the tiles\n", by_rows / tot, by_cols / tot, by_both / tot);
+            if (env_int("LGR_MATCH_DEBUG", 0) >= 2) {
+                // how full are the sweep's VISITS?  A visit = one row block against one 128-tile column chunk: the stages its mask holds, of 32.  Every visit pays
+                // the A fragments, the thresholds of its tile slots, the start of the DMA ring and two barriers before its first MFMA.
+                std::vector<unsigned> hm((size_t) n_rb * n_cc);
+                LGR_HIP(ctx, hipMemcpy(hm.data(), mask, hm.size() * 4, hipMemcpyDeviceToHost));
+                double visits = 0, stages_ = 0, hist[6] = {0, 0, 0, 0, 0, 0}, runs = 0;   // visits holding 1-2, 3-4, 5-8, 9-16, 17-24, 25-32 stages
+                for (unsigned m : hm) {
+                    if (!m) continue;
+                    const int n = __builtin_popcount(m);
+                    visits += 1; stages_ += n; runs += __builtin_popcount(m & ~(m << 1));
+                    hist[n <= 2 ? 0 : n <= 4 ? 1 : n <= 8 ? 2 : n <= 16 ? 3 : n <= 24 ? 4 : 5] += 1;
+                }
+                fprintf(stderr, "[lgr] last pass: %.0f visits (row block x chunk) of %zu, %.2f stages per visit in %.2f runs; visits by stages 1-2: %.3g, 3-4: %.3g, 5-8: %.3g, 9-16: %.3g, 17-24: %.3g, 25-32: %.3g\n",
+                        visits, hm.size(), stages_ / std::max(visits, 1.0), runs / std::max(visits, 1.0), hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+            }
             if (split_used && env_int("LGR_MATCH_DEBUG", 0) >= 2 && h_kept[0] <= (unsigned long long) kept_cap) {
                 // how are the tiles the sweep keeps distributed over the (row block, stage) pairs -- 32 tile slots each?  (Round 5, 900 k points, scene
                 // seed 571: 16 M kept tiles, 78 % of them in pairs that keep more than half of their slots -- blobs of near-duplicate descriptors.

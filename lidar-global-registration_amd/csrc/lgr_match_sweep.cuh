@@ -149,6 +149,8 @@ __global__ __launch_bounds__(NTHR, SW_OCC) void match_sweep(const f16x8* __restr
                 const float x = ca.xmax[rb / rg_blocks];
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
+                    // (a visit tests ~11 of its 128 tile slots on the bench pair: the half of the slots whose stages the mask lacks is not priced)
+                    if (!(h2 ? (mk[r] >> 16) : (mk[r] & 0xffffu))) continue;   // wave uniform
                     const int q = lane + 64 * h2;
                     const int gst = min(cc * STAGES_PER_CHUNK + (q >> 2), ca.n_stage_total - 1);
                     const int gct = min(col_tile0 + q, ca.n_ct_total - 1);
