@@ -274,7 +274,7 @@ static int match_cluster(lgr_ctx* ctx, const float* d_a, int ma, const float* d_
         km2_init<<<KCL, 64, 0, cx->stream>>>(smp, sidx, coff, cen, sub, cen2);
         if (sub > 1) {
             for (int it = 0; it < KM2_ITERS; ++it) {
-                km2_step<<<dim3(cdiv(ns, KM2_THREADS), KCL), KM2_THREADS, 0, cx->stream>>>(smp, sidx, coff, kmax, cen2, sub, acc2);
+                km2_step<<<dim3(KM2_PIECES, KCL), KM2_THREADS, 0, cx->stream>>>(smp, sidx, coff, kmax, cen2, sub, acc2);
                 km2_finalize<<<n_leaves, 64, 0, cx->stream>>>(acc2, kmax, cen2);
             }
         }

@@ -224,32 +224,56 @@ __device__ __forceinline__ int nearest_sub(const float* v, const float* __restri
     }
     return bj;
 }
-constexpr int KM2_THREADS = 256;
-// Lloyd step of the second level: a workgroup takes 256 consecutive samples of ONE cluster (grid: x = piece, y = cluster; pieces
-// past the cluster's end leave at once), labels them with the nearest of the cluster's sub-centres and adds them to the leaves'
-// integer sums in LDS; one global atomic per touched sum at the end.  km2_finalize turns the sums into the new centres (an empty
-// leaf keeps its centre) and clears them for the next step.
+constexpr int KM2_THREADS = 256, KM2_LANES = 4, KM2_SAMPLES = KM2_THREADS / KM2_LANES, KM2_PIECES = 48;
+// Lloyd step of the second level: a workgroup takes 64 consecutive samples of ONE cluster at a time (grid: x = piece, y = cluster; the pieces
+// stride over the cluster), FOUR lanes per sample: each walks a quarter of the cluster's sub-centres (every distance the same k-ordered
+// sum as nearest_sub's), the quarters meet through two shuffles as (distance, index) pairs -- the smallest distance, the lowest index among
+// equals: nearest_sub's answer bit for bit -- and each lane adds a quarter of the sample's coordinates to the leaf's integer sums in LDS; one
+// global atomic per touched sum at the end.  (One lane per sample was a chain of 64 x 33 dependent additions on a device with two waves per
+// CU in flight: 57 us per step, six steps per alignment; round 5.)  km2_finalize turns the sums into the new centres (an empty leaf keeps its
+// centre) and clears them for the next step.
 __global__ __launch_bounds__(KM2_THREADS) void km2_step(const float* __restrict__ smp, const int* __restrict__ sidx, const int* __restrict__ coff,
                                                         const unsigned* __restrict__ kmax, const float* __restrict__ cen2, int sub, KmAcc* __restrict__ acc2) {
     __shared__ float c2s[SUBMAX * 33];
     __shared__ long long acc_s[SUBMAX * 34];
     const int p = blockIdx.y;
-    const int s0 = coff[p] + blockIdx.x * KM2_THREADS, s1 = coff[p + 1];
-    if (s0 >= s1) return;
+    const int c0 = coff[p], s1 = coff[p + 1];
+    if (c0 + (int) blockIdx.x * KM2_SAMPLES >= s1) return;
     for (int e = threadIdx.x; e < sub * 33; e += KM2_THREADS) c2s[e] = cen2[(size_t) p * sub * 33 + e];
     for (int e = threadIdx.x; e < sub * 34; e += KM2_THREADS) acc_s[e] = 0;
     __syncthreads();
-    const int s = s0 + threadIdx.x;
-    if (s < s1) {
-        const double scale = km_scale(*kmax);
-        const float* row = smp + (size_t) sidx[s] * 33;
-        float v[33], d;
+    const double scale = km_scale(*kmax);
+    const int q = threadIdx.x & (KM2_LANES - 1);
+    for (int s0 = c0 + blockIdx.x * KM2_SAMPLES; s0 < s1; s0 += gridDim.x * KM2_SAMPLES) {   // (workgroup uniform)
+        const int s = s0 + (threadIdx.x >> 2);
+        const bool act = s < s1;
+        float v[33];
+        const float* row = smp + (size_t) sidx[act ? s : s1 - 1] * 33;
 #pragma unroll
         for (int k = 0; k < 33; ++k) v[k] = row[k];
-        const int j = nearest_sub(v, c2s, sub, d);
+        // this lane's sub-centres: q, q + 4, q + 8, ... (neighbouring lanes read neighbouring LDS rows)
+        float best = __uint_as_float(0x7f800000u);
+        int bj = 0x7fffffff;
+#pragma unroll 1
+        for (int j = q; j < sub; j += KM2_LANES) {
+            float d = 0.f;
 #pragma unroll
-        for (int k = 0; k < 33; ++k) atomicAdd((unsigned long long*) &acc_s[j * 34 + k], (unsigned long long) (long long) rint((double) v[k] * scale));
-        atomicAdd((unsigned long long*) &acc_s[j * 34 + 33], 1ull);
+            for (int k = 0; k < 33; ++k) { float t = v[k] - c2s[j * 33 + k]; d = d + t * t; }
+            if (d < best) { best = d; bj = j; }
+        }
+#pragma unroll
+        for (int o = 1; o < KM2_LANES; o <<= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oj = __shfl_xor(bj, o);
+            if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
+        if (bj == 0x7fffffff) bj = 0;   // (every distance NaN or +inf: nearest_sub answers 0)
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 33; ++k)
+                if ((k & (KM2_LANES - 1)) == q) atomicAdd((unsigned long long*) &acc_s[bj * 34 + k], (unsigned long long) (long long) rint((double) v[k] * scale));
+            if (q == 1) atomicAdd((unsigned long long*) &acc_s[bj * 34 + 33], 1ull);
+        }
     }
     __syncthreads();
     long long* out = (long long*) (acc2 + (size_t) p * sub);
