@@ -287,10 +287,15 @@ typedef float v2f_c __attribute__((ext_vector_type(2)));
 struct CPair { v2f_c sx, sy, sz, qx, qy, qz, ss, rs; };
 static_assert(sizeof(CPair) == CP_FLOATS * 4, "pack_kernel writes this layout");
 
+// Inlier bit masks, hypothesis-major (round 5): row h = the mask of survivor h, mask_pitch(c) words -- a whole number of 128-correspondence groups,
+// the unit count_item stores (one 16-byte store per lane and group).  The metric phase reads a candidate's row front to back; with the rows
+// word-major ([word][hypothesis], coalesced stores) every word of a candidate was a cache line of its own: 14.9 GB of fetches per 1M cluster-filter
+// alignment, 80 % of metric_kernel's wave cycles parked.
+__host__ __device__ inline size_t mask_pitch(int c) { return (size_t) ((c + 127) >> 7) * 4; }
 __device__ __forceinline__ void count_item(const int bx /* block of CB hypotheses */, const int by /* chunk of cch correspondences */,
                                            const float* Ts, const int* list, int nh,
                                            const CPair* __restrict__ PP, const unsigned* __restrict__ pstats, int c, int2* counts,
-                                           unsigned* maskT /* [ceil(c / 32)][nh] inlier bits, or nullptr */, int cch, const int lane) {
+                                           unsigned* maskT /* [nh][mask_pitch(c)] inlier bits, or nullptr */, int cch, const int lane) {
     const int h = bx * CB + lane;
     const bool act = h < nh;
     float T[16];
@@ -309,6 +314,7 @@ __device__ __forceinline__ void count_item(const int bx /* block of CB hypothese
     if (!(kh < 3.4028234663852886e38f) || !(eta < 3.4028234663852886e38f)) { kh = __uint_as_float(0x7f800000u); eta = 0.f; }
     const float neg_eta = -eta;
     int ninl = 0, nsup = 0;
+    uint4 wq = make_uint4(0u, 0u, 0u, 0u);   // the 128-correspondence group being assembled
     const int c0 = by * cch, c1 = min(c, c0 + cch);
     for (int base = c0; base < c1; base += 64) {
         const CPair* __restrict__ pp = PP + (base >> 1);   // wave-uniform: scalar loads
@@ -354,9 +360,12 @@ __device__ __forceinline__ void count_item(const int bx /* block of CB hypothese
         nsup += __popc(w[0] ^ sd[0]) + __popc(w[1] ^ sd[1]);
         // inlier bits of this hypothesis for the correspondences [base, base + 64): word-major, so the lanes (consecutive
         // hypotheses) store consecutive words; phase 2 walks the set bits instead of testing every correspondence again
-        if (maskT && act) {
-            maskT[(size_t) (base >> 5) * nh + h] = w[0];
-            if (base + 32 < c) maskT[(size_t) ((base >> 5) + 1) * nh + h] = w[1];
+        // (chunks are whole groups: cch is a multiple of 128; the last group of the table may end behind c: its padding pairs are never inliers)
+        if (maskT) {
+            if (((base - c0) & 64) == 0) { wq.x = w[0]; wq.y = w[1]; wq.z = 0u; wq.w = 0u; }
+            else { wq.z = w[0]; wq.w = w[1]; }
+            if (act && ((((base - c0) & 64) != 0) || base + 64 >= c1))
+                *reinterpret_cast<uint4*>(maskT + (size_t) h * mask_pitch(c) + ((size_t) ((base & ~127) >> 5))) = wq;
         }
     }
     if (act) { atomicAdd(&counts[h].x, ninl); atomicAdd(&counts[h].y, nsup); }
@@ -478,20 +487,39 @@ __device__ __forceinline__ void metric_body(const int tid, const int wg, const i
     if (from_bits) {
         // uniformity needs the inlier SET only: walk the set bits of the masks the counting phase left (a candidate has a
         // few thousand inliers among hundreds of thousands of correspondences)
-        const int col = hpos[hb];
+        // (a row is contiguous: consecutive lanes read consecutive words, four words per lane in flight; the bins of up to four inliers are requested
+        //  before the first of them is counted: the loop is a chain of dependent gathers, four deep instead of one)
+        const unsigned* row = maskT + (size_t) hpos[hb] * mask_pitch(c);
         const int n_words = (c + 31) >> 5;
         int cnt = 0;
-        for (int w = tid; w < n_words; w += MB) {
-            unsigned m = maskT[(size_t) w * mask_nh + col];
-            cnt += __popc(m);
-            while (m) {
-                const int i = (w << 5) + __ffs((int) m) - 1;
-                m &= m - 1u;
-                const int bins = __float_as_int(P1[i].w);
-                const int b0 = bins & 0xff, b1 = (bins >> 8) & 0xff, b2 = (bins >> 16) & 0xff;
-                atomicAdd(&hist[(0 * 100 + b1) * 100 + b2], 1);
-                atomicAdd(&hist[(1 * 100 + b2) * 100 + b0], 1);
-                atomicAdd(&hist[(2 * 100 + b0) * 100 + b1], 1);
+        for (int w0 = tid; w0 < n_words; w0 += 4 * MB) {
+            unsigned mw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mw[k] = w0 + k * MB < n_words ? row[w0 + k * MB] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned m = mw[k];
+                cnt += __popc(m);
+                const int i0 = ((w0 + k * MB) << 5) - 1;
+                while (m) {
+                    int bins[4];
+                    bool on[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        on[u] = m != 0u;
+                        const int i = i0 + (on[u] ? __ffs((int) m) : 1);
+                        m &= m - 1u;   // (0 stays 0)
+                        bins[u] = on[u] ? __float_as_int(P1[i].w) : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!on[u]) continue;
+                        const int b0 = bins[u] & 0xff, b1 = (bins[u] >> 8) & 0xff, b2 = (bins[u] >> 16) & 0xff;
+                        atomicAdd(&hist[(0 * 100 + b1) * 100 + b2], 1);
+                        atomicAdd(&hist[(1 * 100 + b2) * 100 + b0], 1);
+                        atomicAdd(&hist[(2 * 100 + b0) * 100 + b1], 1);
+                    }
+                }
             }
         }
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
@@ -601,8 +629,8 @@ __global__ __launch_bounds__(MB) void metric_kernel(const float* __restrict__ Ts
                                                      float* __restrict__ metric_out, int* __restrict__ ninl_out,
                                                      float* __restrict__ rmse_out, uint8_t* __restrict__ mask,
                                                      float2* __restrict__ scratch /* [gridDim.x][c] inlier (dist, thr) lists */,
-                                                     const unsigned* __restrict__ maskT /* count_kernel's inlier bits [words][mask_nh], or nullptr */,
-                                                     const int* __restrict__ hpos /* candidate -> column of maskT */, int mask_nh,
+                                                     const unsigned* __restrict__ maskT /* count_kernel's inlier bits [mask_nh][mask_pitch(c)], or nullptr */,
+                                                     const int* __restrict__ hpos /* candidate -> row of maskT */, int mask_nh,
                                                      const int* __restrict__ ghist = nullptr /* [30000 + 1]: the uniformity histogram and the inlier count of the ONE
                                                         hypothesis, already counted by inlier_hist_kernel (single-transform evaluations) */,
                                                      const int* __restrict__ nh2_dev = nullptr /* device-driven schedule: the number of candidates lives on the
@@ -696,37 +724,39 @@ __global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ P
     if (n_a) c = n_a[0] + n_b[0];   // device-driven schedule: the number of compacted pairs = last exclusive-scan entry + last flag
     // the sums are sequential by definition; the pairs are staged through LDS by the whole block (coalesced loads), so the
     // summing lanes walk LDS instead of waiting on one global load per term
-    __shared__ float sp[RCH * 8];     // [pair][sx sy sz tx ty tz - -]: the summing lanes read consecutive words
+    // (round 5: the staged chunk is COMPONENT-major, so a summing lane reads consecutive words; in the second pass the whole block also forms the
+    //  nine products per pair -- the same two subtractions and one multiplication, by another thread -- and the summing lanes are left with one LDS
+    //  read and the one dependent addition per term: 80 000 inliers 2.0 -> ~1 ms, the lanes were bound by instruction issue, not by the chain)
+    constexpr int RCH2 = 1024;        // pairs per chunk of the second pass (nine products per pair in the same array)
+    __shared__ float sp[RCH * 8];     // pass 1: [6 components][RCH]; pass 2: [9 products][RCH2]
     __shared__ uint8_t sm[RCH];
     __shared__ float cen[6];
     __shared__ float Hs[9];
     __shared__ int sn;
     const int l = threadIdx.x;
-    auto stage = [&](int i0) {
-        __syncthreads();
-        for (int i = l; i < RCH && i0 + i < c; i += blockDim.x) {
-            float4 p = P0[i0 + i], q = P1[i0 + i];
-            *reinterpret_cast<float4*>(&sp[i * 8]) = make_float4(p.x, p.y, p.z, q.x);
-            *reinterpret_cast<float2*>(&sp[i * 8 + 4]) = make_float2(q.y, q.z);
-            sm[i] = mask ? mask[i0 + i] : (uint8_t) 1;
-        }
-        __syncthreads();
-    };
     {
         float acc = 0.f;
         int n = 0;
         for (int i0 = 0; i0 < c; i0 += RCH) {
-            stage(i0);
+            __syncthreads();
+            for (int i = l; i < RCH && i0 + i < c; i += blockDim.x) {
+                const float4 p = P0[i0 + i], q = P1[i0 + i];
+                sp[0 * RCH + i] = p.x; sp[1 * RCH + i] = p.y; sp[2 * RCH + i] = p.z;
+                sp[3 * RCH + i] = q.x; sp[4 * RCH + i] = q.y; sp[5 * RCH + i] = q.z;
+                sm[i] = mask ? mask[i0 + i] : (uint8_t) 1;
+            }
+            __syncthreads();
             if (l < 6) {
                 const int m = min(RCH, c - i0);
+                const float* col = sp + l * RCH;
                 if (!mask) {   // (every caller compacts first: no per-element branch, so the LDS reads run ahead of the dependent adds)
-#pragma unroll 8
-                    for (int i = 0; i < m; ++i) acc += sp[i * 8 + l];
+#pragma unroll 16
+                    for (int i = 0; i < m; ++i) acc += col[i];
                     n += m;
                 } else {
                     for (int i = 0; i < m; ++i) {
                         if (!sm[i]) continue;
-                        acc += sp[i * 8 + l];
+                        acc += col[i];
                         ++n;
                     }
                 }
@@ -736,20 +766,32 @@ __global__ __launch_bounds__(256) void refit_kernel(const float4* __restrict__ P
         if (l == 0) sn = n;
     }
     {
-        const int a = l / 3, b = l % 3;
-        float acc = 0.f, ca = 0.f, cb = 0.f;
-        for (int i0 = 0; i0 < c; i0 += RCH) {
-            stage(i0);   // (its first barrier also publishes cen[])
+        float acc = 0.f;
+        for (int i0 = 0; i0 < c; i0 += RCH2) {
+            __syncthreads();   // (the first one also publishes cen[])
+            float cc[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cc[k] = cen[k];
+            for (int i = l; i < RCH2 && i0 + i < c; i += blockDim.x) {
+                const float4 p = P0[i0 + i], q = P1[i0 + i];
+                const float da[3] = {p.x - cc[0], p.y - cc[1], p.z - cc[2]}, db[3] = {q.x - cc[3], q.y - cc[4], q.z - cc[5]};
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) sp[(3 * a + b) * RCH2 + i] = da[a] * db[b];
+                sm[i] = mask ? mask[i0 + i] : (uint8_t) 1;
+            }
+            __syncthreads();
             if (l < 9) {
-                if (i0 == 0) { ca = cen[a]; cb = cen[3 + b]; }
-                const int m = min(RCH, c - i0);
+                const int m = min(RCH2, c - i0);
+                const float* col = sp + l * RCH2;
                 if (!mask) {
-#pragma unroll 8
-                    for (int i = 0; i < m; ++i) acc += (sp[i * 8 + a] - ca) * (sp[i * 8 + 3 + b] - cb);
+#pragma unroll 16
+                    for (int i = 0; i < m; ++i) acc += col[i];
                 } else {
                     for (int i = 0; i < m; ++i) {
                         if (!sm[i]) continue;
-                        acc += (sp[i * 8 + a] - ca) * (sp[i * 8 + 3 + b] - cb);
+                        acc += col[i];
                     }
                 }
             }
@@ -1460,7 +1502,7 @@ static int run_batch(lgr_ctx* ctx, const float* d_src, const float* d_tgt, const
     // inlier bit masks for phase 2 (uniformity / correspondence-count metrics need the inlier set only); skipped when they
     // would not fit 2 GB (then phase 2 tests every correspondence again)
     unsigned* maskT = nullptr;
-    const size_t mask_words = (size_t) ((c + 31) >> 5) * nh;
+    const size_t mask_words = mask_pitch(c) * nh;
     if (!plane && p->metric_id == LGR_METRIC_UNIFORMITY && mask_words * 4 <= ((size_t) 2 << 30)) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASKT, mask_words, &maskT));
     count_kernel<<<g, CB, 0, ctx->stream>>>(b.Ts, b.list, nh, pk.PP, pk.pstats, c, b.counts, maskT, cch);
     int* pl_cnt = nullptr;
@@ -1571,12 +1613,12 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
         LGR_TRY(evaluate_one_dev(ctx, dS->best_T, pk, c, p->metric_id, p->score_id, d_gm, d_ev, d_ev + 4));
         rs_guess_kernel<<<1, 1, 0, ctx->stream>>>(dS, d_ev + 4);
     }
-    // inlier bit masks for the uniformity metric: [words][survivors], as many columns as 2 GB hold (more survivors: the metric kernel
+    // inlier bit masks for the uniformity metric: [survivors][mask_pitch(c)], as many rows as 2 GB hold (more survivors: the metric kernel
     // tests every correspondence again)
     unsigned* maskT = nullptr;
     int mask_cap = 0;
     if (p->metric_id == LGR_METRIC_UNIFORMITY) {
-        const size_t words = (size_t) ((c + 31) >> 5);
+        const size_t words = mask_pitch(c);
         mask_cap = (int) std::min<size_t>((size_t) nb_max, ((size_t) 2 << 30) / (words * 4));
         if (mask_cap > 0) LGR_TRY(lgr_ws_t(ctx, WS_RANSAC_MASKT, words * (size_t) mask_cap, &maskT));
     }
