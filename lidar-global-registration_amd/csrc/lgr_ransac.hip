@@ -617,19 +617,34 @@ __device__ __forceinline__ void metric_body(const int tid, const int wg, const i
             ninl_out[hb] = n_inl;
         }
     }
+    // The score and the rmse are sequential float sums over the inliers in correspondence order (src/metric.cpp:55-81, 147-155); their TERMS are not:
+    // the whole workgroup turns the list's (distance, threshold) entries into (distance^2, score term) in place -- the same expressions, by another
+    // thread -- and one lane adds them up with its reads running sixteen terms ahead of the two dependent chains.  (Round 5: as one loop on one lane,
+    // every term waited for its own global load and its division.)
+    if (lst && (!uni || rmse_out)) {   // (workgroup uniform)
+        for (int j = tid; j < n_inl; j += MB) {
+            const float2 dt = lst[j];
+            const float d = dt.x, t = dt.y;
+            float value = 1.f;
+            if (score_id == LGR_SCORE_MAE) value = fabsf(d - t) / t;
+            else if (score_id == LGR_SCORE_MSE) value = (d - t) * (d - t) / (t * t);
+            else if (score_id == LGR_SCORE_EXP) value = lgr_expf(-d * d / (2 * t * t));
+            lst[j] = make_float2(d * d, value);
+        }
+        __syncthreads();
+    }
     if (tid == 0 && (!uni || rmse_out)) {
         float score = 0.f, rm = 0.f;
         if (lst) {
-            for (int j = 0; j < n_inl; ++j) {
-                float2 dt = lst[j];
-                float d = dt.x, t = dt.y;
-                rm += d * d;
-                float value = 1.f;
-                if (score_id == LGR_SCORE_MAE) value = fabsf(d - t) / t;
-                else if (score_id == LGR_SCORE_MSE) value = (d - t) * (d - t) / (t * t);
-                else if (score_id == LGR_SCORE_EXP) value = lgr_expf(-d * d / (2 * t * t));
-                score += value;
+            int j = 0;
+            for (; j + 8 <= n_inl; j += 8) {
+                float2 e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = lst[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { rm += e[u].x; score += e[u].y; }
             }
+            for (; j < n_inl; ++j) { const float2 e = lst[j]; rm += e.x; score += e.y; }
         }
         if (!uni) { metric_out[hb] = score / (float) c; ninl_out[hb] = n_inl; }
         if (rmse_out) rmse_out[hb] = n_inl ? __builtin_sqrtf(rm / (float) n_inl) : 3.4028234663852886e38f;
