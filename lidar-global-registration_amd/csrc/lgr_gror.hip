@@ -58,12 +58,20 @@ __global__ __launch_bounds__(DEG_THREADS) void gror_degree_kernel(const float4* 
         __syncthreads();
         for (int k = threadIdx.x; k < m; k += DEG_THREADS) { Ss[k] = S[base + k]; Ts[k] = T[base + k]; }
         __syncthreads();
-        if (live) {
-#pragma unroll 4
-            for (int k = 0; k < m; ++k) {
-                float delta = fabsf(edge_len(si, Ss[k]) - edge_len(ti, Ts[k]));
-                cnt += (delta < two_res && base + k != i) ? 1 : 0;
-            }
+        // The decision |  |s_i s_j| - |t_i t_j|  | < 2 r with the hardware's one-instruction square root (1 ulp) wherever that decides it -- the two
+        // lengths are within 1.5 ulp of the correctly rounded ones, so the difference is within 4 ulp of the larger length of the reference's: a pair
+        // goes through edge_len's correctly rounded square roots (a dozen instructions each) only when it lies within 1e-6 of the larger length of the
+        // threshold, which some lane of a wave does for ~1e-4 of the steps (round 5: 3.3 -> ~2 ms for 50 000 correspondences; dead lanes take part:
+        // their points are the origin).
+        for (int k = 0; k < m; ++k) {
+            const float4 sj = Ss[k], tj = Ts[k];
+            const float ax = si.x - sj.x, ay = si.y - sj.y, az = si.z - sj.z, bx = ti.x - tj.x, by = ti.y - tj.y, bz = ti.z - tj.z;
+            const float la = __builtin_amdgcn_sqrtf((ax * ax + ay * ay) + az * az), lb = __builtin_amdgcn_sqrtf((bx * bx + by * by) + bz * bz);
+            const float d = fabsf(la - lb);
+            bool in = d < two_res;
+            if (__any(!(fabsf(d - two_res) > 1e-6f * fmaxf(la, lb) + 1e-30f)))   // (NaN: taken)
+                in = fabsf(edge_len(si, sj) - edge_len(ti, tj)) < two_res;
+            cnt += (in && live && base + k != i) ? 1 : 0;
         }
     }
     if (live && cnt) atomicAdd(&degree[i], cnt);
@@ -111,28 +119,58 @@ __global__ void gror_compact_kernel(const float4* __restrict__ S, const float4* 
 
 // pcl::umeyama(src, tgt, false) over the compacted inliers.  Lanes 0..5 carry the six mean sums, lanes 0..8 the nine
 // covariance sums, each strictly in correspondence order; lane 0 finishes with the 3x3 SVD.
-__global__ void gror_umeyama_kernel(const float4* __restrict__ Sc, const float4* __restrict__ Tc, const int* __restrict__ n_ptr, float* __restrict__ Tout) {
+// (Round 5: the terms come through LDS, component-major, staged by the whole workgroup -- in the second pass as the nine finished products, the same
+// subtractions and multiplication by another thread -- so that a summing lane is left with consecutive LDS reads running ahead of its one dependent
+// addition per term.  Straight from global memory every term waited for its own load: 1.4 ms for 4 900 inliers.)
+constexpr int GU_CH = 1024, GU_THREADS = 256;
+__global__ __launch_bounds__(GU_THREADS) void gror_umeyama_kernel(const float4* __restrict__ Sc, const float4* __restrict__ Tc, const int* __restrict__ n_ptr, float* __restrict__ Tout) {
     __shared__ float mean[6], sig[9];
-    int l = threadIdx.x, n = *n_ptr;
-    float inv_n = 1.0f / (float) n;
-    if (l < 6) {
-        const float4* A = l < 3 ? Sc : Tc;
-        int a = l % 3;
+    __shared__ float sp[9 * GU_CH];   // pass 1: [6 components][GU_CH]; pass 2: [9 products][GU_CH]
+    const int l = threadIdx.x, n = *n_ptr;
+    const float inv_n = 1.0f / (float) n;
+    {
         float acc = 0.f;
-        for (int i = 0; i < n; ++i) { float4 v = A[i]; acc += a == 0 ? v.x : (a == 1 ? v.y : v.z); }
-        mean[l] = acc * inv_n;
-    }
-    __syncthreads();
-    if (l < 9) {
-        int a = l / 3, b = l % 3;   // sigma(a, b) = sum (tgt_a - mean_t_a) * (src_b - mean_s_b)
-        float mt = mean[3 + a], ms = mean[b];
-        float acc = 0.f;
-        for (int i = 0; i < n; ++i) {
-            float4 s = Sc[i], t = Tc[i];
-            float tv = a == 0 ? t.x : (a == 1 ? t.y : t.z), sv = b == 0 ? s.x : (b == 1 ? s.y : s.z);
-            acc += (tv - mt) * (sv - ms);
+        for (int i0 = 0; i0 < n; i0 += GU_CH) {
+            __syncthreads();
+            for (int i = l; i < GU_CH && i0 + i < n; i += GU_THREADS) {
+                const float4 s4 = Sc[i0 + i], t4 = Tc[i0 + i];
+                sp[0 * GU_CH + i] = s4.x; sp[1 * GU_CH + i] = s4.y; sp[2 * GU_CH + i] = s4.z;
+                sp[3 * GU_CH + i] = t4.x; sp[4 * GU_CH + i] = t4.y; sp[5 * GU_CH + i] = t4.z;
+            }
+            __syncthreads();
+            if (l < 6) {
+                const int m = min(GU_CH, n - i0);
+                const float* col = sp + l * GU_CH;
+#pragma unroll 16
+                for (int i = 0; i < m; ++i) acc += col[i];
+            }
         }
-        sig[l] = acc * inv_n;
+        if (l < 6) mean[l] = acc * inv_n;
+    }
+    {
+        float acc = 0.f;
+        for (int i0 = 0; i0 < n; i0 += GU_CH) {
+            __syncthreads();   // (the first one also publishes mean[])
+            float mm[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) mm[k] = mean[k];
+            for (int i = l; i < GU_CH && i0 + i < n; i += GU_THREADS) {
+                const float4 s4 = Sc[i0 + i], t4 = Tc[i0 + i];
+                const float ds[3] = {s4.x - mm[0], s4.y - mm[1], s4.z - mm[2]}, dt[3] = {t4.x - mm[3], t4.y - mm[4], t4.z - mm[5]};
+#pragma unroll
+                for (int a = 0; a < 3; ++a)      // sigma(a, b) = sum (tgt_a - mean_t_a) * (src_b - mean_s_b)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) sp[(3 * a + b) * GU_CH + i] = dt[a] * ds[b];
+            }
+            __syncthreads();
+            if (l < 9) {
+                const int m = min(GU_CH, n - i0);
+                const float* col = sp + l * GU_CH;
+#pragma unroll 16
+                for (int i = 0; i < m; ++i) acc += col[i];
+            }
+        }
+        if (l < 9) sig[l] = acc * inv_n;
     }
     __syncthreads();
     if (l == 0) {
@@ -424,7 +462,7 @@ extern "C" int lgr_gror_dev(lgr_ctx* ctx, const float* d_src, int ns, const floa
     LGR_TRY(lgr_ws(ctx, WS_GRID_TMP, tb, &tmp));
     LGR_HIP(ctx, rocprim::exclusive_scan(tmp, tb, flags, pos, 0, (size_t) c, rocprim::plus<int>(), ctx->stream));
     gror_compact_kernel<<<cdiv(c, 256), 256, 0, ctx->stream>>>(b.S, b.T, flags, pos, c, Sc, Tc, d_n);
-    gror_umeyama_kernel<<<1, 64, 0, ctx->stream>>>(Sc, Tc, d_n, d_G + 16);
+    gror_umeyama_kernel<<<1, GU_THREADS, 0, ctx->stream>>>(Sc, Tc, d_n, d_G + 16);
     LGR_HIP(ctx, hipGetLastError());
     float* h_out = h_G + 16;
     LGR_HIP(ctx, hipMemcpyAsync(h_out, d_G + 16, 64, hipMemcpyDeviceToHost, ctx->stream));
