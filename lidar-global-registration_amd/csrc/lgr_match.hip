@@ -560,6 +560,8 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     const size_t o_touched = pcarve((size_t) n_rb * n_leaves);   // (inside the range cleared below)
     const size_t o_mask = pcarve((size_t) n_rb * n_cc * 4), o_macc = pcarve((size_t) n_rb * n_cc * 4), o_urb = pcarve((size_t) n_rb * 4), o_urt = pcarve((size_t) n_rb * (BLOCK_ROWS / TILE) * 4), o_ul = pcarve((size_t) MAXLEAF * 4);
     const size_t o_stats = pcarve(sizeof(MaskStats)), o_lbpart = pcarve((size_t) n_rb * sizeof(uint2));
+    const size_t o_lfst = pcarve((size_t) MAXLEAF * 4), o_llst = pcarve((size_t) MAXLEAF * 4);   // first / last column stage of every leaf (mask_sparse_kernel)
+    const size_t o_mchk = pcarve(mo.self_check ? (size_t) 2 * n_rb * n_cc * 4 + 256 : 0);         // self_check: mask_kernel's masks beside the sparse kernel's
     const size_t o_ust = pcarve((size_t) n_stage_total * 4), o_uct = pcarve((size_t) tb * 4);
     const size_t o_cr = pcarve((size_t) n_rb * n_groups), o_cc = pcarve((size_t) n_leaves * n_rg);
     const size_t o_smax = pcarve((size_t) KCL * n_stage_total * 4), o_ccnt = pcarve(32);
@@ -910,8 +912,35 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             }
             if (init_aside) LGR_HIP(ctx, hipEventRecord(ctx->ev[29], sB));
             if (pass == 0 && shell0.rshA) LGR_TRY(join_b());   // (the stage shells come from the column norms, written by the packing)
-            mask_kernel<<<std::min(cdiv((long long) n_rb * n_cc * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
-                                                                                                         pass > 0 ? shell : shell0, mask, (unsigned*) (pb + o_macc), mstats);
+            {
+                // the pass's stage masks from the scheduled (row block, leaf) pairs (mask_sparse_kernel; 0.41 + 0.30 -> 2 x ~0.1 ms at 1M)
+                int* lfst = (int*) (pb + o_lfst);
+                int* llst = (int*) (pb + o_llst);
+                if (pass == 0) {
+                    LGR_HIP(ctx, hipMemsetAsync(lfst, 0x7f, (size_t) MAXLEAF * 4, ctx->stream));
+                    LGR_HIP(ctx, hipMemsetAsync(llst, 0xff, (size_t) MAXLEAF * 4, ctx->stream));
+                    leaf_stage_range_kernel<<<cdiv(tb, 256), 256, 0, ctx->stream>>>(tile_leaf, tb, n_leaves, lfst, llst);
+                }
+                const long long n_pairs_m = (long long) n_rb * n_cc;
+                LGR_HIP(ctx, hipMemsetAsync(mask, 0, (size_t) n_pairs_m * 4, ctx->stream));
+                mask_sparse_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(sched, lfst, llst, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
+                                                                                                    pass > 0 ? shell : shell0, mask);
+                if (mo.self_check) {   // (tests) mask_kernel's masks must be the same words; its bookkeeping goes to scratch
+                    unsigned* chk = (unsigned*) (pb + o_mchk);
+                    unsigned* chk_acc = chk + n_pairs_m;
+                    unsigned* n_diff = chk_acc + n_pairs_m;
+                    MaskStats* scratch_stats = (MaskStats*) (pb + o_lbpart);   // (box_lb_kernel's partial counts: read by the near kernels, long done)
+                    LGR_HIP(ctx, hipMemsetAsync(chk_acc, 0, (size_t) n_pairs_m * 4 + 64, ctx->stream));
+                    mask_kernel<<<std::min(cdiv(n_pairs_m * 32, 256), 4096), 256, 0, ctx->stream>>>(pass, sched, tile_leaf, n_rb, n_cc, n_leaves, n_stage_total, LBsq, u_stage,
+                                                                                                     pass > 0 ? shell : shell0, chk, chk_acc, scratch_stats);
+                    mask_compare_kernel<<<cdiv(n_pairs_m, 256), 256, 0, ctx->stream>>>(mask, chk, n_pairs_m, n_diff);
+                    unsigned h_diff = 0;
+                    LGR_HIP(ctx, hipMemcpyAsync(&h_diff, n_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (h_diff) { ctx->err = "matcher self-check: the sparse stage masks differ from mask_kernel's"; return LGR_ERR_HIP; }
+                }
+                mask_stats_kernel<<<std::min(cdiv(n_pairs_m, 256), 2048), 256, 0, ctx->stream>>>(pass, mask, (unsigned*) (pb + o_macc), n_pairs_m, mstats);
+            }
             if (init_aside) LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[29], 0));
             CoarseArgs ca = ca_on;
             if (coarse && pass > 0) { ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb; }

@@ -369,6 +369,76 @@ __global__ __launch_bounds__(256) void mask_kernel(int pass, const uint8_t* __re
     }
 }
 
+// The same masks from the SCHEDULE's side (round 5).  mask_kernel above evaluates every (row block, chunk, stage) -- 31 M lanes at 1M rows, each with
+// its shell pair and up to four schedule bytes -- although 4 % (pass 0) or 15 % (final pass) of the (row block, leaf) pairs are scheduled at all.
+// Here a thread takes one (row block, leaf) pair, leaves at once when it is not scheduled, and otherwise walks the leaf's own stages (a leaf is a
+// contiguous run of tiles: leaf_stage_range_kernel) with exactly mask_kernel's per-leaf test and per-stage shell refinement, OR-ing the stages it
+// wants into the (zeroed) mask words.  A stage shared by two leaves is the OR of their tests in both kernels, and the refinement depends on
+// (row block, stage) only, so the masks are identical bit for bit (lgr_match_options.self_check compares them).  mask_stats_kernel then does
+// mask_kernel's bookkeeping over the finished words.
+__global__ void leaf_stage_range_kernel(const int* __restrict__ tile_leaf, int n_tiles, int n_leaves, int* __restrict__ first_stage /* 0x7f7f7f7f */, int* __restrict__ last_stage /* -1 */) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int g = tile_leaf[t];
+    if (g < 0 || g >= n_leaves) return;
+    atomicMin(&first_stage[g], t / STAGE_TILES);
+    atomicMax(&last_stage[g], t / STAGE_TILES);
+}
+__global__ __launch_bounds__(256) void mask_sparse_kernel(const uint8_t* __restrict__ sched, const int* __restrict__ first_stage, const int* __restrict__ last_stage,
+                                                          int n_rb, int n_cc, int n_leaves, int n_stage_total, const float* __restrict__ LBsq, const unsigned* __restrict__ u_stage,
+                                                          ShellArgs sh, unsigned* __restrict__ mask /* zeroed */) {
+    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t) n_rb * n_leaves) return;
+    const uint8_t sv = sched[idx];
+    if (!(sv & 3)) return;
+    const int rb = (int) (idx / n_leaves), g = (int) (idx % n_leaves);
+    const int s0 = first_stage[g], s1 = min(last_stage[g], n_stage_total - 1);
+    float2 sa = make_float2(0.f, 0.f);
+    const float2* sshB = nullptr;
+    if (sh.rshA) { sa = sh.rshA[rb]; sshB = sh.sshB + (size_t) sh.blkcl[rb] * n_stage_total; }
+    const float lbsq = LBsq[idx];
+    const float urb = sh.u_rb ? sh.u_rb[rb] : -1.f;
+    for (int gst = s0; gst <= s1; ++gst) {
+        float gap = 0.f;
+        if (sh.rshA) { const float2 sb = sshB[gst]; gap = fmaxf(sb.x - sa.y, sa.x - sb.y) - 4e-6f * (sa.y + sb.y); }
+        const bool overlap = !(gap > 0.f);
+        bool on = (sv & 1) || ((sv & 2) && col_stage_needed(lbsq, u_stage[gst]));
+        if (sh.rshA && !sh.u_rb) on = on && overlap;
+        if (sv & SCHED_NOT_P0) on = on && !overlap;
+        if (on && sh.u_rb && gap > 0.f && gap < FLT_BIG) {
+            const float lb = gap * gap * (LB_SHRINK * LB_SHRINK * LB_SHRINK);
+            const bool rows_need = urb >= 0.f && lb <= urb * LB_GROW + 1e-12f;
+            const bool cols_need = sh.cols != 0 && col_stage_needed(lb, u_stage[gst]);
+            on = rows_need || cols_need;
+        }
+        if (on) atomicOr(&mask[(size_t) rb * n_cc + (gst / STAGES_PER_CHUNK)], 1u << (gst % STAGES_PER_CHUNK));
+    }
+}
+__global__ void mask_compare_kernel(const unsigned* __restrict__ a, const unsigned* __restrict__ b, long long n, unsigned* __restrict__ n_diff) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) atomicAdd(n_diff, 1u);
+}
+__global__ __launch_bounds__(256) void mask_stats_kernel(int pass, const unsigned* __restrict__ mask, unsigned* __restrict__ mask_acc, long long n_pairs, MaskStats* __restrict__ stats) {
+    unsigned long long count = 0ull, fresh = 0ull;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (long long) gridDim.x * blockDim.x) {
+        const unsigned m = mask[i];
+        if (!m) continue;
+        const unsigned before = mask_acc[i];
+        mask_acc[i] = before | m;
+        count += (unsigned long long) __popc(m);
+        fresh += (unsigned long long) __popc(m & ~before);
+    }
+    for (int o = 32; o > 0; o >>= 1) { count += __shfl_xor(count, o); fresh += __shfl_xor(fresh, o); }
+    __shared__ unsigned long long cnt_s[4], fresh_s[4];
+    if ((threadIdx.x & 63) == 0) { cnt_s[threadIdx.x >> 6] = count; fresh_s[threadIdx.x >> 6] = fresh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long c = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3], f = fresh_s[0] + fresh_s[1] + fresh_s[2] + fresh_s[3];
+        if (c) atomicAdd(&stats->stages[pass], c);
+        if (f) atomicAdd(&stats->stages[7], f);
+    }
+}
+
 // Self-check of the filter bound (lgr_match_options.self_check; tests, up to 1M x 1M): for sampled queries and every computed group,
 // |filtered minimum - exact minimum of the squared distance (double)| / eps, maximised through atomicMax on the float
 // bits.  eps is a proven bound, so the ratio must stay <= 1; tests assert it on both operand formats.
