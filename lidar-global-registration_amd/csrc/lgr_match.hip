@@ -618,7 +618,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     group_max_kernel<<<dim3(n_rg, 1), 256, 0, ctx->stream>>>(nAp, ma_pad, rg_rows, nullptr, gmaxA);
     bool b_joined = sB == ctx->stream, b_recorded = false;
     // (the event is recorded behind the last PRODUCER on sB -- record_b, called where the set-up has been enqueued -- not where the first reader
-    //  joins: by then sB also holds pass 0's init_tables_kernel, which mask_kernel is meant to run beside, not behind; it has an event of its own)
+    //  joins: by then sB also holds pass 0's init_tables_sparse_kernel, which mask_kernel is meant to run beside, not behind; it has an event of its own)
     auto record_b = [&]() -> int {
         if (!b_joined && !b_recorded) LGR_HIP(ctx, hipEventRecord(ctx->ev3, sB));
         b_recorded = true;
@@ -649,7 +649,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
     unsigned long long* bestA = (unsigned long long*) (rowmin + tab_floats + (tab_floats & 1));
     unsigned long long* bestB = bestA + ma;
     fill_u64<<<cdiv(ma + mb, 256), 256, 0, sB>>>(bestA, ma + mb, ~0ull);   // (the exact rerank's tables: joined with the column operands)
-    // dense mode: +inf everywhere; skipping mode: init_tables_kernel covers what each pass computes (lgr_match_options.poison_tables, tests: the
+    // dense mode: +inf everywhere; skipping mode: init_tables_sparse_kernel covers what each pass computes (lgr_match_options.poison_tables, tests: the
     // rest is filled with 0 -- the most harmful value a stale entry could have -- to show that nothing reads it)
     if (!prune) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0x7f800000, tab_floats, ctx->stream));
     else if (mo.poison_tables) LGR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t) rowmin, 0, tab_floats, ctx->stream));
@@ -897,7 +897,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 LGR_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev[28], 0));
             }
             if (!defer_init) {
-                init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, init_aside ? sB : ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
+                init_tables_sparse_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, init_aside ? sB : ctx->stream>>>(sched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
                                                                                                         (size_t) ma_pad, colmin, (size_t) mb_pad);
                 init_touched = nullptr;
             } else {
@@ -905,7 +905,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                 init_touched = [&]() -> int {   // (called by launch_mfma between match_sweep and match_tiles, on the context's stream)
                     LGR_HIP(ctx, hipMemsetAsync(touched, 0, (size_t) n_rb * n_leaves, ctx->stream));
                     touched_kernel<<<4 * std::max(1, ctx->n_cu), 256, 0, ctx->stream>>>(kept, kept_count, kept_cap, xcd_start + 48, sched, tile_leaf, n_leaves, (size_t) n_rb * n_leaves, touched);
-                    init_tables_kernel<<<dim3(n_rb, INIT_SLICES), BLOCK_ROWS, 0, ctx->stream>>>(touched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
+                    init_tables_sparse_kernel<<<cdiv((long long) n_rb * n_leaves, 256), 256, 0, ctx->stream>>>(touched, done, n_rb, n_leaves, leaf_g0, group_start, rg_rows / BLOCK_ROWS, rowmin,
                                                                                                (size_t) ma_pad, colmin, (size_t) mb_pad);
                     return LGR_OK;
                 };
@@ -967,7 +967,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
             LGR_HIP(ctx, hipMemsetAsync(coarse_cnt, 0, 32, ctx->stream));
             CoarseArgs ca = ca_on;
             ca.u_rb = u_rb; ca.u_rt = u_rt; ca.u_row = u_row; ca.u_stage = both ? u_stage : nullptr; ca.u_ct = u_ct; ca.u_colv = both ? u_colv : nullptr; ca.n_ct_total = tb;
-            // (touched_kernel saw the overflow: it marked, and init_tables_kernel initialised, every scheduled pair -- the fused kernel finds its tables ready)
+            // (touched_kernel saw the overflow: it marked, and init_tables_sparse_kernel initialised, every scheduled pair -- the fused kernel finds its tables ready)
             LGR_TRY(launch_mfma(mask, ca, false));
             LGR_HIP(ctx, hipMemcpyAsync(h_cc, coarse_cnt, 24, hipMemcpyDeviceToHost, ctx->stream));
             LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -73,7 +73,7 @@ __device__ __forceinline__ float group_eps(int i, int g, float xq, const float* 
 // Table scan of one query: calls f(group, value) for every computed, finite entry table[g][i].  Four loads are in flight
 // before the first value is used (the loop body is short; one dependent global load per iteration was the whole cost).
 // `own` (columns): the computed-flags of the query's own leaf.  A block of 256 columns can span two leaves, so the
-// block's list is a superset; entries that were never computed are never initialised (init_tables_kernel) and must not
+// block's list is a superset; entries that were never computed are never initialised (init_tables_sparse_kernel) and must not
 // be read.  nullptr: the list is exact (rows: one row block per workgroup) or everything was computed.
 template <class F>
 __device__ __forceinline__ void scan_groups(const float* __restrict__ table, size_t q_pad, int i, int n_list, int n_groups,
@@ -218,20 +218,23 @@ __global__ void col_u_kernel(const float* __restrict__ table, int n_rg, int t_pa
 // scheduled block of the group unless an earlier pass already computed that (row group, leaf).  Entries that only a
 // boundary stage touches (a stage is computed when any leaf it overlaps is scheduled) may hold anything: nothing reads
 // them until their own (block, leaf) is scheduled, and that initialises them here.
-// grid (row blocks, INIT_SLICES): a workgroup covers one slice of the leaves of its row block, so that a launch has tens of
-// thousands of workgroups storing at once (one workgroup per row block walking all leaves: 0.23 + 0.48 ms per step at 1M)
-constexpr int INIT_SLICES = 16;
-__global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* __restrict__ sched, const uint8_t* __restrict__ done, int n_rb, int n_leaves,
-                                                                  const int* __restrict__ leaf_g0 /* [n_leaves + 1] */, const int* __restrict__ group_start,
-                                                                  int rg_blocks, int* __restrict__ rowmin, size_t ma_pad, int* __restrict__ colmin, size_t mb_pad) {
-    __shared__ uint8_t s_s[MAXLEAF / INIT_SLICES + 1];   // 0: nothing, 1: rows only, 3: rows and columns
-    const int rb = blockIdx.x, tid = threadIdx.x;
-    const int per = (n_leaves + INIT_SLICES - 1) / INIT_SLICES, l0 = blockIdx.y * per, l1 = min(n_leaves, l0 + per);
-    const int rg = rb / rg_blocks, rb_lo = rg * rg_blocks, rb_hi = min(n_rb, rb_lo + rg_blocks);
-    for (int l = l0 + tid; l < l1; l += BLOCK_ROWS) {
-        const uint8_t sv = sched[(size_t) rb * n_leaves + l];
-        uint8_t f = ((sv & 1) && !(sv & SCHED_NOT_P0)) ? 1 : 0;   // rows of the block: whole-leaf tiles only; not again when pass 0 has minima in them
+// From the schedule's side (round 5): a thread per (row block, leaf) pair finds out what its pair needs (most need nothing and are done), then the
+// wave's lanes together write the entries of each pair that needs some -- 16 k workgroups that mostly return at once.  (Rounds 1-4: a workgroup per
+// (row block, slice of 64 leaves) that scanned its slice, synchronised and walked it again: 63 k workgroups, 0.36 + 0.18 ms per pair at 1M against
+// 2 x 0.16.)
+__global__ __launch_bounds__(256) void init_tables_sparse_kernel(const uint8_t* __restrict__ sched, const uint8_t* __restrict__ done, int n_rb, int n_leaves,
+                                                                 const int* __restrict__ leaf_g0 /* [n_leaves + 1] */, const int* __restrict__ group_start,
+                                                                 int rg_blocks, int* __restrict__ rowmin, size_t ma_pad, int* __restrict__ colmin, size_t mb_pad) {
+    static_assert(BLOCK_ROWS == 256, "a row block is one 16-byte store per lane");
+    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = idx < (size_t) n_rb * n_leaves;
+    const int rb = in ? (int) (idx / n_leaves) : 0, l = in ? (int) (idx % n_leaves) : 0;
+    int f = 0;
+    if (in) {
+        const uint8_t sv = sched[idx];
+        f = ((sv & 1) && !(sv & SCHED_NOT_P0)) ? 1 : 0;   // rows of the block: whole-leaf tiles only; not again when pass 0 has minima in them
         if (sv && colmin) {
+            const int rb_lo = (rb / rg_blocks) * rg_blocks, rb_hi = min(n_rb, rb_lo + rg_blocks);
             bool first = true;
             for (int r = rb_lo; r < rb_hi; ++r) {
                 if (done[(size_t) r * n_leaves + l]) first = false;
@@ -239,17 +242,22 @@ __global__ __launch_bounds__(BLOCK_ROWS) void init_tables_kernel(const uint8_t* 
             }
             if (first) f |= 2;
         }
-        s_s[l - l0] = f;
     }
-    __syncthreads();
+    unsigned long long m = __ballot(f != 0);
+    const int lane = threadIdx.x & 63;
     constexpr int IINF = 0x7f800000;
-    for (int l = l0; l < l1; ++l) {
-        const uint8_t f = s_s[l - l0];
-        if (!f) continue;
-        const int g0 = leaf_g0[l], g1 = leaf_g0[l + 1];
-        if (f & 1) for (int g = g0; g < g1; ++g) rowmin[(size_t) g * ma_pad + (size_t) rb * BLOCK_ROWS + tid] = IINF;
-        if ((f & 2) && g0 < g1)
-            for (int col = group_start[g0] + tid; col < group_start[g1]; col += BLOCK_ROWS) colmin[(size_t) rg * mb_pad + col] = IINF;
+    const int4 inf4 = make_int4(IINF, IINF, IINF, IINF);
+    while (m) {
+        const int src = __ffsll((long long) m) - 1;
+        m &= m - 1ull;
+        const int prb = __shfl(rb, src), pl = __shfl(l, src), pf = __shfl(f, src);
+        const int g0 = leaf_g0[pl], g1 = leaf_g0[pl + 1];
+        if (pf & 1)
+            for (int g = g0; g < g1; ++g) reinterpret_cast<int4*>(rowmin + (size_t) g * ma_pad + (size_t) prb * BLOCK_ROWS)[lane] = inf4;
+        if ((pf & 2) && g0 < g1) {
+            const int rg = prb / rg_blocks;
+            for (int col = group_start[g0] + lane; col < group_start[g1]; col += 64) colmin[(size_t) rg * mb_pad + col] = IINF;
+        }
     }
 }
 

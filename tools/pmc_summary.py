@@ -12,7 +12,7 @@ import re
 import sys
 
 KERNELS = ["normals_kernel", "normals_wave_kernel", "knn_wave_kernel", "knn_tile_kernel", "spfh_tile_kernel", "fpfh_mfma_kernel", "count_kernel", "count_list_kernel", "match_mfma", "match_sweep", "match_tiles", "knn_kernel", "metric_kernel", "plane_kernel",
-           "assign_kernel", "pack16_kernel", "rerank_refilter", "init_tables_kernel", "voxel_accumulate", "filter_flags"]
+           "assign_kernel", "pack16_kernel", "rerank_refilter", "init_tables_sparse_kernel", "voxel_accumulate", "filter_flags"]
 
 
 def short(n):
