@@ -216,15 +216,16 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
     // (bbk == nullptr: the caller does not use the uniformity bins -- unit box)
     const float mnx = bbk ? lgr_bbox_key_inv(bbk[6]) : 0.f, mny = bbk ? lgr_bbox_key_inv(bbk[7]) : 0.f, mnz = bbk ? lgr_bbox_key_inv(bbk[8]) : 0.f;
     const float mxx = bbk ? lgr_bbox_key_inv(bbk[9]) : 1.f, mxy = bbk ? lgr_bbox_key_inv(bbk[10]) : 1.f, mxz = bbk ? lgr_bbox_key_inv(bbk[11]) : 1.f;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned m0 = 0u, m1 = 0u, m2 = 0u;   // this lane's contribution to pstats (padding lanes: the neutral 0)
+  for (int base = blockIdx.x * blockDim.x; base < cpad; base += gridDim.x * blockDim.x) {   // (a few hundred workgroups: their statistics meet in 3 atomics each)
+    const int i = base + threadIdx.x;
     if (i >= c) {
         if (PP && i < cpad) {
             float* r = PP + (size_t) (i >> 1) * CP_FLOATS + (i & 1);
 #pragma unroll
             for (int f = 0; f < 8; ++f) r[2 * f] = 0.f;   // s* = 0: d2 < 0 never holds
         }
-        return;
-    }
+    } else {
     lgr_corr cr = corr[i];
     P3 s = ldp(src, cr.index_query), t = ldp(tgt, cr.index_match);
     float thr = cr.threshold;
@@ -255,9 +256,22 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
         const float sm = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fabsf(s.z)), qm = fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fabsf(t.z));
         // NaN coordinates: the integer max of the bit pattern keeps them (a NaN pattern is above every finite one) -> the band becomes NaN
         // -> every chunk takes the exact path
-        atomicMax(&pstats[0], __float_as_uint(sm));
-        atomicMax(&pstats[1], __float_as_uint(qm));
-        if (ss < 3.4028234663852886e38f) atomicMax(&pstats[2], __float_as_uint(ss));
+        m0 = max(m0, __float_as_uint(sm)); m1 = max(m1, __float_as_uint(qm)); m2 = max(m2, (ss < 3.4028234663852886e38f) ? __float_as_uint(ss) : 0u);
+    }
+    }
+  }
+    // one atomic per wave and statistic (as one per thread: 3 x 282 k updates of the same three words on the bench pair -- even one per wave of a
+    // thread-per-correspondence grid was 13 k same-address atomics, most of the kernel's 0.16 ms); every lane of the wave is here
+    if (PP) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m0 = max(m0, (unsigned) __shfl_xor((int) m0, o)); m1 = max(m1, (unsigned) __shfl_xor((int) m1, o)); m2 = max(m2, (unsigned) __shfl_xor((int) m2, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (m0) atomicMax(&pstats[0], m0);
+            if (m1) atomicMax(&pstats[1], m1);
+            if (m2) atomicMax(&pstats[2], m2);
+        }
     }
 }
 
@@ -1279,7 +1293,7 @@ int pack(lgr_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt, c
     out->PP = (const CPair*) PP; out->pstats = pstats;
     LGR_HIP(ctx, hipMemsetAsync(pstats, 0, 16, ctx->stream));
     if (c > 0)
-        pack_kernel<<<cdiv(cpad, 256), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bbk, out->P0, out->P1, out->sstar, PP, pstats, cpad);
+        pack_kernel<<<std::min(cdiv(cpad, 256), 512), 256, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, bbk, out->P0, out->P1, out->sstar, PP, pstats, cpad);
     LGR_HIP(ctx, hipGetLastError());
     return LGR_OK;
 }
