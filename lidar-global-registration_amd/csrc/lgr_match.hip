@@ -939,7 +939,7 @@ static int match_impl(lgr_ctx* ctx, const float* d_a, int ma, const float* d_b, 
                     LGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
                     if (h_diff) { ctx->err = "matcher self-check: the sparse stage masks differ from mask_kernel's"; return LGR_ERR_HIP; }
                 }
-                mask_stats_kernel<<<std::min(cdiv(n_pairs_m, 256), 2048), 256, 0, ctx->stream>>>(pass, mask, (unsigned*) (pb + o_macc), n_pairs_m, mstats);
+                mask_stats_kernel<<<std::min(cdiv(n_pairs_m, 256), 256), 256, 0, ctx->stream>>>(pass, mask, (unsigned*) (pb + o_macc), n_pairs_m, mstats);
             }
             if (init_aside) LGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[29], 0));
             CoarseArgs ca = ca_on;
