@@ -951,8 +951,10 @@ __device__ __forceinline__ void rs_begin_body(RState* S, BatchStats* st, int fir
 __global__ void rs_begin_kernel(RState* __restrict__ S, BatchStats* __restrict__ st, int first_round) { rs_begin_body(S, st, first_round); }
 
 // iteration `b` of the round (b - lane is wave-uniform; a wave wholly behind the round's end does nothing)
+// (round 5: the sampled pairs come from the packed correspondences -- P0[i].xyz / P1[i].xyz ARE the source / target point of correspondence i, 32
+// contiguous bytes per sample in a 9 MB array instead of a 16-byte record and two 12-byte gathers out of the 48 MB clouds)
 template <int NS>
-__device__ __forceinline__ void rs_hyp_item(const int b, const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
+__device__ __forceinline__ void rs_hyp_item(const int b, const float4* __restrict__ P0, const float4* __restrict__ P1, int c,
                                             unsigned long long seed, RState* S, float edge_thr, float* Ts, int* list, int* posmap, int2* counts) {
     const int nb = S->round_nb;
     bool good = false;
@@ -963,7 +965,7 @@ __device__ __forceinline__ void rs_hyp_item(const int b, const float* __restrict
         select_n<NS>(r, c, smp);
         P3 s[NS], t[NS];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) { lgr_corr cr = corr[smp[j]]; s[j] = ldp(src, cr.index_query); t[j] = ldp(tgt, cr.index_match); }
+        for (int j = 0; j < NS; ++j) { const float4 a = P0[smp[j]], q = P1[smp[j]]; s[j] = P3{a.x, a.y, a.z}; t[j] = P3{q.x, q.y, q.z}; }
         good = poly_ok<NS>(s, t, edge_thr * edge_thr);
         if (good) {
             float T[16];
@@ -986,12 +988,12 @@ __device__ __forceinline__ void rs_hyp_item(const int b, const float* __restrict
     }
 }
 template <int NS>
-__global__ void rs_hyp_kernel(const float* __restrict__ src, const float* __restrict__ tgt, const lgr_corr* __restrict__ corr, int c,
+__global__ void rs_hyp_kernel(const float4* __restrict__ P0, const float4* __restrict__ P1, int c,
                               unsigned long long seed, RState* __restrict__ S, float edge_thr, float* __restrict__ Ts, int* __restrict__ list,
                               int* __restrict__ posmap, int2* __restrict__ counts) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b - (int) threadIdx.x >= S->round_nb) return;   // (whole workgroup; S->stop leaves round_nb = 0)
-    rs_hyp_item<NS>(b, src, tgt, corr, c, seed, S, edge_thr, Ts, list, posmap, counts);
+    rs_hyp_item<NS>(b, P0, P1, c, seed, S, edge_thr, Ts, list, posmap, counts);
 }
 
 // candidates = survivors with enough inliers for the gate.  Up to 2^17 survivors ONE workgroup compacts them in list order (an ordered
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(MB) void rs_resident_kernel(const ResidentArgs a, c
             asm volatile("" : "+v"(tid_h));   // (opaque per round and phase: per-thread values are recomputed in the phase that uses them instead of being carried -- spilled -- through the others)
             for (int b0 = wg * MB + (tid_h & ~63); b0 < nb; b0 += n_wg * MB) {
                 const int b = b0 + (tid_h & 63);
-                LGR_NS_DISPATCH(a.n_samples, (rs_hyp_item<NS>(b, in_src, in_tgt, in_corr, a.c, a.seed, S, a.edge_thr, a.Ts, a.list, a.posmap, a.counts)));
+                LGR_NS_DISPATCH(a.n_samples, (rs_hyp_item<NS>(b, in_P0, in_P1, a.c, a.seed, S, a.edge_thr, a.Ts, a.list, a.posmap, a.counts)));
             }
         }
         work_end(1);
@@ -1681,7 +1683,7 @@ static int ransac_device_schedule(lgr_ctx* ctx, const float* d_src, const float*
     auto enqueue_round = [&](bool first) -> int {
         const int nb_up = first ? std::min(batch, nb_max) : nb_max;
         rs_begin_kernel<<<1, 64, 0, ctx->stream>>>(dS, b.st, first ? 1 : 0);
-        LGR_NS_DISPATCH(p->n_samples, (rs_hyp_kernel<NS><<<cdiv(nb_up, 128), 128, 0, ctx->stream>>>(d_src, d_tgt, d_corr, c, seed, dS, p->edge_thr_coef, b.Ts, b.list,
+        LGR_NS_DISPATCH(p->n_samples, (rs_hyp_kernel<NS><<<cdiv(nb_up, 128), 128, 0, ctx->stream>>>(pk.P0, pk.P1, c, seed, dS, p->edge_thr_coef, b.Ts, b.list,
                                                                                                      posmap, b.counts)));
         count_list_kernel<<<g_count, CB, 0, ctx->stream>>>(b.Ts, b.list, &dS->n_ok, pk.PP, pk.pstats, c, b.counts, maskT, mask_cap);
         if (closest) {
